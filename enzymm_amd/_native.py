@@ -1,0 +1,243 @@
+"""ctypes binding of ``libenzymm_amd.so`` (C ABI: ``include/enzymm_amd.h``).
+
+There is deliberately no CPU fallback: if the shared library is missing or no
+MI355X is visible, every entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import threading
+from pathlib import Path
+
+import numpy as np
+
+TM_MAX_TEMPLATE_ATOMS = 24
+TM_MAX_TEMPLATE_GROUPS = 8
+TM_MAX_STRUCTURE_ATOMS = 65535
+TM_RES_OTHER = 31
+TM_NAME_OTHER = 63
+
+TM_OK, TM_E_INVALID, TM_E_UNSUPPORTED, TM_E_DEVICE, TM_E_NOMEM, TM_E_OVERFLOW = 0, -1, -2, -3, -4, -5
+TM_FLAG_IGNORE_CHAIN, TM_FLAG_BEST_MATCH, TM_FLAG_COUNT_CANDIDATES, TM_FLAG_REBUILD_INDEX = 1, 2, 4, 8
+TM_HIT_TRUNCATED = 1
+
+LIB_PATH = Path(__file__).resolve().parent / "libenzymm_amd.so"
+
+#: numpy view of ``struct tm_hit`` (224 bytes)
+HIT_DTYPE = np.dtype(
+    [
+        ("structure", "<u4"), ("template_sel", "<u4"), ("n_candidates", "<u4"), ("flags", "<u4"),
+        ("rmsd", "<f8"), ("rot", "<f8", (9,)), ("trans", "<f8", (3,)),
+        ("n_atoms", "<u4"), ("atoms", "<u4", (TM_MAX_TEMPLATE_ATOMS,)), ("reserved", "<u4"),
+    ],
+    align=False,
+)
+assert HIT_DTYPE.itemsize == 224
+
+
+class _LibraryDesc(C.Structure):
+    _fields_ = [
+        ("n_templates", C.c_uint32), ("atom_offsets", C.c_void_p), ("xyz", C.c_void_p), ("dist_weight", C.c_void_p),
+        ("res_mask", C.c_void_p), ("name_mask", C.c_void_p), ("any_residue", C.c_void_p), ("group", C.c_void_p),
+        ("chain", C.c_void_p),
+    ]
+
+
+class _BatchDesc(C.Structure):
+    _fields_ = [
+        ("n_structures", C.c_uint32), ("atom_offsets", C.c_void_p), ("xyz", C.c_void_p), ("res_type", C.c_void_p),
+        ("name_id", C.c_void_p), ("residue", C.c_void_p), ("chain", C.c_void_p),
+    ]
+
+
+class _QueryParams(C.Structure):
+    _fields_ = [
+        ("n_selected", C.c_uint32), ("template_index", C.c_void_p), ("rmsd_threshold", C.c_void_p),
+        ("distance_cutoff", C.c_void_p), ("max_dynamic_distance", C.c_void_p), ("max_candidates", C.c_uint32),
+        ("flags", C.c_uint32), ("hit_capacity", C.c_uint64), ("stream", C.c_void_p),
+    ]
+
+
+EXPORTS = (
+    "tm_abi_version", "tm_last_error", "tm_device_count", "tm_library_create", "tm_library_destroy",
+    "tm_batch_create", "tm_batch_destroy", "tm_query", "tm_result_wait", "tm_result_hit_count",
+    "tm_result_copy_hits", "tm_result_copy_candidates", "tm_result_timing", "tm_result_device_hits",
+    "tm_result_destroy",
+)
+
+_lock = threading.Lock()
+_lib = None
+
+
+class NativeError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libenzymm_amd: {msg} (code {code})")
+        self.code = code
+
+
+def load() -> C.CDLL:
+    """Load the shared library (no GPU needed for this step)."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not LIB_PATH.exists():
+                raise ImportError(
+                    f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "or `make -C enzymm_amd/csrc`. There is no CPU fallback."
+                )
+            lib = C.CDLL(str(LIB_PATH))
+            lib.tm_last_error.restype = C.c_char_p
+            lib.tm_result_device_hits.restype = C.c_void_p
+            for name in EXPORTS:
+                getattr(lib, name)  # AttributeError if the ABI is incomplete
+            if lib.tm_abi_version() != 1:
+                raise ImportError("libenzymm_amd.so ABI version mismatch")
+            _lib = lib
+    return _lib
+
+
+def _check(rc: int):
+    if rc != TM_OK:
+        raise NativeError(rc, (load().tm_last_error() or b"").decode(errors="replace"))
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _arr(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    _check(load().tm_device_count(C.byref(n)))
+    return n.value
+
+
+class Library:
+    """Device-resident template library (``tm_library``)."""
+
+    def __init__(self, device, atom_offsets, xyz, dist_weight, res_mask, name_mask, any_residue, group, chain):
+        lib = load()
+        self._h = C.c_void_p()
+        self.n_templates = len(atom_offsets) - 1
+        keep = [
+            _arr(atom_offsets, np.uint32), _arr(xyz, np.float64), _arr(dist_weight, np.float64),
+            _arr(res_mask, np.uint32), _arr(name_mask, np.uint64), _arr(any_residue, np.uint8),
+            _arr(group, np.uint8), _arr(chain, np.uint8),
+        ]
+        desc = _LibraryDesc(self.n_templates, *[_ptr(a) for a in keep])
+        _check(lib.tm_library_create(C.c_int(device), C.byref(desc), C.byref(self._h)))
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().tm_library_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+
+class Batch:
+    """Device-resident batch of target structures (``tm_batch``)."""
+
+    def __init__(self, device, atom_offsets, xyz, res_type, name_id, residue, chain):
+        lib = load()
+        self._h = C.c_void_p()
+        self.n_structures = len(atom_offsets) - 1
+        self.atom_offsets = _arr(atom_offsets, np.uint32)
+        keep = [
+            self.atom_offsets, _arr(xyz, np.float64), _arr(res_type, np.uint8), _arr(name_id, np.uint8),
+            _arr(residue, np.uint32), _arr(chain, np.uint8),
+        ]
+        desc = _BatchDesc(self.n_structures, *[_ptr(a) for a in keep])
+        _check(lib.tm_batch_create(C.c_int(device), C.byref(desc), C.byref(self._h)))
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().tm_batch_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+
+class Result:
+    """Outcome of one ``tm_query`` launch (owns the device hit table)."""
+
+    def __init__(self, handle, n_structures, n_selected):
+        self._h = handle
+        self.n_structures, self.n_selected = n_structures, n_selected
+
+    def wait(self):
+        _check(load().tm_result_wait(self._h))
+
+    def hit_count(self) -> int:
+        n = C.c_uint64(0)
+        _check(load().tm_result_hit_count(self._h, C.byref(n)))
+        return n.value
+
+    def hits(self) -> np.ndarray:
+        """Structured array (HIT_DTYPE) sorted by (structure, template_sel)."""
+        n = self.hit_count()
+        out = np.zeros(n, dtype=HIT_DTYPE)
+        _check(load().tm_result_copy_hits(self._h, _ptr(out), C.c_uint64(n)))
+        return out
+
+    def candidates(self) -> np.ndarray:
+        out = np.zeros((self.n_structures, self.n_selected), dtype=np.uint32)
+        _check(load().tm_result_copy_candidates(self._h, _ptr(out), C.c_uint64(out.size)))
+        return out
+
+    def timing(self):
+        """(index_ms, search_ms) measured with HIP events on the launch stream."""
+        a, b = C.c_float(0), C.c_float(0)
+        _check(load().tm_result_timing(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def device_hits_ptr(self) -> int:
+        return load().tm_result_device_hits(self._h) or 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().tm_result_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+
+def query(library: Library, batch: Batch, template_index, rmsd_threshold, distance_cutoff, max_dynamic_distance,
+          max_candidates: int, flags: int, hit_capacity: int = 0, stream: int = 0) -> Result:
+    n = len(template_index)
+    keep = [
+        _arr(template_index, np.uint32),
+        _arr(np.broadcast_to(np.asarray(rmsd_threshold, dtype=np.float64), (n,)), np.float64),
+        _arr(np.broadcast_to(np.asarray(distance_cutoff, dtype=np.float64), (n,)), np.float64),
+        _arr(np.broadcast_to(np.asarray(max_dynamic_distance, dtype=np.float64), (n,)), np.float64),
+    ]
+    params = _QueryParams(n, *[_ptr(a) for a in keep], int(max_candidates), int(flags), int(hit_capacity),
+                          C.c_void_p(stream or None))
+    handle = C.c_void_p()
+    while True:
+        _check(load().tm_query(library._h, batch._h, C.byref(params), C.byref(handle)))
+        res = Result(handle, batch.n_structures, n)
+        try:
+            res.wait() if hit_capacity == 0 else None
+            return res
+        except NativeError as exc:
+            if exc.code != TM_E_OVERFLOW:
+                raise
+            # automatic capacity was too small: retry with room for everything that was found
+            params.hit_capacity = max(2 * res.hit_count_unchecked(), 8192)
+            res.close()
+            handle = C.c_void_p()
+
+
+def _hit_count_unchecked(self) -> int:
+    n = C.c_uint64(0)
+    load().tm_result_hit_count(self._h, C.byref(n))
+    return n.value
+
+
+Result.hit_count_unchecked = _hit_count_unchecked

@@ -1,0 +1,534 @@
+// Host side of libenzymm_amd.so: packs templates and structures into their HBM layouts,
+// plans the per-template search order, launches the kernels and returns the hit table.
+// C ABI declared in include/enzymm_amd.h.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <new>
+#include <numeric>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "tm_kernels.hip"  // single translation unit: kernels + host API
+
+using namespace tmx;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                  \
+    do {                                                                               \
+        hipError_t e_ = (expr);                                                        \
+        if (e_ != hipSuccess) return fail(TM_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// Owning device buffer.
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    hipError_t alloc(size_t count) {
+        release();
+        n = count;
+        if (count == 0) count = 1;
+        return hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
+    }
+    hipError_t upload(const std::vector<T> &v) {
+        hipError_t e = alloc(v.size());
+        if (e != hipSuccess || v.empty()) return e;
+        return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+};
+
+}  // namespace
+
+struct tm_library {
+    int device = 0;
+    uint32_t n_templates = 0, n_atoms = 0, n_kinds = 0, n_lead = 0;
+    std::vector<uint32_t> t_off;
+    DevBuf<uint32_t> d_t_off, d_k_resmask, d_lead_kind;
+    DevBuf<double> d_xyz, d_w;
+    DevBuf<uint16_t> d_kind;
+    DevBuf<uint8_t> d_group, d_orig, d_chain, d_k_any;
+    DevBuf<uint64_t> d_k_namemask;
+    DevBuf<int32_t> d_k_lead;
+    uint64_t serial = 0;  // identity for the batch-side index cache
+    LibView view() const {
+        LibView v;
+        v.n_templates = n_templates; v.n_kinds = n_kinds; v.n_lead = n_lead;
+        v.t_off = d_t_off.p; v.a_xyz = d_xyz.p; v.a_w = d_w.p; v.a_kind = d_kind.p;
+        v.a_group = d_group.p; v.a_orig = d_orig.p; v.a_chain = d_chain.p;
+        v.k_resmask = d_k_resmask.p; v.k_namemask = d_k_namemask.p; v.k_any = d_k_any.p;
+        v.k_lead = d_k_lead.p; v.lead_kind = d_lead_kind.p;
+        return v;
+    }
+};
+
+struct tm_batch {
+    int device = 0;
+    uint32_t n_structs = 0, n_atoms = 0, max_atoms = 0, max_res = 0;
+    std::vector<uint32_t> s_off;
+    DevBuf<uint32_t> d_s_off, d_s_roff, d_orig, d_kl_off;
+    DevBuf<double> d_xyz;
+    DevBuf<float4> d_rec;
+    DevBuf<uint8_t> d_chain;
+    DevBuf<uint16_t> d_res_start, d_kl_pool;
+    DevBuf<unsigned long long> d_cursor;
+    DevBuf<uint32_t> d_overflow;
+    uint64_t index_for = 0;  // serial of the library the candidate index was built for
+    unsigned long long pool_capacity = 0;
+    BatchView view() const {
+        BatchView v;
+        v.n_structs = n_structs; v.s_off = d_s_off.p; v.s_roff = d_s_roff.p; v.q_xyz = d_xyz.p;
+        v.q_rec = d_rec.p; v.q_chain = d_chain.p; v.q_orig = d_orig.p; v.res_start = d_res_start.p;
+        v.kl_off = d_kl_off.p; v.kl_pool = d_kl_pool.p;
+        return v;
+    }
+};
+
+struct tm_result {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint32_t n_structs = 0, n_sel = 0;
+    unsigned long long capacity = 0;
+    DevBuf<tm_hit> d_hits;
+    DevBuf<unsigned long long> d_n_hits;
+    DevBuf<uint32_t> d_overflow, d_candidates, d_sel;
+    DevBuf<double> d_rmsd, d_cut, d_maxdyn;
+    DevBuf<float2> d_bounds;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    bool waited = false, overflowed = false;
+    unsigned long long n_hits = 0;
+    ~tm_result() {
+        for (auto &e : ev)
+            if (e) (void)hipEventDestroy(e);
+    }
+};
+
+namespace {
+
+uint64_t g_serial = 0;
+
+// Search order of one template: template residues ("groups") by ascending expected number
+// of admissible target atoms of their most selective atom; inside a group that atom first.
+// Any order enumerates the same set of assignments; this one keeps the search tree narrow.
+struct Plan {
+    std::vector<int> order;  // search position -> template atom
+    std::vector<int> group;  // search position -> group index in search order
+};
+
+Plan plan_template(int k, const uint8_t *group, const double *est) {
+    std::vector<int> groups;  // distinct group ids in first-appearance order
+    for (int i = 0; i < k; ++i)
+        if (std::find(groups.begin(), groups.end(), (int)group[i]) == groups.end()) groups.push_back(group[i]);
+    struct G { int id; double best; int lead; int first; };
+    std::vector<G> gs;
+    for (size_t gi = 0; gi < groups.size(); ++gi) {
+        G g{groups[gi], 1e300, -1, (int)gi};
+        for (int i = 0; i < k; ++i)
+            if (group[i] == g.id && est[i] < g.best) { g.best = est[i]; g.lead = i; }
+        gs.push_back(g);
+    }
+    std::stable_sort(gs.begin(), gs.end(), [](const G &a, const G &b) { return a.best < b.best; });
+    Plan p;
+    for (size_t gi = 0; gi < gs.size(); ++gi) {
+        p.order.push_back(gs[gi].lead);
+        p.group.push_back((int)gi);
+        for (int i = 0; i < k; ++i)
+            if (group[i] == gs[gi].id && i != gs[gi].lead) { p.order.push_back(i); p.group.push_back((int)gi); }
+    }
+    return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tm_abi_version(void) { return TM_ABI_VERSION; }
+
+const char *tm_last_error(void) { return g_err.c_str(); }
+
+int tm_device_count(int *count) {
+    if (!count) return fail(TM_E_INVALID, "count is NULL");
+    HIP_TRY(hipGetDeviceCount(count));
+    return TM_OK;
+}
+
+int tm_library_create(int device, const tm_library_desc *d, tm_library **out) {
+    if (!d || !out || !d->atom_offsets || (d->n_templates && (!d->xyz || !d->res_mask || !d->name_mask || !d->group)))
+        return fail(TM_E_INVALID, "tm_library_create: NULL argument");
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(device));
+    const uint32_t nt = d->n_templates;
+    const uint32_t na = d->atom_offsets[nt];
+    std::vector<double> xyz(3 * (size_t)na), w(na);
+    std::vector<uint16_t> kind(na);
+    std::vector<uint8_t> group(na), orig(na), chain(na);
+    std::map<std::tuple<uint8_t, uint32_t, uint64_t>, uint32_t> kinds;
+    std::vector<uint32_t> k_resmask;
+    std::vector<uint64_t> k_namemask;
+    std::vector<uint8_t> k_any;
+    std::vector<int32_t> k_lead;
+    std::vector<uint32_t> lead_kind;
+
+    for (uint32_t t = 0; t < nt; ++t) {
+        const uint32_t o = d->atom_offsets[t];
+        const int k = (int)(d->atom_offsets[t + 1] - o);
+        if (k < 1 || k > kMaxK)
+            return fail(TM_E_UNSUPPORTED, "template " + std::to_string(t) + " has " + std::to_string(k) +
+                                              " atoms; this build supports 1.." + std::to_string(kMaxK));
+        // expected admissible atoms per template atom: (#residue types) x (#atom names)
+        double est[kMaxK];
+        for (int i = 0; i < k; ++i) {
+            const bool any = d->any_residue && d->any_residue[o + i];
+            const double nres = any ? 20.0 : (double)__builtin_popcount(d->res_mask[o + i]);
+            est[i] = nres * (double)__builtin_popcountll(d->name_mask[o + i]);
+        }
+        Plan p = plan_template(k, d->group + o, est);
+        if ((int)p.group.back() + 1 > kMaxG)
+            return fail(TM_E_UNSUPPORTED, "template " + std::to_string(t) + " has more than " +
+                                              std::to_string(kMaxG) + " residues");
+        for (int pos = 0; pos < k; ++pos) {
+            const int i = p.order[pos];
+            const uint32_t dst = o + pos, src = o + i;
+            for (int a = 0; a < 3; ++a) xyz[3 * (size_t)dst + a] = d->xyz[3 * (size_t)src + a];
+            w[dst] = d->dist_weight ? d->dist_weight[src] : 0.0;
+            group[dst] = (uint8_t)p.group[pos];
+            orig[dst] = (uint8_t)i;
+            chain[dst] = d->chain ? d->chain[src] : 0;
+            const uint8_t any = (d->any_residue && d->any_residue[src]) ? 1 : 0;
+            auto key = std::make_tuple(any, any ? 0u : d->res_mask[src], d->name_mask[src]);
+            auto it = kinds.find(key);
+            if (it == kinds.end()) {
+                if (kinds.size() >= 65535) return fail(TM_E_UNSUPPORTED, "more than 65535 distinct atom kinds");
+                it = kinds.emplace(key, (uint32_t)kinds.size()).first;
+                k_any.push_back(any);
+                k_resmask.push_back(std::get<1>(key));
+                k_namemask.push_back(std::get<2>(key));
+                k_lead.push_back(-1);
+            }
+            kind[dst] = (uint16_t)it->second;
+            const bool lead = pos == 0 || p.group[pos] != p.group[pos - 1];
+            if (lead && k_lead[it->second] < 0) {
+                k_lead[it->second] = (int32_t)lead_kind.size();
+                lead_kind.push_back(it->second);
+            }
+        }
+    }
+
+    tm_library *lib = new (std::nothrow) tm_library;
+    if (!lib) return fail(TM_E_NOMEM, "out of host memory");
+    lib->device = device;
+    lib->n_templates = nt; lib->n_atoms = na;
+    lib->n_kinds = (uint32_t)k_any.size(); lib->n_lead = (uint32_t)lead_kind.size();
+    lib->t_off.assign(d->atom_offsets, d->atom_offsets + nt + 1);
+    lib->serial = ++g_serial;
+    hipError_t e = hipSuccess;
+    auto up = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+    up(lib->d_t_off.upload(lib->t_off)); up(lib->d_xyz.upload(xyz)); up(lib->d_w.upload(w));
+    up(lib->d_kind.upload(kind)); up(lib->d_group.upload(group)); up(lib->d_orig.upload(orig));
+    up(lib->d_chain.upload(chain)); up(lib->d_k_resmask.upload(k_resmask));
+    up(lib->d_k_namemask.upload(k_namemask)); up(lib->d_k_any.upload(k_any));
+    up(lib->d_k_lead.upload(k_lead)); up(lib->d_lead_kind.upload(lead_kind));
+    if (e != hipSuccess) {
+        delete lib;
+        return fail(TM_E_DEVICE, std::string("tm_library_create upload: ") + hipGetErrorString(e));
+    }
+    *out = lib;
+    return TM_OK;
+}
+
+void tm_library_destroy(tm_library *lib) {
+    if (!lib) return;
+    (void)hipSetDevice(lib->device);
+    delete lib;
+}
+
+int tm_batch_create(int device, const tm_batch_desc *d, tm_batch **out) {
+    if (!d || !out || !d->atom_offsets ||
+        (d->n_structures && d->atom_offsets[d->n_structures] && (!d->xyz || !d->res_type || !d->name_id || !d->residue)))
+        return fail(TM_E_INVALID, "tm_batch_create: NULL argument");
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(device));
+    const uint32_t ns = d->n_structures;
+    const uint32_t na = d->atom_offsets[ns];
+    std::vector<double> xyz(3 * (size_t)na);
+    std::vector<float4> rec(na);
+    std::vector<uint8_t> chain(na);
+    std::vector<uint32_t> orig(na), s_roff(ns + 1, 0);
+    std::vector<uint16_t> res_start;
+    uint32_t max_atoms = 0, max_res = 0;
+    std::vector<uint32_t> count, perm;
+
+    for (uint32_t s = 0; s < ns; ++s) {
+        const uint32_t o = d->atom_offsets[s], n = d->atom_offsets[s + 1] - o;
+        if (n > TM_MAX_STRUCTURE_ATOMS)
+            return fail(TM_E_UNSUPPORTED, "structure " + std::to_string(s) + " has " + std::to_string(n) +
+                                              " atoms; limit " + std::to_string(TM_MAX_STRUCTURE_ATOMS));
+        uint32_t nres = 0;
+        for (uint32_t i = 0; i < n; ++i) nres = std::max(nres, d->residue[o + i] + 1);
+        if (nres > 65535) return fail(TM_E_UNSUPPORTED, "structure " + std::to_string(s) + " has too many residues");
+        // counting sort by residue ordinal: atoms of a residue become contiguous, file order kept inside
+        count.assign(nres + 1, 0);
+        for (uint32_t i = 0; i < n; ++i) count[d->residue[o + i] + 1]++;
+        for (uint32_t r = 0; r < nres; ++r) count[r + 1] += count[r];
+        s_roff[s] = (uint32_t)res_start.size();
+        for (uint32_t r = 0; r <= nres; ++r) res_start.push_back((uint16_t)count[r]);
+        perm.assign(n, 0);
+        {
+            std::vector<uint32_t> fill(count.begin(), count.end() - 1);
+            for (uint32_t i = 0; i < n; ++i) perm[fill[d->residue[o + i]]++] = i;
+        }
+        double c[3] = {0, 0, 0};
+        for (uint32_t i = 0; i < n; ++i)
+            for (int a = 0; a < 3; ++a) c[a] += d->xyz[3 * (size_t)(o + i) + a];
+        if (n)
+            for (int a = 0; a < 3; ++a) c[a] /= (double)n;
+        for (uint32_t j = 0; j < n; ++j) {
+            const uint32_t src = o + perm[j], dst = o + j;
+            for (int a = 0; a < 3; ++a) xyz[3 * (size_t)dst + a] = d->xyz[3 * (size_t)src + a];
+            float4 r;
+            r.x = (float)(d->xyz[3 * (size_t)src] - c[0]);
+            r.y = (float)(d->xyz[3 * (size_t)src + 1] - c[1]);
+            r.z = (float)(d->xyz[3 * (size_t)src + 2] - c[2]);
+            const uint32_t nm = std::min<uint32_t>(d->name_id[src], TM_NAME_OTHER);
+            const uint32_t rt = std::min<uint32_t>(d->res_type[src], TM_RES_OTHER);
+            const uint32_t m = meta_pack(d->residue[src], nm, rt);
+            std::memcpy(&r.w, &m, 4);
+            rec[dst] = r;
+            chain[dst] = d->chain ? d->chain[src] : 0;
+            orig[dst] = perm[j];
+        }
+        max_atoms = std::max(max_atoms, n);
+        max_res = std::max(max_res, nres);
+    }
+    s_roff[ns] = (uint32_t)res_start.size();
+
+    tm_batch *b = new (std::nothrow) tm_batch;
+    if (!b) return fail(TM_E_NOMEM, "out of host memory");
+    b->device = device;
+    b->n_structs = ns; b->n_atoms = na; b->max_atoms = max_atoms; b->max_res = max_res;
+    b->s_off.assign(d->atom_offsets, d->atom_offsets + ns + 1);
+    hipError_t e = hipSuccess;
+    auto up = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+    up(b->d_s_off.upload(b->s_off)); up(b->d_s_roff.upload(s_roff)); up(b->d_xyz.upload(xyz));
+    up(b->d_rec.upload(rec)); up(b->d_chain.upload(chain)); up(b->d_orig.upload(orig));
+    up(b->d_res_start.upload(res_start)); up(b->d_cursor.alloc(1)); up(b->d_overflow.alloc(1));
+    if (e != hipSuccess) {
+        delete b;
+        return fail(TM_E_DEVICE, std::string("tm_batch_create upload: ") + hipGetErrorString(e));
+    }
+    *out = b;
+    return TM_OK;
+}
+
+void tm_batch_destroy(tm_batch *b) {
+    if (!b) return;
+    (void)hipSetDevice(b->device);
+    delete b;
+}
+
+// (Re)builds the batch's candidate index for `lib`.  Synchronises the stream once to learn
+// whether the bump-allocated pool was large enough; grows it and retries otherwise.
+static int build_index(const tm_library *lib, tm_batch *b, hipStream_t stream) {
+    const size_t off_n = (size_t)b->n_structs * (lib->n_lead + 1);
+    if (b->d_kl_off.n != off_n) HIP_TRY(b->d_kl_off.alloc(off_n));
+    unsigned long long cap = b->pool_capacity ? b->pool_capacity : std::max<unsigned long long>(1024, 32ull * b->n_atoms);
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        if (cap > 0xffffffffull)
+            return fail(TM_E_UNSUPPORTED, "candidate index needs more than 2^32 entries: split the batch");
+        if (b->d_kl_pool.n != cap) HIP_TRY(b->d_kl_pool.alloc(cap));
+        b->pool_capacity = cap;
+        HIP_TRY(hipMemsetAsync(b->d_cursor.p, 0, sizeof(unsigned long long), stream));
+        HIP_TRY(hipMemsetAsync(b->d_overflow.p, 0, sizeof(uint32_t), stream));
+        if (b->n_structs && lib->n_lead) {
+            hipLaunchKernelGGL(k_kind_lists, dim3(b->n_structs), dim3(256), (lib->n_lead + 1) * sizeof(uint32_t), stream,
+                               lib->view(), b->view(), b->d_kl_off.p, b->d_kl_pool.p, b->d_cursor.p, cap,
+                               b->d_overflow.p);
+            HIP_TRY(hipGetLastError());
+        }
+        unsigned long long used = 0;
+        HIP_TRY(hipMemcpyAsync(&used, b->d_cursor.p, sizeof used, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (used <= cap) {
+            b->index_for = lib->serial;
+            return TM_OK;
+        }
+        cap = used + used / 8 + 1024;
+    }
+    return fail(TM_E_NOMEM, "candidate index did not fit");
+}
+
+int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_result **out) {
+    if (!lib || !b || !p || !out) return fail(TM_E_INVALID, "tm_query: NULL argument");
+    *out = nullptr;
+    if (lib->device != b->device) return fail(TM_E_INVALID, "library and batch live on different devices");
+    if (!(p->flags & TM_FLAG_BEST_MATCH)) return fail(TM_E_UNSUPPORTED, "ABI v1 implements best_match queries only");
+    if (p->n_selected && (!p->template_index || !p->rmsd_threshold || !p->distance_cutoff || !p->max_dynamic_distance))
+        return fail(TM_E_INVALID, "tm_query: NULL parameter array");
+    for (uint32_t i = 0; i < p->n_selected; ++i)
+        if (p->template_index[i] >= lib->n_templates) return fail(TM_E_INVALID, "template index out of range");
+    HIP_TRY(hipSetDevice(lib->device));
+    hipStream_t stream = (hipStream_t)p->stream;
+
+    tm_result *r = new (std::nothrow) tm_result;
+    if (!r) return fail(TM_E_NOMEM, "out of host memory");
+    struct Guard { tm_result *r; ~Guard() { delete r; } } guard{r};
+    r->device = lib->device; r->stream = stream;
+    r->n_structs = b->n_structs; r->n_sel = p->n_selected;
+    const uint32_t n_sel = p->n_selected;
+    for (auto &e : r->ev) HIP_TRY(hipEventCreate(&e));
+
+    std::vector<uint32_t> sel(p->template_index, p->template_index + n_sel);
+    std::vector<double> rm(p->rmsd_threshold, p->rmsd_threshold + n_sel), cu(p->distance_cutoff, p->distance_cutoff + n_sel),
+        md(p->max_dynamic_distance, p->max_dynamic_distance + n_sel);
+    HIP_TRY(r->d_sel.upload(sel)); HIP_TRY(r->d_rmsd.upload(rm)); HIP_TRY(r->d_cut.upload(cu)); HIP_TRY(r->d_maxdyn.upload(md));
+    HIP_TRY(r->d_bounds.alloc((size_t)n_sel * kMaxPairs));
+    unsigned long long cap = p->hit_capacity;
+    if (!cap) cap = std::max<unsigned long long>(4096, (unsigned long long)b->n_structs * std::min<uint32_t>(n_sel, 512));
+    r->capacity = cap;
+    HIP_TRY(r->d_hits.alloc(cap));
+    HIP_TRY(r->d_n_hits.alloc(1));
+    HIP_TRY(r->d_overflow.alloc(1));
+    HIP_TRY(hipMemsetAsync(r->d_n_hits.p, 0, sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(r->d_overflow.p, 0, sizeof(uint32_t), stream));
+    if (p->flags & TM_FLAG_COUNT_CANDIDATES) {
+        HIP_TRY(r->d_candidates.alloc((size_t)b->n_structs * n_sel));
+        HIP_TRY(hipMemsetAsync(r->d_candidates.p, 0, (size_t)b->n_structs * n_sel * sizeof(uint32_t), stream));
+    }
+
+    HIP_TRY(hipEventRecord(r->ev[0], stream));
+    if (b->index_for != lib->serial || (p->flags & TM_FLAG_REBUILD_INDEX)) {
+        int rc = build_index(lib, b, stream);
+        if (rc != TM_OK) return rc;
+    }
+    if (n_sel) {
+        hipLaunchKernelGGL(k_pair_bounds, dim3(n_sel), dim3(64), 0, stream, lib->view(), n_sel, r->d_sel.p, r->d_cut.p,
+                           r->d_maxdyn.p, r->d_bounds.p);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(r->ev[1], stream));
+
+    if (n_sel && b->n_structs) {
+        QueryView Q;
+        Q.n_sel = n_sel; Q.sel = r->d_sel.p; Q.rmsd_thr = r->d_rmsd.p; Q.cutoff = r->d_cut.p; Q.maxdyn = r->d_maxdyn.p;
+        Q.bounds = r->d_bounds.p; Q.max_candidates = p->max_candidates; Q.flags = p->flags;
+        OutView O;
+        O.hits = r->d_hits.p; O.n_hits = r->d_n_hits.p; O.capacity = cap; O.overflow = r->d_overflow.p;
+        O.candidates = (p->flags & TM_FLAG_COUNT_CANDIDATES) ? r->d_candidates.p : nullptr;
+        // enough workgroups to fill 256 CUs several times over; every chunk of a structure on one XCD
+        const uint32_t min_chunk = 16;
+        uint32_t n_chunks = (4096 + b->n_structs - 1) / b->n_structs;
+        n_chunks = std::max(1u, std::min(n_chunks, (n_sel + min_chunk - 1) / min_chunk));
+        const uint32_t chunk_size = (n_sel + n_chunks - 1) / n_chunks;
+        n_chunks = (n_sel + chunk_size - 1) / chunk_size;
+        const uint32_t grid = ((b->n_structs + 7) / 8) * 8 * n_chunks;
+        const size_t scratch = search_scratch_bytes();
+        const size_t res_bytes = (((size_t)b->max_res + 1) * sizeof(uint16_t) + 15) & ~size_t(15);
+        const size_t lds_full = scratch + (size_t)b->max_atoms * sizeof(float4) + res_bytes;
+        const size_t lds_limit = 160 * 1024 - 64;
+        if (lds_full <= lds_limit) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_search<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full));
+            hipLaunchKernelGGL(k_search<true>, dim3(grid), dim3(kSearchBlock), lds_full, stream, lib->view(), b->view(),
+                               Q, O, n_chunks, chunk_size, b->max_atoms, b->max_res);
+        } else {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_search<false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)scratch));
+            hipLaunchKernelGGL(k_search<false>, dim3(grid), dim3(kSearchBlock), scratch, stream, lib->view(), b->view(),
+                               Q, O, n_chunks, chunk_size, b->max_atoms, b->max_res);
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(r->ev[2], stream));
+    guard.r = nullptr;
+    *out = r;
+    return TM_OK;
+}
+
+int tm_result_wait(tm_result *r) {
+    if (!r) return fail(TM_E_INVALID, "result is NULL");
+    if (!r->waited) {
+        HIP_TRY(hipSetDevice(r->device));
+        uint32_t ovf = 0;
+        HIP_TRY(hipMemcpyAsync(&r->n_hits, r->d_n_hits.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, r->stream));
+        HIP_TRY(hipMemcpyAsync(&ovf, r->d_overflow.p, sizeof ovf, hipMemcpyDeviceToHost, r->stream));
+        HIP_TRY(hipStreamSynchronize(r->stream));
+        r->waited = true;
+        r->overflowed = ovf != 0 || r->n_hits > r->capacity;
+    }
+    if (r->overflowed)
+        return fail(TM_E_OVERFLOW, "hit table overflow: " + std::to_string(r->n_hits) + " hits, capacity " +
+                                       std::to_string(r->capacity));
+    return TM_OK;
+}
+
+int tm_result_hit_count(tm_result *r, uint64_t *n) {
+    if (!r || !n) return fail(TM_E_INVALID, "NULL argument");
+    int rc = tm_result_wait(r);
+    *n = r->n_hits;
+    return rc;
+}
+
+int tm_result_copy_hits(tm_result *r, tm_hit *out, uint64_t capacity) {
+    int rc = tm_result_wait(r);
+    if (rc != TM_OK) return rc;
+    if (r->n_hits > capacity) return fail(TM_E_INVALID, "output buffer too small");
+    if (r->n_hits == 0) return TM_OK;
+    if (!out) return fail(TM_E_INVALID, "out is NULL");
+    HIP_TRY(hipMemcpy(out, r->d_hits.p, r->n_hits * sizeof(tm_hit), hipMemcpyDeviceToHost));
+    std::sort(out, out + r->n_hits, [](const tm_hit &a, const tm_hit &b) {
+        return a.structure != b.structure ? a.structure < b.structure : a.template_sel < b.template_sel;
+    });
+    return TM_OK;
+}
+
+int tm_result_copy_candidates(tm_result *r, uint32_t *out, uint64_t n) {
+    int rc = tm_result_wait(r);
+    if (rc != TM_OK && rc != TM_E_OVERFLOW) return rc;
+    if (!r->d_candidates.p) return fail(TM_E_INVALID, "query was not run with TM_FLAG_COUNT_CANDIDATES");
+    const uint64_t need = (uint64_t)r->n_structs * r->n_sel;
+    if (n < need || !out) return fail(TM_E_INVALID, "output buffer too small");
+    if (need) HIP_TRY(hipMemcpy(out, r->d_candidates.p, need * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return TM_OK;
+}
+
+int tm_result_timing(tm_result *r, float *index_ms, float *search_ms) {
+    if (!r) return fail(TM_E_INVALID, "result is NULL");
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipEventSynchronize(r->ev[2]));
+    float a = 0, s = 0;
+    HIP_TRY(hipEventElapsedTime(&a, r->ev[0], r->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&s, r->ev[1], r->ev[2]));
+    if (index_ms) *index_ms = a;
+    if (search_ms) *search_ms = s;
+    return TM_OK;
+}
+
+const void *tm_result_device_hits(tm_result *r) { return r ? r->d_hits.p : nullptr; }
+
+void tm_result_destroy(tm_result *r) {
+    if (!r) return;
+    (void)hipSetDevice(r->device);
+    if (!r->waited) (void)hipStreamSynchronize(r->stream);
+    delete r;
+}
+
+}  // extern "C"

@@ -1,0 +1,83 @@
+// Device-side data views shared by the kernels and the host API of libenzymm_amd.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "enzymm_amd.h"
+
+namespace tmx {
+
+constexpr int kMaxK = TM_MAX_TEMPLATE_ATOMS;        // template atoms per template
+constexpr int kMaxG = TM_MAX_TEMPLATE_GROUPS;       // template residues
+constexpr int kMaxPairs = kMaxK * (kMaxK - 1) / 2;  // 276 pair constraints
+constexpr int kWave = 64;
+constexpr int kSearchWaves = 8;  // waves per search workgroup
+constexpr int kSearchBlock = kWave * kSearchWaves;
+
+// fp32 prefilter slack (Angstrom) added to every pair threshold.  Centred fp32
+// coordinates of a <= 300 A structure carry < 4e-5 A of rounding; anything the
+// slack lets through is re-checked in fp64 before it can become a candidate.
+constexpr double kPrefilterSlack = 2e-3;
+
+// bits of the packed per-atom meta word (float4.w of a target atom record)
+//   [15:0] residue ordinal   [21:16] atom-name id   [26:22] residue-type id
+__host__ __device__ inline uint32_t meta_pack(uint32_t res, uint32_t name, uint32_t rtype) {
+    return (res & 0xffffu) | ((name & 63u) << 16) | ((rtype & 31u) << 22);
+}
+__host__ __device__ inline uint32_t meta_res(uint32_t m) { return m & 0xffffu; }
+__host__ __device__ inline uint32_t meta_name(uint32_t m) { return (m >> 16) & 63u; }
+__host__ __device__ inline uint32_t meta_rtype(uint32_t m) { return (m >> 22) & 31u; }
+
+// Template library in HBM.  Per-atom arrays are in SEARCH order (see plan_template()).
+struct LibView {
+    uint32_t n_templates, n_kinds, n_lead;
+    const uint32_t *t_off;   // [n_templates+1] atom offsets
+    const double *a_xyz;     // [n_atoms*3]
+    const double *a_w;       // [n_atoms] distance weight
+    const uint16_t *a_kind;  // [n_atoms] -> kind table
+    const uint8_t *a_group;  // [n_atoms] template residue index, non-decreasing in search order
+    const uint8_t *a_orig;   // [n_atoms] position of this atom in TEMPLATE (file) order
+    const uint8_t *a_chain;  // [n_atoms] template chain ordinal
+    // kind = distinct (any_residue, res_mask, name_mask) triple
+    const uint32_t *k_resmask;
+    const uint64_t *k_namemask;
+    const uint8_t *k_any;
+    const int32_t *k_lead;       // index among lead kinds, or -1
+    const uint32_t *lead_kind;   // [n_lead] kind id of each lead kind
+};
+
+// Target structures in HBM.  Atoms of a structure are stored residue-contiguous.
+struct BatchView {
+    uint32_t n_structs;
+    const uint32_t *s_off;      // [n_structs+1] atom offsets
+    const uint32_t *s_roff;     // [n_structs+1] offsets into res_start
+    const double *q_xyz;        // [n_atoms*3] original coordinates (fp64 re-check, superposition)
+    const float4 *q_rec;        // [n_atoms] centred fp32 xyz + meta word
+    const uint8_t *q_chain;     // [n_atoms]
+    const uint32_t *q_orig;     // [n_atoms] file-order index of this atom within its structure
+    const uint16_t *res_start;  // per structure: n_res+1 local atom indices
+    // candidate index for one library: for each (structure, lead kind) the admissible atoms
+    const uint32_t *kl_off;   // [n_structs*(n_lead+1)] offsets into kl_pool
+    const uint16_t *kl_pool;  // local atom indices, ascending
+};
+
+struct QueryView {
+    uint32_t n_sel;
+    const uint32_t *sel;        // [n_sel] template indices
+    const double *rmsd_thr;     // [n_sel]
+    const double *cutoff;       // [n_sel]
+    const double *maxdyn;       // [n_sel]
+    const float2 *bounds;       // [n_sel*kMaxPairs] (lo^2, hi^2) fp32 prefilter bounds, search order
+    uint32_t max_candidates;
+    uint32_t flags;
+};
+
+struct OutView {
+    tm_hit *hits;
+    unsigned long long *n_hits;  // allocation counter
+    unsigned long long capacity;
+    uint32_t *overflow;          // set to 1 when the table is full
+    uint32_t *candidates;        // optional [n_structs*n_sel]: count | truncated<<31
+};
+
+}  // namespace tmx

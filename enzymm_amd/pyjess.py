@@ -1,0 +1,597 @@
+"""Drop-in for the slice of the ``pyjess`` API that enzymm touches, backed by the MI355X matcher.
+
+Mirrors (names, argument meaning, error behaviour) what enzymm uses of ``pyjess ~=0.5``
+(/root/reference/pyproject.toml:30):
+
+=================  ===========================================================================
+``Jess``           ``Jess(templates)``; ``.query(molecule, rmsd_threshold, distance_cutoff,
+                   max_dynamic_distance, *, max_candidates, ignore_chain, best_match)``
+                   -- /root/reference/enzymm/jess_run.py:800-811, tests/test_jess_run.py:32-40
+``Hit``            ``.rmsd .log_evalue .template .molecule(transform) .atoms(transform)``
+                   -- jess_run.py:148-182, 243-267, 357, 397, 485-495
+``Atom``           PDB fields + ``!=``           -- jess_run.py:142-145, 365, 441
+``Molecule``       ``load(path_or_file, id=)``, ``.id``, ``.conserved(cutoff)``, ``len``, iteration,
+                   hashable                       -- jess_run.py:538-556, 915-917, 954-958
+``Template``       ``__init__(atoms, id=None)``, ``.id``, ``.dimension``, iterable, subclassable
+                   -- enzymm/template.py:455, 535
+``TemplateAtom``   ``loads(line)``, keyword constructor, attributes, ``==``/hash
+                   -- template.py:679, 258-319, 374-407; tests/test_template.py:234-268
+=================  ===========================================================================
+
+Install as a replacement with ``sys.modules["pyjess"] = enzymm_amd.pyjess``.
+
+The search itself runs in ``libenzymm_amd.so`` (hand-written HIP, gfx950).  There is no CPU
+fallback: without the library and a GPU, ``Jess.query`` raises.
+"""
+from __future__ import annotations
+
+import collections
+import collections.abc
+import io
+import math
+import os
+import threading
+from typing import Iterable, Iterator, List, Optional, Sequence
+
+import numpy as np
+
+from . import _native
+from ._vocab import ONE_LETTER, VOCAB, raw_atom_name, raw_residue_name
+
+__version__ = "0.5.0+enzymm_amd.1"
+
+__all__ = ["Atom", "Molecule", "TemplateAtom", "Template", "Jess", "Query", "Hit", "__version__"]
+
+_UNLIMITED = 0xFFFFFFFF
+
+
+def default_device() -> int:
+    """GPU ordinal used by this process: $ENZYMM_AMD_DEVICE, else $LOCAL_RANK, else 0."""
+    return int(os.environ.get("ENZYMM_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+
+
+# ---------------------------------------------------------------------------------- Atom
+
+
+class Atom:
+    """One ATOM/HETATM record of a target structure."""
+
+    __slots__ = (
+        "serial", "name", "altloc", "residue_name", "chain_id", "residue_number", "insertion_code",
+        "x", "y", "z", "occupancy", "temperature_factor", "segment", "element", "charge", "_raw_name",
+    )
+
+    def __init__(self, *, serial: int, name: str, residue_name: str, chain_id: str, residue_number: int,
+                 x: float, y: float, z: float, altloc: Optional[str] = None, insertion_code: str = " ",
+                 occupancy: float = 0.0, temperature_factor: float = 0.0, segment: str = "", element: str = "",
+                 charge: int = 0, _raw_name: Optional[bytes] = None):
+        self.serial = int(serial)
+        self.name = name
+        self.altloc = altloc
+        self.residue_name = residue_name
+        self.chain_id = chain_id
+        self.residue_number = int(residue_number)
+        self.insertion_code = insertion_code
+        self.x, self.y, self.z = float(x), float(y), float(z)
+        self.occupancy = float(occupancy)
+        self.temperature_factor = float(temperature_factor)
+        self.segment = segment
+        self.element = element
+        self.charge = int(charge)
+        self._raw_name = _raw_name if _raw_name is not None else raw_atom_name(name)
+
+    def _key(self):
+        return (self.serial, self.name, self.altloc, self.residue_name, self.chain_id, self.residue_number,
+                self.insertion_code, self.x, self.y, self.z, self.occupancy, self.temperature_factor,
+                self.segment, self.element, self.charge)
+
+    def __eq__(self, other):
+        return self._key() == other._key() if isinstance(other, Atom) else NotImplemented
+
+    def __ne__(self, other):
+        return self._key() != other._key() if isinstance(other, Atom) else NotImplemented
+
+    def __hash__(self):
+        return hash(self._key())
+
+    def __repr__(self):
+        return (f"Atom(serial={self.serial}, name={self.name!r}, residue_name={self.residue_name!r}, "
+                f"chain_id={self.chain_id!r}, residue_number={self.residue_number}, "
+                f"x={self.x}, y={self.y}, z={self.z})")
+
+    def copy(self) -> "Atom":
+        new = Atom.__new__(Atom)
+        for f in Atom.__slots__:
+            setattr(new, f, getattr(self, f))
+        return new
+
+    def _moved(self, x, y, z) -> "Atom":
+        new = self.copy()
+        new.x, new.y, new.z = float(x), float(y), float(z)
+        return new
+
+
+# ---------------------------------------------------------------------------------- Molecule
+
+
+class Molecule:
+    """Atom table of one target structure."""
+
+    def __init__(self, atoms: Iterable[Atom] = (), id: Optional[str] = None):
+        self._atoms: List[Atom] = list(atoms)
+        self.id = id
+        self._enc = None  # (vocabulary version, encoded arrays)
+        self._lock = threading.Lock()
+
+    # -- loading ------------------------------------------------------------
+    @classmethod
+    def loads(cls, text: str, id: Optional[str] = None, ignore_endmdl: bool = False) -> "Molecule":
+        return cls.load(io.StringIO(text), id=id, ignore_endmdl=ignore_endmdl)
+
+    @classmethod
+    def load(cls, file, id: Optional[str] = None, ignore_endmdl: bool = False) -> "Molecule":
+        """Parse ATOM and HETATM records of a PDB file (path or text file object).
+
+        Reading stops at the first ENDMDL unless ``ignore_endmdl`` (jess_run.py:538-540).  Without an
+        explicit ``id`` the HEADER record's idCode is used (tests/test_jess_run.py:34-35, 62).
+        """
+        if hasattr(file, "read"):
+            lines = file.read().splitlines()
+        else:
+            with open(os.fspath(file)) as handle:
+                lines = handle.read().splitlines()
+        atoms = []
+        header_id = None
+        for line in lines:
+            rec = line[:6]
+            if rec in ("ATOM  ", "HETATM"):
+                line = line.ljust(80)
+                try:
+                    charge_txt = line[78:80].strip()
+                    charge = 0
+                    if charge_txt and charge_txt[0].isdigit():
+                        charge = int(charge_txt[0]) * (-1 if charge_txt[1:2] == "-" else 1)
+                    occ, bfac = line[54:60].strip(), line[60:66].strip()
+                    atoms.append(Atom(
+                        serial=int(line[6:11]), name=line[12:16].strip(),
+                        altloc=None if line[16] == " " else line[16],
+                        residue_name=line[17:20].strip(), chain_id=line[20:22].strip(),
+                        residue_number=int(line[22:26]), insertion_code=line[26],
+                        x=float(line[30:38]), y=float(line[38:46]), z=float(line[46:54]),
+                        occupancy=float(occ) if occ else 0.0, temperature_factor=float(bfac) if bfac else 0.0,
+                        segment=line[72:76].strip(), element=line[76:78].strip(), charge=charge,
+                        _raw_name=line[12:16].encode("ascii", "replace"),
+                    ))
+                except ValueError as exc:
+                    raise ValueError(f"malformed PDB record: {line.rstrip()!r}") from exc
+            elif rec == "ENDMDL" and not ignore_endmdl:
+                break
+            elif rec == "HEADER" and header_id is None and len(line) >= 66:
+                header_id = line[62:66].strip() or None
+        return cls(atoms, id=id if id is not None else header_id)
+
+    # -- container protocol -------------------------------------------------
+    def __len__(self):
+        return len(self._atoms)
+
+    def __bool__(self):
+        return bool(self._atoms)
+
+    def __iter__(self) -> Iterator[Atom]:
+        return iter(self._atoms)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return Molecule(self._atoms[i], id=self.id)
+        return self._atoms[i]
+
+    def __repr__(self):
+        return f"Molecule(id={self.id!r}, atoms={len(self._atoms)})"
+
+    def conserved(self, cutoff: float = 0.0) -> "Molecule":
+        """New molecule keeping atoms whose temperature factor is >= ``cutoff``."""
+        return Molecule([a for a in self._atoms if a.temperature_factor >= cutoff], id=self.id)
+
+    def copy(self) -> "Molecule":
+        return Molecule([a.copy() for a in self._atoms], id=self.id)
+
+    # -- flattening for the device -------------------------------------------
+    def _encoded(self):
+        """SoA view of the molecule for tm_batch_create, cached per vocabulary version."""
+        with self._lock:
+            if self._enc is not None and self._enc[0] == VOCAB.version:
+                return self._enc[1]
+            n = len(self._atoms)
+            xyz = np.empty((n, 3), dtype=np.float64)
+            raw_name = np.empty(n, dtype="S4")
+            raw_res = np.empty(n, dtype="S3")
+            res_key = {}
+            chain_key = {}
+            residue = np.empty(n, dtype=np.uint32)
+            chain = np.empty(n, dtype=np.uint8)
+            for i, a in enumerate(self._atoms):
+                xyz[i] = (a.x, a.y, a.z)
+                raw_name[i] = a._raw_name
+                raw_res[i] = raw_residue_name(a.residue_name)
+                residue[i] = res_key.setdefault((a.chain_id, a.residue_number, a.insertion_code), len(res_key))
+                chain[i] = chain_key.setdefault(a.chain_id, len(chain_key)) & 0xFF
+            enc = dict(xyz=xyz, res_type=VOCAB.encode_residues(raw_res), name_id=VOCAB.encode_names(raw_name),
+                       residue=residue, chain=chain, n_chains=len(chain_key))
+            self._enc = (VOCAB.version, enc)
+            return enc
+
+
+# ---------------------------------------------------------------------------------- TemplateAtom
+
+
+class TemplateAtom:
+    """One atom line of a Jess template."""
+
+    __slots__ = ("chain_id", "residue_number", "residue_names", "atom_names", "distance_weight", "match_mode",
+                 "x", "y", "z", "_raw_names", "_raw_residues")
+
+    def __init__(self, *, chain_id: str, residue_number: int, x: float, y: float, z: float,
+                 residue_names: Sequence[str], atom_names: Sequence[str], distance_weight: float = 0.0,
+                 match_mode: int = 0):
+        if not atom_names:
+            raise ValueError("a template atom needs at least one atom name")
+        if not residue_names:
+            raise ValueError("a template atom needs at least one residue name")
+        for nm in atom_names:
+            if not 0 < len(nm) <= 4:
+                raise ValueError(f"invalid atom name {nm!r}")
+        for nm in residue_names:
+            if not 0 < len(nm) <= 3:
+                raise ValueError(f"invalid residue name {nm!r}")
+        self.chain_id = chain_id
+        self.residue_number = int(residue_number)
+        self.residue_names = tuple(residue_names)
+        self.atom_names = tuple(atom_names)
+        self.distance_weight = float(distance_weight)
+        self.match_mode = int(match_mode)
+        self.x, self.y, self.z = float(x), float(y), float(z)
+        self._raw_names = tuple(raw_atom_name(n) for n in self.atom_names)
+        self._raw_residues = tuple(raw_residue_name(n) for n in self.residue_names)
+
+    @classmethod
+    def loads(cls, text: str) -> "TemplateAtom":
+        """Parse a template ATOM line (SURVEY.md 8(a6) column layout)."""
+        line = text.rstrip("\r\n")
+        if not line.startswith("ATOM"):
+            raise ValueError(f"not a template ATOM line: {line!r}")
+        if len(line) < 54:
+            raise ValueError(f"template ATOM line too short: {line!r}")
+        line = line.ljust(66)
+        try:
+            mode = int(line[6:11])
+            resnum = int(line[22:26])
+            x, y, z = float(line[30:38]), float(line[38:46]), float(line[46:54])
+            weight_txt = line[60:66].strip()
+            weight = float(weight_txt) if weight_txt else 0.0
+        except ValueError as exc:
+            raise ValueError(f"malformed template ATOM line: {line!r}") from exc
+        name = line[12:16]
+        if not name.strip():
+            raise ValueError(f"template ATOM line without an atom name: {line!r}")
+        residues = [line[17:20].strip()]
+        for letter in line[54:60].strip():
+            if letter not in ONE_LETTER:
+                raise ValueError(f"unknown one-letter residue code {letter!r} in {line!r}")
+            if ONE_LETTER[letter] not in residues:
+                residues.append(ONE_LETTER[letter])
+        atom = cls(chain_id=line[20:22].strip(), residue_number=resnum, x=x, y=y, z=z, residue_names=residues,
+                   atom_names=[name.strip()], distance_weight=weight, match_mode=mode)
+        atom._raw_names = (name.encode("ascii"),)
+        return atom
+
+    def _key(self):
+        return (self.chain_id, self.residue_number, self.residue_names, self.atom_names, self.distance_weight,
+                self.match_mode, self.x, self.y, self.z)
+
+    def __eq__(self, other):
+        return self._key() == other._key() if isinstance(other, TemplateAtom) else NotImplemented
+
+    def __hash__(self):
+        return hash(self._key())
+
+    def __repr__(self):
+        return (f"TemplateAtom(chain_id={self.chain_id!r}, residue_number={self.residue_number}, "
+                f"residue_names={list(self.residue_names)!r}, atom_names={list(self.atom_names)!r}, "
+                f"match_mode={self.match_mode}, x={self.x}, y={self.y}, z={self.z})")
+
+    def copy(self) -> "TemplateAtom":
+        new = TemplateAtom.__new__(TemplateAtom)
+        for f in TemplateAtom.__slots__:
+            setattr(new, f, getattr(self, f))
+        return new
+
+
+# ---------------------------------------------------------------------------------- Template
+
+
+class Template:
+    """A Jess template: an ordered list of ``TemplateAtom``.  Meant to be subclassed
+    (enzymm/template.py:455 adds residues, cluster, EC/CATH ... on top)."""
+
+    def __init__(self, atoms: Iterable[TemplateAtom] = (), id: Optional[str] = None):
+        self._atoms = tuple(atoms)
+        for a in self._atoms:
+            if not isinstance(a, TemplateAtom):
+                raise TypeError(f"expected TemplateAtom, found {type(a).__name__}")
+        self.id = id
+
+    @classmethod
+    def loads(cls, text: str, id: Optional[str] = None) -> "Template":
+        return cls.load(io.StringIO(text), id=id)
+
+    @classmethod
+    def load(cls, file, id: Optional[str] = None) -> "Template":
+        if hasattr(file, "read"):
+            lines = file.read().splitlines()
+        else:
+            with open(os.fspath(file)) as handle:
+                lines = handle.read().splitlines()
+        atoms = [TemplateAtom.loads(l) for l in lines if l.startswith("ATOM")]
+        if id is None:
+            for l in lines:
+                tok = l.split()
+                if len(tok) >= 3 and tok[0] == "REMARK" and tok[1] in ("PDB_ID", "ID"):
+                    id = tok[2]
+                    break
+        return cls(atoms, id=id)
+
+    def __len__(self):
+        return len(self._atoms)
+
+    def __iter__(self):
+        return iter(self._atoms)
+
+    def __getitem__(self, i):
+        return self._atoms[i]
+
+    def __eq__(self, other):
+        if isinstance(other, Template):
+            return self.id == other.id and self._atoms == other._atoms
+        return NotImplemented
+
+    def __hash__(self):
+        return hash((self.id, self._atoms))
+
+    def copy(self) -> "Template":
+        return Template(self._atoms, id=self.id)
+
+    @property
+    def dimension(self) -> int:
+        """Number of template residues (distinct chain + residue number)."""
+        return len({(a.chain_id, a.residue_number) for a in self._atoms})
+
+
+# ---------------------------------------------------------------------------------- packing
+
+
+class _PackedLibrary:
+    """Host tables + device handle of a list of templates (what ``Jess(templates)`` builds)."""
+
+    def __init__(self, templates: Sequence[Template], device: int):
+        for t in templates:
+            if len(t._atoms) == 0:
+                raise ValueError("cannot search an empty template")
+            for a in t._atoms:
+                VOCAB.register_template_atom(a.match_mode, a._raw_names, a._raw_residues)
+        self.vocab_version = VOCAB.version
+        n_atoms = sum(len(t._atoms) for t in templates)
+        self.offsets = np.zeros(len(templates) + 1, dtype=np.uint32)
+        xyz = np.empty((n_atoms, 3), dtype=np.float64)
+        weight = np.empty(n_atoms, dtype=np.float64)
+        res_mask = np.empty(n_atoms, dtype=np.uint32)
+        name_mask = np.empty(n_atoms, dtype=np.uint64)
+        any_res = np.empty(n_atoms, dtype=np.uint8)
+        group = np.empty(n_atoms, dtype=np.uint8)
+        chain = np.empty(n_atoms, dtype=np.uint8)
+        mask_cache = {}
+        i = 0
+        for ti, t in enumerate(templates):
+            groups, chains = {}, {}
+            for a in t._atoms:
+                key = (a.match_mode, a._raw_names, a._raw_residues)
+                masks = mask_cache.get(key)
+                if masks is None:
+                    masks = mask_cache[key] = (VOCAB.res_mask(a.match_mode, a._raw_residues),
+                                               VOCAB.name_mask(a.match_mode, a._raw_names))
+                xyz[i] = (a.x, a.y, a.z)
+                weight[i] = a.distance_weight
+                res_mask[i], name_mask[i] = masks
+                any_res[i] = 1 if a.match_mode >= 100 else 0
+                group[i] = groups.setdefault((a.chain_id, a.residue_number), len(groups))
+                chain[i] = chains.setdefault(a.chain_id, len(chains))
+                i += 1
+            self.offsets[ti + 1] = i
+        self.native = _native.Library(device, self.offsets, xyz, weight, res_mask, name_mask, any_res, group, chain)
+        self.device = device
+
+
+_pack_lock = threading.Lock()
+_pack_cache: "collections.OrderedDict[tuple, tuple]" = collections.OrderedDict()
+_PACK_CACHE_SIZE = 32
+
+
+def _packed(templates: Sequence[Template], device: int) -> _PackedLibrary:
+    """enzymm rebuilds ``Jess(templates)`` for every (molecule, size) call (jess_run.py:800);
+    the device copy of a template list is therefore cached by identity of its members."""
+    key = (device, tuple(id(t) for t in templates))
+    with _pack_lock:
+        hit = _pack_cache.get(key)
+        if hit is not None and hit[1].vocab_version == VOCAB.version:
+            _pack_cache.move_to_end(key)
+            return hit[1]
+        packed = _PackedLibrary(templates, device)
+        _pack_cache[key] = (tuple(templates), packed)  # keeps the templates alive: ids stay unique
+        while len(_pack_cache) > _PACK_CACHE_SIZE:
+            _pack_cache.popitem(last=False)
+        return packed
+
+
+def make_batch(molecules: Sequence[Molecule], device: int) -> "_native.Batch":
+    """Flatten molecules into one device-resident batch (``tm_batch_create``)."""
+    enc = [m._encoded() for m in molecules]
+    offsets = np.zeros(len(enc) + 1, dtype=np.uint32)
+    for i, e in enumerate(enc):
+        offsets[i + 1] = offsets[i] + len(e["residue"])
+    cat = lambda k, dt: (np.concatenate([e[k] for e in enc]) if enc else np.zeros(0, dtype=dt)).astype(dt, copy=False)
+    return _native.Batch(device, offsets, cat("xyz", np.float64).reshape(-1, 3), cat("res_type", np.uint8),
+                         cat("name_id", np.uint8), cat("residue", np.uint32), cat("chain", np.uint8))
+
+
+# ---------------------------------------------------------------------------------- Hit / Query / Jess
+
+
+class Hit:
+    """Best superposition of one template on one molecule."""
+
+    __slots__ = ("template", "_molecule", "rmsd", "_rot", "_trans", "_atom_index", "n_candidates", "truncated")
+
+    def __init__(self, template, molecule, rmsd, rot, trans, atom_index, n_candidates=0, truncated=False):
+        self.template = template
+        self._molecule = molecule
+        self.rmsd = float(rmsd)
+        self._rot = np.asarray(rot, dtype=np.float64).reshape(3, 3)
+        self._trans = np.asarray(trans, dtype=np.float64).reshape(3)
+        self._atom_index = tuple(int(i) for i in atom_index)
+        self.n_candidates = int(n_candidates)
+        self.truncated = bool(truncated)
+
+    @property
+    def determinant(self) -> float:
+        return float(np.linalg.det(self._rot))
+
+    @property
+    def log_evalue(self) -> float:
+        """Jess's log E-value model lives in the absent pyjess/Jess C source and is pinned by only two
+        known answers (tests/test_jess_run.py:78, 134); it is reported as NaN rather than invented."""
+        return math.nan
+
+    @property
+    def evalue(self) -> float:
+        return math.nan
+
+    def _transform(self, atom: Atom) -> Atom:
+        r, t = self._rot, self._trans
+        x, y, z = atom.x, atom.y, atom.z
+        return atom._moved(r[0, 0] * x + r[0, 1] * y + r[0, 2] * z + t[0],
+                           r[1, 0] * x + r[1, 1] * y + r[1, 2] * z + t[1],
+                           r[2, 0] * x + r[2, 1] * y + r[2, 2] * z + t[2])
+
+    def atoms(self, transform: bool = False) -> List[Atom]:
+        """Matched target atoms in template-atom order; ``transform`` maps them into the template frame."""
+        picked = [self._molecule._atoms[i] for i in self._atom_index]
+        return [self._transform(a) for a in picked] if transform else [a.copy() for a in picked]
+
+    def molecule(self, transform: bool = False) -> Molecule:
+        if not transform:
+            return self._molecule
+        return Molecule([self._transform(a) for a in self._molecule._atoms], id=self._molecule.id)
+
+    def __repr__(self):
+        return f"Hit(template={getattr(self.template, 'id', None)!r}, rmsd={self.rmsd:.4f})"
+
+
+class Query(collections.abc.Iterator):
+    """Iterator over the hits of one ``Jess.query`` call, in template order."""
+
+    def __init__(self, jess, molecule, rmsd_threshold, distance_cutoff, max_dynamic_distance, max_candidates,
+                 ignore_chain, best_match, hits):
+        self.jess = jess
+        self.molecule = molecule
+        self.rmsd_threshold = rmsd_threshold
+        self.distance_cutoff = distance_cutoff
+        self.max_dynamic_distance = max_dynamic_distance
+        self.max_candidates = max_candidates
+        self.ignore_chain = ignore_chain
+        self.best_match = best_match
+        self._hits = iter(hits)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self) -> Hit:
+        return next(self._hits)
+
+
+class Jess:
+    """A set of templates to search structures with (device-resident once constructed)."""
+
+    def __init__(self, templates: Iterable[Template] = (), device: Optional[int] = None):
+        self._templates = tuple(templates)
+        for t in self._templates:
+            if not isinstance(t, Template):
+                raise TypeError(f"expected Template, found {type(t).__name__}")
+        self._device = default_device() if device is None else int(device)
+
+    def __len__(self):
+        return len(self._templates)
+
+    def __iter__(self):
+        return iter(self._templates)
+
+    def __getitem__(self, i):
+        return self._templates[i]
+
+    # -- batched entry point (what enzymm_amd.jess_run.Matcher uses) ---------
+    def query_batch(self, molecules: Sequence[Molecule], rmsd_threshold, distance_cutoff, max_dynamic_distance, *,
+                    max_candidates: Optional[int] = None, ignore_chain: bool = False, best_match: bool = True,
+                    template_index=None, batch=None, count_candidates: bool = False, return_raw: bool = False):
+        """Search every molecule with every (selected) template in one launch.
+
+        The three thresholds are scalars or arrays with one entry per selected template, so all of
+        enzymm's size buckets (jess_run.py:564-571) go through a single call.  Returns
+        ``[[Hit, ...] per molecule]`` in template order, or the raw structured hit table.
+        """
+        if not best_match:
+            raise NotImplementedError("enzymm_amd implements best_match=True queries only "
+                                      "(the only mode enzymm uses: jess_run.py:809)")
+        molecules = list(molecules)
+        for m in molecules:
+            if not isinstance(m, Molecule):
+                raise TypeError(f"expected Molecule, found {type(m).__name__}")
+        sel = np.arange(len(self._templates), dtype=np.uint32) if template_index is None \
+            else np.ascontiguousarray(template_index, dtype=np.uint32)
+        if not len(self._templates) or not len(sel) or not molecules:
+            return np.zeros(0, dtype=_native.HIT_DTYPE) if return_raw else [[] for _ in molecules]
+        packed = _packed(self._templates, self._device)
+        own_batch = batch is None
+        if own_batch:
+            batch = make_batch(molecules, self._device)
+        flags = _native.TM_FLAG_BEST_MATCH
+        if ignore_chain:
+            flags |= _native.TM_FLAG_IGNORE_CHAIN
+        if count_candidates:
+            flags |= _native.TM_FLAG_COUNT_CANDIDATES
+        cap = _UNLIMITED if max_candidates is None else max(0, min(int(max_candidates), _UNLIMITED))
+        res = _native.query(packed.native, batch, sel, rmsd_threshold, distance_cutoff, max_dynamic_distance, cap,
+                            flags)
+        try:
+            table = res.hits()
+            cands = res.candidates() if count_candidates else None
+        finally:
+            res.close()
+            if own_batch:
+                batch.close()
+        if return_raw:
+            return (table, cands) if count_candidates else table
+        out: List[List[Hit]] = [[] for _ in molecules]
+        for h in table:
+            tpl = self._templates[int(sel[h["template_sel"]])]
+            k = int(h["n_atoms"])
+            out[int(h["structure"])].append(
+                Hit(tpl, molecules[int(h["structure"])], h["rmsd"], h["rot"], h["trans"], h["atoms"][:k],
+                    h["n_candidates"], bool(h["flags"] & _native.TM_HIT_TRUNCATED)))
+        return out
+
+    # -- the pyjess call enzymm makes ----------------------------------------
+    def query(self, molecule: Molecule, rmsd_threshold: float, distance_cutoff: float,
+              max_dynamic_distance: float, *, max_candidates: Optional[int] = None, ignore_chain: bool = False,
+              best_match: bool = False) -> Query:
+        hits = self.query_batch([molecule], rmsd_threshold, distance_cutoff, max_dynamic_distance,
+                                max_candidates=max_candidates, ignore_chain=ignore_chain, best_match=best_match)
+        return Query(self, molecule, rmsd_threshold, distance_cutoff, max_dynamic_distance, max_candidates,
+                     ignore_chain, best_match, hits[0])

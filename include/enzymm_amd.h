@@ -1,0 +1,145 @@
+/*
+ * enzymm_amd.h -- C ABI of libenzymm_amd.so, the MI355X (gfx950) template matcher
+ * that replaces the PyJess call inside enzymm/jess_run.py.
+ *
+ * Plain pointers and sizes only; no C++/torch types cross this boundary.  All
+ * functions return TM_OK (0) or a negative TM_E_* code; none throws.
+ *
+ * What each entry point replaces in the reference (/root/reference):
+ *
+ *   tm_library_create   pyjess.Jess(templates)               enzymm/jess_run.py:800-802
+ *                       (+ pyjess.Template/TemplateAtom      enzymm/template.py:535, 679)
+ *   tm_batch_create     the atom table pyjess.Molecule.load  enzymm/jess_run.py:538-540
+ *                       yields, flattened for many molecules
+ *   tm_query            Jess.query(molecule, rmsd_threshold, enzymm/jess_run.py:803-811,
+ *                       distance_cutoff, max_dynamic_        tests/test_jess_run.py:37-39
+ *                       distance, max_candidates,
+ *                       best_match, ignore_chain)
+ *   tm_result_*         iteration over the pyjess.Hit        enzymm/jess_run.py:839-843
+ *                       objects (rmsd, atoms, transform)     enzymm/jess_run.py:348-373
+ *
+ * The library is semantics-free with respect to Jess "match modes": the host
+ * (enzymm_amd/pyjess.py) turns each template atom's match_mode / atom names /
+ * residue names into two bit masks over small integer vocabularies, and encodes
+ * every target atom with the ids of its residue name and atom name.
+ *
+ * Threading: handles are not internally locked; use one tm_batch per thread.
+ * A tm_library is immutable after creation and may be shared.
+ */
+#ifndef ENZYMM_AMD_H
+#define ENZYMM_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TM_ABI_VERSION 1
+
+/* limits of this build */
+#define TM_MAX_TEMPLATE_ATOMS 24   /* 8 residues x 3 atoms: enzymm's largest size bucket (jess_run.py:564-571) */
+#define TM_MAX_TEMPLATE_GROUPS 8   /* template residues */
+#define TM_MAX_STRUCTURE_ATOMS 65535
+#define TM_RES_OTHER 31            /* residue-type id of "not in the vocabulary" */
+#define TM_NAME_OTHER 63           /* atom-name id of "not in the vocabulary" */
+
+enum {
+    TM_OK = 0,
+    TM_E_INVALID = -1,     /* bad argument */
+    TM_E_UNSUPPORTED = -2, /* over a TM_MAX_* limit or an unimplemented flag combination */
+    TM_E_DEVICE = -3,      /* HIP runtime error (tm_last_error() has the text) */
+    TM_E_NOMEM = -4,
+    TM_E_OVERFLOW = -5     /* hit table too small: retry with a larger hit_capacity */
+};
+
+enum {
+    TM_FLAG_IGNORE_CHAIN = 1u,     /* Jess.query(ignore_chain=True), jess_run.py:810 */
+    TM_FLAG_BEST_MATCH = 2u,       /* Jess.query(best_match=True), jess_run.py:809 (required in ABI v1) */
+    TM_FLAG_COUNT_CANDIDATES = 4u, /* also record the candidate count of every (structure, template) pair */
+    TM_FLAG_REBUILD_INDEX = 8u     /* recompute the per-structure candidate index even if cached */
+};
+
+/* bits of tm_hit.flags */
+enum {
+    TM_HIT_TRUNCATED = 1u /* more than max_candidates complete assignments exist; search was cut short */
+};
+
+typedef struct tm_library tm_library;
+typedef struct tm_batch tm_batch;
+typedef struct tm_result tm_result;
+
+/* Templates, concatenated; every per-atom array is in TEMPLATE (file) order. */
+typedef struct tm_library_desc {
+    uint32_t n_templates;
+    const uint32_t *atom_offsets; /* [n_templates + 1] */
+    const double *xyz;            /* [n_atoms * 3] template coordinates */
+    const double *dist_weight;    /* [n_atoms] cols 61-66 of the template ATOM line */
+    const uint32_t *res_mask;     /* [n_atoms] bit r: residue-type id r admissible */
+    const uint64_t *name_mask;    /* [n_atoms] bit a: atom-name id a admissible */
+    const uint8_t *any_residue;   /* [n_atoms] 1: residue type not checked (match_mode >= 100) */
+    const uint8_t *group;         /* [n_atoms] template residue ordinal (atoms sharing chain + resSeq) */
+    const uint8_t *chain;         /* [n_atoms] template chain ordinal */
+} tm_library_desc;
+
+/* Target structures, concatenated; atoms in file order. */
+typedef struct tm_batch_desc {
+    uint32_t n_structures;
+    const uint32_t *atom_offsets; /* [n_structures + 1] */
+    const double *xyz;            /* [n_atoms * 3] */
+    const uint8_t *res_type;      /* [n_atoms] residue-type id, TM_RES_OTHER if unknown */
+    const uint8_t *name_id;       /* [n_atoms] atom-name id, TM_NAME_OTHER if unknown */
+    const uint32_t *residue;      /* [n_atoms] residue ordinal within its structure: equal (chain, resSeq, iCode) <=> equal ordinal */
+    const uint8_t *chain;         /* [n_atoms] chain ordinal within its structure */
+} tm_batch_desc;
+
+typedef struct tm_query_params {
+    uint32_t n_selected;                /* templates to search */
+    const uint32_t *template_index;     /* [n_selected] indices into the library */
+    const double *rmsd_threshold;       /* [n_selected] */
+    const double *distance_cutoff;      /* [n_selected] */
+    const double *max_dynamic_distance; /* [n_selected] */
+    uint32_t max_candidates;            /* per (structure, template) */
+    uint32_t flags;                     /* TM_FLAG_* */
+    uint64_t hit_capacity;              /* 0: choose automatically */
+    void *stream;                       /* hipStream_t to launch on, NULL = default stream */
+} tm_query_params;
+
+/* One best hit of a (structure, template) pair. */
+typedef struct tm_hit {
+    uint32_t structure;    /* index into the batch */
+    uint32_t template_sel; /* index into tm_query_params.template_index */
+    uint32_t n_candidates; /* complete assignments evaluated for this pair */
+    uint32_t flags;        /* TM_HIT_* */
+    double rmsd;
+    double rot[9];   /* row-major R: x_template = R * x_target + trans */
+    double trans[3];
+    uint32_t n_atoms;
+    uint32_t atoms[TM_MAX_TEMPLATE_ATOMS]; /* target atom (file-order index within its structure) per template atom */
+    uint32_t reserved;
+} tm_hit;
+
+int tm_abi_version(void);
+const char *tm_last_error(void);
+int tm_device_count(int *count);
+
+int tm_library_create(int device, const tm_library_desc *desc, tm_library **out);
+void tm_library_destroy(tm_library *lib);
+
+int tm_batch_create(int device, const tm_batch_desc *desc, tm_batch **out);
+void tm_batch_destroy(tm_batch *batch);
+
+/* Asynchronous on params->stream; the result owns the device-side hit table. */
+int tm_query(const tm_library *lib, tm_batch *batch, const tm_query_params *params, tm_result **out);
+int tm_result_wait(tm_result *res);                          /* blocks; TM_E_OVERFLOW if the table filled up */
+int tm_result_hit_count(tm_result *res, uint64_t *n_hits);   /* implies wait */
+int tm_result_copy_hits(tm_result *res, tm_hit *out, uint64_t capacity); /* sorted by (structure, template_sel) */
+int tm_result_copy_candidates(tm_result *res, uint32_t *out, uint64_t n); /* [n_structures * n_selected], needs TM_FLAG_COUNT_CANDIDATES */
+int tm_result_timing(tm_result *res, float *index_ms, float *search_ms); /* HIP-event durations of the two device phases */
+const void *tm_result_device_hits(tm_result *res);           /* device pointer to the unsorted tm_hit table */
+void tm_result_destroy(tm_result *res);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ENZYMM_AMD_H */
