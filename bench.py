@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Headline benchmark: structures/s against the full shipped M-CSA template library.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2]): per GPU a batch of 1000 seeded synthetic
+~300-residue structures (enzymm_amd/synthetic.py), each matched against the 6780 default-eligible
+templates of jess_templates_20230210 (effective size >= 3) in their six size buckets with enzymm's
+default parameters (jess_run.py:564-571), best_match=True, ignore_chain=True,
+max_candidates=10000 (jess_run.py:803-811).  One step = one full pass over the resident batch:
+candidate-index build + pair bounds + search kernel (+ the RCCL gather of the hit tables to rank 0
+when N > 1).  Inputs are uploaded to HBM before the timed region.
+
+For N > 1 the driver launches this file under torch.distributed.run, one rank per GPU; ranks
+shard the structures (weak scaling: 1000 structures per GPU), there is no data-path collective
+other than the final hit-table gather.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+DEFAULT_DISTANCE = {3: 0.9, 4: 1.7, 5: 2.0, 6: 2.0, 7: 2.0, 8: 2.0}  # jess_run.py:564-571
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8 TB/s
+
+
+def load_library():
+    """Shipped templates as enzymm_amd Templates + the default selection (index, cutoff)."""
+    from enzymm_amd import template as tmod
+
+    templates = tmod.load_packed_library()
+    eff = np.array([t.effective_size for t in templates])
+    idx = np.nonzero(eff >= 3)[0].astype(np.uint32)
+    cut = np.array([DEFAULT_DISTANCE[min(int(e), 8)] for e in eff[idx]], dtype=np.float64)
+    return templates, idx, cut
+
+
+def cpu_baseline(molecules, idx, cut, target_seconds):
+    """Oracle (CPU restatement, NOT PyJess) timed on this host's cores, bounded sample."""
+    from enzymm_amd import synthetic
+    from oracle import oracle, parse
+
+    texts = parse.read_packed_library(ROOT / "enzymm_amd" / "data" / "jess_templates_20230210.txt.gz")
+    otpl = [parse.parse_template(t) for _, t in texts]
+    olib = oracle.OracleLibrary([otpl[i] for i in idx])
+    cores = len(os.sched_getaffinity(0))
+    done, results = 0, []
+    t0 = time.perf_counter()
+    while done < len(molecules):
+        om = parse.parse_molecule(synthetic.to_pdb(molecules[done]))
+        results.append(oracle.query_library(om, olib, 2.0, cut, cut, max_candidates=10000, ignore_chain=True,
+                                            threads=cores))
+        done += 1
+        if time.perf_counter() - t0 > target_seconds:
+            break
+    dt = time.perf_counter() - t0
+    return dict(value=done / dt, unit="structures/s", cores=cores, kind="port",
+                sample=f"first {done} structures of the bench batch vs the same 6780 templates, "
+                       f"oracle/jess_oracle.c with OpenMP over templates ({dt:.1f} s)"), results
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--structures", type=int, default=1000, help="synthetic structures per GPU")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    os.environ["ENZYMM_AMD_DEVICE"] = str(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from enzymm_amd import _native, distributed, pyjess, synthetic
+
+    templates, idx, cut = load_library()
+    jess = pyjess.Jess(templates, device=local_rank)
+    packed = pyjess._packed(jess._templates, local_rank)
+
+    # this rank's shard of the synthetic proteome (weak scaling: fixed work per GPU)
+    lo, hi = distributed.shard_range(args.structures * world, rank, world)
+    molecules = synthetic.structures(hi - lo, start=lo)
+    n_atoms = sum(len(m) for m in molecules)
+    batch = pyjess.make_batch(molecules, local_rank)  # upload: outside the timed region
+    stream = torch.cuda.current_stream().cuda_stream
+    flags = _native.TM_FLAG_BEST_MATCH | _native.TM_FLAG_IGNORE_CHAIN | _native.TM_FLAG_REBUILD_INDEX
+    capacity = max(4096, 64 * len(molecules))
+
+    search_ms, index_ms, hit_total = [], [], 0
+    last_hits = None
+
+    def step(record):
+        nonlocal hit_total, last_hits
+        res = _native.query(packed.native, batch, idx, 2.0, cut, cut, 10000, flags, hit_capacity=capacity,
+                            stream=stream)
+        n = res.hit_count()  # waits for the kernels on `stream`
+        table = distributed.gather_hit_table(res, n, lo, world, rank, local_rank)
+        if record:
+            a, b = res.timing()
+            index_ms.append(a)
+            search_ms.append(b)
+            hit_total = n
+            last_hits = table
+        res.close()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        total_structs = args.structures * world
+        ms_per_step = 1e3 * elapsed / args.steps
+        # algorithmic HBM bytes of ONE search launch on this rank (DESIGN.md "Measurement"):
+        # 16 B per target atom + 224 B per hit + the template library read once per batch
+        lib_atoms = int(packed.offsets[-1])
+        lib_bytes = lib_atoms * (24 + 8 + 2 + 3) + len(idx) * 276 * 8
+        algo_bytes = n_atoms * 16 + hit_total * 224 + lib_bytes
+        k_ms = float(np.mean(search_ms))
+        achieved = algo_bytes / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "structures_per_sec_vs_full_mcsa_library",
+            "value": total_structs / (elapsed / args.steps),
+            "unit": "structures/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 prefilter + f64 re-check/superposition", "data": "synthetic",
+            "config": {
+                "workload": "batch of 1000 synthetic ~300-residue structures per GPU vs the 6780 default-eligible "
+                            "templates of jess_templates_20230210 (BASELINE.json configs[2])",
+                "structures_per_gpu": args.structures, "templates": int(len(idx)),
+                "atoms_per_structure": n_atoms / max(1, len(molecules)),
+                "parallelism": f"structures sharded over {world} GPU(s), hit-table gather to rank 0",
+                "hits_rank0": int(hit_total), "index_ms": float(np.mean(index_ms)), "search_ms": k_ms,
+            },
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_search",
+                         "algorithmic_bytes_per_launch": algo_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            base, oracle_results = cpu_baseline(molecules, idx, cut, args.cpu_baseline_seconds)
+            out["cpu_baseline"] = base
+            # the sample doubles as a parity check of the timed GPU output
+            mism = 0
+            for s, r in enumerate(oracle_results):
+                mine = {int(h["template_sel"]): h for h in last_hits if int(h["structure"]) == s}
+                theirs = set(np.nonzero(r["hit"])[0].tolist())
+                mism += len(theirs ^ set(mine))
+                for ti in theirs & set(mine):
+                    k = int(mine[ti]["n_atoms"])
+                    if not np.array_equal(mine[ti]["atoms"][:k], r["atoms"][ti][:k]) or \
+                            abs(mine[ti]["rmsd"] - r["rmsd"][ti]) > 1e-5:
+                        mism += 1
+            out["parity_sample"] = {"structures": len(oracle_results), "mismatches": mism}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

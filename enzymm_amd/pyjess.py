@@ -114,14 +114,69 @@ class Atom:
 # ---------------------------------------------------------------------------------- Molecule
 
 
+_MOL_COLUMNS = (
+    ("serial", "<i4"), ("name", "S4"), ("altloc", "S1"), ("residue_name", "S3"), ("chain_id", "S2"),
+    ("residue_number", "<i4"), ("insertion_code", "S1"), ("occupancy", "<f8"), ("temperature_factor", "<f8"),
+    ("segment", "S4"), ("element", "S2"), ("charge", "i1"),
+)
+
+
 class Molecule:
-    """Atom table of one target structure."""
+    """Atom table of one target structure.
+
+    Stored column-wise (numpy) so thousands of molecules flatten into a device batch without
+    touching Python objects; ``Atom`` objects are materialised lazily on iteration.
+    """
 
     def __init__(self, atoms: Iterable[Atom] = (), id: Optional[str] = None):
-        self._atoms: List[Atom] = list(atoms)
+        atoms = list(atoms)
+        n = len(atoms)
+        cols = {k: np.zeros(n, dtype=dt) for k, dt in _MOL_COLUMNS}
+        xyz = np.zeros((n, 3), dtype=np.float64)
+        for i, a in enumerate(atoms):
+            if not isinstance(a, Atom):
+                raise TypeError(f"expected Atom, found {type(a).__name__}")
+            cols["serial"][i] = a.serial
+            cols["name"][i] = a._raw_name
+            cols["altloc"][i] = (a.altloc or " ").encode()
+            cols["residue_name"][i] = raw_residue_name(a.residue_name)
+            cols["chain_id"][i] = a.chain_id.rjust(2).encode()
+            cols["residue_number"][i] = a.residue_number
+            cols["insertion_code"][i] = (a.insertion_code or " ").encode()
+            cols["occupancy"][i] = a.occupancy
+            cols["temperature_factor"][i] = a.temperature_factor
+            cols["segment"][i] = a.segment.encode()
+            cols["element"][i] = a.element.encode()
+            cols["charge"][i] = a.charge
+            xyz[i] = (a.x, a.y, a.z)
+        self._init_columns(cols, xyz, id)
+        self._atoms = [a.copy() for a in atoms]
+
+    def _init_columns(self, cols, xyz, id):
+        self._cols = cols
+        self._xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
         self.id = id
+        self._atoms = None
         self._enc = None  # (vocabulary version, encoded arrays)
         self._lock = threading.Lock()
+
+    @classmethod
+    def from_columns(cls, id: Optional[str] = None, *, xyz, name, residue_name, chain_id, residue_number, **other):
+        """Build from arrays: ``name`` raw 4-char PDB fields (``S4``), ``residue_name`` (``S3``),
+        ``chain_id`` (``S2``, right-justified) and any other column of the table."""
+        n = len(residue_number)
+        cols = {k: np.zeros(n, dtype=dt) for k, dt in _MOL_COLUMNS}
+        cols["altloc"][:] = b" "
+        cols["insertion_code"][:] = b" "
+        cols["serial"][:] = np.arange(1, n + 1)
+        given = dict(name=name, residue_name=residue_name, chain_id=chain_id, residue_number=residue_number, **other)
+        for k, v in given.items():
+            if k not in cols:
+                raise TypeError(f"unknown column {k!r}")
+            cols[k][:] = v
+        mol = cls.__new__(cls)
+        mol._init_columns(cols, xyz, id)
+        return mol
 
     # -- loading ------------------------------------------------------------
     @classmethod
@@ -140,60 +195,92 @@ class Molecule:
         else:
             with open(os.fspath(file)) as handle:
                 lines = handle.read().splitlines()
-        atoms = []
+        rows = []
         header_id = None
         for line in lines:
             rec = line[:6]
             if rec in ("ATOM  ", "HETATM"):
-                line = line.ljust(80)
-                try:
-                    charge_txt = line[78:80].strip()
-                    charge = 0
-                    if charge_txt and charge_txt[0].isdigit():
-                        charge = int(charge_txt[0]) * (-1 if charge_txt[1:2] == "-" else 1)
-                    occ, bfac = line[54:60].strip(), line[60:66].strip()
-                    atoms.append(Atom(
-                        serial=int(line[6:11]), name=line[12:16].strip(),
-                        altloc=None if line[16] == " " else line[16],
-                        residue_name=line[17:20].strip(), chain_id=line[20:22].strip(),
-                        residue_number=int(line[22:26]), insertion_code=line[26],
-                        x=float(line[30:38]), y=float(line[38:46]), z=float(line[46:54]),
-                        occupancy=float(occ) if occ else 0.0, temperature_factor=float(bfac) if bfac else 0.0,
-                        segment=line[72:76].strip(), element=line[76:78].strip(), charge=charge,
-                        _raw_name=line[12:16].encode("ascii", "replace"),
-                    ))
-                except ValueError as exc:
-                    raise ValueError(f"malformed PDB record: {line.rstrip()!r}") from exc
+                rows.append(line.ljust(80))
             elif rec == "ENDMDL" and not ignore_endmdl:
                 break
             elif rec == "HEADER" and header_id is None and len(line) >= 66:
                 header_id = line[62:66].strip() or None
-        return cls(atoms, id=id if id is not None else header_id)
+        n = len(rows)
+        cols = {k: np.zeros(n, dtype=dt) for k, dt in _MOL_COLUMNS}
+        xyz = np.zeros((n, 3), dtype=np.float64)
+        for i, line in enumerate(rows):
+            try:
+                cols["serial"][i] = int(line[6:11])
+                cols["residue_number"][i] = int(line[22:26])
+                xyz[i] = (float(line[30:38]), float(line[38:46]), float(line[46:54]))
+                occ, bfac = line[54:60].strip(), line[60:66].strip()
+                cols["occupancy"][i] = float(occ) if occ else 0.0
+                cols["temperature_factor"][i] = float(bfac) if bfac else 0.0
+            except ValueError as exc:
+                raise ValueError(f"malformed PDB record: {line.rstrip()!r}") from exc
+            cols["name"][i] = line[12:16].encode("ascii", "replace")
+            cols["altloc"][i] = line[16].encode("ascii", "replace")
+            cols["residue_name"][i] = line[17:20].encode("ascii", "replace")
+            cols["chain_id"][i] = line[20:22].encode("ascii", "replace")
+            cols["insertion_code"][i] = line[26].encode("ascii", "replace")
+            cols["segment"][i] = line[72:76].strip().encode("ascii", "replace")
+            cols["element"][i] = line[76:78].strip().encode("ascii", "replace")
+            chg = line[78:80].strip()
+            if chg and chg[0].isdigit():
+                cols["charge"][i] = int(chg[0]) * (-1 if chg[1:2] == "-" else 1)
+        mol = cls.__new__(cls)
+        mol._init_columns(cols, xyz, id if id is not None else header_id)
+        return mol
 
     # -- container protocol -------------------------------------------------
+    def _atom(self, i: int) -> Atom:
+        c = self._cols
+        altloc = bytes(c["altloc"][i]).decode() or " "
+        return Atom(
+            serial=int(c["serial"][i]), name=bytes(c["name"][i]).decode().strip(),
+            altloc=None if altloc == " " else altloc,
+            residue_name=bytes(c["residue_name"][i]).decode().strip(),
+            chain_id=bytes(c["chain_id"][i]).decode().strip(), residue_number=int(c["residue_number"][i]),
+            insertion_code=bytes(c["insertion_code"][i]).decode() or " ",
+            x=self._xyz[i, 0], y=self._xyz[i, 1], z=self._xyz[i, 2], occupancy=c["occupancy"][i],
+            temperature_factor=c["temperature_factor"][i], segment=bytes(c["segment"][i]).decode(),
+            element=bytes(c["element"][i]).decode(), charge=int(c["charge"][i]),
+            _raw_name=bytes(c["name"][i]).ljust(4),
+        )
+
+    def _atom_list(self) -> List[Atom]:
+        if self._atoms is None:
+            self._atoms = [self._atom(i) for i in range(len(self))]
+        return self._atoms
+
     def __len__(self):
-        return len(self._atoms)
+        return len(self._xyz)
 
     def __bool__(self):
-        return bool(self._atoms)
+        return len(self._xyz) > 0
 
     def __iter__(self) -> Iterator[Atom]:
-        return iter(self._atoms)
+        return iter(self._atom_list())
 
     def __getitem__(self, i):
         if isinstance(i, slice):
-            return Molecule(self._atoms[i], id=self.id)
-        return self._atoms[i]
+            return self._subset(np.arange(len(self))[i])
+        return self._atom_list()[i]
 
     def __repr__(self):
-        return f"Molecule(id={self.id!r}, atoms={len(self._atoms)})"
+        return f"Molecule(id={self.id!r}, atoms={len(self)})"
+
+    def _subset(self, keep) -> "Molecule":
+        mol = Molecule.__new__(Molecule)
+        mol._init_columns({k: v[keep] for k, v in self._cols.items()}, self._xyz[keep], self.id)
+        return mol
 
     def conserved(self, cutoff: float = 0.0) -> "Molecule":
         """New molecule keeping atoms whose temperature factor is >= ``cutoff``."""
-        return Molecule([a for a in self._atoms if a.temperature_factor >= cutoff], id=self.id)
+        return self._subset(self._cols["temperature_factor"] >= cutoff)
 
     def copy(self) -> "Molecule":
-        return Molecule([a.copy() for a in self._atoms], id=self.id)
+        return self._subset(np.arange(len(self)))
 
     # -- flattening for the device -------------------------------------------
     def _encoded(self):
@@ -201,22 +288,17 @@ class Molecule:
         with self._lock:
             if self._enc is not None and self._enc[0] == VOCAB.version:
                 return self._enc[1]
-            n = len(self._atoms)
-            xyz = np.empty((n, 3), dtype=np.float64)
-            raw_name = np.empty(n, dtype="S4")
-            raw_res = np.empty(n, dtype="S3")
-            res_key = {}
-            chain_key = {}
-            residue = np.empty(n, dtype=np.uint32)
-            chain = np.empty(n, dtype=np.uint8)
-            for i, a in enumerate(self._atoms):
-                xyz[i] = (a.x, a.y, a.z)
-                raw_name[i] = a._raw_name
-                raw_res[i] = raw_residue_name(a.residue_name)
-                residue[i] = res_key.setdefault((a.chain_id, a.residue_number, a.insertion_code), len(res_key))
-                chain[i] = chain_key.setdefault(a.chain_id, len(chain_key)) & 0xFF
-            enc = dict(xyz=xyz, res_type=VOCAB.encode_residues(raw_res), name_id=VOCAB.encode_names(raw_name),
-                       residue=residue, chain=chain, n_chains=len(chain_key))
+            c = self._cols
+            n = len(self)
+            chain16 = c["chain_id"].view(np.uint8).reshape(n, 2).astype(np.int64) if n else np.zeros((0, 2), np.int64)
+            icode = c["insertion_code"].view(np.uint8).astype(np.int64) if n else np.zeros(0, np.int64)
+            # one integer per (chain, resSeq, iCode): equal keys <=> same residue
+            key = ((chain16[:, 0] << 8 | chain16[:, 1]) << 40) | ((c["residue_number"].astype(np.int64) + (1 << 24)) << 8) | icode
+            _, residue = np.unique(key, return_inverse=True)
+            _, chain = np.unique(chain16[:, 0] << 8 | chain16[:, 1], return_inverse=True)
+            enc = dict(xyz=self._xyz, res_type=VOCAB.encode_residues(c["residue_name"]),
+                       name_id=VOCAB.encode_names(c["name"]), residue=residue.astype(np.uint32),
+                       chain=(chain & 0xFF).astype(np.uint8))
             self._enc = (VOCAB.version, enc)
             return enc
 
@@ -483,13 +565,16 @@ class Hit:
 
     def atoms(self, transform: bool = False) -> List[Atom]:
         """Matched target atoms in template-atom order; ``transform`` maps them into the template frame."""
-        picked = [self._molecule._atoms[i] for i in self._atom_index]
+        mol_atoms = self._molecule._atom_list()
+        picked = [mol_atoms[i] for i in self._atom_index]
         return [self._transform(a) for a in picked] if transform else [a.copy() for a in picked]
 
     def molecule(self, transform: bool = False) -> Molecule:
         if not transform:
             return self._molecule
-        return Molecule([self._transform(a) for a in self._molecule._atoms], id=self._molecule.id)
+        mol = self._molecule.copy()
+        mol._xyz = self._molecule._xyz @ self._rot.T + self._trans
+        return mol
 
     def __repr__(self):
         return f"Hit(template={getattr(self.template, 'id', None)!r}, rmsd={self.rmsd:.4f})"

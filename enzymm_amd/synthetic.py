@@ -1,0 +1,150 @@
+"""Seeded synthetic query structures for benchmarks and parity tests.
+
+The reference ships no benchmark inputs, so the workload "batch of synthetic
+~300-residue structures" (BASELINE.json configs[2], [3]) is defined here:
+
+* chain length L ~ N(300, 30^2), clipped to [150, 450] residues; structure ``i`` uses seed
+  ``1234 + i``;
+* the chain is assembled from backbone-contiguous fragments (8-20 residues, all heavy atoms) cut
+  from the two structures the reference's own tests use (1AMY and AF-P0DUB6, packed in
+  ``data/residue_pool.npz`` by tests/golden/make_fixtures.py).  Fragments are placed as rigid
+  bodies: local geometry (bond lengths, side-chain conformers, secondary structure) is therefore
+  real, the global fold is new, and the residue composition is that of the two sources;
+* growth is greedy and compact: each fragment tries 48 random poses whose first C-alpha sits 3.8 A
+  from the previous fragment's last C-alpha; the pose with no C-alpha closer than 4 A to the
+  existing chain and the smallest distance to the running centroid wins (radius of gyration comes
+  out near the 2.2 L^0.38 A of globular proteins);
+* coordinates are rounded to 3 decimals (PDB precision), B-factors are U(30, 100), residues are
+  renumbered 1..L on chain A.
+"""
+from __future__ import annotations
+
+import functools
+from pathlib import Path
+from typing import List
+
+import numpy as np
+
+from . import pyjess
+
+_POOL = Path(__file__).resolve().parent / "data" / "residue_pool.npz"
+BASE_SEED = 1234
+TRIALS = 48  # poses tried per fragment
+
+
+@functools.lru_cache(maxsize=1)
+def _pool():
+    z = np.load(_POOL)
+    xyz, name, res, resid, source = z["xyz"], z["name"], z["res"], z["resid"], z["source"]
+    # global residue index over both sources, atom ranges per residue, C-alpha per residue
+    gid = resid.astype(np.int64) + source.astype(np.int64) * (int(resid.max()) + 1)
+    uniq, first, counts = np.unique(gid, return_index=True, return_counts=True)
+    order = np.argsort(first)
+    first, counts, uniq = first[order], counts[order], uniq[order]
+    ca = np.full(len(first), -1, dtype=np.int64)
+    for r, (f, c) in enumerate(zip(first, counts)):
+        hit = np.nonzero(name[f:f + c] == b" CA ")[0]
+        if len(hit):
+            ca[r] = f + hit[0]
+    res_source = source[first]
+    return dict(xyz=xyz, name=name, res=res, first=first, counts=counts, ca=ca, res_source=res_source)
+
+
+def _random_rotations(rng, count: int) -> np.ndarray:
+    q = rng.normal(size=(count, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = np.empty((count, 3, 3))
+    R[:, 0, 0] = 1 - 2 * (y * y + z * z); R[:, 0, 1] = 2 * (x * y - w * z); R[:, 0, 2] = 2 * (x * z + w * y)
+    R[:, 1, 0] = 2 * (x * y + w * z); R[:, 1, 1] = 1 - 2 * (x * x + z * z); R[:, 1, 2] = 2 * (y * z - w * x)
+    R[:, 2, 0] = 2 * (x * z - w * y); R[:, 2, 1] = 2 * (y * z + w * x); R[:, 2, 2] = 1 - 2 * (x * x + y * y)
+    return R
+
+
+def structure_columns(index: int, mean_residues: float = 300.0, sd_residues: float = 30.0,
+                      min_residues: int = 150, max_residues: int = 450):
+    """Columns (xyz, name, residue_name, residue_number, temperature_factor) of synthetic structure ``index``."""
+    P = _pool()
+    rng = np.random.default_rng(BASE_SEED + int(index))
+    length = int(np.clip(round(rng.normal(mean_residues, sd_residues)), min_residues, max_residues))
+    n_pool = len(P["first"])
+    xyz_parts, name_parts, res_parts, resnum_parts = [], [], [], []
+    ca_all = np.zeros((0, 3))
+    last_ca = None
+    built = 0
+    while built < length:
+        flen = int(min(rng.integers(8, 21), length - built))
+        # a fragment must stay inside one source and have all its C-alphas
+        for _ in range(100):
+            start = int(rng.integers(0, n_pool - flen))
+            rs = np.arange(start, start + flen)
+            if P["res_source"][rs[0]] == P["res_source"][rs[-1]] and (P["ca"][rs] >= 0).all():
+                break
+        a0, a1 = P["first"][rs[0]], P["first"][rs[-1]] + P["counts"][rs[-1]]
+        frag = P["xyz"][a0:a1]
+        frag_ca = P["xyz"][P["ca"][rs]]
+        # all trial poses at once: rotated C-alphas [T, flen, 3]
+        Rs = _random_rotations(rng, TRIALS)
+        ca_rot = np.einsum("tij,fj->tfi", Rs, frag_ca)
+        if last_ca is None:
+            shifts = -ca_rot[:, 0, :]
+        else:
+            d = rng.normal(size=(TRIALS, 3))
+            d *= 3.8 / np.linalg.norm(d, axis=1, keepdims=True)
+            shifts = last_ca + d - ca_rot[:, 0, :]
+        ca_new_all = ca_rot + shifts[:, None, :]
+        if len(ca_all):
+            d2 = np.zeros(ca_new_all.shape[:2] + (len(ca_all),))
+            for axis in range(3):  # elementwise only: bit-reproducible on any host
+                diff = ca_new_all[:, :, None, axis] - ca_all[None, None, :, axis]
+                diff *= diff
+                d2 += diff
+            clashes = (d2 < 16.0).sum(axis=(1, 2))
+            spread = np.linalg.norm(ca_new_all - ca_all.mean(0), axis=2).mean(axis=1)
+            pick = int(np.argmin(1000.0 * clashes + spread))
+        else:
+            pick = 0
+        R, shift, ca_new = Rs[pick], shifts[pick], ca_new_all[pick]
+        xyz_parts.append(frag @ R.T + shift)
+        name_parts.append(P["name"][a0:a1])
+        res_parts.append(P["res"][a0:a1])
+        local = np.repeat(np.arange(flen), P["counts"][rs])
+        resnum_parts.append(built + 1 + local)
+        ca_all = np.vstack([ca_all, ca_new])
+        last_ca = ca_new[-1]
+        built += flen
+    xyz = np.round(np.concatenate(xyz_parts), 3)
+    name = np.concatenate(name_parts)
+    res = np.concatenate(res_parts)
+    resnum = np.concatenate(resnum_parts).astype(np.int32)
+    bfac = np.round(rng.uniform(30.0, 100.0, size=len(resnum)), 2)
+    return dict(xyz=xyz, name=name, residue_name=res, residue_number=resnum, temperature_factor=bfac)
+
+
+def structure(index: int, **kw) -> pyjess.Molecule:
+    c = structure_columns(index, **kw)
+    n = len(c["residue_number"])
+    element = np.array([nm[1:2] for nm in c["name"]], dtype="S2")
+    return pyjess.Molecule.from_columns(
+        id=f"synthetic_{index:06d}", xyz=c["xyz"], name=c["name"], residue_name=c["residue_name"],
+        chain_id=np.full(n, b" A", dtype="S2"), residue_number=c["residue_number"],
+        temperature_factor=c["temperature_factor"], occupancy=np.ones(n), element=element)
+
+
+def structures(count: int, start: int = 0, **kw) -> List[pyjess.Molecule]:
+    return [structure(start + i, **kw) for i in range(count)]
+
+
+def to_pdb(mol: pyjess.Molecule) -> str:
+    """PDB text of a molecule (used to hand identical input to the oracle's own parser)."""
+    out = []
+    c = mol._cols
+    for i in range(len(mol)):
+        out.append("ATOM  %5d %4s%1s%3s%2s%4d%1s   %8.3f%8.3f%8.3f%6.2f%6.2f      %-4s%2s  " % (
+            c["serial"][i] % 100000, bytes(c["name"][i]).decode().ljust(4), bytes(c["altloc"][i]).decode() or " ",
+            bytes(c["residue_name"][i]).decode().rjust(3), bytes(c["chain_id"][i]).decode().rjust(2),
+            c["residue_number"][i], bytes(c["insertion_code"][i]).decode() or " ",
+            mol._xyz[i, 0], mol._xyz[i, 1], mol._xyz[i, 2], c["occupancy"][i], c["temperature_factor"][i],
+            bytes(c["segment"][i]).decode(), bytes(c["element"][i]).decode().rjust(2)))
+    out.append("END")
+    return "\n".join(out) + "\n"

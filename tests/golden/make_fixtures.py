@@ -166,6 +166,29 @@ def main():
             if not f.read_bytes().endswith(b"\n"):
                 gz.write(b"\n")
     print("packed", len(files), "templates ->", out, out.stat().st_size, "bytes")
+    # 5. residue pool for the synthetic-structure generator (enzymm_amd/synthetic.py): the protein
+    #    ATOM records of the two test structures as plain arrays
+    import numpy as np
+    cols = {k: [] for k in ("xyz", "name", "res", "resid", "source")}
+    for src, fname in enumerate(("1AMY.pdb", "AF-P0DUB6-F1-model_v4.pdb")):
+        last, rid = None, -1
+        for line in (REF / "tests" / "test_data" / fname).read_text().splitlines():
+            if line.startswith("ENDMDL"):
+                break
+            if not line.startswith("ATOM  "):
+                continue
+            key = (line[20:22], line[22:27])
+            if key != last:
+                rid, last = rid + 1, key
+            cols["xyz"].append((float(line[30:38]), float(line[38:46]), float(line[46:54])))
+            cols["name"].append(line[12:16])
+            cols["res"].append(line[17:20])
+            cols["resid"].append(rid)
+            cols["source"].append(src)
+    np.savez_compressed(REPO / "enzymm_amd" / "data" / "residue_pool.npz",
+                        xyz=np.array(cols["xyz"], dtype=np.float64), name=np.array(cols["name"], dtype="S4"),
+                        res=np.array(cols["res"], dtype="S3"), resid=np.array(cols["resid"], dtype=np.int32),
+                        source=np.array(cols["source"], dtype=np.int8))
     # logistic models are data the filter (jess_run.py:499-520) needs
     shutil.copyfile(REF / "enzymm" / "data" / "logistic_regression_models.json",
                     REPO / "enzymm_amd" / "data" / "logistic_regression_models.json")
