@@ -1,0 +1,410 @@
+"""Driver of the matching path: the batch counterpart of ``enzymm/jess_run.py``.
+
+Same public names, arguments and results as the reference:
+
+* ``Matcher``  -- groups templates by ``effective_size``, walks the sizes in descending order
+  with per-size (rmsd, distance, max_dynamic_distance) (/root/reference/enzymm/jess_run.py:559-736,
+  896-988), filters with the logistic models (:867-894);
+* ``Match``    -- wraps a ``Hit``: residue triplets, orientation angle, logistic filter,
+  completeness, TSV / PDB writers (:59-496);
+* ``load_molecules`` (:523-556), including the reference's quirk that ``conserved()`` is called
+  and its result discarded (:541-545).
+
+What is different is *how* ``Matcher.run`` reaches the search: the reference builds
+``pyjess.Jess(templates)`` and queries once per (molecule, size) on a thread pool
+(:785-843, 919-921, 977-981); here every molecule and every size bucket go to the GPU in ONE
+``Jess.query_batch`` launch and the per-size sequential logic (skip_smaller_hits, filtering,
+completeness, insertion order) is replayed on the returned hit table.
+"""
+from __future__ import annotations
+
+import collections
+import csv
+import io
+import itertools
+import json
+import math
+import os
+import sys
+import warnings
+from dataclasses import dataclass, field
+from functools import cached_property
+from pathlib import Path
+from typing import IO, ClassVar, Dict, Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import pyjess
+from .template import Template, Vec3, check_template
+
+__all__ = ["LogisticRegressionModel", "Match", "Matcher", "load_molecules"]
+
+PROTEINOGENIC_AMINO_ACIDS = [
+    "ALA", "ARG", "ASN", "ASP", "CYS", "GLN", "GLU", "GLY", "HIS", "ILE",
+    "LEU", "LYS", "MET", "PHE", "PRO", "SER", "THR", "TRP", "TYR", "VAL",
+]
+SPECIAL_AMINO_ACIDS = [
+    "ASX", "GLX", "SEC", "PYL", "UNK", "MSE", "SEP", "TPO", "PTR", "HYP",
+    "CME", "CSO", "CSD", "PCA", "MLY", "DAL", "DAR", "DSG", "ORN", "PTM",
+]
+_COUNTED_RESIDUES = frozenset(PROTEINOGENIC_AMINO_ACIDS + SPECIAL_AMINO_ACIDS)
+
+_TSV_HEADER = [
+    "query_id", "pairwise_distance", "match_index", "template_pdb_id", "template_pdb_chains",
+    "template_cluster_id", "template_cluster_member", "template_cluster_size", "template_effective_size",
+    "template_dimension", "template_mcsa_id", "template_uniprot_id", "template_ec", "template_cath",
+    "template_multimeric", "query_multimeric", "query_atom_count", "query_residue_count", "rmsd", "log_evalue",
+    "orientation", "preserved_order", "completeness", "predicted_correct", "matched_residues",
+    "number_of_mutated_residues", "number_of_side_chain_residues_(template,reference)",
+    "number_of_metal_ligands_(template,reference)", "number_of_ptm_residues_(template, reference)",
+    "total_reference_residues",
+]
+_ONE_CHAR_ELEMENTS = frozenset("HBCNOFPSKVYIWU")
+
+
+def ranked_argsort(values: Sequence[int]) -> List[int]:
+    rank = {v: i + 1 for i, v in enumerate(sorted(set(values)))}
+    return [rank[v] for v in values]
+
+
+@dataclass(frozen=True)
+class LogisticRegressionModel:
+    """f(x) = 1 / (1 + exp(-(intercept + coef . x))) with a decision threshold."""
+
+    coefficents: List[float]
+    intercept: float
+    threshold: float
+
+
+def _load_models() -> Dict[str, Dict[str, List[LogisticRegressionModel]]]:
+    path = Path(__file__).resolve().parent / "data" / "logistic_regression_models.json"
+    raw = json.loads(path.read_text())
+    return {
+        size: {dist: [LogisticRegressionModel(m["coef"], m["intercept"], m["threshold"]) for m in entry["model_list"]]
+               for dist, entry in by_dist["pairwise_distance"].items()}
+        for size, by_dist in raw["match_size"].items()
+    }
+
+
+@dataclass
+class Match:
+    """An annotated hit (reference: jess_run.py:59-496)."""
+
+    hit: pyjess.Hit
+    complete: bool = field(default=False)
+    pairwise_distance: float = field(default=0)
+    index: int = field(default=0)
+    _logistic_regression_models: ClassVar[Dict[str, Dict[str, List[LogisticRegressionModel]]]] = _load_models()
+
+    # ---- geometry --------------------------------------------------------
+    @cached_property
+    def atom_triplets(self) -> List[Tuple[pyjess.Atom, pyjess.Atom, pyjess.Atom]]:
+        """Matched atoms in the template frame, three per template residue."""
+        atoms = self.hit.atoms(transform=True)
+        out = []
+        for i in range(0, len(atoms), 3):
+            trip = tuple(atoms[i:i + 3])
+            if len(trip) != 3:
+                raise ValueError(f"Failed to construct residues. Got only {len(trip)} ATOM lines")
+            owners = {(a.residue_name, a.chain_id, a.residue_number) for a in trip}
+            if len(owners) != 1:
+                raise ValueError(f"Mixed up atom triplets {owners}. The atoms come from different residues!")
+            out.append(trip)
+        return out
+
+    @property
+    def matched_residues(self) -> List[Tuple[str, str, str]]:
+        return [(t[0].residue_name, t[0].chain_id, str(t[0].residue_number)) for t in self.atom_triplets]
+
+    @property
+    def multimeric(self) -> bool:
+        atoms = self.hit.atoms()
+        return any(a.chain_id != atoms[0].chain_id for a in atoms)
+
+    @property
+    def preserved_resid_order(self) -> bool:
+        if self.hit.template.multimeric or self.multimeric:
+            return False
+        return ranked_argsort([t[0].residue_number for t in self.atom_triplets]) == self.hit.template.relative_order
+
+    @cached_property
+    def match_vector_list(self) -> List[Vec3]:
+        """Orientation vector of every matched residue, in the template frame (template.py:213-304)."""
+        out = []
+        for trip, residue in zip(self.atom_triplets, self.hit.template.residues):
+            i, j = residue.orientation_vector_indices
+            if j == 9:  # centre atom -> midpoint of the other two
+                others = [Vec3.from_xyz(a) for n, a in enumerate(trip) if n != i]
+                out.append((others[0] + others[1]) / 2 - Vec3.from_xyz(trip[i]))
+            else:
+                out.append(Vec3.from_xyz(trip[j]) - Vec3.from_xyz(trip[i]))
+        return out
+
+    @property
+    def template_vector_list(self) -> List[Vec3]:
+        return [r.orientation_vector for r in self.hit.template.residues]
+
+    @property
+    def orientation(self) -> float:
+        """Mean angle (radians) between template and matched residue orientation vectors."""
+        tv, mv = self.template_vector_list, self.match_vector_list
+        if len(tv) != len(mv):
+            raise ValueError("Vector lists for Template and matching Query structure had different lengths.")
+        return sum(a.angle_to(b) for a, b in zip(tv, mv)) / len(tv)
+
+    @property
+    def query_atom_count(self) -> int:
+        return len(self.hit.molecule())
+
+    @property
+    def query_residue_count(self) -> int:
+        mol = self.hit.molecule()
+        names = np.char.strip(mol._cols["residue_name"].astype("U3"))
+        keep = np.isin(names, list(_COUNTED_RESIDUES))
+        return len(set(mol._cols["residue_number"][keep].tolist()))
+
+    # ---- filter -----------------------------------------------------------
+    @property
+    def predicted_correct(self) -> bool:
+        """Majority vote of the logistic models for (effective size, pairwise distance);
+        sizes without models (>= 5, < 3) are accepted (jess_run.py:298-346)."""
+        size = str(self.hit.template.effective_size)
+        if size not in self._logistic_regression_models:
+            return True
+        try:
+            models = self._logistic_regression_models[size][str(self.pairwise_distance)]
+            votes = 0
+            for m in models:
+                z = m.intercept + m.coefficents[0] * self.hit.rmsd + m.coefficents[1] * self.orientation
+                votes += (1 / (1 + math.e ** -z)) >= m.threshold
+            return bool(votes >= round(len(models) / 2, 0))
+        except KeyError as exc:
+            raise KeyError("Missing appropriate model parameters to predict correctness. No models for the "
+                           f"pairwise distance {self.pairwise_distance} were provided") from exc
+        except IndexError as exc:
+            raise IndexError("Missing coefficients for both RMSD and Residue Orientation. "
+                             "Expecting models with 2 coeficients.") from exc
+
+    def get_identifying_attributes(self) -> Tuple[int, int, int]:
+        t = self.hit.template
+        return (t.mcsa_id, t.cluster.id, t.dimension)
+
+    # ---- writers ----------------------------------------------------------
+    def dumps(self, header: bool = False) -> str:
+        buf = io.StringIO()
+        self.dump(buf, header=header)
+        return buf.getvalue()
+
+    def dump(self, file: IO[str], header: bool = False, predict_correctness: bool = True):
+        """One TSV row (jess_run.py:185-284)."""
+        w = csv.writer(file, dialect="excel-tab", delimiter="\t", lineterminator="\n")
+        if header:
+            w.writerow(_TSV_HEADER)
+        t = self.hit.template
+        c = t.cluster
+        row = [
+            str(self.hit.molecule().id), str(self.pairwise_distance), str(self.index),
+            str(t.pdb_id if t.pdb_id else ""), ",".join(set(r.chain_id for r in t.residues)),
+            str(c.id if c else ""), str(c.member if c else ""), str(c.size if c else ""),
+            str(t.effective_size), str(t.dimension), str(t.mcsa_id if t.mcsa_id else ""),
+            str(t.uniprot_id if t.uniprot_id else ""), ",".join(t.ec if t.ec is not None else ""),
+            ",".join(t.cath if t.cath else ""), str(t.multimeric), str(self.multimeric),
+            str(self.query_atom_count), str(self.query_residue_count), str(round(self.hit.rmsd, 5)),
+            str(round(self.hit.log_evalue, 5)), str(round(self.orientation, 5)), str(self.preserved_resid_order),
+            str(self.complete), str(self.predicted_correct) if predict_correctness else "",
+            ",".join("_".join(r) for r in self.matched_residues),
+        ]
+        if hasattr(t, "number_of_mutated_residues"):
+            row += [str(t.number_of_mutated_residues), ",".join(map(str, t.number_of_side_chain_residues)),
+                    ",".join(map(str, t.number_of_metal_ligands)), ",".join(map(str, t.number_of_ptm_residues)),
+                    str(t.total_reference_residues)]
+        else:
+            row += [""] * 6
+        w.writerow(row)
+
+    @staticmethod
+    def _atom_line(a: pyjess.Atom) -> str:
+        altloc = a.altloc if a.altloc is not None else ""
+        name = f" {a.name:<3s}" if a.element in _ONE_CHAR_ELEMENTS else f"{a.name:<4s}"
+        return (f"ATOM  {a.serial:>5} {name}{altloc:<1}{a.residue_name:<3}{a.chain_id:>2}{a.residue_number:>4}"
+                f"{a.insertion_code:1s}   {a.x:>8.3f}{a.y:>8.3f}{a.z:>8.3f}{a.occupancy:>6.2f}"
+                f"{a.temperature_factor:>6.2f}      {a.segment:<4s}{a.element:>2s} \n")
+
+    def dump2pdb(self, file: IO[str], include_query: bool = False, transform: bool = False):
+        """Matched atoms (optionally the whole query first) as PDB text (jess_run.py:96-183)."""
+        mol = self.hit.molecule()
+        if include_query:
+            file.write(f"HEADER MOLECULE_ID {mol.id}\n")
+            for a in self.hit.molecule(transform=transform):
+                file.write(self._atom_line(a))
+            file.write("END\n\n")
+        t = self.hit.template
+        file.write(f"HEADER {self.predicted_correct} MATCH {mol.id} {self.index}\n")
+        file.write(f"REMARK TEMPLATE_PDB {t.pdb_id}_{','.join(set(r.chain_id for r in t.residues))}\n")
+        if t.cluster:
+            file.write(f"REMARK TEMPLATE CLUSTER {t.cluster.id}_{t.cluster.member}_{t.cluster.size}\n")
+        if t.represented_sites:
+            file.write(f"REMARK TEMPLATE RESIDUES {t.template_id_string}\n")
+        file.write(f"REMARK MOLECULE_ID {mol.id}\n")
+        file.write(f"REMARK MATCH INDEX {self.index}\n")
+        file.write("REMARK TEMPLATE COORDINATE FRAME\n" if transform else "REMARK QUERY COORDINATE FRAME\n")
+        for a in self.hit.atoms(transform=transform):
+            file.write(self._atom_line(a))
+        file.write("END\n\n")
+
+
+def load_molecules(molecule_paths: List[Path], conservation_cutoff: float = 0, warn: bool = False
+                   ) -> List[pyjess.Molecule]:
+    """Load query structures; duplicate file stems get ``_2``, ``_3`` ... suffixes."""
+    molecules, seen = [], collections.Counter()
+    for path in molecule_paths:
+        stem = Path(path).stem
+        seen[stem] += 1
+        mol = pyjess.Molecule.load(str(path), id=stem if seen[stem] == 1 else f"{stem}_{seen[stem]}")
+        if conservation_cutoff:
+            # the reference computes the filtered molecule and drops it (jess_run.py:541-545); kept as is
+            mol.conserved(conservation_cutoff)
+        if mol:
+            molecules.append(mol)
+        elif warn:
+            warnings.warn(f"received an empty molecule from {path}")
+    if not molecules and warn:
+        warnings.warn("received no molecules from input")
+    return molecules
+
+
+def _default_cpus() -> int:
+    return len(os.sched_getaffinity(0)) if sys.platform == "linux" else (os.cpu_count() or 1)
+
+
+class Matcher:
+    """Match query molecules against a list of templates (reference: jess_run.py:559-1000)."""
+
+    _DEFAULT_JESS_PARAMS = {
+        3: {"rmsd": 2, "distance": 0.9, "max_dynamic_distance": 0.9},
+        4: {"rmsd": 2, "distance": 1.7, "max_dynamic_distance": 1.7},
+        5: {"rmsd": 2, "distance": 2.0, "max_dynamic_distance": 2.0},
+        6: {"rmsd": 2, "distance": 2.0, "max_dynamic_distance": 2.0},
+        7: {"rmsd": 2, "distance": 2.0, "max_dynamic_distance": 2.0},
+        8: {"rmsd": 2, "distance": 2.0, "max_dynamic_distance": 2.0},
+    }
+    MAX_CANDIDATES = 10000  # jess_run.py:792
+
+    def __init__(self, templates: List[Template], jess_params: Optional[Dict[int, Dict[str, float]]] = None,
+                 conservation_cutoff: int = 0, warn: bool = False, verbose: bool = False,
+                 skip_smaller_hits: bool = False, match_small_templates: bool = False,
+                 cpus: Optional[int] = None, filter_matches: bool = True, console=None,
+                 jess_factory=pyjess.Jess):
+        self.templates = templates
+        self.cpus = _default_cpus() if cpus is None else cpus
+        self.conservation_cutoff = conservation_cutoff
+        self.warn, self.verbose = warn, verbose
+        self.skip_smaller_hits = skip_smaller_hits
+        self.match_small_templates = match_small_templates
+        self.filter_matches = filter_matches
+        self.jess_params = self._DEFAULT_JESS_PARAMS if jess_params is None else jess_params
+        self.console = console
+        self._jess_factory = jess_factory
+
+        if len(set(templates)) < len(templates):
+            raise ValueError("Duplicate templates were found.")
+        if self.cpus <= 0:
+            self.cpus = max(1, _default_cpus() + self.cpus)
+        self.verbose_print(f"PyJess Version: {pyjess.__version__}")
+
+        self.templates_by_effective_size: Dict[int, List[Template]] = collections.defaultdict(list)
+        for t in templates:
+            if check_template(t, warn=self.warn):
+                self.templates_by_effective_size[t.effective_size].append(t)
+        self.template_effective_sizes = sorted(self.templates_by_effective_size, reverse=True)
+
+        small = [t for s in self.template_effective_sizes if s < 3 for t in self.templates_by_effective_size[s]]
+        if self.warn and small:
+            tail = ("For small templates Jess parameters for templates of 3 residues will be used."
+                    if self.match_small_templates else "These will be excluded since these templates are too general.")
+            warnings.warn(f"{len(small)} Templates with an effective size smaller than 3 defined sidechain "
+                          f"residues were supplied.\n{tail}")
+
+    def verbose_print(self, *args):
+        if self.verbose:
+            print(*args)
+
+    def _get_jess_parameters(self, template_size: int) -> Tuple[float, float, float]:
+        p = self.jess_params[min(max(template_size, 3), 8)]
+        return p["rmsd"], p["distance"], p["max_dynamic_distance"]
+
+    @staticmethod
+    def _check_completeness(matches: List[Match]) -> List[Match]:
+        """A match is complete when every member 1..size of its template cluster hit the molecule."""
+        grouped = collections.defaultdict(list)
+        for m in matches:
+            t = m.hit.template
+            if t.mcsa_id is not None and t.cluster is not None:
+                grouped[m.get_identifying_attributes()].append(m)
+            else:
+                m.complete = True
+        for members in grouped.values():
+            want = list(range(1, members[0].hit.template.cluster.size + 1))
+            if sorted(m.hit.template.cluster.member for m in members) == want:
+                for m in members:
+                    m.complete = True
+        return matches
+
+    @staticmethod
+    def _run_jess(molecule: pyjess.Molecule, templates: List[Template], rmsd_threshold: float = 2.0,
+                  distance_cutoff: float = 1.5, max_dynamic_distance: float = 1.5, max_candidates: int = 10000,
+                  jess_factory=pyjess.Jess) -> List[Match]:
+        """Single (molecule, template list) query with the reference's exact call (jess_run.py:785-843)."""
+        query = jess_factory(templates).query(
+            molecule=molecule, rmsd_threshold=rmsd_threshold, distance_cutoff=distance_cutoff,
+            max_dynamic_distance=max_dynamic_distance, max_candidates=max_candidates, best_match=True,
+            ignore_chain=True)
+        return [Match(hit=h, pairwise_distance=distance_cutoff) for h in query]
+
+    def run(self, molecules: List[pyjess.Molecule]) -> Dict[pyjess.Molecule, List[Match]]:
+        """Search all molecules; larger templates first, sizes < 3 skipped unless match_small_templates."""
+        sizes = [s for s in self.template_effective_sizes if s >= 3 or self.match_small_templates]
+        searched: List[Template] = []
+        rmsd, dist, dyn, bucket_of = [], [], [], []
+        for s in sizes:
+            r, d, m = self._get_jess_parameters(s)
+            for t in self.templates_by_effective_size[s]:
+                searched.append(t)
+                rmsd.append(r); dist.append(d); dyn.append(m); bucket_of.append(s)
+
+        # ONE launch for every (molecule, template) pair of every bucket
+        per_molecule: List[List[pyjess.Hit]] = [[] for _ in molecules]
+        if searched and molecules:
+            jess = self._jess_factory(searched)
+            per_molecule = jess.query_batch(molecules, np.array(rmsd, float), np.array(dist, float),
+                                            np.array(dyn, float), max_candidates=self.MAX_CANDIDATES,
+                                            best_match=True, ignore_chain=True)
+        position = {id(t): i for i, t in enumerate(searched)}
+
+        processed: Dict[pyjess.Molecule, List[Match]] = collections.defaultdict(list)
+        for s in sizes:  # replay the reference's per-size loop on the hit table
+            _, distance, _ = self._get_jess_parameters(s)
+            self.verbose_print(f"Now matching query structure(s) to template of size {s}")
+            total = 0
+            staged = []
+            for mol, hits in zip(molecules, per_molecule):
+                if self.skip_smaller_hits and mol in processed:
+                    continue
+                matches = [Match(hit=h, pairwise_distance=distance) for h in hits
+                           if bucket_of[position[id(h.template)]] == s]
+                staged.append((mol, self._check_completeness(matches)))
+            for mol, matches in staged:
+                if self.filter_matches:
+                    for m in matches:
+                        if m.predicted_correct:
+                            processed[mol].append(m)
+                            total += 1
+                else:
+                    if matches:
+                        processed[mol].extend(matches)
+                    total += len(matches)
+            self.verbose_print(f"{total} matches found!")
+        return processed
+
+    def run_single(self, molecule: pyjess.Molecule) -> List[Match]:
+        return self.run([molecule])[molecule]

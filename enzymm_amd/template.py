@@ -10,16 +10,19 @@ Mirrors the reference's public names and behaviour for
 * ``load_templates``                                             :1505-1575
 
 so that the bucket key (``effective_size``, :786-808), the orientation definition the
-hit filter needs (:213-304) and the exception types the reference's tests expect
-(tests/test_template.py:453-497, 697-707) are the same.  The M-CSA/SIFTS annotation layer
-(``AnnotatedTemplate``, EC/CATH enrichment, :839-885, :1024-1474) is metadata that never touches
-geometry and is out of scope.
+hit filter needs (:213-304), the EC/CATH enrichment of the TSV columns (:839-885) and the exception
+types the reference's tests expect (tests/test_template.py:453-497, 697-707) are the same.  The
+``AnnotatedTemplate`` layer (catalytic-residue homolog counts, :1024-1474) needs a data blob the
+reference itself does not ship (.MISSING_LARGE_BLOBS) and never touches geometry: out of scope
+(SURVEY.md section 2, rows 8 and 12).
 """
 from __future__ import annotations
 
+import functools
 import glob
 import gzip
 import io
+import json
 import math
 import os
 import re
@@ -281,6 +284,14 @@ def _remark_handlers():
 _HANDLERS = _remark_handlers()
 
 
+@functools.lru_cache(maxsize=1)
+def _annotation_tables():
+    data = Path(__file__).resolve().parent / "data"
+    return {"cath": json.loads((data / "MCSA_CATH_mapping.json").read_text()),
+            "ec": json.loads((data / "MCSA_EC_mapping.json").read_text()),
+            "sifts": json.loads((data / "pdb_sifts.json").read_text())}
+
+
 class Template(pyjess.Template):
     """A template with its residues and M-CSA bookkeeping (same constructor and attributes as the
     reference's ``enzymm.template.Template``)."""
@@ -304,7 +315,25 @@ class Template(pyjess.Template):
         self.uniprot_id, self.organism, self.organism_id = uniprot_id, organism, organism_id
         self.resolution, self.experimental_method = resolution, experimental_method
         self.enzyme_discription, self.represented_sites = enzyme_discription, represented_sites
-        self.ec, self.cath = tuple(sorted(set(ec))), tuple(sorted(set(cath)))
+        self.ec = tuple(sorted({*ec, *self._annotations("ec")}))
+        self.cath = tuple(sorted({*cath, *self._annotations("cath")}))
+
+    def _annotations(self, what: str) -> List[str]:
+        """EC / CATH numbers known for this template's M-CSA entry and PDB chains
+        (reference: template.py:839-885, tables loaded at :1459-1468)."""
+        tables = _annotation_tables()
+        found: List[str] = []
+        if what == "ec":
+            if self.mcsa_id is not None:
+                found.append(tables["ec"][str(self.mcsa_id)])
+        elif self.mcsa_id:
+            found.extend(tables["cath"][str(self.mcsa_id)])
+        if self.pdb_id is not None if what == "ec" else bool(self.pdb_id):
+            for chain in {f"{self.pdb_id}{r.chain_id}" for r in self.residues}:
+                entry = tables["sifts"].get(chain)
+                if entry is not None:
+                    found.extend(v for v in entry.get(what) if v != "?")
+        return found
 
     # -- identity ------------------------------------------------------------
     def _state(self):

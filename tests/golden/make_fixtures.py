@@ -190,8 +190,11 @@ def main():
                         res=np.array(cols["res"], dtype="S3"), resid=np.array(cols["resid"], dtype=np.int32),
                         source=np.array(cols["source"], dtype=np.int8))
     # logistic models are data the filter (jess_run.py:499-520) needs
-    shutil.copyfile(REF / "enzymm" / "data" / "logistic_regression_models.json",
-                    REPO / "enzymm_amd" / "data" / "logistic_regression_models.json")
+    # ... and the M-CSA / SIFTS id -> EC / CATH tables Template.ec / Template.cath are enriched from
+    # (template.py:839-885, loaded at :1459-1468)
+    for name in ("logistic_regression_models.json", "MCSA_CATH_mapping.json", "MCSA_EC_mapping.json",
+                 "pdb_sifts.json"):
+        shutil.copyfile(REF / "enzymm" / "data" / name, REPO / "enzymm_amd" / "data" / name)
 
 
 if __name__ == "__main__":

@@ -43,3 +43,72 @@ def default_selection():
 
 def golden_text(rel):
     return (GOLDEN / rel).read_text()
+
+
+# ---------------------------------------------------------------------------------------------
+# product objects -> oracle tables, and an oracle-backed stand-in for pyjess.Jess (CPU tests only)
+
+
+def to_oracle_molecule(mol):
+    from oracle import parse
+    c = mol._cols
+    return parse.OracleMolecule(mol._xyz, c["name"], c["residue_name"], c["chain_id"], c["residue_number"],
+                                c["insertion_code"], c["temperature_factor"], c["serial"])
+
+
+def to_oracle_template(tpl):
+    from oracle import parse
+    t = parse.OracleTemplate([], [])
+    k = len(tpl)
+    t.k = k
+    t.xyz = np.array([[a.x, a.y, a.z] for a in tpl], dtype=np.float64).reshape(k, 3)
+    t.mode = np.array([a.match_mode for a in tpl], dtype=np.int32)
+    t.name = np.array([a._raw_names[0] for a in tpl], dtype="S4")
+    t.resnames = np.zeros((k, parse.MAXRESN), dtype="S3")
+    t.nres = np.zeros(k, dtype=np.int32)
+    for i, a in enumerate(tpl):
+        t.nres[i] = len(a._raw_residues)
+        for r, nm in enumerate(a._raw_residues):
+            t.resnames[i, r] = nm
+    t.chain = np.array([a.chain_id.rjust(2).encode() for a in tpl], dtype="S2")
+    t.resseq = np.array([a.residue_number for a in tpl], dtype=np.int32)
+    t.weight = np.array([a.distance_weight for a in tpl], dtype=np.float64)
+    return t
+
+
+class OracleJess:
+    """Duck-types enzymm_amd.pyjess.Jess on top of the CPU oracle so host logic (Match, Matcher)
+    can be exercised without a GPU.  TESTS ONLY."""
+
+    def __init__(self, templates=(), device=None):
+        self._templates = tuple(templates)
+
+    def query_batch(self, molecules, rmsd_threshold, distance_cutoff, max_dynamic_distance, *,
+                    max_candidates=None, ignore_chain=False, best_match=True, **_):
+        from enzymm_amd import pyjess
+        from oracle import oracle
+        assert best_match
+        nt = len(self._templates)
+        if nt == 0:
+            return [[] for _ in molecules]
+        lib = oracle.OracleLibrary([to_oracle_template(t) for t in self._templates])
+        cap = 2**31 - 1 if max_candidates is None else int(max_candidates)
+        out = []
+        for mol in molecules:
+            r = oracle.query_library(to_oracle_molecule(mol), lib, rmsd_threshold, distance_cutoff,
+                                     max_dynamic_distance, max_candidates=cap, ignore_chain=ignore_chain)
+            hits = []
+            for t in np.nonzero(r["hit"])[0]:
+                k = lib.templates[t].k
+                hits.append(pyjess.Hit(self._templates[t], mol, r["rmsd"][t], r["rot"][t], r["trans"][t],
+                                       r["atoms"][t][:k], r["candidates"][t], bool(r["truncated"][t])))
+            out.append(hits)
+        return out
+
+    def query(self, molecule, rmsd_threshold, distance_cutoff, max_dynamic_distance, *, max_candidates=None,
+              ignore_chain=False, best_match=False):
+        from enzymm_amd import pyjess
+        hits = self.query_batch([molecule], rmsd_threshold, distance_cutoff, max_dynamic_distance,
+                                max_candidates=max_candidates, ignore_chain=ignore_chain, best_match=best_match)
+        return pyjess.Query(self, molecule, rmsd_threshold, distance_cutoff, max_dynamic_distance, max_candidates,
+                            ignore_chain, best_match, hits[0])

@@ -1,0 +1,89 @@
+"""The N>1 path on CPU: structure sharding + variable-length hit-table gather over gloo, world size 2.
+The per-rank compute is the oracle (tests may use it); on the GPU box the same code runs over RCCL."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from tests import helpers
+from enzymm_amd import _native, distributed
+
+
+def test_shard_range_partitions():
+    for n in (0, 1, 7, 1000, 100003):
+        for world in (1, 2, 3, 8):
+            spans = [distributed.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        distributed.shard_range(10, 2, 2)
+    spans = distributed.shard_by_atoms([100, 100, 5000, 100, 100, 4000], 2)
+    assert spans[0][0] == 0 and spans[-1][1] == 6 and spans[0][1] == spans[1][0]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _oracle_table(molecules, lo):
+    """Hit table (HIT_DTYPE) of molecules against a few templates, computed with the oracle."""
+    from enzymm_amd import template
+    tdir = helpers.GOLDEN / "templates"
+    tpls = list(template.load_templates(tdir / "5_residues")) + list(template.load_templates(tdir / "4_residues"))
+    tpls.sort(key=lambda t: t.template_id_string + str(t.cluster))
+    per_mol = helpers.OracleJess(tpls).query_batch(molecules, 2.0, 2.0, 2.0, max_candidates=10000,
+                                                   ignore_chain=True, best_match=True)
+    rows = []
+    for s, hits in enumerate(per_mol):
+        for h in hits:
+            row = np.zeros((), dtype=_native.HIT_DTYPE)
+            row["structure"], row["template_sel"] = s, tpls.index(h.template)
+            row["rmsd"], row["rot"], row["trans"] = h.rmsd, h._rot.ravel(), h._trans
+            row["n_atoms"] = len(h._atom_index)
+            row["atoms"][: len(h._atom_index)] = h._atom_index
+            rows.append(row)
+    return np.array(rows, dtype=_native.HIT_DTYPE) if rows else np.zeros(0, dtype=_native.HIT_DTYPE)
+
+
+def _worker(rank, world, port, out_path):
+    import torch.distributed as dist
+    from enzymm_amd import pyjess, synthetic
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mols = [pyjess.Molecule.load(helpers.GOLDEN / "1AMY.pdb"),
+                pyjess.Molecule.load(helpers.GOLDEN / "AF-P0DUB6-F1-model_v4.pdb")] + synthetic.structures(1)
+        lo, hi = distributed.shard_range(len(mols), rank, world)
+        local = _oracle_table(mols[lo:hi], lo)
+        table = distributed.gather_tables(local, lo, device="cpu")
+        if rank == 0:
+            np.save(out_path, table)
+        else:
+            assert table is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_world_size_2(tmp_path):
+    import torch.multiprocessing as mp
+    from enzymm_amd import pyjess, synthetic
+    out = tmp_path / "table.npy"
+    mp.spawn(_worker, args=(2, _free_port(), str(out)), nprocs=2, join=True)
+    got = np.load(out)
+    mols = [pyjess.Molecule.load(helpers.GOLDEN / "1AMY.pdb"),
+            pyjess.Molecule.load(helpers.GOLDEN / "AF-P0DUB6-F1-model_v4.pdb")] + synthetic.structures(1)
+    want = _oracle_table(mols, 0)
+    assert len(got) == len(want) > 0
+    assert got.tobytes() == want.tobytes()  # same table as the unsharded run, globally indexed and sorted
+
+
+def test_gather_without_process_group_is_identity():
+    local = np.zeros(3, dtype=_native.HIT_DTYPE)
+    local["structure"] = [0, 1, 1]
+    out = distributed.gather_tables(local, 10)
+    assert out["structure"].tolist() == [10, 11, 11]

@@ -1,0 +1,252 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and the reference's known answers.
+Needs a real MI355X: every test here is marked gpu."""
+import io
+import json
+
+import numpy as np
+import pytest
+
+from tests import helpers
+from enzymm_amd import _native, jess_run, pyjess, synthetic, template
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+G = json.loads((helpers.GOLDEN / "golden.json").read_text())
+TPL = helpers.GOLDEN / "templates"
+RMSD_TOL = 1e-5  # north_star: RMSD within 1e-5 (observed agreement is ~1e-12)
+
+
+@pytest.fixture(scope="module")
+def amy():
+    return pyjess.Molecule.load(helpers.GOLDEN / "1AMY.pdb")
+
+
+@pytest.fixture(scope="module")
+def af():
+    return pyjess.Molecule.load(helpers.GOLDEN / "AF-P0DUB6-F1-model_v4.pdb", id="AF-P0DUB6-F1-model_v4")
+
+
+@pytest.fixture(scope="module")
+def default_library():
+    idx, cut = helpers.default_selection()
+    ptpl = helpers.product_library_templates()
+    otpl = helpers.oracle_library_templates()
+    return pyjess.Jess(ptpl), oracle.OracleLibrary([otpl[i] for i in idx]), idx, cut
+
+
+def compare(table, cands, s, r, lib, check_candidates=True):
+    """GPU hit table rows of structure s vs the oracle's query_library result r."""
+    mine = {int(h["template_sel"]): h for h in table if int(h["structure"]) == s}
+    if check_candidates:
+        assert np.array_equal(cands[s] & 0x7FFFFFFF, r["candidates"])  # same number of complete assignments
+        assert np.array_equal((cands[s] >> 31).astype(bool), r["truncated"].astype(bool))
+    ok = ~r["truncated"].astype(bool)  # parity is defined for searches that were not cut short
+    theirs = set(np.nonzero(r["hit"] & ok)[0].tolist())
+    assert {t for t in mine if ok[t]} == theirs
+    for t in theirs:
+        k = lib.templates[t].k
+        assert np.array_equal(mine[t]["atoms"][:k], r["atoms"][t][:k]), t  # bit-identical hit set
+        assert abs(mine[t]["rmsd"] - r["rmsd"][t]) < RMSD_TOL
+        assert np.abs(mine[t]["rot"].reshape(3, 3) - r["rot"][t]).max() < 1e-6
+        assert np.abs(mine[t]["trans"] - r["trans"][t]).max() < 1e-5
+        assert int(mine[t]["n_candidates"]) == int(r["candidates"][t])
+    return len(theirs)
+
+
+@pytest.mark.parametrize("key", ["G1", "G2"])
+def test_reference_known_answers(amy, key):
+    """tests/test_jess_run.py:24-59, 77, 133: the exact reference call, on the GPU."""
+    g = G[key]
+    tpl = template.Template.load(TPL / g["template"])
+    hits = list(pyjess.Jess([tpl]).query(amy, g["rmsd_threshold"], g["distance_cutoff"], g["max_dynamic_distance"],
+                                         max_candidates=g["max_candidates"], best_match=True))
+    assert len(hits) == 1 and hits[0].template is tpl
+    m = jess_run.Match(hit=hits[0], pairwise_distance=g["distance_cutoff"], complete=True, index=0)
+    assert m.hit.rmsd == pytest.approx(g["rmsd"], abs=5e-8)
+    assert m.orientation == pytest.approx(g["orientation"], abs=5e-8)
+    assert [list(r) for r in m.matched_residues] == g["matched_residues"]
+    assert m.preserved_resid_order == g["preserved_resid_order"]
+    if key == "G1":
+        for fname, kw in (("1AMY_matches_no_query.pdb", dict(transform=False, include_query=False)),
+                          ("1AMY_matches_template.pdb", dict(transform=True, include_query=False)),
+                          ("1AMY_matches_query_included.pdb", dict(transform=False, include_query=True))):
+            buf = io.StringIO()
+            m.dump2pdb(buf, **kw)
+            assert buf.getvalue() == (helpers.GOLDEN / fname).read_text()
+
+
+def test_full_library_real_structures(amy, af, default_library):
+    """configs[1]: one structure vs the full shipped library -- hit sets, candidate counts, RMSD."""
+    jess, olib, idx, cut = default_library
+    table, cands = jess.query_batch([amy, af], 2.0, cut, cut, max_candidates=10000, ignore_chain=True,
+                                    template_index=idx, count_candidates=True, return_raw=True)
+    n = 0
+    for s, mol in enumerate((amy, af)):
+        r = oracle.query_library(helpers.to_oracle_molecule(mol), olib, 2.0, cut, cut, max_candidates=10000,
+                                 ignore_chain=True)
+        n += compare(table, cands, s, r, olib)
+    assert n >= 20
+
+
+def test_synthetic_batch_vs_oracle(default_library):
+    jess, olib, idx, cut = default_library
+    mols = synthetic.structures(24)
+    table, cands = jess.query_batch(mols, 2.0, cut, cut, max_candidates=10000, ignore_chain=True,
+                                    template_index=idx, count_candidates=True, return_raw=True)
+    for s, mol in enumerate(mols):
+        r = oracle.query_library(helpers.to_oracle_molecule(mol), olib, 2.0, cut, cut, max_candidates=10000,
+                                 ignore_chain=True)
+        compare(table, cands, s, r, olib)
+
+
+def _subset(n_per_size=40):
+    """A few templates of every effective size 3..8 (library order)."""
+    otpl = helpers.oracle_library_templates()
+    eff = np.array([t.effective_size for t in otpl])
+    idx = np.concatenate([np.nonzero(eff == e)[0][:: max(1, (eff == e).sum() // n_per_size)][:n_per_size]
+                          for e in range(3, 9)])
+    return np.sort(idx)
+
+
+def test_loose_thresholds_dynamic_distance_and_truncation(amy):
+    """configs[4] flavour: loosened -j, max_dynamic_distance > distance_cutoff (distance weights take
+    part), and a max_candidates small enough that some searches are cut short."""
+    idx = _subset(25)
+    ptpl, otpl = helpers.product_library_templates(), helpers.oracle_library_templates()
+    jess, olib = pyjess.Jess([ptpl[i] for i in idx]), oracle.OracleLibrary([otpl[i] for i in idx])
+    for cutoff, maxdyn, cap in ((2.0, 2.6, 10000), (2.5, 2.5, 50)):
+        table, cands = jess.query_batch([amy], 3.0, cutoff, maxdyn, max_candidates=cap, ignore_chain=True,
+                                        count_candidates=True, return_raw=True)
+        r = oracle.query_library(helpers.to_oracle_molecule(amy), olib, 3.0, cutoff, maxdyn, max_candidates=cap,
+                                 ignore_chain=True)
+        # truncated pairs: both sides must agree WHICH pairs are truncated (the total is order independent)
+        assert np.array_equal((cands[0] >> 31).astype(bool), r["truncated"].astype(bool))
+        compare(table, cands, 0, r, olib, check_candidates=False)
+        assert np.array_equal((cands[0] & 0x7FFFFFFF)[~r["truncated"].astype(bool)],
+                              r["candidates"][~r["truncated"].astype(bool)])
+    assert r["truncated"].sum() > 0
+
+
+def _multichain(mol, copies, shift=45.0):
+    """mol repeated as chains A, B, ... shifted along x (a crude oligomer)."""
+    cols = {k: np.concatenate([v] * copies) for k, v in mol._cols.items()}
+    n = len(mol)
+    xyz = np.concatenate([mol._xyz + np.array([shift * c, 0.0, 0.0]) for c in range(copies)])
+    cols["chain_id"] = np.concatenate([np.full(n, (" " + "ABCDEFGH"[c]).encode(), dtype="S2") for c in range(copies)])
+    out = pyjess.Molecule.__new__(pyjess.Molecule)
+    out._init_columns(cols, xyz, f"{mol.id}x{copies}")
+    return out
+
+
+def test_ignore_chain_false_and_multichain(amy):
+    """ignore_chain=False (the default of the reference's test calls) on a two-chain target with
+    multi-chain templates."""
+    ptpl, otpl = helpers.product_library_templates(), helpers.oracle_library_templates()
+    multi = [i for i, t in enumerate(ptpl) if len({a.chain_id for a in t}) > 1][:150]
+    idx = np.array(sorted(set(multi) | set(_subset(10).tolist())))
+    jess, olib = pyjess.Jess([ptpl[i] for i in idx]), oracle.OracleLibrary([otpl[i] for i in idx])
+    dimer = _multichain(amy, 2, shift=38.0)
+    for ignore in (False, True):
+        table, cands = jess.query_batch([dimer], 2.0, 2.0, 2.0, max_candidates=10000, ignore_chain=ignore,
+                                        count_candidates=True, return_raw=True)
+        r = oracle.query_library(helpers.to_oracle_molecule(dimer), olib, 2.0, 2.0, 2.0, max_candidates=10000,
+                                 ignore_chain=ignore)
+        assert compare(table, cands, 0, r, olib) > 0
+
+
+def test_large_structure_global_memory_path(af, default_library):
+    """> 10k atoms does not fit the LDS-resident kernel variant: the global-memory variant must agree too."""
+    jess, olib, idx, cut = default_library
+    big = _multichain(af, 3, shift=70.0)
+    assert len(big) == 3 * 4079
+    sel = np.arange(0, len(idx), 7)
+    sub = oracle.OracleLibrary([olib.templates[i] for i in sel])
+    table, cands = jess.query_batch([big], 2.0, cut[sel], cut[sel], max_candidates=10000, ignore_chain=True,
+                                    template_index=idx[sel], count_candidates=True, return_raw=True)
+    r = oracle.query_library(helpers.to_oracle_molecule(big), sub, 2.0, cut[sel], cut[sel], max_candidates=10000,
+                             ignore_chain=True)
+    compare(table, cands, 0, r, sub)
+
+
+def test_edge_cases(amy):
+    tpl = template.Template.load(TPL / G["G1"]["template"])
+    jess = pyjess.Jess([tpl])
+    empty = pyjess.Molecule()
+    one_atom = amy[:1]
+    waters = amy._subset(amy._cols["residue_name"] == b"HOH")
+    out = jess.query_batch([empty, one_atom, waters, amy, empty], 2, 1.5, 1.5, max_candidates=10000)
+    assert [len(h) for h in out] == [0, 0, 0, 1, 0]
+    assert out[3][0].rmsd == pytest.approx(G["G1"]["rmsd"], abs=5e-8)
+    # max_candidates = 0 evaluates nothing and flags the search
+    t, c = jess.query_batch([amy], 2, 1.5, 1.5, max_candidates=0, count_candidates=True, return_raw=True)
+    assert len(t) == 0 and c[0, 0] == 0x80000000
+    # None = unlimited
+    assert len(jess.query_batch([amy], 2, 1.5, 1.5, max_candidates=None)[0]) == 1
+    # a template with more atoms than the build supports is refused, not mis-searched
+    atoms = list(tpl) + [a.copy() for a in tpl]
+    for i, a in enumerate(atoms[15:]):
+        a.residue_number += 1000
+    with pytest.raises(_native.NativeError):
+        pyjess.Jess([pyjess.Template(atoms, id="too_big")]).query_batch([amy], 2, 1.5, 1.5)
+
+
+def test_matcher_end_to_end(amy, af):
+    """tests/test_jess_run.py:301-357 through the real GPU-backed Jess."""
+    a1 = G["A1"]
+    tpls = [template.Template.load(TPL / p) for p in a1["templates"]]
+    params = {int(k): dict(rmsd=v[0], distance=v[1], max_dynamic_distance=v[2]) for k, v in a1["jess_params"].items()}
+    unf = jess_run.Matcher(tpls, jess_params=params, filter_matches=False).run_single(amy)
+    fil = jess_run.Matcher(tpls, jess_params=params, filter_matches=True).run_single(amy)
+    assert sorted(m.hit.template.pdb_id for m in unf) == a1["unfiltered_pdb_ids"]
+    assert sorted(m.hit.template.pdb_id for m in fil) == a1["filtered_pdb_ids"]
+    load = lambda d: list(template.load_templates(TPL / d))
+    t54 = load("5_residues/results/csa3d_0285") + load("4_residues/results/csa3d_0285")
+    r1 = jess_run.Matcher(t54).run([amy, af])
+    assert list(r1.keys()) == [amy, af] and len(r1[amy]) == 2 and len(r1[af]) == 2
+    af80 = af.conserved(80)
+    r2 = jess_run.Matcher(t54, skip_smaller_hits=True).run([amy, af80])
+    assert len(r2[amy]) == 1 and len(r2[af80]) == 1
+    m3 = jess_run.Matcher(t54 + load("3_residues/results/csa3d_0344"), match_small_templates=True)
+    assert len(m3.run([amy])[amy]) == 3
+    # the reference's own single-call boundary
+    single = jess_run.Matcher._run_jess(amy, t54[:2], 2.0, 2.0, 2.0)
+    assert all(isinstance(m, jess_run.Match) for m in single)
+
+
+def test_full_batch_properties(default_library):
+    """configs[2] size (1000 structures x 6780 templates): properties that need no oracle."""
+    jess, olib, idx, cut = default_library
+    mols = synthetic.structures(1000)
+    batch = pyjess.make_batch(mols, jess._device)
+    run = lambda: jess.query_batch(mols, 2.0, cut, cut, max_candidates=10000, ignore_chain=True, template_index=idx,
+                                   batch=batch, return_raw=True)
+    a, b = run(), run()
+    assert len(a) > 100 and a.tobytes() == b.tobytes()  # deterministic, independent of scheduling
+    # a structure's hits do not depend on what else is in the batch
+    pick = [3, 500, 999]
+    alone = jess.query_batch([mols[i] for i in pick], 2.0, cut, cut, max_candidates=10000, ignore_chain=True,
+                             template_index=idx, return_raw=True)
+    for j, i in enumerate(pick):
+        x, y = a[a["structure"] == i].copy(), alone[alone["structure"] == j].copy()
+        x["structure"] = y["structure"] = 0
+        assert x.tobytes() == y.tobytes()
+    # every hit is what it claims to be
+    tpls = jess._templates
+    for h in a[:: max(1, len(a) // 300)]:
+        mol, tpl = mols[int(h["structure"])], tpls[int(idx[h["template_sel"]])]
+        k = int(h["n_atoms"])
+        assert k == len(tpl) and h["rmsd"] <= 2.0
+        q = mol._xyz[h["atoms"][:k]]
+        p = np.array([[t.x, t.y, t.z] for t in tpl])
+        R, T = h["rot"].reshape(3, 3), h["trans"]
+        assert abs(np.linalg.det(R) - 1) < 1e-9 and np.abs(R @ R.T - np.eye(3)).max() < 1e-9
+        assert np.sqrt((((q @ R.T + T) - p) ** 2).sum(1).mean()) == pytest.approx(h["rmsd"], abs=1e-9)
+        res = mol._cols["residue_number"][h["atoms"][:k]]
+        groups = [(t.chain_id, t.residue_number) for t in tpl]
+        for i in range(k):
+            for j in range(i):
+                assert (groups[i] == groups[j]) == (res[i] == res[j])
+                dq, dt = np.linalg.norm(q[i] - q[j]), np.linalg.norm(p[i] - p[j])
+                assert abs(dq - dt) <= cut[h["template_sel"]] + 1e-12
+    batch.close()

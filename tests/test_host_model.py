@@ -1,0 +1,214 @@
+"""Host-side mirror of the reference interface: parsers, object surface, error behaviour, vocabulary
+masks, and that the C-ABI library loads and exports every symbol include/enzymm_amd.h declares.
+CPU only -- no compute call is made."""
+import json
+import re
+
+import numpy as np
+import pytest
+
+from tests import helpers
+from enzymm_amd import _native, _vocab, jess_run, pyjess, template
+from oracle import parse
+
+G = json.loads((helpers.GOLDEN / "golden.json").read_text())
+TPL = helpers.GOLDEN / "templates"
+BAD = helpers.GOLDEN / "bad_templates"
+
+
+def test_cabi_exports_every_declared_symbol():
+    header = (helpers.ROOT / "include" / "enzymm_amd.h").read_text()
+    declared = set(re.findall(r"\b(tm_[a-z_]+)\s*\(", header))
+    assert declared == set(_native.EXPORTS)
+    lib = _native.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.tm_abi_version() == 1
+    assert _native.HIT_DTYPE.itemsize == 224
+
+
+def test_molecule_load_matches_oracle_parser():
+    for fname, n in (("1AMY.pdb", 3339), ("AF-P0DUB6-F1-model_v4.pdb", 4079)):
+        mol = pyjess.Molecule.load(helpers.GOLDEN / fname)
+        om = parse.parse_molecule(helpers.golden_text(fname))
+        assert len(mol) == len(om) == n  # 3339: tests/test_jess_run.py:75
+        assert np.array_equal(mol._xyz, om.xyz)
+        assert (mol._cols["name"] == om.name).all() and (mol._cols["residue_name"] == om.res).all()
+        assert (mol._cols["residue_number"] == om.resseq).all()
+        assert (mol._cols["temperature_factor"] == om.bfac).all()
+    amy = pyjess.Molecule.load(helpers.GOLDEN / "1AMY.pdb")
+    assert amy.id == "1AMY"  # HEADER idCode, tests/test_jess_run.py:62
+    ca_ion = amy[3184]
+    assert (ca_ion.name, ca_ion.residue_name, ca_ion.element, ca_ion.serial) == ("CA", "CA", "CA", 3186)
+    assert ca_ion._raw_name == b"CA  " and amy[1]._raw_name == b" CA "
+    assert amy[0].altloc is None and amy[0] != amy[1] and amy[0] == amy[0].copy()
+    # load from a file object and an explicit id (jess_run.py:538-540)
+    with open(helpers.GOLDEN / "1AMY.pdb") as f:
+        assert pyjess.Molecule.load(f, id="x").id == "x"
+
+
+def test_molecule_surface():
+    af = pyjess.Molecule.load(helpers.GOLDEN / "AF-P0DUB6-F1-model_v4.pdb", id="af")
+    kept = af.conserved(80)
+    assert kept is not af and len(kept) < len(af) and kept.id == "af"
+    assert all(a.temperature_factor >= 80 for a in kept)
+    d = {af: 1}
+    assert af in d and kept not in d and bool(af) and not pyjess.Molecule()
+    rebuilt = pyjess.Molecule(list(af)[:50], id="r")
+    assert len(rebuilt) == 50 and rebuilt[10] == af[10]
+    assert np.array_equal(rebuilt._encoded()["name_id"], af._encoded()["name_id"][:50])
+    text = "MODEL 1\n" + "ATOM      1  N   GLY A   1       0.000   0.000   0.000  1.00  0.00           N\nENDMDL\n" * 2
+    assert len(pyjess.Molecule.loads(text)) == 1 and len(pyjess.Molecule.loads(text, ignore_endmdl=True)) == 2
+    with pytest.raises(ValueError):
+        pyjess.Molecule.loads("ATOM      1  N   GLY A   1       0.000   x.000   0.000\n")
+
+
+def test_template_atom():
+    a = pyjess.TemplateAtom.loads("ATOM      8  ND1ZHIS A 471      56.123  41.172  16.180 H     3.77 ")
+    assert (a.match_mode, a.atom_names, a.residue_names, a.chain_id, a.residue_number) == \
+           (8, ("ND1",), ("HIS",), "A", 471)
+    assert (a.x, a.y, a.z, a.distance_weight) == (56.123, 41.172, 16.18, 3.77)
+    b = pyjess.TemplateAtom.loads("ATOM    100  CA ZANYAA 126      -6.116  -3.869 -42.900 VLI   0.84 ")
+    assert b.residue_names == ("ANY", "VAL", "LEU", "ILE") and b.chain_id == "AA" and b.match_mode == 100
+    assert a == a.copy() and hash(a) == hash(a.copy()) and a != b
+    k = pyjess.TemplateAtom(chain_id="A", residue_number=51, residue_names=["ANY"], atom_names=["C"],
+                            distance_weight=1.5, match_mode=1, x=1.0, y=0, z=-99.5)  # tests/test_template.py:234
+    assert k._raw_names == (b" C  ",)
+    for bad in ("HETATM    1  N   GLY A   1       0.000   0.000   0.000", "ATOM      x  CA ZANY A 126      -6.116  -3.869 -42.900",
+                "ATOM      0  CA ZANY A 126      -6.116  -3.869 -42.900 J     0.84 "):
+        with pytest.raises(ValueError):
+            pyjess.TemplateAtom.loads(bad)
+    with pytest.raises(ValueError):
+        pyjess.TemplateAtom(chain_id="A", residue_number=1, residue_names=[], atom_names=["C"], x=0, y=0, z=0)
+
+
+def test_template_metadata_known_answers():
+    """tests/test_template.py:335-395"""
+    for key in ("1b74", "1qum"):
+        want = G["A5"][key]
+        t = template.Template.load(TPL / want["path"])
+        assert t.effective_size == want["effective_size"] and t.dimension == want["dimension"]
+        assert t.multimeric == want["multimeric"] and t.relative_order == want["relative_order"]
+        assert t.pdb_id == want["pdb_id"] and t.mcsa_id == want["mcsa_id"]
+        assert (t.cluster.id, t.cluster.member, t.cluster.size) == tuple(want["cluster"])
+        assert t.uniprot_id == want["uniprot_id"] and t.organism == want["organism"]
+        assert t.organism_id == want["organism_id"] and t.resolution == want["resolution"]
+        assert t.represented_sites == want["represented_sites"] and len(t.residues) == want["dimension"]
+    t = template.Template.load(TPL / G["A5"]["1b74"]["path"])
+    assert t.ec == ("5.1.1.3",) and t.cath == ("3.40.50.1860",)
+    assert t.enzyme_discription == "GLUTAMATE RACEMASE (E.C.5.1.1.3)"
+    assert template.Template.load(TPL / G["A5"]["1qum"]["path"], id="hello_world").id == "hello_world"
+    # residues (tests/test_template.py:709-736)
+    r1, r2 = t.residues[0], t.residues[1]
+    assert (r1.residue_name, r1.allowed_residues, r1.match_mode, r1.backbone, r1.residue_number, r1.chain_id) == \
+           ("GLU", "E", 3, False, 147, "A")
+    assert r1.orientation_vector_indices == (0, 9) and r2.orientation_vector_indices == (0, 1)
+    assert (r1.orientation_vector.x, r1.orientation_vector.y, r1.orientation_vector.z) == \
+           pytest.approx((-0.125, -0.3475, 0.456), abs=1e-7)
+    assert (r2.orientation_vector.x, r2.orientation_vector.y, r2.orientation_vector.z) == \
+           pytest.approx((1.079, -0.638, 0.57), abs=1e-7)
+    # copy / eq / hash and subclass identity survive (tests/test_template.py:397-451)
+    c = t.copy()
+    assert c == t and hash(c) == hash(t) and c is not t and len({t, c}) == 1
+    assert template.Template.load(TPL / G["A5"]["1qum"]["path"]) != t
+
+
+def test_bad_templates_raise_like_the_reference():
+    """tests/test_template.py:453-497, 697-707"""
+    load = lambda n: template.Template.loads((BAD / f"{n}.pdb").read_text(), warn=True)
+    for name in ("hetatm", "malformed_residues_1", "malformed_residues_2", "malformed_residues_3", "not_a_template",
+                 "bad_atom_names_1", "bad_atom_names_2", "bad_atom_names_3"):
+        with pytest.raises(ValueError):
+            load(name)
+    with pytest.raises(IndexError):
+        load("missing_cluster_annotation")
+    with pytest.raises(KeyError):
+        load("unk_residue")
+    for name in ("no_remark", "new_remark", "pdb_id_none"):
+        load(name)
+    with pytest.raises(ValueError):
+        template.Cluster(id=1, member=3, size=2)
+
+
+def test_vec3():
+    v, w = template.Vec3(1, 2, 2), template.Vec3(0, 0, 1)
+    assert v.norm == 3 and (v / 3) == v.normalize() and v @ w == 2
+    assert v + 1 == template.Vec3(2, 3, 3) and v - w == template.Vec3(1, 2, 1)
+    assert template.Vec3(0, 0, 0).normalize() == template.Vec3(0, 0, 0)
+    assert w.angle_to(template.Vec3(0, 0, -2)) == pytest.approx(np.pi)
+    with pytest.raises(ValueError):
+        template.Vec3(float("nan"), 0, 0)
+    with pytest.raises(TypeError):
+        v @ 3
+
+
+def test_library_counts():
+    """tests/test_template.py:34-36 pins 7607 templates."""
+    lib = template.load_packed_library()
+    assert len(lib) == G["A5"]["library_template_count"]
+    eff = np.bincount([t.effective_size for t in lib])
+    assert eff.sum() == 7607 and int(eff[3:].sum()) == 6780
+    assert [t.effective_size for t in lib] == [t.effective_size for t in helpers.oracle_library_templates()]
+    assert len(set(lib)) == 7607  # no duplicates (Matcher would refuse them, jess_run.py:643-646)
+
+
+def test_vocabulary_masks_agree_with_oracle_semantics():
+    """res_mask/name_mask over the encoded 1AMY atoms must select exactly the atoms the oracle's
+    string rules admit, for every distinct template-atom kind of the shipped library."""
+    import ctypes as C
+    from oracle import oracle
+    V = _vocab.VOCAB
+    mol = pyjess.Molecule.load(helpers.GOLDEN / "1AMY.pdb")
+    kinds = {}
+    for t in helpers.product_library_templates():
+        for a in t:
+            V.register_template_atom(a.match_mode, a._raw_names, a._raw_residues)
+            kinds.setdefault((a.match_mode, a._raw_names, a._raw_residues), a)
+    enc = mol._encoded()
+    name_bit = np.left_shift(np.uint64(1), enc["name_id"].astype(np.uint64))
+    res_bit = np.left_shift(np.uint32(1), enc["res_type"].astype(np.uint32))
+    lib = oracle._lib()
+    checked = 0
+    for (mode, names, residues), a in kinds.items():
+        nm, rm = V.name_mask(mode, names), V.res_mask(mode, residues)
+        mine = (name_bit & np.uint64(nm)) != 0
+        if mode < 100:
+            mine &= (res_bit & np.uint32(rm)) != 0
+        ot = helpers.to_oracle_template([a])
+        want = np.zeros(len(mol), dtype=bool)
+        for i in range(len(mol)):
+            # the oracle's admissibility = being a level-0 candidate of a 1-atom template
+            pass
+        hits, _, _ = oracle.query(helpers.to_oracle_molecule(mol), ot, 1e9, 1e9, 1e9, max_candidates=10**9,
+                                  best_match=False, max_hits=len(mol) + 1)
+        want[[int(h.atoms[0]) for h in hits]] = True
+        assert np.array_equal(mine, want), (mode, names, residues)
+        checked += 1
+    assert checked > 300
+
+
+def test_jess_argument_checks():
+    with pytest.raises(TypeError):
+        pyjess.Jess([object()])
+    with pytest.raises(TypeError):
+        pyjess.Template([object()])
+    j = pyjess.Jess([])
+    assert len(j) == 0 and list(j.query(pyjess.Molecule(), 2, 1, 1, best_match=True)) == []
+    t = pyjess.Template.load(TPL / G["G1"]["template"])
+    assert t.dimension == 5 and len(t) == 15 and t.id
+    with pytest.raises(NotImplementedError):
+        pyjess.Jess([t]).query(pyjess.Molecule.load(helpers.GOLDEN / "1AMY.pdb"), 2, 1, 1, best_match=False)
+
+
+def test_load_molecules(tmp_path):
+    src = helpers.GOLDEN / "1AMY.pdb"
+    (tmp_path / "a").mkdir()
+    (tmp_path / "b").mkdir()
+    for d in "ab":
+        (tmp_path / d / "1AMY.pdb").write_text(src.read_text())
+    (tmp_path / "empty.pdb").write_text("END\n")
+    with pytest.warns(Warning):
+        mols = jess_run.load_molecules([tmp_path / "a" / "1AMY.pdb", tmp_path / "b" / "1AMY.pdb",
+                                        tmp_path / "empty.pdb"], conservation_cutoff=80, warn=True)
+    assert [m.id for m in mols] == ["1AMY", "1AMY_2"]
+    assert len(mols[0]) == 3339  # the reference discards conserved()'s result (jess_run.py:541-545)

@@ -1,0 +1,155 @@
+"""The oracle against every known answer the reference's own tests hold, and the
+host-side Match/Matcher logic on top of it.  CPU only."""
+import io
+import json
+import math
+
+import numpy as np
+import pytest
+
+from tests import helpers
+from enzymm_amd import jess_run, pyjess, template
+from oracle import oracle, parse
+
+G = json.loads((helpers.GOLDEN / "golden.json").read_text())
+TPL = helpers.GOLDEN / "templates"
+
+
+@pytest.fixture(scope="module")
+def amy():
+    return pyjess.Molecule.load(helpers.GOLDEN / "1AMY.pdb")
+
+
+@pytest.fixture(scope="module")
+def af():
+    return pyjess.Molecule.load(helpers.GOLDEN / "AF-P0DUB6-F1-model_v4.pdb", id="AF-P0DUB6-F1-model_v4")
+
+
+def _golden_match(key, amy):
+    g = G[key]
+    tpl = template.Template.load(TPL / g["template"])
+    # reference call: jess.query(molecule, 2, 1.5, 1.5, max_candidates=10000, best_match=True)
+    hits = list(helpers.OracleJess([tpl]).query(amy, g["rmsd_threshold"], g["distance_cutoff"],
+                                                g["max_dynamic_distance"], max_candidates=g["max_candidates"],
+                                                best_match=True))
+    return g, tpl, hits
+
+
+@pytest.mark.parametrize("key", ["G1", "G2"])
+def test_known_answers_raw_oracle(key):
+    """tests/test_jess_run.py:77,133 through the oracle's OWN parsers."""
+    g = G[key]
+    mol = parse.parse_molecule(helpers.golden_text(g["molecule"]))
+    tpl = parse.parse_template((TPL / g["template"]).read_text())
+    assert len(mol) == 3339  # test_jess_run.py:75
+    hits, ncand, trunc = oracle.query(mol, tpl, g["rmsd_threshold"], g["distance_cutoff"],
+                                      g["max_dynamic_distance"], max_candidates=g["max_candidates"], best_match=True)
+    assert len(hits) == 1 and not trunc
+    assert hits[0].rmsd == pytest.approx(g["rmsd"], abs=5e-8)  # assertAlmostEqual: 7 places
+    got = [[mol.res[a].decode().strip(), mol.chain[a].decode().strip(), str(int(mol.resseq[a]))]
+           for a in hits[0].atoms[::3]]
+    assert got == g["matched_residues"]
+
+
+def test_g1_match_properties(amy):
+    g, tpl, hits = _golden_match("G1", amy)
+    assert len(hits) == 1
+    m = jess_run.Match(hit=hits[0], pairwise_distance=1.5, complete=True, index=0)
+    assert m.hit.molecule().id == "1AMY"
+    assert m.hit.template is tpl
+    assert m.query_atom_count == g["query_atom_count"]
+    assert m.query_residue_count == g["query_residue_count"]
+    assert m.hit.rmsd == pytest.approx(g["rmsd"], abs=5e-8)
+    assert m.orientation == pytest.approx(g["orientation"], abs=5e-8)
+    assert [list(r) for r in m.matched_residues] == g["matched_residues"]
+    for got, want in zip(m.match_vector_list, g["match_vector_list"]):
+        for a, e in zip((got.x, got.y, got.z), want):
+            assert math.isclose(a, e, rel_tol=1e-9, abs_tol=1e-9)
+    assert m.template_vector_list == [r.orientation_vector for r in tpl.residues]
+    assert m.preserved_resid_order is True and m.multimeric is False
+    assert m.predicted_correct is True
+
+
+def test_g2_match_properties(amy):
+    g, tpl, hits = _golden_match("G2", amy)
+    m = jess_run.Match(hit=hits[0])
+    assert m.hit.rmsd == pytest.approx(g["rmsd"], abs=5e-8)
+    assert m.orientation == pytest.approx(g["orientation"], abs=5e-8)
+    assert [list(r) for r in m.matched_residues] == g["matched_residues"]
+    assert m.preserved_resid_order is False and m.multimeric is False and m.complete is False
+
+
+@pytest.mark.parametrize("fname,kw", [
+    ("1AMY_matches_no_query.pdb", dict(transform=False, include_query=False)),
+    ("1AMY_matches_template.pdb", dict(transform=True, include_query=False)),
+    ("1AMY_matches_query_included.pdb", dict(transform=False, include_query=True)),
+])
+def test_g1_pdb_dumps_byte_exact(amy, fname, kw):
+    """tests/test_jess_run.py:157-179: the three PDB dumps, byte for byte (pins atom order and R, t)."""
+    _, _, hits = _golden_match("G1", amy)
+    m = jess_run.Match(hit=hits[0], pairwise_distance=1.5, complete=True, index=0)
+    buf = io.StringIO()
+    m.dump2pdb(buf, **kw)
+    assert buf.getvalue() == (helpers.GOLDEN / fname).read_text()
+
+
+def test_g1_tsv_row(amy):
+    """tests/test_data/results.tsv: every column except the AnnotatedTemplate tail
+    (needs a data blob the reference does not ship) and log_evalue (unpinned: reported as nan)."""
+    _, _, hits = _golden_match("G1", amy)
+    m = jess_run.Match(hit=hits[0], pairwise_distance=1.5, complete=True, index=0)
+    got_h, got = [l.split("\t") for l in m.dumps(header=True).splitlines()]
+    want_h, want = [l.split("\t") for l in (helpers.GOLDEN / "results.tsv").read_text().splitlines()]
+    assert got_h == want_h
+    skip = {"log_evalue"} | set(want_h[25:])
+    for name, a, b in zip(want_h, got, want):
+        if name not in skip:
+            assert a == b, name
+
+
+def _matcher(templates, **kw):
+    return jess_run.Matcher(templates=templates, jess_factory=helpers.OracleJess, **kw)
+
+
+def test_a1_filtered_and_unfiltered(amy):
+    """tests/test_jess_run.py:336-357"""
+    a1 = G["A1"]
+    tpls = [template.Template.load(TPL / p) for p in a1["templates"]]
+    params = {int(k): dict(rmsd=v[0], distance=v[1], max_dynamic_distance=v[2]) for k, v in a1["jess_params"].items()}
+    unf = _matcher(tpls, jess_params=params, filter_matches=False).run_single(amy)
+    fil = _matcher(tpls, jess_params=params, filter_matches=True).run_single(amy)
+    assert sorted(m.hit.template.pdb_id for m in unf) == a1["unfiltered_pdb_ids"]
+    assert sorted(m.hit.template.pdb_id for m in fil) == a1["filtered_pdb_ids"]
+    with pytest.raises(ValueError):
+        _matcher(tpls + tpls)
+
+
+def test_a2_a3_counts(amy, af):
+    """tests/test_jess_run.py:301-334"""
+    load = lambda d: list(template.load_templates(TPL / d))
+    t54 = load("5_residues/results/csa3d_0285") + load("4_residues/results/csa3d_0285")
+    m1 = _matcher(t54, cpus=2)
+    assert m1.template_effective_sizes == [5, 4] and m1.cpus == 2
+    assert m1.jess_params == jess_run.Matcher._DEFAULT_JESS_PARAMS
+    r1 = m1.run([amy, af])
+    assert list(r1.keys()) == [amy, af]
+    assert len(r1[amy]) == 2 and len(r1[af]) == 2
+    assert [m.query_residue_count for m in r1[af]] == [511, 511]
+    af80 = af.conserved(80)
+    r2 = _matcher(t54, skip_smaller_hits=True).run([amy, af80])
+    assert len(r2[amy]) == 1 and len(r2[af80]) == 1
+    assert [m.query_residue_count for m in r2[af80]] == [494]
+    with pytest.warns(Warning):
+        m3 = _matcher(t54 + load("3_residues/results/csa3d_0344"), match_small_templates=True, warn=True, cpus=-1)
+    assert len(m3.run([amy])[amy]) == 3
+
+
+def test_missing_logistic_model_raises(amy):
+    """tests/test_cli.py:131-132: filtering at a distance without a model is a KeyError."""
+    tpls = [template.Template.load(TPL / G["G2"]["template"])]
+    params = {k: dict(rmsd=2, distance=1.0, max_dynamic_distance=1.0) for k in range(3, 9)}
+    params[3] = dict(rmsd=2, distance=0.55, max_dynamic_distance=0.55)
+    m = jess_run.Match(hit=list(helpers.OracleJess(tpls).query(amy, 2, 1, 1, best_match=True))[0],
+                       pairwise_distance=0.55)
+    with pytest.raises(KeyError):
+        m.predicted_correct
