@@ -19,6 +19,9 @@ constexpr int kSearchBlock = kWave * kSearchWaves;
 // slack lets through is re-checked in fp64 before it can become a candidate.
 constexpr double kPrefilterSlack = 2e-3;
 
+// best_match: RMSDs closer than this are a tie, resolved by the smaller atom-index tuple.
+constexpr double kTieEps = 1e-9;
+
 // bits of the packed per-atom meta word (float4.w of a target atom record)
 //   [15:0] residue ordinal   [21:16] atom-name id   [26:22] residue-type id
 __host__ __device__ inline uint32_t meta_pack(uint32_t res, uint32_t name, uint32_t rtype) {

@@ -512,9 +512,10 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(LibView L, BatchView B,
             }
             const double rmsd = sqrt(sum * inv_k);
             if (!(rmsd <= rmsd_thr)) continue;
-            bool better = !found || rmsd < best_rmsd;
-            if (found && rmsd == best_rmsd) {
-                // tie: lexicographically smaller tuple in TEMPLATE order wins (the oracle's first)
+            bool better = !found || rmsd < best_rmsd - kTieEps;
+            if (found && !better && rmsd <= best_rmsd + kTieEps) {
+                // tie (symmetric copies of a site): the lexicographically smaller tuple in TEMPLATE
+                // order wins, whatever order the two were found in
                 // lane l < k compares the atom at template position orig[l]
                 uint32_t mine = 0, theirs = 0, pos = 0xffffffffu;
                 if (lane < k) { mine = S.aidx[lane]; theirs = S.best[lane]; pos = S.orig[lane]; }

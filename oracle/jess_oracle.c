@@ -50,8 +50,12 @@
  *  - every complete assignment ("candidate") is superposed onto the template
  *    with the optimal PROPER rotation; RMSD = sqrt(sum |R q + t - p|^2 / k).
  *  - a candidate is a hit when RMSD <= rmsd_threshold.  best_match keeps, per
- *    template, the hit of minimum RMSD (ties: the first in enumeration order,
- *    i.e. the lexicographically smallest tuple of target atom indices).
+ *    template, the hit of minimum RMSD.  Two hits whose RMSDs differ by less
+ *    than ORACLE_TIE_EPS (1e-9 A: exact symmetric copies of a site, e.g. the
+ *    chains of a homo-oligomer built by symmetry operators) count as tied and
+ *    the first in enumeration order -- the lexicographically smallest tuple of
+ *    target atom indices -- is kept.  [UNPINNED: which of two tied sites PyJess
+ *    reports depends on Jess's traversal order.]
  *  - max_candidates: at most that many candidates are evaluated per
  *    (template, molecule); if more exist the search stops and `truncated` is
  *    set.  Which candidates Jess would have seen first is [UNPINNED]; parity
@@ -70,6 +74,7 @@
 #define ORACLE_MAXK 64
 #define ORACLE_EUNSUPPORTED (-2)
 #define ORACLE_EINVAL (-1)
+#define ORACLE_TIE_EPS 1e-9
 
 /* ------------------------------------------------------------------ names */
 
@@ -275,7 +280,7 @@ static void on_candidate(search_t *s)
     rmsd = superpose(s->k, (const double (*)[3])q, s->txyz, rot, trans);
     if (!(rmsd <= s->rmsd_thr)) return;
     if (s->best_match) {
-        if (s->nhits == 1 && !(rmsd < s->out_rmsd[0])) return; /* ties keep the earlier */
+        if (s->nhits == 1 && !(rmsd < s->out_rmsd[0] - ORACLE_TIE_EPS)) return; /* ties keep the earlier */
         slot = 0;
         s->nhits = 1;
     } else {
