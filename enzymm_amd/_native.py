@@ -21,7 +21,10 @@ TM_OK, TM_E_INVALID, TM_E_UNSUPPORTED, TM_E_DEVICE, TM_E_NOMEM, TM_E_OVERFLOW = 
 TM_FLAG_IGNORE_CHAIN, TM_FLAG_BEST_MATCH, TM_FLAG_COUNT_CANDIDATES, TM_FLAG_REBUILD_INDEX = 1, 2, 4, 8
 TM_HIT_TRUNCATED = 1
 
-LIB_PATH = Path(__file__).resolve().parent / "libenzymm_amd.so"
+import os
+
+# $ENZYMM_AMD_LIB selects another build of the same ABI (the diagnostic `make stats` library)
+LIB_PATH = Path(os.environ.get("ENZYMM_AMD_LIB") or Path(__file__).resolve().parent / "libenzymm_amd.so")
 
 #: numpy view of ``struct tm_hit`` (224 bytes)
 HIT_DTYPE = np.dtype(

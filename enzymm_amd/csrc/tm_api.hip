@@ -66,7 +66,7 @@ struct tm_library {
     DevBuf<uint32_t> d_t_off, d_k_resmask, d_lead_kind;
     DevBuf<double> d_xyz, d_w;
     DevBuf<uint16_t> d_kind;
-    DevBuf<uint8_t> d_group, d_orig, d_chain, d_k_any;
+    DevBuf<uint8_t> d_group, d_orig, d_chain, d_k_any, d_ref;
     DevBuf<uint64_t> d_k_namemask;
     DevBuf<int32_t> d_k_lead;
     uint64_t serial = 0;  // identity for the batch-side index cache
@@ -74,7 +74,7 @@ struct tm_library {
         LibView v;
         v.n_templates = n_templates; v.n_kinds = n_kinds; v.n_lead = n_lead;
         v.t_off = d_t_off.p; v.a_xyz = d_xyz.p; v.a_w = d_w.p; v.a_kind = d_kind.p;
-        v.a_group = d_group.p; v.a_orig = d_orig.p; v.a_chain = d_chain.p;
+        v.a_group = d_group.p; v.a_ref = d_ref.p; v.a_orig = d_orig.p; v.a_chain = d_chain.p;
         v.k_resmask = d_k_resmask.p; v.k_namemask = d_k_namemask.p; v.k_any = d_k_any.p;
         v.k_lead = d_k_lead.p; v.lead_kind = d_lead_kind.p;
         return v;
@@ -126,34 +126,67 @@ namespace {
 
 uint64_t g_serial = 0;
 
-// Search order of one template: template residues ("groups") by ascending expected number
-// of admissible target atoms of their most selective atom; inside a group that atom first.
-// Any order enumerates the same set of assignments; this one keeps the search tree narrow.
+// Search order of one template.  Any order enumerates the same set of assignments; this one keeps
+// the search tree narrow:
+//   1. the LEAD atom (most selective atom) of every template residue first -- greedily, starting
+//      with the rarest kind and then always the residue whose lead is rare AND close to the leads
+//      already placed (a short template distance means a thin shell of admissible positions);
+//      lead-to-lead distances prune whole residues before any residue is expanded;
+//   2. then the remaining atoms, residue by residue in that order, each looked up inside the target
+//      residue its lead was assigned to.
 struct Plan {
     std::vector<int> order;  // search position -> template atom
-    std::vector<int> group;  // search position -> group index in search order
+    std::vector<int> group;  // search position -> group index (numbered in lead order)
+    std::vector<int> ref;    // search position -> search position of the group's lead
 };
 
-Plan plan_template(int k, const uint8_t *group, const double *est) {
-    std::vector<int> groups;  // distinct group ids in first-appearance order
+Plan plan_template(int k, const uint8_t *group, const double *est, const double *xyz) {
+    std::vector<int> ids;  // distinct group ids in first-appearance order
     for (int i = 0; i < k; ++i)
-        if (std::find(groups.begin(), groups.end(), (int)group[i]) == groups.end()) groups.push_back(group[i]);
-    struct G { int id; double best; int lead; int first; };
-    std::vector<G> gs;
-    for (size_t gi = 0; gi < groups.size(); ++gi) {
-        G g{groups[gi], 1e300, -1, (int)gi};
+        if (std::find(ids.begin(), ids.end(), (int)group[i]) == ids.end()) ids.push_back(group[i]);
+    const int G = (int)ids.size();
+    std::vector<int> lead(G, -1);
+    for (int g = 0; g < G; ++g)
         for (int i = 0; i < k; ++i)
-            if (group[i] == g.id && est[i] < g.best) { g.best = est[i]; g.lead = i; }
-        gs.push_back(g);
+            if (group[i] == ids[g] && (lead[g] < 0 || est[i] < est[lead[g]])) lead[g] = i;
+    std::vector<int> chosen;  // group slots in lead order
+    std::vector<bool> used(G, false);
+    for (int step = 0; step < G; ++step) {
+        int best = -1;
+        double best_score = 0;
+        for (int g = 0; g < G; ++g) {
+            if (used[g]) continue;
+            double score = est[lead[g]];
+            if (!chosen.empty()) {
+                double dmin2 = 1e300;
+                for (int c : chosen) {
+                    double d2 = 0;
+                    for (int a = 0; a < 3; ++a) {
+                        const double d = xyz[3 * lead[g] + a] - xyz[3 * lead[c] + a];
+                        d2 += d * d;
+                    }
+                    dmin2 = std::min(dmin2, d2);
+                }
+                score *= dmin2 + 1.0;
+            }
+            if (best < 0 || score < best_score) { best = g; best_score = score; }
+        }
+        used[best] = true;
+        chosen.push_back(best);
     }
-    std::stable_sort(gs.begin(), gs.end(), [](const G &a, const G &b) { return a.best < b.best; });
     Plan p;
-    for (size_t gi = 0; gi < gs.size(); ++gi) {
-        p.order.push_back(gs[gi].lead);
-        p.group.push_back((int)gi);
-        for (int i = 0; i < k; ++i)
-            if (group[i] == gs[gi].id && i != gs[gi].lead) { p.order.push_back(i); p.group.push_back((int)gi); }
+    for (int n = 0; n < G; ++n) {
+        p.order.push_back(lead[chosen[n]]);
+        p.group.push_back(n);
+        p.ref.push_back(n);
     }
+    for (int n = 0; n < G; ++n)
+        for (int i = 0; i < k; ++i)
+            if (group[i] == ids[chosen[n]] && i != lead[chosen[n]]) {
+                p.order.push_back(i);
+                p.group.push_back(n);
+                p.ref.push_back(n);
+            }
     return p;
 }
 
@@ -180,7 +213,7 @@ int tm_library_create(int device, const tm_library_desc *d, tm_library **out) {
     const uint32_t na = d->atom_offsets[nt];
     std::vector<double> xyz(3 * (size_t)na), w(na);
     std::vector<uint16_t> kind(na);
-    std::vector<uint8_t> group(na), orig(na), chain(na);
+    std::vector<uint8_t> group(na), orig(na), chain(na), ref(na);
     std::map<std::tuple<uint8_t, uint32_t, uint64_t>, uint32_t> kinds;
     std::vector<uint32_t> k_resmask;
     std::vector<uint64_t> k_namemask;
@@ -201,8 +234,8 @@ int tm_library_create(int device, const tm_library_desc *d, tm_library **out) {
             const double nres = any ? 20.0 : (double)__builtin_popcount(d->res_mask[o + i]);
             est[i] = nres * (double)__builtin_popcountll(d->name_mask[o + i]);
         }
-        Plan p = plan_template(k, d->group + o, est);
-        if ((int)p.group.back() + 1 > kMaxG)
+        Plan p = plan_template(k, d->group + o, est, d->xyz + 3 * (size_t)o);
+        if (*std::max_element(p.group.begin(), p.group.end()) + 1 > kMaxG)
             return fail(TM_E_UNSUPPORTED, "template " + std::to_string(t) + " has more than " +
                                               std::to_string(kMaxG) + " residues");
         for (int pos = 0; pos < k; ++pos) {
@@ -211,6 +244,7 @@ int tm_library_create(int device, const tm_library_desc *d, tm_library **out) {
             for (int a = 0; a < 3; ++a) xyz[3 * (size_t)dst + a] = d->xyz[3 * (size_t)src + a];
             w[dst] = d->dist_weight ? d->dist_weight[src] : 0.0;
             group[dst] = (uint8_t)p.group[pos];
+            ref[dst] = (uint8_t)p.ref[pos];
             orig[dst] = (uint8_t)i;
             chain[dst] = d->chain ? d->chain[src] : 0;
             const uint8_t any = (d->any_residue && d->any_residue[src]) ? 1 : 0;
@@ -225,7 +259,7 @@ int tm_library_create(int device, const tm_library_desc *d, tm_library **out) {
                 k_lead.push_back(-1);
             }
             kind[dst] = (uint16_t)it->second;
-            const bool lead = pos == 0 || p.group[pos] != p.group[pos - 1];
+            const bool lead = p.ref[pos] == pos;
             if (lead && k_lead[it->second] < 0) {
                 k_lead[it->second] = (int32_t)lead_kind.size();
                 lead_kind.push_back(it->second);
@@ -243,7 +277,7 @@ int tm_library_create(int device, const tm_library_desc *d, tm_library **out) {
     hipError_t e = hipSuccess;
     auto up = [&](hipError_t r) { if (e == hipSuccess) e = r; };
     up(lib->d_t_off.upload(lib->t_off)); up(lib->d_xyz.upload(xyz)); up(lib->d_w.upload(w));
-    up(lib->d_kind.upload(kind)); up(lib->d_group.upload(group)); up(lib->d_orig.upload(orig));
+    up(lib->d_kind.upload(kind)); up(lib->d_group.upload(group)); up(lib->d_ref.upload(ref)); up(lib->d_orig.upload(orig));
     up(lib->d_chain.upload(chain)); up(lib->d_k_resmask.upload(k_resmask));
     up(lib->d_k_namemask.upload(k_namemask)); up(lib->d_k_any.upload(k_any));
     up(lib->d_k_lead.upload(k_lead)); up(lib->d_lead_kind.upload(lead_kind));
@@ -523,6 +557,17 @@ int tm_result_timing(tm_result *r, float *index_ms, float *search_ms) {
 }
 
 const void *tm_result_device_hits(tm_result *r) { return r ? r->d_hits.p : nullptr; }
+
+#ifdef TM_STATS
+// diagnostic build only (make stats): read and reset the search counters
+int tm_debug_stats(unsigned long long *out) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(tmx::g_stats), 64 * sizeof(unsigned long long)));
+    unsigned long long zero[64] = {0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(tmx::g_stats), zero, sizeof zero));
+    return TM_OK;
+}
+#endif
 
 void tm_result_destroy(tm_result *r) {
     if (!r) return;

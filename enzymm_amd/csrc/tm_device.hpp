@@ -38,7 +38,8 @@ struct LibView {
     const double *a_xyz;     // [n_atoms*3]
     const double *a_w;       // [n_atoms] distance weight
     const uint16_t *a_kind;  // [n_atoms] -> kind table
-    const uint8_t *a_group;  // [n_atoms] template residue index, non-decreasing in search order
+    const uint8_t *a_group;  // [n_atoms] template residue index (search-order numbering)
+    const uint8_t *a_ref;    // [n_atoms] search position of the residue's lead atom (== own position for a lead)
     const uint8_t *a_orig;   // [n_atoms] position of this atom in TEMPLATE (file) order
     const uint8_t *a_chain;  // [n_atoms] template chain ordinal
     // kind = distinct (any_residue, res_mask, name_mask) triple

@@ -15,6 +15,15 @@
 
 namespace tmx {
 
+#ifdef TM_STATS
+// diagnostic build only: [0..23] chunk evaluations per level, [24..47] survivors per level,
+// [48] complete assignments, [49] searches, [50] pair tests (j-loop trips), [51] fp64 rejects
+__device__ unsigned long long g_stats[64];
+#define TM_STAT(i, v) do { if (lane_id() == 0) atomicAdd(&g_stats[i], (unsigned long long)(v)); } while (0)
+#else
+#define TM_STAT(i, v) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------ wave helpers
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
@@ -235,7 +244,7 @@ struct __align__(16) WaveScratch {
     uint32_t cnt[kMaxK];              // number of candidates at this level
     uint32_t best[kMaxK];             // best assignment so far (search order)
     uint16_t surv[kMaxG][64];         // lead levels: candidate atom of every lane of the current chunk
-    uint8_t group[kMaxK], tchain[kMaxK], orig[kMaxK], any[kMaxK], lead[kMaxK], achain[kMaxK];
+    uint8_t group[kMaxK], tchain[kMaxK], orig[kMaxK], any[kMaxK], lead[kMaxK], achain[kMaxK], ref[kMaxK];
 };
 
 struct SearchCtx {
@@ -280,6 +289,7 @@ __device__ __forceinline__ unsigned long long eval_chunk(const SearchCtx &C, int
         cchain = C.qchain[cand];
         mychain = uni((uint32_t)S.tchain[level]);
     }
+    TM_STAT(level, 1);
     if (__ballot(ok) == 0ull) return 0ull;
     const int pbase = tri(level);
     for (int j = 0; j < level; ++j) {
@@ -295,8 +305,10 @@ __device__ __forceinline__ unsigned long long eval_chunk(const SearchCtx &C, int
             const bool qc = (uint32_t)S.achain[j] == cchain;
             ok = ok && (tc == qc);
         }
+        TM_STAT(50, 1);
         if (__ballot(ok) == 0ull) return 0ull;
     }
+    TM_STAT(24 + level, __popcll(__ballot(ok)));
     return __ballot(ok);
 }
 
@@ -307,8 +319,8 @@ __device__ __forceinline__ void init_level(const SearchCtx &C, int level) {
         S.cur[level] = 0;
         S.pend[level] = 0ull;
         if (!S.lead[level]) {
-            // same template residue as level-1: scan the atoms of that target residue
-            const uint32_t res = meta_res(__float_as_uint(S.arec[level - 1].w));
+            // same template residue as an already placed lead atom: scan the atoms of that target residue
+            const uint32_t res = meta_res(__float_as_uint(S.arec[S.ref[level]].w));
             const uint32_t s0 = C.res_start[res], s1 = C.res_start[res + 1];
             S.lo[level] = s0;
             S.cnt[level] = s1 - s0;
@@ -369,13 +381,16 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(LibView L, BatchView B,
         const int k = (int)(L.t_off[t + 1] - off);
         const int npairs = tri(k);
         C.k = k;
+        TM_STAT(49, 1);
 
         // ---- stage the template: per-level admissibility, candidate source, pair bounds
         if (lane < k) {
             const uint32_t kind = L.a_kind[off + lane];
             const uint8_t g = L.a_group[off + lane];
-            const bool lead = lane == 0 || L.a_group[off + lane - 1] != g;
+            const uint8_t ref = L.a_ref[off + lane];
+            const bool lead = ref == lane;
             S.group[lane] = g;
+            S.ref[lane] = ref;
             S.tchain[lane] = L.a_chain[off + lane];
             S.orig[lane] = L.a_orig[off + lane];
             S.resmask[lane] = L.k_resmask[kind];
@@ -468,7 +483,8 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(LibView L, BatchView B,
                     if (fabs(dq - dt) > thr) bad = true;
                 }
             }
-            if (__ballot(bad)) continue;  // fp32 prefilter false positive
+            TM_STAT(48, 1);
+            if (__ballot(bad)) { TM_STAT(51, 1); continue; }  // fp32 prefilter false positive
             if (ncand >= Q.max_candidates) {
                 truncated = true;
                 break;
