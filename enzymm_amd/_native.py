@@ -58,12 +58,13 @@ class _QueryParams(C.Structure):
         ("n_selected", C.c_uint32), ("template_index", C.c_void_p), ("rmsd_threshold", C.c_void_p),
         ("distance_cutoff", C.c_void_p), ("max_dynamic_distance", C.c_void_p), ("max_candidates", C.c_uint32),
         ("flags", C.c_uint32), ("hit_capacity", C.c_uint64), ("stream", C.c_void_p),
+        ("candidate_capacity", C.c_uint64),
     ]
 
 
 EXPORTS = (
     "tm_abi_version", "tm_last_error", "tm_device_count", "tm_library_create", "tm_library_destroy",
-    "tm_batch_create", "tm_batch_destroy", "tm_query", "tm_result_wait", "tm_result_hit_count",
+    "tm_batch_create", "tm_batch_destroy", "tm_query", "tm_result_wait", "tm_result_needed", "tm_result_hit_count",
     "tm_result_copy_hits", "tm_result_copy_candidates", "tm_result_timing", "tm_result_device_hits",
     "tm_result_destroy",
 )
@@ -194,9 +195,15 @@ class Result:
         return out
 
     def timing(self):
-        """(index_ms, search_ms) measured with HIP events on the launch stream."""
-        a, b = C.c_float(0), C.c_float(0)
-        _check(load().tm_result_timing(self._h, C.byref(a), C.byref(b)))
+        """(index_ms, search_ms, finish_ms) measured with HIP events on the launch stream."""
+        a, b, c = C.c_float(0), C.c_float(0), C.c_float(0)
+        _check(load().tm_result_timing(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def needed(self):
+        """(candidates, pairs) this query produced -- the capacities a retry after TM_E_OVERFLOW needs."""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        _check(load().tm_result_needed(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
     def device_hits_ptr(self) -> int:
@@ -211,7 +218,10 @@ class Result:
 
 
 def query(library: Library, batch: Batch, template_index, rmsd_threshold, distance_cutoff, max_dynamic_distance,
-          max_candidates: int, flags: int, hit_capacity: int = 0, stream: int = 0) -> Result:
+          max_candidates: int, flags: int, hit_capacity: int = 0, stream: int = 0,
+          candidate_capacity: int = 0, retry: bool = True) -> Result:
+    """Launch one query.  With ``retry`` the call waits for the result and, if a result table
+    overflowed, re-runs with the sizes the first run reported."""
     n = len(template_index)
     keep = [
         _arr(template_index, np.uint32),
@@ -220,27 +230,21 @@ def query(library: Library, batch: Batch, template_index, rmsd_threshold, distan
         _arr(np.broadcast_to(np.asarray(max_dynamic_distance, dtype=np.float64), (n,)), np.float64),
     ]
     params = _QueryParams(n, *[_ptr(a) for a in keep], int(max_candidates), int(flags), int(hit_capacity),
-                          C.c_void_p(stream or None))
-    handle = C.c_void_p()
-    while True:
+                          C.c_void_p(stream or None), int(candidate_capacity))
+    for _ in range(4):
+        handle = C.c_void_p()
         _check(load().tm_query(library._h, batch._h, C.byref(params), C.byref(handle)))
         res = Result(handle, batch.n_structures, n)
+        if not retry:
+            return res
         try:
-            res.wait() if hit_capacity == 0 else None
+            res.wait()
             return res
         except NativeError as exc:
             if exc.code != TM_E_OVERFLOW:
                 raise
-            # automatic capacity was too small: retry with room for everything that was found
-            params.hit_capacity = max(2 * res.hit_count_unchecked(), 8192)
+            cands, pairs = res.needed()
             res.close()
-            handle = C.c_void_p()
-
-
-def _hit_count_unchecked(self) -> int:
-    n = C.c_uint64(0)
-    load().tm_result_hit_count(self._h, C.byref(n))
-    return n.value
-
-
-Result.hit_count_unchecked = _hit_count_unchecked
+            params.candidate_capacity = max(int(1.25 * cands) + 1024, 65536)
+            params.hit_capacity = max(int(1.25 * pairs) + 1024, 4096)
+    raise NativeError(TM_E_OVERFLOW, "result tables kept overflowing")

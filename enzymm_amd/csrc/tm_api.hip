@@ -107,15 +107,19 @@ struct tm_result {
     int device = 0;
     hipStream_t stream = nullptr;
     uint32_t n_structs = 0, n_sel = 0;
-    unsigned long long capacity = 0;
+    unsigned long long hit_capacity = 0, cand_capacity = 0;
     DevBuf<tm_hit> d_hits;
-    DevBuf<unsigned long long> d_n_hits;
+    DevBuf<Cand> d_cands;
+    DevBuf<PairEntry> d_pairs;
+    DevBuf<unsigned long long> d_counters;  // [0] hits, [1] candidates, [2] pairs
     DevBuf<uint32_t> d_overflow, d_candidates, d_sel;
-    DevBuf<double> d_rmsd, d_cut, d_maxdyn;
+    DevBuf<double> d_rmsd, d_cut, d_maxdyn, d_cand_rmsd;
     DevBuf<float2> d_bounds;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-    bool waited = false, overflowed = false;
-    unsigned long long n_hits = 0;
+    DevBuf<Staged> d_staged;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool waited = false;
+    uint32_t overflow = 0;
+    unsigned long long n_hits = 0, n_cands = 0, n_pairs = 0;
     ~tm_result() {
         for (auto &e : ev)
             if (e) (void)hipEventDestroy(e);
@@ -435,13 +439,19 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
         md(p->max_dynamic_distance, p->max_dynamic_distance + n_sel);
     HIP_TRY(r->d_sel.upload(sel)); HIP_TRY(r->d_rmsd.upload(rm)); HIP_TRY(r->d_cut.upload(cu)); HIP_TRY(r->d_maxdyn.upload(md));
     HIP_TRY(r->d_bounds.alloc((size_t)n_sel * kMaxPairs));
-    unsigned long long cap = p->hit_capacity;
-    if (!cap) cap = std::max<unsigned long long>(4096, (unsigned long long)b->n_structs * std::min<uint32_t>(n_sel, 512));
-    r->capacity = cap;
-    HIP_TRY(r->d_hits.alloc(cap));
-    HIP_TRY(r->d_n_hits.alloc(1));
+    HIP_TRY(r->d_staged.alloc(n_sel));
+    unsigned long long hcap = p->hit_capacity, ccap = p->candidate_capacity;
+    if (!hcap) hcap = std::max<unsigned long long>(4096, 64ull * b->n_structs);
+    if (!ccap) ccap = std::max<unsigned long long>(65536, 256ull * b->n_structs);
+    if (ccap > 0xfffffffeull) return fail(TM_E_UNSUPPORTED, "candidate_capacity must be below 2^32 - 1");
+    r->hit_capacity = hcap; r->cand_capacity = ccap;
+    HIP_TRY(r->d_hits.alloc(hcap));
+    HIP_TRY(r->d_pairs.alloc(hcap));
+    HIP_TRY(r->d_cands.alloc(ccap));
+    HIP_TRY(r->d_cand_rmsd.alloc(ccap));
+    HIP_TRY(r->d_counters.alloc(3));
     HIP_TRY(r->d_overflow.alloc(1));
-    HIP_TRY(hipMemsetAsync(r->d_n_hits.p, 0, sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(r->d_counters.p, 0, 3 * sizeof(unsigned long long), stream));
     HIP_TRY(hipMemsetAsync(r->d_overflow.p, 0, sizeof(uint32_t), stream));
     if (p->flags & TM_FLAG_COUNT_CANDIDATES) {
         HIP_TRY(r->d_candidates.alloc((size_t)b->n_structs * n_sel));
@@ -454,22 +464,24 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
         if (rc != TM_OK) return rc;
     }
     if (n_sel) {
-        hipLaunchKernelGGL(k_pair_bounds, dim3(n_sel), dim3(64), 0, stream, lib->view(), n_sel, r->d_sel.p, r->d_cut.p,
-                           r->d_maxdyn.p, r->d_bounds.p);
+        hipLaunchKernelGGL(k_stage_templates, dim3(n_sel), dim3(64), 0, stream, lib->view(), n_sel, r->d_sel.p,
+                           r->d_cut.p, r->d_maxdyn.p, r->d_staged.p, r->d_bounds.p);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(r->ev[1], stream));
 
+    QueryView Q;
+    Q.n_sel = n_sel; Q.sel = r->d_sel.p; Q.rmsd_thr = r->d_rmsd.p; Q.cutoff = r->d_cut.p; Q.maxdyn = r->d_maxdyn.p;
+    Q.staged = r->d_staged.p; Q.bounds = r->d_bounds.p; Q.max_candidates = p->max_candidates; Q.flags = p->flags;
+    OutView O;
+    O.cands = r->d_cands.p; O.cand_rmsd = r->d_cand_rmsd.p; O.n_cands = r->d_counters.p + 1; O.cand_capacity = ccap;
+    O.pairs = r->d_pairs.p; O.n_pairs = r->d_counters.p + 2; O.pair_capacity = hcap;
+    O.hits = r->d_hits.p; O.n_hits = r->d_counters.p; O.hit_capacity = hcap; O.overflow = r->d_overflow.p;
+    O.candidates = (p->flags & TM_FLAG_COUNT_CANDIDATES) ? r->d_candidates.p : nullptr;
     if (n_sel && b->n_structs) {
-        QueryView Q;
-        Q.n_sel = n_sel; Q.sel = r->d_sel.p; Q.rmsd_thr = r->d_rmsd.p; Q.cutoff = r->d_cut.p; Q.maxdyn = r->d_maxdyn.p;
-        Q.bounds = r->d_bounds.p; Q.max_candidates = p->max_candidates; Q.flags = p->flags;
-        OutView O;
-        O.hits = r->d_hits.p; O.n_hits = r->d_n_hits.p; O.capacity = cap; O.overflow = r->d_overflow.p;
-        O.candidates = (p->flags & TM_FLAG_COUNT_CANDIDATES) ? r->d_candidates.p : nullptr;
         // enough workgroups to fill 256 CUs several times over; every chunk of a structure on one XCD
-        const uint32_t min_chunk = 16;
-        uint32_t n_chunks = (4096 + b->n_structs - 1) / b->n_structs;
+        const uint32_t min_chunk = 2 * kSearchWaves;
+        uint32_t n_chunks = (2048 + b->n_structs - 1) / b->n_structs;
         n_chunks = std::max(1u, std::min(n_chunks, (n_sel + min_chunk - 1) / min_chunk));
         const uint32_t chunk_size = (n_sel + n_chunks - 1) / n_chunks;
         n_chunks = (n_sel + chunk_size - 1) / chunk_size;
@@ -492,6 +504,14 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(r->ev[2], stream));
+    if (n_sel && b->n_structs) {
+        // candidate and pair counts live on the device: fixed grids with grid-stride loops, no host sync
+        hipLaunchKernelGGL(k_superpose, dim3(512), dim3(256), 0, stream, lib->view(), b->view(), Q, O);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k_select, dim3(256), dim3(256), 0, stream, lib->view(), b->view(), Q, O);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(r->ev[3], stream));
     guard.r = nullptr;
     *out = r;
     return TM_OK;
@@ -501,16 +521,26 @@ int tm_result_wait(tm_result *r) {
     if (!r) return fail(TM_E_INVALID, "result is NULL");
     if (!r->waited) {
         HIP_TRY(hipSetDevice(r->device));
-        uint32_t ovf = 0;
-        HIP_TRY(hipMemcpyAsync(&r->n_hits, r->d_n_hits.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, r->stream));
-        HIP_TRY(hipMemcpyAsync(&ovf, r->d_overflow.p, sizeof ovf, hipMemcpyDeviceToHost, r->stream));
+        unsigned long long counters[3] = {0, 0, 0};
+        HIP_TRY(hipMemcpyAsync(counters, r->d_counters.p, sizeof counters, hipMemcpyDeviceToHost, r->stream));
+        HIP_TRY(hipMemcpyAsync(&r->overflow, r->d_overflow.p, sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
         HIP_TRY(hipStreamSynchronize(r->stream));
+        r->n_hits = counters[0]; r->n_cands = counters[1]; r->n_pairs = counters[2];
         r->waited = true;
-        r->overflowed = ovf != 0 || r->n_hits > r->capacity;
     }
-    if (r->overflowed)
-        return fail(TM_E_OVERFLOW, "hit table overflow: " + std::to_string(r->n_hits) + " hits, capacity " +
-                                       std::to_string(r->capacity));
+    if (r->overflow)
+        return fail(TM_E_OVERFLOW, "result tables too small: " + std::to_string(r->n_cands) + " candidates (capacity " +
+                                       std::to_string(r->cand_capacity) + "), " + std::to_string(r->n_pairs) +
+                                       " pairs (capacity " + std::to_string(r->hit_capacity) + ")");
+    return TM_OK;
+}
+
+int tm_result_needed(tm_result *r, uint64_t *candidates, uint64_t *pairs) {
+    if (!r) return fail(TM_E_INVALID, "result is NULL");
+    int rc = tm_result_wait(r);
+    if (rc != TM_OK && rc != TM_E_OVERFLOW) return rc;
+    if (candidates) *candidates = r->n_cands;
+    if (pairs) *pairs = r->n_pairs;
     return TM_OK;
 }
 
@@ -544,15 +574,17 @@ int tm_result_copy_candidates(tm_result *r, uint32_t *out, uint64_t n) {
     return TM_OK;
 }
 
-int tm_result_timing(tm_result *r, float *index_ms, float *search_ms) {
+int tm_result_timing(tm_result *r, float *index_ms, float *search_ms, float *finish_ms) {
     if (!r) return fail(TM_E_INVALID, "result is NULL");
     HIP_TRY(hipSetDevice(r->device));
-    HIP_TRY(hipEventSynchronize(r->ev[2]));
-    float a = 0, s = 0;
+    HIP_TRY(hipEventSynchronize(r->ev[3]));
+    float a = 0, s = 0, f = 0;
     HIP_TRY(hipEventElapsedTime(&a, r->ev[0], r->ev[1]));
     HIP_TRY(hipEventElapsedTime(&s, r->ev[1], r->ev[2]));
+    HIP_TRY(hipEventElapsedTime(&f, r->ev[2], r->ev[3]));
     if (index_ms) *index_ms = a;
     if (search_ms) *search_ms = s;
+    if (finish_ms) *finish_ms = f;
     return TM_OK;
 }
 

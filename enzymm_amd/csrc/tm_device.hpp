@@ -11,8 +11,9 @@ constexpr int kMaxK = TM_MAX_TEMPLATE_ATOMS;        // template atoms per templa
 constexpr int kMaxG = TM_MAX_TEMPLATE_GROUPS;       // template residues
 constexpr int kMaxPairs = kMaxK * (kMaxK - 1) / 2;  // 276 pair constraints
 constexpr int kWave = 64;
-constexpr int kSearchWaves = 8;  // waves per search workgroup
+constexpr int kSearchWaves = 16;  // waves per search workgroup (one structure copy in LDS serves all)
 constexpr int kSearchBlock = kWave * kSearchWaves;
+constexpr int kJointList = 256;   // lead lists up to this length are staged in LDS for the joint top-level scan
 
 // fp32 prefilter slack (Angstrom) added to every pair threshold.  Centred fp32
 // coordinates of a <= 300 A structure carry < 4e-5 A of rounding; anything the
@@ -65,23 +66,54 @@ struct BatchView {
     const uint16_t *kl_pool;  // local atom indices, ascending
 };
 
+// One selected template, flattened for the search kernel (written by k_stage_templates).
+struct __align__(16) Staged {
+    unsigned long long namemask[kMaxK];
+    uint32_t resmask[kMaxK];
+    uint16_t lead_li[kMaxK];  // lead levels: index among lead kinds; 0xffff otherwise
+    uint8_t group[kMaxK], tchain[kMaxK], orig[kMaxK], any[kMaxK], ref[kMaxK];
+    uint8_t k, n_groups, pad[6];
+};
+
 struct QueryView {
     uint32_t n_sel;
     const uint32_t *sel;        // [n_sel] template indices
     const double *rmsd_thr;     // [n_sel]
     const double *cutoff;       // [n_sel]
     const double *maxdyn;       // [n_sel]
+    const Staged *staged;       // [n_sel]
     const float2 *bounds;       // [n_sel*kMaxPairs] (lo^2, hi^2) fp32 prefilter bounds, search order
     uint32_t max_candidates;
     uint32_t flags;
 };
 
+// A complete, fp64-verified assignment waiting for superposition.
+struct __align__(16) Cand {
+    uint32_t s, ti;
+    uint32_t prev;               // previous candidate of the same (s, ti) pair, 0xffffffff = none
+    uint32_t pad;
+    uint16_t atoms[kMaxK];       // target atom (device order) per template atom, TEMPLATE order
+};
+static_assert(sizeof(Cand) == 64, "Cand layout");
+
+// A (structure, template) pair that produced at least one candidate (or was cut short).
+struct PairEntry {
+    uint32_t s, ti, last, count;  // count: candidates | truncated << 31
+};
+
 struct OutView {
+    Cand *cands;
+    double *cand_rmsd;
+    unsigned long long *n_cands;
+    unsigned long long cand_capacity;
+    PairEntry *pairs;
+    unsigned long long *n_pairs;
+    unsigned long long pair_capacity;
     tm_hit *hits;
-    unsigned long long *n_hits;  // allocation counter
-    unsigned long long capacity;
-    uint32_t *overflow;          // set to 1 when the table is full
-    uint32_t *candidates;        // optional [n_structs*n_sel]: count | truncated<<31
+    unsigned long long *n_hits;
+    unsigned long long hit_capacity;
+    uint32_t *overflow;      // bit 0: candidate buffer, bit 1: pair table, bit 2: hit table
+    uint32_t *candidates;    // optional [n_structs*n_sel]: count | truncated<<31
 };
 
 }  // namespace tmx

@@ -50,7 +50,7 @@ enum {
     TM_E_UNSUPPORTED = -2, /* over a TM_MAX_* limit or an unimplemented flag combination */
     TM_E_DEVICE = -3,      /* HIP runtime error (tm_last_error() has the text) */
     TM_E_NOMEM = -4,
-    TM_E_OVERFLOW = -5     /* hit table too small: retry with a larger hit_capacity */
+    TM_E_OVERFLOW = -5     /* result tables too small: retry with the sizes tm_result_needed() reports */
 };
 
 enum {
@@ -101,8 +101,9 @@ typedef struct tm_query_params {
     const double *max_dynamic_distance; /* [n_selected] */
     uint32_t max_candidates;            /* per (structure, template) */
     uint32_t flags;                     /* TM_FLAG_* */
-    uint64_t hit_capacity;              /* 0: choose automatically */
+    uint64_t hit_capacity;              /* rows of the hit table / pairs with candidates; 0: automatic */
     void *stream;                       /* hipStream_t to launch on, NULL = default stream */
+    uint64_t candidate_capacity;        /* complete assignments buffered for superposition; 0: automatic */
 } tm_query_params;
 
 /* One best hit of a (structure, template) pair. */
@@ -131,11 +132,13 @@ void tm_batch_destroy(tm_batch *batch);
 
 /* Asynchronous on params->stream; the result owns the device-side hit table. */
 int tm_query(const tm_library *lib, tm_batch *batch, const tm_query_params *params, tm_result **out);
-int tm_result_wait(tm_result *res);                          /* blocks; TM_E_OVERFLOW if the table filled up */
+int tm_result_wait(tm_result *res);                          /* blocks; TM_E_OVERFLOW if a table filled up */
+int tm_result_needed(tm_result *res, uint64_t *candidates, uint64_t *pairs); /* sizes a retry needs */
 int tm_result_hit_count(tm_result *res, uint64_t *n_hits);   /* implies wait */
 int tm_result_copy_hits(tm_result *res, tm_hit *out, uint64_t capacity); /* sorted by (structure, template_sel) */
 int tm_result_copy_candidates(tm_result *res, uint32_t *out, uint64_t n); /* [n_structures * n_selected], needs TM_FLAG_COUNT_CANDIDATES */
-int tm_result_timing(tm_result *res, float *index_ms, float *search_ms); /* HIP-event durations of the two device phases */
+/* HIP-event durations on the launch stream: candidate index + template staging, k_search, superposition + selection */
+int tm_result_timing(tm_result *res, float *index_ms, float *search_ms, float *finish_ms);
 const void *tm_result_device_hits(tm_result *res);           /* device pointer to the unsorted tm_hit table */
 void tm_result_destroy(tm_result *res);
 
