@@ -23,6 +23,8 @@ namespace tmx {
 // [52] joint-scan tiles, [53] joint-scan survivors
 __device__ unsigned long long g_stats[64];
 #define TM_STAT(i, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_stats[i], (unsigned long long)(v)); } while (0)
+// [54] searches with >= 1 joint-scan survivor.  Ablation (diagnostic build only): query flag bit 8 skips the
+// subtrees below the joint scan, bit 9 skips the joint scan too (template staging only).
 #else
 #define TM_STAT(i, v) do { } while (0)
 #endif
@@ -424,6 +426,9 @@ __device__ __forceinline__ bool joint_top_scan(const SearchCtx &C, const LibView
     const uint32_t TJ = 1u << tj_shift, TI = 64u >> tj_shift;
     const uint32_t li = (uint32_t)lane >> tj_shift, lj = (uint32_t)lane & (TJ - 1);
     const float2 b10 = C.bnd[0];  // pair (1, 0)
+#ifdef TM_STATS
+    bool any_surv = false;
+#endif
     const bool tc = uni((uint32_t)S.tchain[0]) == uni((uint32_t)S.tchain[1]);
     for (uint32_t i0 = 0; i0 < n0; i0 += TI) {
         const uint32_t i = i0 + li;
@@ -445,6 +450,9 @@ __device__ __forceinline__ bool joint_top_scan(const SearchCtx &C, const LibView
             unsigned long long m = __ballot(ok);
             TM_STAT(52, 1);
             TM_STAT(53, __popcll(m));
+#ifdef TM_STATS
+            if (m) any_surv = true;
+#endif
             while (m) {
                 const int bit = __ffsll((long long)m) - 1;
                 m &= m - 1ull;
@@ -452,10 +460,16 @@ __device__ __forceinline__ bool joint_top_scan(const SearchCtx &C, const LibView
                 assign_level(C, 0, sa);
                 assign_level(C, 1, sb);
                 wave_sync();
+#if defined(TM_STATS) || defined(TM_ABLATE)
+                if (Q.flags & 0x100u) continue;
+#endif
                 if (!dfs(C, L, qx, Q, O, P, 2)) return false;
             }
         }
     }
+#ifdef TM_STATS
+    if (any_surv) TM_STAT(54, 1);
+#endif
     return true;
 }
 
@@ -533,6 +547,7 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(LibView L, BatchView B,
             }
         }
         const bool feasible = __ballot(empty) == 0ull;  // an empty lead list: no assignment exists
+        bool feasible_override = true;
         wave_sync();
 
         PairState P;
@@ -540,7 +555,10 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(LibView L, BatchView B,
         P.ncand = 0; P.prev = 0xffffffffu; P.truncated = false;
         P.cut = Q.cutoff[ti]; P.mx = Q.maxdyn[ti];
 
-        if (feasible) {
+#if defined(TM_STATS) || defined(TM_ABLATE)
+        if (Q.flags & 0x200u) feasible_override = false;
+#endif
+        if (feasible && feasible_override) {
             if (T.n_groups >= 2) joint_top_scan(C, L, qx, Q, O, P);
             else dfs(C, L, qx, Q, O, P, 0);
         }

@@ -6,7 +6,7 @@ import time
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
-os.environ["ENZYMM_AMD_LIB"] = str(ROOT / "enzymm_amd" / "libenzymm_amd_stats.so")
+os.environ.setdefault("ENZYMM_AMD_LIB", str(ROOT / "enzymm_amd" / "libenzymm_amd_stats.so"))
 sys.path.insert(0, str(ROOT))
 import numpy as np  # noqa: E402
 from tests import helpers  # noqa: E402
@@ -17,8 +17,9 @@ idx, cut = helpers.default_selection()
 jess = pyjess.Jess(helpers.product_library_templates())
 mols = synthetic.structures(n)
 lib = _native.load()
+print("loaded", flush=True)
 buf = (C.c_ulonglong * 64)()
-lib.tm_debug_stats(buf)
+print("stats0", lib.tm_debug_stats(buf), flush=True)
 t0 = time.time()
 table = jess.query_batch(mols, 2.0, cut, cut, max_candidates=10000, ignore_chain=True, template_index=idx,
                          return_raw=True)
@@ -30,3 +31,17 @@ print("searches", int(searches), "chunk evals/search", s[:24].sum() / searches, 
       "survivors/search", s[24:48].sum() / searches, "completes", int(s[48]), "fp64 rejects", int(s[51]))
 print("evals per level  ", np.round(s[:24] / searches, 2))
 print("surv per level   ", np.round(s[24:48] / searches, 2))
+print("joint tiles/search", s[52] / searches, "joint survivors/search", s[53] / searches,
+      "searches with survivor", s[54] / searches)
+
+# ablation: k_search time with (a) everything, (b) no subtrees below the joint scan, (c) staging only
+packed = pyjess._packed(jess._templates, jess._device)
+batch = pyjess.make_batch(mols, jess._device)
+base = _native.TM_FLAG_BEST_MATCH | _native.TM_FLAG_IGNORE_CHAIN
+for label, extra in (("full", 0), ("no subtrees", 0x100), ("staging only", 0x200)):
+    times = []
+    for _ in range(3):
+        res = _native.query(packed.native, batch, idx, 2.0, cut, cut, 10000, base | extra)
+        times.append(res.timing()[1])
+        res.close()
+    print("k_search ms (%s): %.3f" % (label, min(times)))
