@@ -13,6 +13,7 @@ constexpr int kMaxPairs = kMaxK * (kMaxK - 1) / 2;  // 276 pair constraints
 constexpr int kWave = 64;
 constexpr int kSearchWaves = 16;  // waves per search workgroup (one structure copy in LDS serves all)
 constexpr int kSearchBlock = kWave * kSearchWaves;
+constexpr int kJointQueue = 128;  // joint-scan survivors buffered per wave before their subtrees are searched
 constexpr int kJointList = 256;   // lead lists up to this length are staged in LDS for the joint top-level scan
 
 // fp32 prefilter slack (Angstrom) added to every pair threshold.  Centred fp32

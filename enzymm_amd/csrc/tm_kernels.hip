@@ -187,113 +187,130 @@ __global__ __launch_bounds__(256) void k_kind_lists(LibView L, BatchView B, uint
 
 // ------------------------------------------------------------------ k_search
 
-// Per-wave scratch in LDS.  Everything indexed by "level" = position in the search order.
+// Per-wave LDS: only what lanes exchange.  All search state lives in registers (see WaveRegs).
 struct __align__(16) WaveScratch {
-    float4 arec[kMaxK];               // assigned target atom record per level
-    unsigned long long pend[kMaxK];   // survivors of the current chunk not yet descended into
-    unsigned long long namemask[kMaxK];
-    uint32_t resmask[kMaxK];
-    uint32_t aidx[kMaxK];             // assigned target atom (local index) per level
-    uint32_t cur[kMaxK];              // next chunk base to evaluate
-    uint32_t base[kMaxK];             // base of the chunk `pend` refers to
-    uint32_t lo[kMaxK];               // lead: pool offset of the kind list; else: first atom of the residue
-    uint32_t cnt[kMaxK];              // number of candidates at this level
-    uint16_t surv[kMaxG][64];         // lead levels: candidate atom of every lane of the current chunk
+    float2 bnd_lead[kMaxG * (kMaxG - 1) / 2];  // pair bounds among lead atoms (search positions < n_groups)
+    uint16_t surv[kMaxG][64];                  // per template residue: one 64-entry chunk of its lead list
     uint16_t list0[kJointList], list1[kJointList];  // the two top lead lists, staged for the joint scan
-    uint8_t group[kMaxK], tchain[kMaxK], orig[kMaxK], any[kMaxK], lead[kMaxK], achain[kMaxK], ref[kMaxK];
+    uint32_t queue[kJointQueue];               // joint-scan survivors (a | b << 16) waiting for their subtree
 };
+
+// Search state of one wave, held in VGPRs and indexed BY LANE: lane L holds the entry of search
+// level L.  Uniform reads are v_readlane (SGPR result), uniform writes v_writelane: the DFS state
+// machine touches no memory at all.
+struct WaveRegs {
+    // template constants per level (loaded once per template by lane < k)
+    uint32_t group, ref, tchain, orig, any, lead, resmask, nm_lo, nm_hi;
+    // per level: candidate source and cursor
+    uint32_t lo, cnt;      // lead: pool offset/length of the kind list; else first atom/size of the residue
+    uint32_t cur, base;    // next chunk to evaluate; chunk the pending mask refers to
+    uint32_t pend_lo, pend_hi;
+    // per level: assigned target atom
+    uint32_t aidx, ameta, achain;
+    float ax, ay, az;
+    // per template residue (lane = group): which chunk of its lead list sits in WaveScratch::surv
+    uint32_t surv_base;
+};
+
+__device__ __forceinline__ uint32_t RL(uint32_t v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ float RLf(float v, int lane) {
+    return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), lane));
+}
+// "write lane": a compare + select (this clang has no v_writelane builtin)
+__device__ __forceinline__ void WL(uint32_t &v, int lane, uint32_t x) { v = lane_id() == lane ? x : v; }
+__device__ __forceinline__ void WLf(float &v, int lane, float x) { v = lane_id() == lane ? x : v; }
 
 struct SearchCtx {
     const float4 *rec;          // structure atom records (LDS or global)
     const uint16_t *res_start;  // residue -> first atom (LDS or global)
     const uint16_t *pool;       // kind-list pool
     const uint8_t *qchain;      // global, per atom of this structure
-    const float2 *bnd;          // this template's pair bounds (global, read with uniform addresses)
+    const float2 *bnd;          // this template's pair bounds (global)
     WaveScratch *S;
-    int lane, k;
+    int lane, k, n_groups;
     bool ignore_chain;
 };
 
 // Tests up to 64 candidates for `level`; returns the survivor mask.
-__device__ __forceinline__ unsigned long long eval_chunk(const SearchCtx &C, int level, uint32_t base) {
+__device__ __forceinline__ unsigned long long eval_chunk(const SearchCtx &C, WaveRegs &W, int level, uint32_t base) {
     WaveScratch &S = *C.S;
     const int lane = C.lane;
-    const uint32_t cnt = uni(S.cnt[level]);
-    const uint32_t lo = uni(S.lo[level]);
-    const bool lead = uni((uint32_t)S.lead[level]) != 0;
+    const uint32_t cnt = RL(W.cnt, level), lo = RL(W.lo, level);
+    const bool lead = RL(W.lead, level) != 0;
+    const uint32_t mygroup = RL(W.group, level);
+    // this level's row of pair bounds, one entry per lane j < level, loaded before the candidate gather
+    float2 brow = make_float2(0.f, 0.f);
+    if (lane < level) brow = level < C.n_groups ? S.bnd_lead[tri(level) + lane] : C.bnd[tri(level) + lane];
     const uint32_t idx = base + lane;
     bool ok = idx < cnt;
-    uint32_t cand = 0;
+    uint32_t cand;
     if (lead) {
-        if (ok) cand = C.pool[lo + idx];
-        S.surv[uni((uint32_t)S.group[level])][lane] = (uint16_t)cand;
-        wave_sync();
+        if (RL(W.surv_base, (int)mygroup) != base) {  // the chunk is not the one cached in LDS
+            S.surv[mygroup][lane] = ok ? C.pool[lo + idx] : (uint16_t)0;
+            WL(W.surv_base, (int)mygroup, base);
+            wave_sync();
+        }
+        cand = S.surv[mygroup][lane];
     } else {
         cand = ok ? lo + idx : lo;
     }
     const float4 r = C.rec[cand];
     const uint32_t m = __float_as_uint(r.w);
     if (!lead) {
-        const unsigned long long nm = uni64(S.namemask[level]);
-        const uint32_t rm = uni(S.resmask[level]);
-        const bool any = uni((uint32_t)S.any[level]) != 0;
+        const unsigned long long nm = ((unsigned long long)RL(W.nm_hi, level) << 32) | RL(W.nm_lo, level);
+        const uint32_t rm = RL(W.resmask, level);
+        const bool any = RL(W.any, level) != 0;
         ok = ok && ((nm >> meta_name(m)) & 1ull) && (any || ((rm >> meta_rtype(m)) & 1u));
     }
     const uint32_t cres = meta_res(m);
-    const uint32_t mygroup = uni((uint32_t)S.group[level]);
     uint32_t cchain = 0, mychain = 0;
     if (!C.ignore_chain) {
         cchain = C.qchain[cand];
-        mychain = uni((uint32_t)S.tchain[level]);
+        mychain = RL(W.tchain, level);
     }
     TM_STAT(level, 1);
-    if (__ballot(ok) == 0ull) return 0ull;
-    const float2 *brow = C.bnd + tri(level);
-    for (int j = 0; j < level; ++j) {
-        const float4 a = S.arec[j];
-        const float2 b = brow[j];
-        const float dx = r.x - a.x, dy = r.y - a.y, dz = r.z - a.z;
+    unsigned long long alive = __ballot(ok);
+    for (int j = 0; j < level && alive; ++j) {
+        const float dx = r.x - RLf(W.ax, j), dy = r.y - RLf(W.ay, j), dz = r.z - RLf(W.az, j);
         const float d2 = dx * dx + dy * dy + dz * dz;
-        const bool same_t = uni((uint32_t)S.group[j]) == mygroup;
-        const bool same_q = meta_res(__float_as_uint(a.w)) == cres;
-        ok = ok && (d2 >= b.x) && (d2 <= b.y) && (same_t == same_q) && (cand != S.aidx[j]);
+        const float blo = RLf(brow.x, j), bhi = RLf(brow.y, j);
+        const bool same_t = RL(W.group, j) == mygroup;
+        const bool same_q = meta_res(RL(W.ameta, j)) == cres;
+        ok = ok && (d2 >= blo) && (d2 <= bhi) && (same_t == same_q) && (cand != RL(W.aidx, j));
         if (!C.ignore_chain) {
-            const bool tc = uni((uint32_t)S.tchain[j]) == mychain;
-            const bool qc = (uint32_t)S.achain[j] == cchain;
+            const bool tc = RL(W.tchain, j) == mychain;
+            const bool qc = RL(W.achain, j) == cchain;
             ok = ok && (tc == qc);
         }
         TM_STAT(50, 1);
-        if (__ballot(ok) == 0ull) return 0ull;
+        alive = __ballot(ok);
     }
-    const unsigned long long out = __ballot(ok);
-    TM_STAT(24 + level, __popcll(out));
-    return out;
+    TM_STAT(24 + level, __popcll(alive));
+    return alive;
 }
 
 // Prepares `level` after levels < level were assigned.
-__device__ __forceinline__ void init_level(const SearchCtx &C, int level) {
-    WaveScratch &S = *C.S;
-    if (C.lane == 0) {
-        S.cur[level] = 0;
-        S.pend[level] = 0ull;
-        if (!S.lead[level]) {
-            // same template residue as an already placed lead atom: scan the atoms of that target residue
-            const uint32_t res = meta_res(__float_as_uint(S.arec[S.ref[level]].w));
-            const uint32_t s0 = C.res_start[res], s1 = C.res_start[res + 1];
-            S.lo[level] = s0;
-            S.cnt[level] = s1 - s0;
-        }
+__device__ __forceinline__ void init_level(const SearchCtx &C, WaveRegs &W, int level) {
+    WL(W.cur, level, 0u);
+    WL(W.pend_lo, level, 0u);
+    WL(W.pend_hi, level, 0u);
+    if (RL(W.lead, level) == 0) {
+        // same template residue as an already placed lead atom: scan the atoms of that target residue
+        const uint32_t res = meta_res(RL(W.ameta, (int)RL(W.ref, level)));
+        const uint32_t s0 = uni((uint32_t)C.res_start[res]), s1 = uni((uint32_t)C.res_start[res + 1]);
+        WL(W.lo, level, s0);
+        WL(W.cnt, level, s1 - s0);
     }
-    wave_sync();
 }
 
-__device__ __forceinline__ void assign_level(const SearchCtx &C, int level, uint32_t cand) {
-    WaveScratch &S = *C.S;
-    if (C.lane == 0) {
-        S.aidx[level] = cand;
-        S.arec[level] = C.rec[cand];
-        if (!C.ignore_chain) S.achain[level] = C.qchain[cand];
-    }
+__device__ __forceinline__ void assign_level(const SearchCtx &C, WaveRegs &W, int level, uint32_t cand) {
+    const float4 r = C.rec[cand];  // uniform address
+    WL(W.aidx, level, cand);
+    WLf(W.ax, level, __uint_as_float(uni(__float_as_uint(r.x))));
+    WLf(W.ay, level, __uint_as_float(uni(__float_as_uint(r.y))));
+    WLf(W.az, level, __uint_as_float(uni(__float_as_uint(r.z))));
+    WL(W.ameta, level, uni(__float_as_uint(r.w)));
+    if (!C.ignore_chain) WL(W.achain, level, uni((uint32_t)C.qchain[cand]));
 }
 
 // Everything the wave needs to know about the (structure, template) pair it is searching.
@@ -307,23 +324,26 @@ struct PairState {
 // A complete assignment passed the fp32 prefilter: re-check every pair in fp64
 // (| |q_i - q_j| - |t_i - t_j| | <= thr_ij exactly as the oracle does) and append it to the
 // candidate buffer.  Returns false when the search must stop (max_candidates reached).
-__device__ __forceinline__ bool on_complete(const SearchCtx &C, const LibView &L, const double *qx, const QueryView &Q,
-                                            const OutView &O, PairState &P) {
-    WaveScratch &S = *C.S;
+__device__ __forceinline__ bool on_complete(const SearchCtx &C, WaveRegs &W, const LibView &L, const double *qx,
+                                            const QueryView &Q, const OutView &O, PairState &P) {
     const int lane = C.lane, k = C.k, npairs = tri(k);
     bool bad = false;
-    for (int p = lane; p < npairs; p += 64) {
-        int i, j;
-        pair_of(p, i, j);
-        const double *qa = qx + 3 * (size_t)S.aidx[i], *qb = qx + 3 * (size_t)S.aidx[j];
-        const double *ta = L.a_xyz + 3 * (size_t)(P.off + i), *tb = L.a_xyz + 3 * (size_t)(P.off + j);
-        double dx = qa[0] - qb[0], dy = qa[1] - qb[1], dz = qa[2] - qb[2];
-        const double dq = sqrt(dx * dx + dy * dy + dz * dz);
-        dx = ta[0] - tb[0]; dy = ta[1] - tb[1]; dz = ta[2] - tb[2];
-        const double dt = sqrt(dx * dx + dy * dy + dz * dz);
-        double thr = P.cut + L.a_w[P.off + i] + L.a_w[P.off + j];
-        thr = thr < P.mx ? thr : P.mx;
-        if (fabs(dq - dt) > thr) bad = true;
+    for (int p0 = 0; p0 < npairs; p0 += 64) {  // uniform trip count: the shuffles below need every lane
+        const int p = p0 + lane;
+        int i = 1, j = 0;
+        if (p < npairs) pair_of(p, i, j);
+        const uint32_t ai = (uint32_t)__shfl((int)W.aidx, i), aj = (uint32_t)__shfl((int)W.aidx, j);
+        if (p < npairs) {
+            const double *qa = qx + 3 * (size_t)ai, *qb = qx + 3 * (size_t)aj;
+            const double *ta = L.a_xyz + 3 * (size_t)(P.off + i), *tb = L.a_xyz + 3 * (size_t)(P.off + j);
+            double dx = qa[0] - qb[0], dy = qa[1] - qb[1], dz = qa[2] - qb[2];
+            const double dq = sqrt(dx * dx + dy * dy + dz * dz);
+            dx = ta[0] - tb[0]; dy = ta[1] - tb[1]; dz = ta[2] - tb[2];
+            const double dt = sqrt(dx * dx + dy * dy + dz * dz);
+            double thr = P.cut + L.a_w[P.off + i] + L.a_w[P.off + j];
+            thr = thr < P.mx ? thr : P.mx;
+            if (fabs(dq - dt) > thr) bad = true;
+        }
     }
     TM_STAT(48, 1);
     if (__ballot(bad)) {  // fp32 prefilter false positive
@@ -350,7 +370,7 @@ __device__ __forceinline__ bool on_complete(const SearchCtx &C, const LibView &L
         c->pad = 0;
     }
     if (lane < kMaxK) {
-        if (lane < k) c->atoms[S.orig[lane]] = (uint16_t)S.aidx[lane];
+        if (lane < k) c->atoms[W.orig] = (uint16_t)W.aidx;
         else c->atoms[lane] = 0xffffu;
     }
     P.prev = (uint32_t)slot;
@@ -359,22 +379,21 @@ __device__ __forceinline__ bool on_complete(const SearchCtx &C, const LibView &L
 
 // Depth-first search over levels >= floor (levels < floor are already assigned).
 // Returns false when the pair was cut short by max_candidates.
-__device__ __forceinline__ bool dfs(const SearchCtx &C, const LibView &L, const double *qx, const QueryView &Q,
-                                    const OutView &O, PairState &P, int floor) {
-    WaveScratch &S = *C.S;
-    const int lane = C.lane, k = C.k;
-    if (floor >= k) return on_complete(C, L, qx, Q, O, P);
+__device__ __forceinline__ bool dfs(const SearchCtx &C, WaveRegs &W, const LibView &L, const double *qx,
+                                    const QueryView &Q, const OutView &O, PairState &P, int floor) {
+    const int k = C.k;
+    if (floor >= k) return on_complete(C, W, L, qx, Q, O, P);
     int level = floor;
-    init_level(C, level);
+    init_level(C, W, level);
     for (;;) {
-        unsigned long long pend = uni64(S.pend[level]);
+        unsigned long long pend = ((unsigned long long)RL(W.pend_hi, level) << 32) | RL(W.pend_lo, level);
         if (pend == 0ull) {
             // evaluate further chunks of this level until one has survivors
-            uint32_t cur = uni(S.cur[level]);
-            const uint32_t cnt = uni(S.cnt[level]);
+            uint32_t cur = RL(W.cur, level);
+            const uint32_t cnt = RL(W.cnt, level);
             uint32_t base = 0;
             while (cur < cnt) {
-                pend = eval_chunk(C, level, cur);
+                pend = eval_chunk(C, W, level, cur);
                 base = cur;
                 cur += 64;
                 if (pend) break;
@@ -384,53 +403,70 @@ __device__ __forceinline__ bool dfs(const SearchCtx &C, const LibView &L, const 
                 --level;
                 continue;
             }
-            if (lane == 0) {
-                S.cur[level] = cur;
-                S.base[level] = base;
-            }
+            WL(W.cur, level, cur);
+            WL(W.base, level, base);
         }
         const int b = __ffsll((long long)pend) - 1;
         pend &= pend - 1ull;
+        WL(W.pend_lo, level, (uint32_t)pend);
+        WL(W.pend_hi, level, (uint32_t)(pend >> 32));
         uint32_t cand;
-        if (uni((uint32_t)S.lead[level])) cand = S.surv[uni((uint32_t)S.group[level])][b];
-        else cand = uni(S.lo[level]) + uni(S.base[level]) + (uint32_t)b;
-        cand = uni(cand);
-        if (lane == 0) S.pend[level] = pend;
-        assign_level(C, level, cand);
-        wave_sync();
+        if (RL(W.lead, level)) cand = uni((uint32_t)C.S->surv[RL(W.group, level)][b]);
+        else cand = RL(W.lo, level) + RL(W.base, level) + (uint32_t)b;
+        assign_level(C, W, level, cand);
         if (level < k - 1) {
             ++level;
-            init_level(C, level);
+            init_level(C, W, level);
             continue;
         }
-        if (!on_complete(C, L, qx, Q, O, P)) return false;
+        if (!on_complete(C, W, L, qx, Q, O, P)) return false;
     }
 }
 
 // Levels 0 and 1 are the lead atoms of two different template residues.  Instead of scanning
 // list1 once per element of list0 (a handful of busy lanes each time), the wave tiles the
 // cross product list0 x list1 over its 64 lanes and tests the single pair constraint (1, 0).
-__device__ __forceinline__ bool joint_top_scan(const SearchCtx &C, const LibView &L, const double *qx,
+// Survivors of several tiles are queued in LDS so that the tile loop keeps several independent
+// LDS gathers in flight; their subtrees (levels >= 2) are then searched one after the other.
+__device__ __forceinline__ bool joint_top_scan(const SearchCtx &C, WaveRegs &W, const LibView &L, const double *qx,
                                                const QueryView &Q, const OutView &O, PairState &P) {
     WaveScratch &S = *C.S;
     const int lane = C.lane;
-    const uint32_t n0 = uni(S.cnt[0]), n1 = uni(S.cnt[1]);
-    const uint32_t lo0 = uni(S.lo[0]), lo1 = uni(S.lo[1]);
+    const uint32_t n0 = RL(W.cnt, 0), n1 = RL(W.cnt, 1);
+    const uint32_t lo0 = RL(W.lo, 0), lo1 = RL(W.lo, 1);
     const bool in_lds = n0 <= (uint32_t)kJointList && n1 <= (uint32_t)kJointList;
     if (in_lds) {
         for (uint32_t i = lane; i < n0; i += 64) S.list0[i] = C.pool[lo0 + i];
         for (uint32_t i = lane; i < n1; i += 64) S.list1[i] = C.pool[lo1 + i];
         wave_sync();
     }
-    const uint32_t tj_shift = n1 <= 8 ? 3 : n1 <= 16 ? 4 : n1 <= 32 ? 5 : 6;
+    // tile shape TI x TJ = 64 that needs the fewest tiles
+    uint32_t tj_shift = 3, best_tiles = 0xffffffffu;
+    for (uint32_t sh = 3; sh <= 6; ++sh) {
+        const uint32_t tiles = ((n0 + (64u >> sh) - 1) >> (6 - sh)) * ((n1 + (1u << sh) - 1) >> sh);
+        if (tiles < best_tiles) { best_tiles = tiles; tj_shift = sh; }
+    }
     const uint32_t TJ = 1u << tj_shift, TI = 64u >> tj_shift;
     const uint32_t li = (uint32_t)lane >> tj_shift, lj = (uint32_t)lane & (TJ - 1);
-    const float2 b10 = C.bnd[0];  // pair (1, 0)
-#ifdef TM_STATS
-    bool any_surv = false;
+    const float2 b10 = S.bnd_lead[0];  // pair (1, 0)
+    const bool tc = RL(W.tchain, 0) == RL(W.tchain, 1);
+    uint32_t nq = 0;  // queued survivors (uniform)
+    bool go_on = true;
+
+    auto drain = [&]() {
+        for (uint32_t e = 0; e < nq && go_on; ++e) {
+            const uint32_t ab = uni(S.queue[e]);
+            assign_level(C, W, 0, ab & 0xffffu);
+            assign_level(C, W, 1, ab >> 16);
+#if defined(TM_STATS) || defined(TM_ABLATE)
+            if (Q.flags & 0x100u) continue;
 #endif
-    const bool tc = uni((uint32_t)S.tchain[0]) == uni((uint32_t)S.tchain[1]);
-    for (uint32_t i0 = 0; i0 < n0; i0 += TI) {
+            go_on = dfs(C, W, L, qx, Q, O, P, 2);
+        }
+        nq = 0;
+    };
+
+    for (uint32_t i0 = 0; i0 < n0 && go_on; i0 += TI) {
         const uint32_t i = i0 + li;
         const bool vi = i < n0;
         uint32_t a = 0;
@@ -447,30 +483,23 @@ __device__ __forceinline__ bool joint_top_scan(const SearchCtx &C, const LibView
             bool ok = vi && vj && d2 >= b10.x && d2 <= b10.y &&
                       meta_res(__float_as_uint(ra.w)) != meta_res(__float_as_uint(rb.w));
             if (!C.ignore_chain) ok = ok && ((C.qchain[a] == C.qchain[b]) == tc);
-            unsigned long long m = __ballot(ok);
+            const unsigned long long m = __ballot(ok);
             TM_STAT(52, 1);
             TM_STAT(53, __popcll(m));
-#ifdef TM_STATS
-            if (m) any_surv = true;
-#endif
-            while (m) {
-                const int bit = __ffsll((long long)m) - 1;
-                m &= m - 1ull;
-                const uint32_t sa = __builtin_amdgcn_readlane(a, bit), sb = __builtin_amdgcn_readlane(b, bit);
-                assign_level(C, 0, sa);
-                assign_level(C, 1, sb);
-                wave_sync();
-#if defined(TM_STATS) || defined(TM_ABLATE)
-                if (Q.flags & 0x100u) continue;
-#endif
-                if (!dfs(C, L, qx, Q, O, P, 2)) return false;
+            if (m) {
+                const uint32_t cntm = (uint32_t)__popcll(m);
+                if (nq + cntm > (uint32_t)kJointQueue) {  // make room first (uniform branch)
+                    wave_sync();
+                    drain();
+                }
+                if (ok) S.queue[nq + __popcll(m & ((1ull << lane) - 1ull))] = a | (b << 16);
+                nq += cntm;
             }
         }
     }
-#ifdef TM_STATS
-    if (any_surv) TM_STAT(54, 1);
-#endif
-    return true;
+    wave_sync();
+    if (go_on) drain();
+    return go_on;
 }
 
 template <bool kLds>
@@ -522,32 +551,38 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(LibView L, BatchView B,
         if (ti >= t_end) break;
         const Staged &T = Q.staged[ti];
         const int k = (int)T.k;
+        const int G = (int)T.n_groups;
         C.k = k;
+        C.n_groups = G;
         C.bnd = Q.bounds + (size_t)ti * kMaxPairs;
         TM_STAT(49, 1);
 
-        // ---- stage the template: per-level admissibility and candidate source
+        // ---- stage the template: lane L < k takes level L's constants straight into registers
+        WaveRegs W = {};
+        W.surv_base = 0xffffffffu;
         bool empty = false;
         if (lane < k) {
             const uint16_t li = T.lead_li[lane];
-            const bool lead = li != 0xffffu;
-            S.group[lane] = T.group[lane];
-            S.ref[lane] = T.ref[lane];
-            S.tchain[lane] = T.tchain[lane];
-            S.orig[lane] = T.orig[lane];
-            S.resmask[lane] = T.resmask[lane];
-            S.namemask[lane] = T.namemask[lane];
-            S.any[lane] = T.any[lane];
-            S.lead[lane] = lead ? 1 : 0;
-            if (lead) {
+            const unsigned long long nm = T.namemask[lane];
+            W.group = T.group[lane];
+            W.ref = T.ref[lane];
+            W.tchain = T.tchain[lane];
+            W.orig = T.orig[lane];
+            W.any = T.any[lane];
+            W.resmask = T.resmask[lane];
+            W.nm_lo = (uint32_t)nm;
+            W.nm_hi = (uint32_t)(nm >> 32);
+            W.lead = li != 0xffffu ? 1u : 0u;
+            if (W.lead) {
                 const uint32_t o0 = kl_off[li], o1 = kl_off[li + 1];
-                S.lo[lane] = o0;
-                S.cnt[lane] = o1 - o0;
+                W.lo = o0;
+                W.cnt = o1 - o0;
                 empty = o1 == o0;
             }
         }
         const bool feasible = __ballot(empty) == 0ull;  // an empty lead list: no assignment exists
         bool feasible_override = true;
+        if (lane < tri(G)) S.bnd_lead[lane] = C.bnd[lane];  // leads are search positions 0..G-1
         wave_sync();
 
         PairState P;
@@ -559,8 +594,8 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(LibView L, BatchView B,
         if (Q.flags & 0x200u) feasible_override = false;
 #endif
         if (feasible && feasible_override) {
-            if (T.n_groups >= 2) joint_top_scan(C, L, qx, Q, O, P);
-            else dfs(C, L, qx, Q, O, P, 0);
+            if (G >= 2) joint_top_scan(C, W, L, qx, Q, O, P);
+            else dfs(C, W, L, qx, Q, O, P, 0);
         }
 
         // ---- the pair's outcome
