@@ -191,8 +191,9 @@ __global__ __launch_bounds__(256) void k_kind_lists(LibView L, BatchView B, uint
 struct __align__(16) WaveScratch {
     float2 bnd_lead[kMaxG * (kMaxG - 1) / 2];  // pair bounds among lead atoms (search positions < n_groups)
     uint16_t surv[kMaxG][64];                  // per template residue: one 64-entry chunk of its lead list
-    uint16_t list0[kJointList], list1[kJointList];  // the two top lead lists, staged for the joint scan
-    uint32_t queue[kJointQueue];               // joint-scan survivors (a | b << 16) waiting for their subtree
+    uint16_t list0[kJointList], list1[kJointList], list2[kJointList];  // the top lead lists, staged for the tiled scans
+    uint32_t queue[kJointQueue];               // pair-scan survivors (a | b << 16)
+    uint32_t queue3[kJointQueue][2];           // triple-scan survivors ((a | b << 16), c) waiting for their subtree
 };
 
 // Search state of one wave, held in VGPRs and indexed BY LANE: lane L holds the entry of search
@@ -423,11 +424,27 @@ __device__ __forceinline__ bool dfs(const SearchCtx &C, WaveRegs &W, const LibVi
     }
 }
 
-// Levels 0 and 1 are the lead atoms of two different template residues.  Instead of scanning
-// list1 once per element of list0 (a handful of busy lanes each time), the wave tiles the
-// cross product list0 x list1 over its 64 lanes and tests the single pair constraint (1, 0).
-// Survivors of several tiles are queued in LDS so that the tile loop keeps several independent
-// LDS gathers in flight; their subtrees (levels >= 2) are then searched one after the other.
+// tile shape TI x TJ = 64 lanes (TJ = 1 << shift) that covers an n_i x n_j cross product with the fewest tiles
+__device__ __forceinline__ uint32_t best_tile_shift(uint32_t n_i, uint32_t n_j) {
+    uint32_t shift = 3, best = 0xffffffffu;
+    for (uint32_t sh = 3; sh <= 6; ++sh) {
+        const uint32_t tiles = ((n_i + (64u >> sh) - 1) >> (6 - sh)) * ((n_j + (1u << sh) - 1) >> sh);
+        if (tiles < best) { best = tiles; shift = sh; }
+    }
+    return shift;
+}
+
+__device__ __forceinline__ bool in_window(const float4 &p, const float4 &q, const float2 &b) {
+    const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
+    const float d2 = dx * dx + dy * dy + dz * dz;
+    return d2 >= b.x && d2 <= b.y;
+}
+
+// The lead atoms of the first two (three) template residues are matched by tiled scans: the
+// wave lays the cross product list0 x list1 over its 64 lanes and tests the pair constraint
+// (1, 0); surviving pairs are queued in LDS and, when the template has a third residue, the
+// cross product queue x list2 is tiled the same way against the constraints (2, 0) and (2, 1).
+// Only what survives that is searched depth-first (levels >= 3, or >= 2 for two-residue templates).
 __device__ __forceinline__ bool joint_top_scan(const SearchCtx &C, WaveRegs &W, const LibView &L, const double *qx,
                                                const QueryView &Q, const OutView &O, PairState &P) {
     WaveScratch &S = *C.S;
@@ -435,34 +452,105 @@ __device__ __forceinline__ bool joint_top_scan(const SearchCtx &C, WaveRegs &W, 
     const uint32_t n0 = RL(W.cnt, 0), n1 = RL(W.cnt, 1);
     const uint32_t lo0 = RL(W.lo, 0), lo1 = RL(W.lo, 1);
     const bool in_lds = n0 <= (uint32_t)kJointList && n1 <= (uint32_t)kJointList;
+    const uint32_t n2 = C.n_groups >= 3 ? RL(W.cnt, 2) : 0u;
+    const bool tiled2 = C.n_groups >= 3 && n2 <= (uint32_t)kJointList;  // third lead scanned by tiles too
     if (in_lds) {
         for (uint32_t i = lane; i < n0; i += 64) S.list0[i] = C.pool[lo0 + i];
         for (uint32_t i = lane; i < n1; i += 64) S.list1[i] = C.pool[lo1 + i];
-        wave_sync();
     }
-    // tile shape TI x TJ = 64 that needs the fewest tiles
-    uint32_t tj_shift = 3, best_tiles = 0xffffffffu;
-    for (uint32_t sh = 3; sh <= 6; ++sh) {
-        const uint32_t tiles = ((n0 + (64u >> sh) - 1) >> (6 - sh)) * ((n1 + (1u << sh) - 1) >> sh);
-        if (tiles < best_tiles) { best_tiles = tiles; tj_shift = sh; }
+    if (tiled2) {
+        const uint32_t lo2 = RL(W.lo, 2);
+        for (uint32_t i = lane; i < n2; i += 64) S.list2[i] = C.pool[lo2 + i];
     }
+    wave_sync();
+    const uint32_t tj_shift = best_tile_shift(n0, n1);
     const uint32_t TJ = 1u << tj_shift, TI = 64u >> tj_shift;
     const uint32_t li = (uint32_t)lane >> tj_shift, lj = (uint32_t)lane & (TJ - 1);
-    const float2 b10 = S.bnd_lead[0];  // pair (1, 0)
-    const bool tc = RL(W.tchain, 0) == RL(W.tchain, 1);
-    uint32_t nq = 0;  // queued survivors (uniform)
+    const float2 b10 = S.bnd_lead[0];                                       // pair (1, 0)
+    const float2 b20 = S.bnd_lead[tri(2)], b21 = S.bnd_lead[tri(2) + 1];    // pairs (2, 0), (2, 1)
+    const bool tc10 = RL(W.tchain, 0) == RL(W.tchain, 1);
+    const bool tc20 = RL(W.tchain, 0) == RL(W.tchain, 2), tc21 = RL(W.tchain, 1) == RL(W.tchain, 2);
+    uint32_t nq = 0, nq3 = 0;  // queued survivors (uniform)
+    int floor = 3;             // levels already assigned by the queue3 entries
     bool go_on = true;
 
-    auto drain = [&]() {
-        for (uint32_t e = 0; e < nq && go_on; ++e) {
-            const uint32_t ab = uni(S.queue[e]);
-            assign_level(C, W, 0, ab & 0xffffu);
-            assign_level(C, W, 1, ab >> 16);
-#if defined(TM_STATS) || defined(TM_ABLATE)
-            if (Q.flags & 0x100u) continue;
-#endif
-            go_on = dfs(C, W, L, qx, Q, O, P, 2);
+    // depth-first search below every queued partial assignment (the ONLY call site of dfs)
+    auto drain3 = [&]() {
+        for (uint32_t e = 0; e < nq3 && go_on; ++e) {
+            const uint32_t ab = uni(S.queue3[e][0]), c = uni(S.queue3[e][1]);
+            if (floor >= 2) {
+                assign_level(C, W, 0, ab & 0xffffu);
+                assign_level(C, W, 1, ab >> 16);
+            }
+            if (floor >= 3) assign_level(C, W, 2, c);
+            go_on = dfs(C, W, L, qx, Q, O, P, floor);
         }
+        nq3 = 0;
+    };
+
+    if (C.n_groups < 2) {  // single-residue template: plain depth-first search from level 0
+        floor = 0;
+        nq3 = 1;
+        drain3();
+        return go_on;
+    }
+
+    // queued pairs -> tiled scan against list2, or straight to the depth-first search
+    auto drain = [&]() {
+#if defined(TM_STATS) || defined(TM_ABLATE)
+        if (Q.flags & 0x100u) { nq = 0; return; }
+#endif
+        if (!tiled2) {  // the pairs go to the depth-first search as they are
+            floor = 2;
+            if (lane < (int)nq) S.queue3[lane][0] = S.queue[lane];
+            if (lane + 64 < (int)nq) S.queue3[lane + 64][0] = S.queue[lane + 64];
+            wave_sync();
+            nq3 = nq;
+            drain3();
+            nq = 0;
+            return;
+        }
+        const uint32_t sh = best_tile_shift(nq, n2);
+        const uint32_t TJ2 = 1u << sh, TI2 = 64u >> sh;
+        const uint32_t le = (uint32_t)lane >> sh, lc = (uint32_t)lane & (TJ2 - 1);
+        for (uint32_t e0 = 0; e0 < nq && go_on; e0 += TI2) {
+            const uint32_t e = e0 + le;
+            const bool ve = e < nq;
+            const uint32_t ab = ve ? S.queue[e] : 0u;
+            const uint32_t a = ab & 0xffffu, b = ab >> 16;
+            const float4 ra = C.rec[a], rb = C.rec[b];
+            const uint32_t res_a = meta_res(__float_as_uint(ra.w)), res_b = meta_res(__float_as_uint(rb.w));
+            for (uint32_t j0 = 0; j0 < n2; j0 += TJ2) {
+                const uint32_t j = j0 + lc;
+                const bool vj = j < n2;
+                const uint32_t c = vj ? (uint32_t)S.list2[j] : 0u;
+                const float4 rc = C.rec[c];
+                const uint32_t res_c = meta_res(__float_as_uint(rc.w));
+                bool ok = ve && vj && in_window(rc, ra, b20) && in_window(rc, rb, b21) && res_c != res_a && res_c != res_b;
+                if (!C.ignore_chain) {
+                    const uint8_t qc = C.qchain[c];
+                    ok = ok && ((qc == C.qchain[a]) == tc20) && ((qc == C.qchain[b]) == tc21);
+                }
+                const unsigned long long m = __ballot(ok);
+                TM_STAT(2, 1);
+                TM_STAT(24 + 2, __popcll(m));
+                if (m) {
+                    const uint32_t cntm = (uint32_t)__popcll(m);
+                    if (nq3 + cntm > (uint32_t)kJointQueue) {
+                        wave_sync();
+                        drain3();
+                    }
+                    if (ok) {
+                        const uint32_t slot = nq3 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                        S.queue3[slot][0] = ab;
+                        S.queue3[slot][1] = c;
+                    }
+                    nq3 += cntm;
+                }
+            }
+        }
+        wave_sync();
+        if (go_on) drain3();
         nq = 0;
     };
 
@@ -478,11 +566,9 @@ __device__ __forceinline__ bool joint_top_scan(const SearchCtx &C, WaveRegs &W, 
             uint32_t b = 0;
             if (vj) b = in_lds ? (uint32_t)S.list1[j] : (uint32_t)C.pool[lo1 + j];
             const float4 rb = C.rec[b];
-            const float dx = ra.x - rb.x, dy = ra.y - rb.y, dz = ra.z - rb.z;
-            const float d2 = dx * dx + dy * dy + dz * dz;
-            bool ok = vi && vj && d2 >= b10.x && d2 <= b10.y &&
+            bool ok = vi && vj && in_window(ra, rb, b10) &&
                       meta_res(__float_as_uint(ra.w)) != meta_res(__float_as_uint(rb.w));
-            if (!C.ignore_chain) ok = ok && ((C.qchain[a] == C.qchain[b]) == tc);
+            if (!C.ignore_chain) ok = ok && ((C.qchain[a] == C.qchain[b]) == tc10);
             const unsigned long long m = __ballot(ok);
             TM_STAT(52, 1);
             TM_STAT(53, __popcll(m));
@@ -594,8 +680,7 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(LibView L, BatchView B,
         if (Q.flags & 0x200u) feasible_override = false;
 #endif
         if (feasible && feasible_override) {
-            if (G >= 2) joint_top_scan(C, W, L, qx, Q, O, P);
-            else dfs(C, W, L, qx, Q, O, P, 0);
+            joint_top_scan(C, W, L, qx, Q, O, P);
         }
 
         // ---- the pair's outcome
