@@ -88,10 +88,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
+    # ENZYMM_AMD_BENCH_ONE_GPU=1: every rank on GPU 0 with a gloo group -- only to exercise the N > 1
+    # control flow on a 1-GPU box; the driver's real runs use one GPU per rank over RCCL.
+    one_gpu = os.environ.get("ENZYMM_AMD_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     os.environ["ENZYMM_AMD_DEVICE"] = str(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    gather_device = "cpu" if one_gpu else f"cuda:{local_rank}"
 
     from enzymm_amd import _native, distributed, pyjess, synthetic
 
@@ -117,7 +126,7 @@ def main():
         res = _native.query(packed.native, batch, idx, 2.0, cut, cut, 10000, flags, hit_capacity=capacity,
                             stream=stream, candidate_capacity=cand_capacity, retry=False)
         n = res.hit_count()  # waits for the kernels on `stream`
-        table = distributed.gather_hit_table(res, n, lo, world, rank, local_rank)
+        table = distributed.gather_hit_table(res, n, lo, world, rank, gather_device)
         if record:
             a, b, c = res.timing()
             index_ms.append(a)
@@ -141,7 +150,7 @@ def main():
         step(True)
     fence()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_gpu else "cuda")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())

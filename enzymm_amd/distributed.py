@@ -74,9 +74,10 @@ def gather_tables(local: np.ndarray, structure_offset: int, group=None, device=N
 
 
 def gather_hit_table(result: "_native.Result", n_hits: int, structure_offset: int, world: int, rank: int,
-                     local_rank: int):
-    """bench.py's per-step exchange: this rank's (sorted) hit table, gathered over RCCL when world > 1."""
+                     device: str):
+    """bench.py's per-step exchange: this rank's (sorted) hit table, gathered to rank 0 when world > 1
+    (``device`` "cuda:N" = staged in HBM and moved by RCCL)."""
     table = result.hits()
     if world == 1:
         return table
-    return gather_tables(table, structure_offset, device=f"cuda:{local_rank}")
+    return gather_tables(table, structure_offset, device=device)

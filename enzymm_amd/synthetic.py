@@ -14,7 +14,7 @@ The reference ships no benchmark inputs, so the workload "batch o
   from the previous fragment's last C-alpha; the pose with no C-alpha closer than 4 A to the
   existing chain and the smallest distance to the running centroid wins (radius of gyration comes
   out near the 2.2 L^0.38 A of globular proteins);
-* coordinates are rounded to 3 decimals (PDB precision), B-factors are U(30, 100), residues are
+* coordinates are rounded to 3 decimals (PDB precision), B-factors are U(30, 100) per residue (pLDDT-like), residues are
   renumbered 1..L on chain A.
 """
 from __future__ import annotations
@@ -117,7 +117,8 @@ def structure_columns(index: int, mean_residues: float = 300.0, sd_residues: flo
     name = np.concatenate(name_parts)
     res = np.concatenate(res_parts)
     resnum = np.concatenate(resnum_parts).astype(np.int32)
-    bfac = np.round(rng.uniform(30.0, 100.0, size=len(resnum)), 2)
+    # one value per residue, like the pLDDT column of a predicted model
+    bfac = np.round(rng.uniform(30.0, 100.0, size=length), 2)[resnum - 1]
     return dict(xyz=xyz, name=name, residue_name=res, residue_number=resnum, temperature_factor=bfac)
 
 
