@@ -2,6 +2,7 @@
 // plans the per-template search order, launches the kernels and returns the hit table.
 // C ABI declared in include/enzymm_amd.h.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -128,7 +129,7 @@ struct tm_result {
 
 namespace {
 
-uint64_t g_serial = 0;
+std::atomic<uint64_t> g_serial{0};
 
 // Search order of one template.  Any order enumerates the same set of assignments; this one keeps
 // the search tree narrow:
@@ -418,7 +419,6 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
     if (!lib || !b || !p || !out) return fail(TM_E_INVALID, "tm_query: NULL argument");
     *out = nullptr;
     if (lib->device != b->device) return fail(TM_E_INVALID, "library and batch live on different devices");
-    if (!(p->flags & TM_FLAG_BEST_MATCH)) return fail(TM_E_UNSUPPORTED, "ABI v1 implements best_match queries only");
     if (p->n_selected && (!p->template_index || !p->rmsd_threshold || !p->distance_cutoff || !p->max_dynamic_distance))
         return fail(TM_E_INVALID, "tm_query: NULL parameter array");
     for (uint32_t i = 0; i < p->n_selected; ++i)
@@ -540,7 +540,7 @@ int tm_result_needed(tm_result *r, uint64_t *candidates, uint64_t *pairs) {
     int rc = tm_result_wait(r);
     if (rc != TM_OK && rc != TM_E_OVERFLOW) return rc;
     if (candidates) *candidates = r->n_cands;
-    if (pairs) *pairs = r->n_pairs;
+    if (pairs) *pairs = std::max(r->n_pairs, r->n_hits);  // the hit table shares hit_capacity
     return TM_OK;
 }
 
@@ -558,8 +558,12 @@ int tm_result_copy_hits(tm_result *r, tm_hit *out, uint64_t capacity) {
     if (r->n_hits == 0) return TM_OK;
     if (!out) return fail(TM_E_INVALID, "out is NULL");
     HIP_TRY(hipMemcpy(out, r->d_hits.p, r->n_hits * sizeof(tm_hit), hipMemcpyDeviceToHost));
+    // (structure, template) order; several hits of one pair (best_match off) by ascending atom tuple,
+    // which is the enumeration order of the reference semantics
     std::sort(out, out + r->n_hits, [](const tm_hit &a, const tm_hit &b) {
-        return a.structure != b.structure ? a.structure < b.structure : a.template_sel < b.template_sel;
+        if (a.structure != b.structure) return a.structure < b.structure;
+        if (a.template_sel != b.template_sel) return a.template_sel < b.template_sel;
+        return std::lexicographical_compare(a.atoms, a.atoms + a.n_atoms, b.atoms, b.atoms + b.n_atoms);
     });
     return TM_OK;
 }

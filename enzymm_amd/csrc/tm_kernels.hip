@@ -823,50 +823,64 @@ __global__ __launch_bounds__(256) void k_superpose(LibView L, BatchView B, Query
     }
 }
 
-// true when tuple a (TEMPLATE order) is lexicographically smaller than b
-__device__ __forceinline__ bool tuple_less(const Cand &a, const Cand &b, int k) {
-    for (int i = 0; i < k; ++i)
-        if (a.atoms[i] != b.atoms[i]) return a.atoms[i] < b.atoms[i];
+// true when tuple a (TEMPLATE order, file-order atom indices) is lexicographically smaller than b
+__device__ __forceinline__ bool tuple_less(const uint32_t *orig, const Cand &a, const Cand &b, int k) {
+    for (int i = 0; i < k; ++i) {
+        const uint32_t x = orig[a.atoms[i]], y = orig[b.atoms[i]];
+        if (x != y) return x < y;
+    }
     return false;
 }
 
-// One lane per (structure, template) pair with candidates: walk the pair's candidate chain,
-// keep the minimum-RMSD one (ties within kTieEps: smaller atom tuple), emit the hit.
+__device__ void emit_hit(const LibView &L, const BatchView &B, const QueryView &Q, const OutView &O,
+                         const PairEntry &pe, const Cand &c, int k) {
+    const unsigned long long slot = atomicAdd(O.n_hits, 1ull);
+    if (slot >= O.hit_capacity) {
+        atomicOr(O.overflow, 4u);
+        return;
+    }
+    tm_hit *h = O.hits + slot;
+    double R[9], T[3];
+    h->rmsd = superpose_candidate(L, B, Q, c, R, T);
+    for (int a = 0; a < 9; ++a) h->rot[a] = R[a];
+    for (int a = 0; a < 3; ++a) h->trans[a] = T[a];
+    h->structure = pe.s;
+    h->template_sel = pe.ti;
+    h->n_candidates = pe.count & 0x7fffffffu;
+    h->flags = (pe.count >> 31) ? TM_HIT_TRUNCATED : 0u;
+    h->n_atoms = (uint32_t)k;
+    h->reserved = 0;
+    const uint32_t a0 = B.s_off[pe.s];
+    for (int i = 0; i < kMaxK; ++i) h->atoms[i] = i < k ? B.q_orig[a0 + c.atoms[i]] : 0xffffffffu;
+}
+
+// One lane per (structure, template) pair with candidates: walk the pair's candidate chain.
+// best_match: keep the minimum-RMSD candidate (ties within kTieEps: smaller atom tuple) and emit it;
+// otherwise emit every candidate whose RMSD is within the threshold.
 __global__ __launch_bounds__(256) void k_select(LibView L, BatchView B, QueryView Q, OutView O) {
     unsigned long long n = *O.n_pairs;
     if (n > O.pair_capacity) n = O.pair_capacity;
+    const bool best_match = (Q.flags & TM_FLAG_BEST_MATCH) != 0;
     const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
     for (unsigned long long e = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
         const PairEntry pe = O.pairs[e];
         const double thr = Q.rmsd_thr[pe.ti];
         const int k = (int)Q.staged[pe.ti].k;
+        const uint32_t *orig = B.q_orig + B.s_off[pe.s];
         uint32_t best = 0xffffffffu;
         double best_rmsd = 0.0;
         for (uint32_t c = pe.last; c != 0xffffffffu; c = O.cands[c].prev) {
-            if (c >= O.cand_capacity) break;  // the chain ran into the overflowed part of the buffer
             const double r = O.cand_rmsd[c];
             if (!(r <= thr)) continue;
+            if (!best_match) {
+                emit_hit(L, B, Q, O, pe, O.cands[c], k);
+                continue;
+            }
             bool better = best == 0xffffffffu || r < best_rmsd - kTieEps;
-            if (!better && r <= best_rmsd + kTieEps) better = tuple_less(O.cands[c], O.cands[best], k);
+            if (!better && r <= best_rmsd + kTieEps) better = tuple_less(orig, O.cands[c], O.cands[best], k);
             if (better) { best = c; best_rmsd = r; }
         }
-        if (best == 0xffffffffu) continue;
-        const unsigned long long slot = atomicAdd(O.n_hits, 1ull);
-        if (slot >= O.hit_capacity) { atomicOr(O.overflow, 4u); continue; }
-        tm_hit *h = O.hits + slot;
-        const Cand &c = O.cands[best];
-        double R[9], T[3];
-        h->rmsd = superpose_candidate(L, B, Q, c, R, T);
-        for (int a = 0; a < 9; ++a) h->rot[a] = R[a];
-        for (int a = 0; a < 3; ++a) h->trans[a] = T[a];
-        h->structure = pe.s;
-        h->template_sel = pe.ti;
-        h->n_candidates = pe.count & 0x7fffffffu;
-        h->flags = (pe.count >> 31) ? TM_HIT_TRUNCATED : 0u;
-        h->n_atoms = (uint32_t)k;
-        h->reserved = 0;
-        const uint32_t a0 = B.s_off[pe.s];
-        for (int i = 0; i < kMaxK; ++i) h->atoms[i] = i < k ? B.q_orig[a0 + c.atoms[i]] : 0xffffffffu;
+        if (best != 0xffffffffu) emit_hit(L, B, Q, O, pe, O.cands[best], k);
     }
 }
 

@@ -631,9 +631,6 @@ class Jess:
         enzymm's size buckets (jess_run.py:564-571) go through a single call.  Returns
         ``[[Hit, ...] per molecule]`` in template order, or the raw structured hit table.
         """
-        if not best_match:
-            raise NotImplementedError("enzymm_amd implements best_match=True queries only "
-                                      "(the only mode enzymm uses: jess_run.py:809)")
         molecules = list(molecules)
         for m in molecules:
             if not isinstance(m, Molecule):
@@ -646,7 +643,7 @@ class Jess:
         own_batch = batch is None
         if own_batch:
             batch = make_batch(molecules, self._device)
-        flags = _native.TM_FLAG_BEST_MATCH
+        flags = _native.TM_FLAG_BEST_MATCH if best_match else 0
         if ignore_chain:
             flags |= _native.TM_FLAG_IGNORE_CHAIN
         if count_candidates:

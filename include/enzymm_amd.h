@@ -55,7 +55,7 @@ enum {
 
 enum {
     TM_FLAG_IGNORE_CHAIN = 1u,     /* Jess.query(ignore_chain=True), jess_run.py:810 */
-    TM_FLAG_BEST_MATCH = 2u,       /* Jess.query(best_match=True), jess_run.py:809 (required in ABI v1) */
+    TM_FLAG_BEST_MATCH = 2u,       /* Jess.query(best_match=True), jess_run.py:809; off: every hit within rmsd_threshold */
     TM_FLAG_COUNT_CANDIDATES = 4u, /* also record the candidate count of every (structure, template) pair */
     TM_FLAG_REBUILD_INDEX = 8u     /* recompute the per-structure candidate index even if cached */
 };
@@ -106,7 +106,7 @@ typedef struct tm_query_params {
     uint64_t candidate_capacity;        /* complete assignments buffered for superposition; 0: automatic */
 } tm_query_params;
 
-/* One best hit of a (structure, template) pair. */
+/* One hit of a (structure, template) pair (the best one under TM_FLAG_BEST_MATCH). */
 typedef struct tm_hit {
     uint32_t structure;    /* index into the batch */
     uint32_t template_sel; /* index into tm_query_params.template_index */
@@ -135,7 +135,7 @@ int tm_query(const tm_library *lib, tm_batch *batch, const tm_query_params *para
 int tm_result_wait(tm_result *res);                          /* blocks; TM_E_OVERFLOW if a table filled up */
 int tm_result_needed(tm_result *res, uint64_t *candidates, uint64_t *pairs); /* sizes a retry needs */
 int tm_result_hit_count(tm_result *res, uint64_t *n_hits);   /* implies wait */
-int tm_result_copy_hits(tm_result *res, tm_hit *out, uint64_t capacity); /* sorted by (structure, template_sel) */
+int tm_result_copy_hits(tm_result *res, tm_hit *out, uint64_t capacity); /* sorted by (structure, template_sel, atoms) */
 int tm_result_copy_candidates(tm_result *res, uint32_t *out, uint64_t n); /* [n_structures * n_selected], needs TM_FLAG_COUNT_CANDIDATES */
 /* HIP-event durations on the launch stream: candidate index + template staging, k_search, superposition + selection */
 int tm_result_timing(tm_result *res, float *index_ms, float *search_ms, float *finish_ms);

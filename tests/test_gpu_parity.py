@@ -191,6 +191,29 @@ def test_edge_cases(amy):
         pyjess.Jess([pyjess.Template(atoms, id="too_big")]).query_batch([amy], 2, 1.5, 1.5)
 
 
+def test_all_hits_mode_and_thread_pool(amy):
+    """best_match=False (pyjess's default) yields every hit within the RMSD threshold in enumeration order;
+    and the query entry point is re-entrant: enzymm calls it from ThreadPool workers (jess_run.py:919-921)."""
+    from multiprocessing.pool import ThreadPool
+    g = G["G1"]
+    tpl = template.Template.load(TPL / g["template"])
+    otpl = helpers.to_oracle_template(tpl)
+    want, _, _ = oracle.query(helpers.to_oracle_molecule(amy), otpl, 2, 1.5, 1.5, max_candidates=10000,
+                              best_match=False)
+    got = list(pyjess.Jess([tpl]).query(amy, 2, 1.5, 1.5, max_candidates=10000))
+    assert len(got) == len(want) == 10
+    for h, w in zip(got, want):
+        assert list(h._atom_index) == w.atoms.tolist() and abs(h.rmsd - w.rmsd) < RMSD_TOL
+    assert min(h.rmsd for h in got) == pytest.approx(g["rmsd"], abs=5e-8)
+
+    def one(_):
+        return [round(h.rmsd, 9) for h in pyjess.Jess([tpl]).query(amy, 2, 1.5, 1.5, max_candidates=10000,
+                                                                   best_match=True)]
+    with ThreadPool(4) as pool:
+        results = pool.map(one, range(16))
+    assert all(r == results[0] and len(r) == 1 for r in results)
+
+
 def test_matcher_end_to_end(amy, af):
     """tests/test_jess_run.py:301-357 through the real GPU-backed Jess."""
     a1 = G["A1"]

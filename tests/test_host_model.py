@@ -196,8 +196,6 @@ def test_jess_argument_checks():
     assert len(j) == 0 and list(j.query(pyjess.Molecule(), 2, 1, 1, best_match=True)) == []
     t = pyjess.Template.load(TPL / G["G1"]["template"])
     assert t.dimension == 5 and len(t) == 15 and t.id
-    with pytest.raises(NotImplementedError):
-        pyjess.Jess([t]).query(pyjess.Molecule.load(helpers.GOLDEN / "1AMY.pdb"), 2, 1, 1, best_match=False)
 
 
 def test_load_molecules(tmp_path):
