@@ -19,30 +19,32 @@ TM_NAME_OTHER = 63
 
 TM_OK, TM_E_INVALID, TM_E_UNSUPPORTED, TM_E_DEVICE, TM_E_NOMEM, TM_E_OVERFLOW = 0, -1, -2, -3, -4, -5
 TM_FLAG_IGNORE_CHAIN, TM_FLAG_BEST_MATCH, TM_FLAG_COUNT_CANDIDATES, TM_FLAG_REBUILD_INDEX = 1, 2, 4, 8
-TM_HIT_TRUNCATED = 1
+TM_HIT_TRUNCATED, TM_HIT_PREDICTED, TM_HIT_CORRECT = 1, 2, 4
 
 import os
 
 # $ENZYMM_AMD_LIB selects another build of the same ABI (the diagnostic `make stats` library)
 LIB_PATH = Path(os.environ.get("ENZYMM_AMD_LIB") or Path(__file__).resolve().parent / "libenzymm_amd.so")
 
-#: numpy view of ``struct tm_hit`` (224 bytes)
+#: numpy view of ``struct tm_hit`` (232 bytes)
 HIT_DTYPE = np.dtype(
     [
         ("structure", "<u4"), ("template_sel", "<u4"), ("n_candidates", "<u4"), ("flags", "<u4"),
         ("rmsd", "<f8"), ("rot", "<f8", (9,)), ("trans", "<f8", (3,)),
         ("n_atoms", "<u4"), ("atoms", "<u4", (TM_MAX_TEMPLATE_ATOMS,)), ("reserved", "<u4"),
+        ("orientation", "<f8"),
     ],
     align=False,
 )
-assert HIT_DTYPE.itemsize == 224
+assert HIT_DTYPE.itemsize == 232
 
 
 class _LibraryDesc(C.Structure):
     _fields_ = [
         ("n_templates", C.c_uint32), ("atom_offsets", C.c_void_p), ("xyz", C.c_void_p), ("dist_weight", C.c_void_p),
         ("res_mask", C.c_void_p), ("name_mask", C.c_void_p), ("any_residue", C.c_void_p), ("group", C.c_void_p),
-        ("chain", C.c_void_p),
+        ("chain", C.c_void_p), ("residue_offsets", C.c_void_p), ("orient_first", C.c_void_p),
+        ("orient_second", C.c_void_p), ("orient_vec", C.c_void_p),
     ]
 
 
@@ -58,7 +60,8 @@ class _QueryParams(C.Structure):
         ("n_selected", C.c_uint32), ("template_index", C.c_void_p), ("rmsd_threshold", C.c_void_p),
         ("distance_cutoff", C.c_void_p), ("max_dynamic_distance", C.c_void_p), ("max_candidates", C.c_uint32),
         ("flags", C.c_uint32), ("hit_capacity", C.c_uint64), ("stream", C.c_void_p),
-        ("candidate_capacity", C.c_uint64),
+        ("candidate_capacity", C.c_uint64), ("n_model_sets", C.c_uint32), ("model_set", C.c_void_p),
+        ("model_offsets", C.c_void_p), ("model_votes", C.c_void_p), ("models", C.c_void_p),
     ]
 
 
@@ -122,7 +125,9 @@ def device_count() -> int:
 class Library:
     """Device-resident template library (``tm_library``)."""
 
-    def __init__(self, device, atom_offsets, xyz, dist_weight, res_mask, name_mask, any_residue, group, chain):
+    def __init__(self, device, atom_offsets, xyz, dist_weight, res_mask, name_mask, any_residue, group, chain,
+                 orientation=None):
+        """``orientation`` = (residue_offsets, first, second, vectors) or None (see tm_library_desc)."""
         lib = load()
         self._h = C.c_void_p()
         self.n_templates = len(atom_offsets) - 1
@@ -131,6 +136,11 @@ class Library:
             _arr(res_mask, np.uint32), _arr(name_mask, np.uint64), _arr(any_residue, np.uint8),
             _arr(group, np.uint8), _arr(chain, np.uint8),
         ]
+        if orientation is not None:
+            keep += [_arr(orientation[0], np.uint32), _arr(orientation[1], np.uint8), _arr(orientation[2], np.uint8),
+                     _arr(orientation[3], np.float64)]
+        else:
+            keep += [None, None, None, None]
         desc = _LibraryDesc(self.n_templates, *[_ptr(a) for a in keep])
         _check(lib.tm_library_create(C.c_int(device), C.byref(desc), C.byref(self._h)))
         self.device = device
@@ -219,7 +229,7 @@ class Result:
 
 def query(library: Library, batch: Batch, template_index, rmsd_threshold, distance_cutoff, max_dynamic_distance,
           max_candidates: int, flags: int, hit_capacity: int = 0, stream: int = 0,
-          candidate_capacity: int = 0, retry: bool = True) -> Result:
+          candidate_capacity: int = 0, retry: bool = True, models=None) -> Result:
     """Launch one query.  With ``retry`` the call waits for the result and, if a result table
     overflowed, re-runs with the sizes the first run reported."""
     n = len(template_index)
@@ -229,8 +239,17 @@ def query(library: Library, batch: Batch, template_index, rmsd_threshold, distan
         _arr(np.broadcast_to(np.asarray(distance_cutoff, dtype=np.float64), (n,)), np.float64),
         _arr(np.broadcast_to(np.asarray(max_dynamic_distance, dtype=np.float64), (n,)), np.float64),
     ]
-    params = _QueryParams(n, *[_ptr(a) for a in keep], int(max_candidates), int(flags), int(hit_capacity),
-                          C.c_void_p(stream or None), int(candidate_capacity))
+    if models is not None:  # (model_set [n], model_offsets [sets+1], model_votes [sets], models [n_models, 4])
+        mk = [_arr(models[0], np.int32), _arr(models[1], np.uint32), _arr(models[2], np.uint32),
+              _arr(models[3], np.float64)]
+        if len(mk[0]) != n:
+            raise ValueError("models[0] needs one entry per selected template")
+        keep += mk
+        margs = (len(mk[2]), _ptr(mk[0]), _ptr(mk[1]), _ptr(mk[2]), _ptr(mk[3]))
+    else:
+        margs = (0, None, None, None, None)
+    params = _QueryParams(n, *[_ptr(a) for a in keep[:4]], int(max_candidates), int(flags), int(hit_capacity),
+                          C.c_void_p(stream or None), int(candidate_capacity), *margs)
     for _ in range(4):
         handle = C.c_void_p()
         _check(load().tm_query(library._h, batch._h, C.byref(params), C.byref(handle)))

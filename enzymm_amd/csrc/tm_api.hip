@@ -64,10 +64,11 @@ struct tm_library {
     int device = 0;
     uint32_t n_templates = 0, n_atoms = 0, n_kinds = 0, n_lead = 0;
     std::vector<uint32_t> t_off;
-    DevBuf<uint32_t> d_t_off, d_k_resmask, d_lead_kind;
-    DevBuf<double> d_xyz, d_w;
+    DevBuf<uint32_t> d_t_off, d_k_resmask, d_lead_kind, d_r_off;
+    DevBuf<double> d_xyz, d_w, d_r_vec;
     DevBuf<uint16_t> d_kind;
-    DevBuf<uint8_t> d_group, d_orig, d_chain, d_k_any, d_ref;
+    DevBuf<uint8_t> d_group, d_orig, d_chain, d_k_any, d_ref, d_r_first, d_r_second;
+    bool has_orient = false;
     DevBuf<uint64_t> d_k_namemask;
     DevBuf<int32_t> d_k_lead;
     uint64_t serial = 0;  // identity for the batch-side index cache
@@ -78,6 +79,8 @@ struct tm_library {
         v.a_group = d_group.p; v.a_ref = d_ref.p; v.a_orig = d_orig.p; v.a_chain = d_chain.p;
         v.k_resmask = d_k_resmask.p; v.k_namemask = d_k_namemask.p; v.k_any = d_k_any.p;
         v.k_lead = d_k_lead.p; v.lead_kind = d_lead_kind.p;
+        v.r_off = has_orient ? d_r_off.p : nullptr; v.r_first = d_r_first.p; v.r_second = d_r_second.p;
+        v.r_vec = d_r_vec.p;
         return v;
     }
 };
@@ -114,7 +117,9 @@ struct tm_result {
     DevBuf<PairEntry> d_pairs;
     DevBuf<unsigned long long> d_counters;  // [0] hits, [1] candidates, [2] pairs
     DevBuf<uint32_t> d_overflow, d_candidates, d_sel;
-    DevBuf<double> d_rmsd, d_cut, d_maxdyn, d_cand_rmsd;
+    DevBuf<double> d_rmsd, d_cut, d_maxdyn, d_cand_rmsd, d_models;
+    DevBuf<int32_t> d_model_set;
+    DevBuf<uint32_t> d_model_offsets, d_model_votes;
     DevBuf<float2> d_bounds;
     DevBuf<Staged> d_staged;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -286,6 +291,14 @@ int tm_library_create(int device, const tm_library_desc *d, tm_library **out) {
     up(lib->d_chain.upload(chain)); up(lib->d_k_resmask.upload(k_resmask));
     up(lib->d_k_namemask.upload(k_namemask)); up(lib->d_k_any.upload(k_any));
     up(lib->d_k_lead.upload(k_lead)); up(lib->d_lead_kind.upload(lead_kind));
+    if (d->residue_offsets && d->orient_first && d->orient_second && d->orient_vec) {
+        const uint32_t nr = d->residue_offsets[nt];
+        up(lib->d_r_off.upload(std::vector<uint32_t>(d->residue_offsets, d->residue_offsets + nt + 1)));
+        up(lib->d_r_first.upload(std::vector<uint8_t>(d->orient_first, d->orient_first + nr)));
+        up(lib->d_r_second.upload(std::vector<uint8_t>(d->orient_second, d->orient_second + nr)));
+        up(lib->d_r_vec.upload(std::vector<double>(d->orient_vec, d->orient_vec + 3 * (size_t)nr)));
+        lib->has_orient = true;
+    }
     if (e != hipSuccess) {
         delete lib;
         return fail(TM_E_DEVICE, std::string("tm_library_create upload: ") + hipGetErrorString(e));
@@ -473,6 +486,18 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
     QueryView Q;
     Q.n_sel = n_sel; Q.sel = r->d_sel.p; Q.rmsd_thr = r->d_rmsd.p; Q.cutoff = r->d_cut.p; Q.maxdyn = r->d_maxdyn.p;
     Q.staged = r->d_staged.p; Q.bounds = r->d_bounds.p; Q.max_candidates = p->max_candidates; Q.flags = p->flags;
+    Q.model_set = nullptr; Q.model_offsets = nullptr; Q.model_votes = nullptr; Q.models = nullptr;
+    if (p->model_set && p->n_model_sets && p->model_offsets && p->model_votes && p->models) {
+        const uint32_t ns = p->n_model_sets, nm = p->model_offsets[ns];
+        for (uint32_t i = 0; i < n_sel; ++i)
+            if (p->model_set[i] >= (int32_t)ns) return fail(TM_E_INVALID, "model_set index out of range");
+        HIP_TRY(r->d_model_set.upload(std::vector<int32_t>(p->model_set, p->model_set + n_sel)));
+        HIP_TRY(r->d_model_offsets.upload(std::vector<uint32_t>(p->model_offsets, p->model_offsets + ns + 1)));
+        HIP_TRY(r->d_model_votes.upload(std::vector<uint32_t>(p->model_votes, p->model_votes + ns)));
+        HIP_TRY(r->d_models.upload(std::vector<double>(p->models, p->models + 4 * (size_t)nm)));
+        Q.model_set = r->d_model_set.p; Q.model_offsets = r->d_model_offsets.p;
+        Q.model_votes = r->d_model_votes.p; Q.models = r->d_models.p;
+    }
     OutView O;
     O.cands = r->d_cands.p; O.cand_rmsd = r->d_cand_rmsd.p; O.n_cands = r->d_counters.p + 1; O.cand_capacity = ccap;
     O.pairs = r->d_pairs.p; O.n_pairs = r->d_counters.p + 2; O.pair_capacity = hcap;

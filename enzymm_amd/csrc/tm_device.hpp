@@ -50,6 +50,10 @@ struct LibView {
     const uint8_t *k_any;
     const int32_t *k_lead;       // index among lead kinds, or -1
     const uint32_t *lead_kind;   // [n_lead] kind id of each lead kind
+    // optional residue-orientation table (template order), NULL when absent
+    const uint32_t *r_off;       // [n_templates+1]
+    const uint8_t *r_first, *r_second;
+    const double *r_vec;         // [n_residues*3]
 };
 
 // Target structures in HBM.  Atoms of a structure are stored residue-contiguous.
@@ -86,6 +90,11 @@ struct QueryView {
     const float2 *bounds;       // [n_sel*kMaxPairs] (lo^2, hi^2) fp32 prefilter bounds, search order
     uint32_t max_candidates;
     uint32_t flags;
+    // optional logistic filter
+    const int32_t *model_set;       // [n_sel] or NULL
+    const uint32_t *model_offsets;  // [n_sets+1]
+    const uint32_t *model_votes;    // [n_sets]
+    const double *models;           // [n_models*4]
 };
 
 // A complete, fp64-verified assignment waiting for superposition.

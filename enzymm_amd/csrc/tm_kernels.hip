@@ -852,6 +852,58 @@ __device__ void emit_hit(const LibView &L, const BatchView &B, const QueryView &
     h->reserved = 0;
     const uint32_t a0 = B.s_off[pe.s];
     for (int i = 0; i < kMaxK; ++i) h->atoms[i] = i < k ? B.q_orig[a0 + c.atoms[i]] : 0xffffffffu;
+
+    // ---- fused epilogue: residue-orientation angle and logistic filter
+    // (what enzymm computes per hit in Python: jess_run.py:425-478 and 298-346)
+    double orientation = __longlong_as_double(0x7ff8000000000000ll);  // NaN
+    const uint32_t t = Q.sel[pe.ti];
+    if (L.r_off && L.r_off[t + 1] > L.r_off[t] && 3u * (L.r_off[t + 1] - L.r_off[t]) == (uint32_t)k) {
+        const uint32_t r0 = L.r_off[t], nres = L.r_off[t + 1] - r0;
+        const double *qx = B.q_xyz + 3 * (size_t)a0;
+        double acc = 0.0;
+        for (uint32_t r = 0; r < nres; ++r) {
+            double p[3][3];  // the residue's three matched atoms in the template frame
+            for (int n = 0; n < 3; ++n) {
+                const double *q = qx + 3 * (size_t)c.atoms[3 * r + n];
+                for (int a = 0; a < 3; ++a) p[n][a] = R[3 * a] * q[0] + R[3 * a + 1] * q[1] + R[3 * a + 2] * q[2] + T[a];
+            }
+            const int fi = L.r_first[r0 + r] < 3 ? L.r_first[r0 + r] : 0, se = L.r_second[r0 + r];
+            double v[3];
+            if (se == 9) {
+                const int s1 = fi == 0 ? 1 : 0, s2 = fi == 2 ? 1 : 2;
+                for (int a = 0; a < 3; ++a) v[a] = (p[s1][a] + p[s2][a]) / 2 - p[fi][a];
+            } else {
+                const int sj = se < 3 ? se : 0;
+                for (int a = 0; a < 3; ++a) v[a] = p[sj][a] - p[fi][a];
+            }
+            const double *tv = L.r_vec + 3 * (size_t)(r0 + r);
+            const double nv = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+            const double nt = sqrt(tv[0] * tv[0] + tv[1] * tv[1] + tv[2] * tv[2]);
+            double a3[3] = {tv[0], tv[1], tv[2]}, b3[3] = {v[0], v[1], v[2]};
+            if (nt != 0.0) for (int a = 0; a < 3; ++a) a3[a] = tv[a] / nt;
+            if (nv != 0.0) for (int a = 0; a < 3; ++a) b3[a] = v[a] / nv;
+            double dot = a3[0] * b3[0] + a3[1] * b3[1] + a3[2] * b3[2];
+            if (dot > 1.0 && dot <= 1.0 + 1e-5) dot = 1.0;     // Vec3.angle_to's tolerance, template.py:157-181
+            if (dot < -1.0 && dot >= -1.0 - 1e-5) dot = -1.0;
+            acc += acos(dot);
+        }
+        orientation = acc / (double)nres;
+    }
+    h->orientation = orientation;
+    if (Q.model_set && orientation == orientation) {
+        const int m = Q.model_set[pe.ti];
+        bool correct = true;
+        if (m >= 0) {
+            uint32_t votes = 0;
+            for (uint32_t i = Q.model_offsets[m]; i < Q.model_offsets[m + 1]; ++i) {
+                const double *mo = Q.models + 4 * (size_t)i;
+                const double z = mo[2] + mo[0] * h->rmsd + mo[1] * orientation;
+                votes += (1.0 / (1.0 + exp(-z))) >= mo[3];
+            }
+            correct = votes >= Q.model_votes[m];
+        }
+        h->flags |= TM_HIT_PREDICTED | (correct ? TM_HIT_CORRECT : 0u);
+    }
 }
 
 // One lane per (structure, template) pair with candidates: walk the pair's candidate chain.

@@ -372,13 +372,15 @@ class Matcher:
                 searched.append(t)
                 rmsd.append(r); dist.append(d); dyn.append(m); bucket_of.append(s)
 
-        # ONE launch for every (molecule, template) pair of every bucket
+        # ONE launch for every (molecule, template) pair of every bucket; the orientation angle and the
+        # logistic filter are evaluated in the hit epilogue on the GPU (Hit.orientation, Hit.predicted)
         per_molecule: List[List[pyjess.Hit]] = [[] for _ in molecules]
         if searched and molecules:
             jess = self._jess_factory(searched)
             per_molecule = jess.query_batch(molecules, np.array(rmsd, float), np.array(dist, float),
                                             np.array(dyn, float), max_candidates=self.MAX_CANDIDATES,
-                                            best_match=True, ignore_chain=True)
+                                            best_match=True, ignore_chain=True,
+                                            models=self._model_tables(searched, dist))
         position = {id(t): i for i, t in enumerate(searched)}
 
         processed: Dict[pyjess.Molecule, List[Match]] = collections.defaultdict(list)
@@ -396,7 +398,11 @@ class Matcher:
             for mol, matches in staged:
                 if self.filter_matches:
                     for m in matches:
-                        if m.predicted_correct:
+                        # the epilogue's verdict when it had a model set for this bucket; otherwise the
+                        # reference's Python rule (which also raises KeyError for a distance without models)
+                        verdict = m.hit.predicted if getattr(m.hit, "predicted", None) is not None \
+                            else m.predicted_correct
+                        if verdict:
                             processed[mol].append(m)
                             total += 1
                 else:
@@ -405,6 +411,38 @@ class Matcher:
                     total += len(matches)
             self.verbose_print(f"{total} matches found!")
         return processed
+
+    @staticmethod
+    def _model_tables(templates: Sequence[Template], distances: Sequence[float]):
+        """Flatten Match._logistic_regression_models for tm_query: one model set per (effective size,
+        pairwise distance) that has models; templates of sizes without models get -1 (always correct), and
+        so do (size, distance) combinations the JSON lacks -- for those Hit.predicted stays None and the Python
+        rule decides (it raises KeyError, jess_run.py:339-342)."""
+        table = Match._logistic_regression_models
+        sets, offsets, votes, params, index = {}, [0], [], [], []
+        lacking = False
+        for t, d in zip(templates, distances):
+            by_dist = table.get(str(t.effective_size))
+            if by_dist is None:
+                index.append(-1)
+                continue
+            models = by_dist.get(str(d))
+            if models is None:
+                lacking = True
+                index.append(-1)
+                continue
+            key = (str(t.effective_size), str(d))
+            if key not in sets:
+                sets[key] = len(votes)
+                for m in models:
+                    params.append((m.coefficents[0], m.coefficents[1], m.intercept, m.threshold))
+                offsets.append(len(params))
+                votes.append(int(round(len(models) / 2, 0)))
+            index.append(sets[key])
+        if lacking or not votes:
+            return None  # keep the pure-Python filter so the reference's KeyError behaviour is untouched
+        return (np.array(index, np.int32), np.array(offsets, np.uint32), np.array(votes, np.uint32),
+                np.array(params, np.float64).reshape(-1, 4))
 
     def run_single(self, molecule: pyjess.Molecule) -> List[Match]:
         return self.run([molecule])[molecule]

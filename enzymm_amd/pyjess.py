@@ -488,8 +488,31 @@ class _PackedLibrary:
                 chain[i] = chains.setdefault(a.chain_id, len(chains))
                 i += 1
             self.offsets[ti + 1] = i
-        self.native = _native.Library(device, self.offsets, xyz, weight, res_mask, name_mask, any_res, group, chain)
+        self.native = _native.Library(device, self.offsets, xyz, weight, res_mask, name_mask, any_res, group, chain,
+                                      orientation=self._orientation_table(templates))
         self.device = device
+
+
+    @staticmethod
+    def _orientation_table(templates):
+        """Residue-orientation definitions of enzymm-style templates (objects with ``.residues`` whose
+        members expose ``orientation_vector`` / ``orientation_vector_indices``, template.py:409-422) for the
+        fused hit epilogue; None when any template lacks them."""
+        offsets, first, second, vec = [0], [], [], []
+        for t in templates:
+            residues = getattr(t, "residues", None)
+            if residues is None or 3 * len(residues) != len(t._atoms):
+                return None
+            flat = [a for r in residues for a in r.atoms]
+            if any(x is not y for x, y in zip(flat, t._atoms)):
+                return None
+            for r in residues:
+                i, j = r.orientation_vector_indices
+                v = r.orientation_vector
+                first.append(i); second.append(j); vec.append((v.x, v.y, v.z))
+            offsets.append(len(first))
+        return (np.array(offsets, dtype=np.uint32), np.array(first, dtype=np.uint8),
+                np.array(second, dtype=np.uint8), np.array(vec, dtype=np.float64).reshape(-1, 3))
 
 
 _pack_lock = threading.Lock()
@@ -530,9 +553,11 @@ def make_batch(molecules: Sequence[Molecule], device: int) -> "_native.Batch":
 class Hit:
     """Best superposition of one template on one molecule."""
 
-    __slots__ = ("template", "_molecule", "rmsd", "_rot", "_trans", "_atom_index", "n_candidates", "truncated")
+    __slots__ = ("template", "_molecule", "rmsd", "_rot", "_trans", "_atom_index", "n_candidates", "truncated",
+                 "orientation", "predicted")
 
-    def __init__(self, template, molecule, rmsd, rot, trans, atom_index, n_candidates=0, truncated=False):
+    def __init__(self, template, molecule, rmsd, rot, trans, atom_index, n_candidates=0, truncated=False,
+                 orientation=math.nan, predicted=None):
         self.template = template
         self._molecule = molecule
         self.rmsd = float(rmsd)
@@ -541,6 +566,10 @@ class Hit:
         self._atom_index = tuple(int(i) for i in atom_index)
         self.n_candidates = int(n_candidates)
         self.truncated = bool(truncated)
+        #: mean residue-orientation angle computed in the hit epilogue on the GPU (NaN if the template
+        #: carries no orientation definitions); ``predicted`` is the fused logistic filter's verdict or None
+        self.orientation = float(orientation)
+        self.predicted = predicted
 
     @property
     def determinant(self) -> float:
@@ -624,7 +653,8 @@ class Jess:
     # -- batched entry point (what enzymm_amd.jess_run.Matcher uses) ---------
     def query_batch(self, molecules: Sequence[Molecule], rmsd_threshold, distance_cutoff, max_dynamic_distance, *,
                     max_candidates: Optional[int] = None, ignore_chain: bool = False, best_match: bool = True,
-                    template_index=None, batch=None, count_candidates: bool = False, return_raw: bool = False):
+                    template_index=None, batch=None, count_candidates: bool = False, return_raw: bool = False,
+                    models=None):
         """Search every molecule with every (selected) template in one launch.
 
         The three thresholds are scalars or arrays with one entry per selected template, so all of
@@ -650,7 +680,7 @@ class Jess:
             flags |= _native.TM_FLAG_COUNT_CANDIDATES
         cap = _UNLIMITED if max_candidates is None else max(0, min(int(max_candidates), _UNLIMITED))
         res = _native.query(packed.native, batch, sel, rmsd_threshold, distance_cutoff, max_dynamic_distance, cap,
-                            flags)
+                            flags, models=models)
         try:
             table = res.hits()
             cands = res.candidates() if count_candidates else None
@@ -666,7 +696,8 @@ class Jess:
             k = int(h["n_atoms"])
             out[int(h["structure"])].append(
                 Hit(tpl, molecules[int(h["structure"])], h["rmsd"], h["rot"], h["trans"], h["atoms"][:k],
-                    h["n_candidates"], bool(h["flags"] & _native.TM_HIT_TRUNCATED)))
+                    h["n_candidates"], bool(h["flags"] & _native.TM_HIT_TRUNCATED), h["orientation"],
+                    bool(h["flags"] & _native.TM_HIT_CORRECT) if h["flags"] & _native.TM_HIT_PREDICTED else None))
         return out
 
     # -- the pyjess call enzymm makes ----------------------------------------

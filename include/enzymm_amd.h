@@ -62,7 +62,9 @@ enum {
 
 /* bits of tm_hit.flags */
 enum {
-    TM_HIT_TRUNCATED = 1u /* more than max_candidates complete assignments exist; search was cut short */
+    TM_HIT_TRUNCATED = 1u,  /* more than max_candidates complete assignments exist; search was cut short */
+    TM_HIT_PREDICTED = 2u,  /* logistic filter evaluated for this hit (orientation table + model set present) */
+    TM_HIT_CORRECT = 4u     /* ... and it predicts the hit as correct */
 };
 
 typedef struct tm_library tm_library;
@@ -80,6 +82,14 @@ typedef struct tm_library_desc {
     const uint8_t *any_residue;   /* [n_atoms] 1: residue type not checked (match_mode >= 100) */
     const uint8_t *group;         /* [n_atoms] template residue ordinal (atoms sharing chain + resSeq) */
     const uint8_t *chain;         /* [n_atoms] template chain ordinal */
+    /* Optional residue-orientation table for the fused hit epilogue (enzymm/template.py:213-304,
+     * jess_run.py:425-478); NULL: tm_hit.orientation is NaN.  Template residue r covers template atoms
+     * 3r..3r+2.  orient_first/orient_second index into that triplet; orient_second == 9 means "from atom
+     * orient_first to the midpoint of the other two".  orient_vec is the template-frame vector. */
+    const uint32_t *residue_offsets; /* [n_templates + 1] */
+    const uint8_t *orient_first;     /* [n_residues] */
+    const uint8_t *orient_second;    /* [n_residues] */
+    const double *orient_vec;        /* [n_residues * 3] */
 } tm_library_desc;
 
 /* Target structures, concatenated; atoms in file order. */
@@ -104,6 +114,15 @@ typedef struct tm_query_params {
     uint64_t hit_capacity;              /* rows of the hit table / pairs with candidates; 0: automatic */
     void *stream;                       /* hipStream_t to launch on, NULL = default stream */
     uint64_t candidate_capacity;        /* complete assignments buffered for superposition; 0: automatic */
+    /* Optional logistic filter fused into the hit epilogue (enzymm/jess_run.py:298-346): model set m holds
+     * models model_offsets[m] .. model_offsets[m+1]-1, each {coef_rmsd, coef_orientation, intercept, threshold};
+     * a hit is "predicted correct" when at least model_votes[m] of them fire.  model_set[i] < 0: no models for
+     * selected template i (always predicted correct). */
+    uint32_t n_model_sets;
+    const int32_t *model_set;           /* [n_selected] or NULL */
+    const uint32_t *model_offsets;      /* [n_model_sets + 1] */
+    const uint32_t *model_votes;        /* [n_model_sets] */
+    const double *models;               /* [n_models * 4] */
 } tm_query_params;
 
 /* One hit of a (structure, template) pair (the best one under TM_FLAG_BEST_MATCH). */
@@ -118,6 +137,7 @@ typedef struct tm_hit {
     uint32_t n_atoms;
     uint32_t atoms[TM_MAX_TEMPLATE_ATOMS]; /* target atom (file-order index within its structure) per template atom */
     uint32_t reserved;
+    double orientation; /* mean angle (rad) between template and matched residue orientation vectors; NaN if unknown */
 } tm_hit;
 
 int tm_abi_version(void);

@@ -84,7 +84,7 @@ class OracleJess:
         self._templates = tuple(templates)
 
     def query_batch(self, molecules, rmsd_threshold, distance_cutoff, max_dynamic_distance, *,
-                    max_candidates=None, ignore_chain=False, best_match=True, **_):
+                    max_candidates=None, ignore_chain=False, best_match=True, **_):  # `models` ignored: no epilogue here
         from enzymm_amd import pyjess
         from oracle import oracle
         assert best_match

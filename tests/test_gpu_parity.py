@@ -237,6 +237,35 @@ def test_matcher_end_to_end(amy, af):
     assert all(isinstance(m, jess_run.Match) for m in single)
 
 
+def test_fused_epilogue_matches_python_filter(amy, af):
+    """orientation angle and logistic verdict computed in the hit epilogue on the GPU must
+    equal what Match.orientation / Match.predicted_correct compute in Python (jess_run.py:298-346, 425-478)."""
+    lib = template.load_packed_library()
+    matcher = jess_run.Matcher(lib, filter_matches=False)
+    mols = [amy, af] + synthetic.structures(60)
+    out = matcher.run(mols)
+    n = decided = 0
+    for mol, matches in out.items():
+        for m in matches:
+            assert m.hit.orientation == pytest.approx(m.orientation, abs=1e-9)
+            if str(m.hit.template.effective_size) in jess_run.Match._logistic_regression_models:
+                assert m.hit.predicted is not None and m.hit.predicted == m.predicted_correct
+                decided += 1
+            else:
+                assert m.hit.predicted in (None, True) and m.predicted_correct is True
+            n += 1
+    assert n > 40 and decided > 10
+    # filtered run == Python-filtered unfiltered run
+    kept = jess_run.Matcher(lib, filter_matches=True).run(mols)
+    for mol in mols:
+        want = [id(m.hit.template) for m in out.get(mol, []) if m.predicted_correct]
+        assert [id(m.hit.template) for m in kept.get(mol, [])] == want
+    # G1's pinned orientation straight from the epilogue
+    tpl = template.Template.load(TPL / G["G1"]["template"])
+    h = list(pyjess.Jess([tpl]).query(amy, 2, 1.5, 1.5, max_candidates=10000, best_match=True))[0]
+    assert h.orientation == pytest.approx(G["G1"]["orientation"], abs=5e-8)
+
+
 def test_full_batch_properties(default_library):
     """configs[2] size (1000 structures x 6780 templates): properties that need no oracle."""
     jess, olib, idx, cut = default_library

@@ -24,7 +24,7 @@ def test_cabi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.tm_abi_version() == 1
-    assert _native.HIT_DTYPE.itemsize == 224
+    assert _native.HIT_DTYPE.itemsize == 232
 
 
 def test_molecule_load_matches_oracle_parser():
