@@ -55,6 +55,17 @@ class _BatchDesc(C.Structure):
     ]
 
 
+class _Vocab(C.Structure):
+    _fields_ = [
+        ("n_atom_names", C.c_uint32), ("atom_names", C.c_void_p), ("atom_name_ids", C.c_void_p),
+        ("n_elements", C.c_uint32), ("elements", C.c_void_p), ("element_ids", C.c_void_p),
+        ("n_residues", C.c_uint32), ("residue_names", C.c_void_p), ("residue_ids", C.c_void_p),
+    ]
+
+
+TM_PDB_IGNORE_ENDMDL = 1
+
+
 class _QueryParams(C.Structure):
     _fields_ = [
         ("n_selected", C.c_uint32), ("template_index", C.c_void_p), ("rmsd_threshold", C.c_void_p),
@@ -67,7 +78,8 @@ class _QueryParams(C.Structure):
 
 EXPORTS = (
     "tm_abi_version", "tm_last_error", "tm_device_count", "tm_library_create", "tm_library_destroy",
-    "tm_batch_create", "tm_batch_destroy", "tm_query", "tm_result_wait", "tm_result_needed", "tm_result_hit_count",
+    "tm_batch_create", "tm_batch_create_from_pdb", "tm_batch_atom_counts", "tm_batch_line_offsets",
+    "tm_batch_destroy", "tm_query", "tm_result_wait", "tm_result_needed", "tm_result_hit_count",
     "tm_result_copy_hits", "tm_result_copy_candidates", "tm_result_timing", "tm_result_device_hits",
     "tm_result_destroy",
 )
@@ -168,6 +180,34 @@ class Batch:
         desc = _BatchDesc(self.n_structures, *[_ptr(a) for a in keep])
         _check(lib.tm_batch_create(C.c_int(device), C.byref(desc), C.byref(self._h)))
         self.device = device
+
+    @classmethod
+    def from_pdb(cls, device, texts, vocab_tables, min_bfactor: float = 0.0, ignore_endmdl: bool = False) -> "Batch":
+        """Upload raw PDB texts (bytes) and parse them on the GPU (``tm_batch_create_from_pdb``)."""
+        lib = load()
+        self = cls.__new__(cls)
+        self._h = C.c_void_p()
+        self.n_structures = len(texts)
+        names, name_ids, els, el_ids, res, res_ids, _ = vocab_tables
+        keep = [_arr(names, "S4"), _arr(name_ids, np.uint8), _arr(els, "S2"), _arr(el_ids, np.uint8),
+                _arr(res, "S3"), _arr(res_ids, np.uint8)]
+        vocab = _Vocab(len(keep[0]), _ptr(keep[0]), _ptr(keep[1]), len(keep[2]), _ptr(keep[2]), _ptr(keep[3]),
+                       len(keep[4]), _ptr(keep[4]), _ptr(keep[5]))
+        ptrs = (C.c_char_p * max(1, len(texts)))(*texts)
+        lens = (C.c_uint64 * max(1, len(texts)))(*[len(t) for t in texts])
+        _check(lib.tm_batch_create_from_pdb(C.c_int(device), C.c_uint32(len(texts)), ptrs, lens, C.byref(vocab),
+                                            C.c_uint32(TM_PDB_IGNORE_ENDMDL if ignore_endmdl else 0),
+                                            C.c_double(min_bfactor), C.byref(self._h)))
+        self.device = device
+        self.atom_offsets = np.zeros(len(texts) + 1, dtype=np.uint32)
+        _check(lib.tm_batch_atom_counts(self._h, _ptr(self.atom_offsets)))
+        return self
+
+    def line_offsets(self) -> np.ndarray:
+        """Byte offset of every kept ATOM/HETATM record inside its file (device-parsed batches)."""
+        out = np.zeros(int(self.atom_offsets[-1]), dtype=np.uint32)
+        _check(load().tm_batch_line_offsets(self._h, _ptr(out), C.c_uint64(out.size)))
+        return out
 
     def close(self):
         if getattr(self, "_h", None):

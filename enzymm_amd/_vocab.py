@@ -181,4 +181,16 @@ class Vocabulary:
         return lut[inv].reshape(raw3.shape)
 
 
+    def native_tables(self):
+        """(names S4, name ids, elements S2, element ids, residues S3, residue ids) for tm_vocab."""
+        with self._lock:
+            names = np.array(list(self.name_ids), dtype="S4")
+            name_ids = np.array(list(self.name_ids.values()), dtype=np.uint8)
+            els = np.array(list(self.element_ids), dtype="S2")
+            el_ids = np.array(list(self.element_ids.values()), dtype=np.uint8)
+            res = np.array(list(self.res_ids), dtype="S3")
+            res_ids = np.array(list(self.res_ids.values()), dtype=np.uint8)
+            return names, name_ids, els, el_ids, res, res_ids, self.version
+
+
 VOCAB = Vocabulary()

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "tm_kernels.hip"  // single translation unit: kernels + host API
+#include "tm_pdb.hip"
 
 using namespace tmx;
 
@@ -96,6 +97,7 @@ struct tm_batch {
     DevBuf<uint16_t> d_res_start, d_kl_pool;
     DevBuf<unsigned long long> d_cursor;
     DevBuf<uint32_t> d_overflow;
+    DevBuf<uint32_t> d_line_off;  // device-parsed batches: byte offset of every atom record in its file
     uint64_t index_for = 0;  // serial of the library the candidate index was built for
     unsigned long long pool_capacity = 0;
     BatchView view() const {
@@ -388,6 +390,176 @@ int tm_batch_create(int device, const tm_batch_desc *d, tm_batch **out) {
         return fail(TM_E_DEVICE, std::string("tm_batch_create upload: ") + hipGetErrorString(e));
     }
     *out = b;
+    return TM_OK;
+}
+
+// exclusive prefix sum of n u32 values on the device; *total (device) receives the sum
+static int device_scan(const uint32_t *in, uint64_t n, uint32_t *out, uint32_t *total, DevBuf<uint32_t> &block_sums,
+                       hipStream_t stream) {
+    const uint64_t per_block = (uint64_t)kScanBlock * kScanItems;
+    const uint32_t blocks = (uint32_t)std::max<uint64_t>(1, (n + per_block - 1) / per_block);
+    HIP_TRY(block_sums.alloc(blocks));
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(blocks), dim3(kScanBlock), 0, stream, in, n, block_sums.p);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, stream, block_sums.p, blocks, total);
+    hipLaunchKernelGGL(k_scan_apply, dim3(blocks), dim3(kScanBlock), 0, stream, in, n, block_sums.p, out);
+    HIP_TRY(hipGetLastError());
+    return TM_OK;
+}
+
+int tm_batch_create_from_pdb(int device, uint32_t n_files, const char *const *text, const uint64_t *length,
+                             const tm_vocab *vocab, uint32_t flags, double min_bfactor, tm_batch **out) {
+    if (!out || !vocab || (n_files && (!text || !length))) return fail(TM_E_INVALID, "tm_batch_create_from_pdb: NULL argument");
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t stream = nullptr;
+
+    // ---- one contiguous text buffer, every file newline-terminated, padded to 16-byte granules
+    std::vector<uint64_t> file_off(n_files + 1, 0);
+    for (uint32_t f = 0; f < n_files; ++f) {
+        const bool need_nl = length[f] == 0 || text[f][length[f] - 1] != '\n';
+        file_off[f + 1] = file_off[f] + length[f] + (need_nl ? 1 : 0);
+    }
+    const uint64_t n_bytes = (file_off[n_files] + 15) & ~15ull;
+    if (n_bytes >= (1ull << 36)) return fail(TM_E_UNSUPPORTED, "more than 64 GiB of PDB text in one batch");
+    std::vector<char> host(n_bytes + 16, ' ');
+    for (uint32_t f = 0; f < n_files; ++f) {
+        if (length[f]) std::memcpy(host.data() + file_off[f], text[f], length[f]);
+        if (file_off[f + 1] - file_off[f] != length[f]) host[file_off[f + 1] - 1] = '\n';
+    }
+    DevBuf<char> d_text;
+    DevBuf<uint64_t> d_file_off, d_nl;
+    DevBuf<uint32_t> d_counts, d_rank, d_sums, d_total, d_line_file, d_first_end, d_keep, d_atom_rank, d_bad;
+    DevBuf<uint8_t> d_kind;
+    HIP_TRY(d_text.upload(host));
+    HIP_TRY(d_file_off.upload(file_off));
+    const uint64_t n_gran = n_bytes / 16;
+    HIP_TRY(d_counts.alloc(n_gran)); HIP_TRY(d_rank.alloc(n_gran)); HIP_TRY(d_total.alloc(2)); HIP_TRY(d_bad.alloc(1));
+    HIP_TRY(hipMemsetAsync(d_bad.p, 0, sizeof(uint32_t), stream));
+    uint32_t n_lines = 0, n_atoms = 0;
+    if (n_gran) {
+        hipLaunchKernelGGL(k_pdb_count_newlines, dim3(2048), dim3(256), 0, stream,
+                           reinterpret_cast<const uint4 *>(d_text.p), n_gran, d_counts.p);
+        int rc = device_scan(d_counts.p, n_gran, d_rank.p, d_total.p, d_sums, stream);
+        if (rc != TM_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(&n_lines, d_total.p, sizeof n_lines, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
+    HIP_TRY(d_nl.alloc(n_lines)); HIP_TRY(d_line_file.alloc(n_lines)); HIP_TRY(d_kind.alloc(n_lines));
+    HIP_TRY(d_keep.alloc(n_lines)); HIP_TRY(d_atom_rank.alloc(n_lines));
+    std::vector<uint32_t> first_end(std::max<uint32_t>(n_files, 1), 0xffffffffu);
+    HIP_TRY(d_first_end.upload(first_end));
+    DevBuf<uint32_t> d_s_off_tmp;
+    HIP_TRY(d_s_off_tmp.alloc(n_files + 1));
+    if (n_lines) {
+        const uint32_t lb = (n_lines + 255) / 256;
+        hipLaunchKernelGGL(k_pdb_mark_lines, dim3(2048), dim3(256), 0, stream,
+                           reinterpret_cast<const uint8_t *>(d_text.p), n_gran, d_rank.p, d_nl.p);
+        hipLaunchKernelGGL(k_pdb_classify, dim3(lb), dim3(256), 0, stream, reinterpret_cast<const uint8_t *>(d_text.p),
+                           d_nl.p, n_lines, d_file_off.p, n_files, (flags & TM_PDB_IGNORE_ENDMDL) ? 1u : 0u,
+                           d_line_file.p, d_kind.p, d_first_end.p);
+        hipLaunchKernelGGL(k_pdb_keep, dim3(lb), dim3(256), 0, stream, reinterpret_cast<const uint8_t *>(d_text.p),
+                           d_nl.p, n_lines, d_line_file.p, d_kind.p, d_first_end.p, min_bfactor, d_keep.p, d_bad.p);
+        HIP_TRY(hipGetLastError());
+        int rc = device_scan(d_keep.p, n_lines, d_atom_rank.p, d_total.p + 1, d_sums, stream);
+        if (rc != TM_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(&n_atoms, d_total.p + 1, sizeof n_atoms, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
+
+    tm_batch *b = new (std::nothrow) tm_batch;
+    if (!b) return fail(TM_E_NOMEM, "out of host memory");
+    struct Guard { tm_batch *b; ~Guard() { delete b; } } guard{b};
+    b->device = device; b->n_structs = n_files; b->n_atoms = n_atoms;
+    DevBuf<uint32_t> d_meta, d_runs, d_needs_host;
+    DevBuf<uint64_t> d_key;
+    HIP_TRY(b->d_xyz.alloc(3 * (size_t)n_atoms)); HIP_TRY(d_meta.alloc(n_atoms)); HIP_TRY(d_key.alloc(n_atoms));
+    HIP_TRY(b->d_line_off.alloc(n_atoms)); HIP_TRY(d_runs.alloc(n_files)); HIP_TRY(d_needs_host.alloc(n_files));
+    HIP_TRY(hipMemsetAsync(d_needs_host.p, 0, std::max<uint32_t>(n_files, 1) * sizeof(uint32_t), stream));
+    HIP_TRY(hipMemsetAsync(d_runs.p, 0, std::max<uint32_t>(n_files, 1) * sizeof(uint32_t), stream));
+    ParsedAtoms P{b->d_xyz.p, d_meta.p, d_key.p, b->d_line_off.p};
+
+    // the vocabulary as integer tables
+    std::vector<uint32_t> v_names(vocab->n_atom_names), v_res(vocab->n_residues);
+    std::vector<uint16_t> v_el(vocab->n_elements);
+    for (uint32_t i = 0; i < vocab->n_atom_names; ++i) std::memcpy(&v_names[i], vocab->atom_names + 4 * i, 4);
+    for (uint32_t i = 0; i < vocab->n_elements; ++i) std::memcpy(&v_el[i], vocab->elements + 2 * i, 2);
+    for (uint32_t i = 0; i < vocab->n_residues; ++i) { v_res[i] = 0; std::memcpy(&v_res[i], vocab->residue_names + 3 * i, 3); }
+    DevBuf<uint32_t> dv_names, dv_res;
+    DevBuf<uint16_t> dv_el;
+    DevBuf<uint8_t> dv_name_ids, dv_el_ids, dv_res_ids;
+    HIP_TRY(dv_names.upload(v_names)); HIP_TRY(dv_res.upload(v_res)); HIP_TRY(dv_el.upload(v_el));
+    HIP_TRY(dv_name_ids.upload(std::vector<uint8_t>(vocab->atom_name_ids, vocab->atom_name_ids + vocab->n_atom_names)));
+    HIP_TRY(dv_el_ids.upload(std::vector<uint8_t>(vocab->element_ids, vocab->element_ids + vocab->n_elements)));
+    HIP_TRY(dv_res_ids.upload(std::vector<uint8_t>(vocab->residue_ids, vocab->residue_ids + vocab->n_residues)));
+    VocabView V{vocab->n_atom_names, vocab->n_elements, vocab->n_residues, dv_names.p, dv_name_ids.p,
+                dv_el.p, dv_el_ids.p, dv_res.p, dv_res_ids.p};
+
+    hipLaunchKernelGGL(k_pdb_file_offsets, dim3((n_files + 256) / 256), dim3(256), 0, stream, d_nl.p, n_lines,
+                       d_file_off.p, n_files, d_atom_rank.p, d_total.p + 1, d_s_off_tmp.p);
+    if (n_lines) {
+        hipLaunchKernelGGL(k_pdb_parse, dim3((n_lines + 255) / 256), dim3(256), 0, stream,
+                           reinterpret_cast<const uint8_t *>(d_text.p), d_nl.p, n_lines, d_keep.p, d_atom_rank.p,
+                           d_line_file.p, d_file_off.p, V, P, d_bad.p);
+    }
+    if (n_files)
+        hipLaunchKernelGGL(k_pdb_residues, dim3(n_files), dim3(256), 0, stream, d_s_off_tmp.p, d_key.p, d_runs.p,
+                           d_needs_host.p);
+    HIP_TRY(hipGetLastError());
+    std::vector<uint32_t> s_off(n_files + 1, 0), runs(n_files, 0), needs_host(n_files, 0);
+    uint32_t bad = 0;
+    if (n_lines == 0) {
+        HIP_TRY(hipMemsetAsync(d_s_off_tmp.p, 0, (n_files + 1) * sizeof(uint32_t), stream));
+    }
+    HIP_TRY(hipMemcpyAsync(s_off.data(), d_s_off_tmp.p, (n_files + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    if (n_files) {
+        HIP_TRY(hipMemcpyAsync(runs.data(), d_runs.p, n_files * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(needs_host.data(), d_needs_host.p, n_files * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    }
+    HIP_TRY(hipMemcpyAsync(&bad, d_bad.p, sizeof bad, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (bad) return fail(TM_E_INVALID, "malformed ATOM/HETATM record in the PDB text");
+    std::vector<uint32_t> s_roff(n_files + 1, 0);
+    uint32_t max_atoms = 0, max_res = 0;
+    for (uint32_t f = 0; f < n_files; ++f) {
+        const uint32_t n = s_off[f + 1] - s_off[f];
+        if (n > TM_MAX_STRUCTURE_ATOMS)
+            return fail(TM_E_UNSUPPORTED, "structure " + std::to_string(f) + " has " + std::to_string(n) + " atoms; limit " +
+                                              std::to_string(TM_MAX_STRUCTURE_ATOMS));
+        if (needs_host[f])
+            return fail(TM_E_UNSUPPORTED, "structure " + std::to_string(f) + " is not residue-contiguous (or has more than " +
+                                              std::to_string(kMaxSortedRuns) + " residues): use tm_batch_create");
+        s_roff[f + 1] = s_roff[f] + runs[f] + 1;
+        max_atoms = std::max(max_atoms, n);
+        max_res = std::max(max_res, runs[f]);
+    }
+    b->max_atoms = max_atoms; b->max_res = max_res; b->s_off = s_off;
+    HIP_TRY(b->d_s_off.upload(s_off)); HIP_TRY(b->d_s_roff.upload(s_roff));
+    HIP_TRY(b->d_rec.alloc(n_atoms)); HIP_TRY(b->d_chain.alloc(n_atoms)); HIP_TRY(b->d_orig.alloc(n_atoms));
+    HIP_TRY(b->d_res_start.alloc(s_roff[n_files]));
+    HIP_TRY(b->d_cursor.alloc(1)); HIP_TRY(b->d_overflow.alloc(1));
+    if (n_files) {
+        hipLaunchKernelGGL(k_pdb_finalize, dim3(n_files), dim3(256), 0, stream, b->d_s_off.p, b->d_s_roff.p, P,
+                           b->d_rec.p, b->d_chain.p, b->d_orig.p, b->d_res_start.p);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipStreamSynchronize(stream));
+    guard.b = nullptr;
+    *out = b;
+    return TM_OK;
+}
+
+int tm_batch_atom_counts(tm_batch *b, uint32_t *atom_offsets) {
+    if (!b || !atom_offsets) return fail(TM_E_INVALID, "NULL argument");
+    std::memcpy(atom_offsets, b->s_off.data(), b->s_off.size() * sizeof(uint32_t));
+    return TM_OK;
+}
+
+int tm_batch_line_offsets(tm_batch *b, uint32_t *out, uint64_t n) {
+    if (!b || (!out && n)) return fail(TM_E_INVALID, "NULL argument");
+    if (b->d_line_off.n != b->n_atoms) return fail(TM_E_INVALID, "batch was not created from PDB text");
+    if (n < b->n_atoms) return fail(TM_E_INVALID, "output buffer too small");
+    HIP_TRY(hipSetDevice(b->device));
+    if (b->n_atoms) HIP_TRY(hipMemcpy(out, b->d_line_off.p, b->n_atoms * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return TM_OK;
 }
 

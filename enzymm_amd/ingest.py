@@ -1,0 +1,91 @@
+"""Batch ingestion of PDB files on the GPU.
+
+``load_molecules`` (/root/reference/enzymm/jess_run.py:523-556) parses one file at a time through
+``pyjess.Molecule.load``; at tens of thousands of structures per second that parse, not the
+search, is the wall clock.  ``PdbBatch`` uploads the raw file bytes once and lets
+``tm_batch_create_from_pdb`` do the fixed-column parse, the ENDMDL cut, the temperature-factor
+filter and the structure-of-arrays packing on the device.  The ``Molecule`` objects it hands out
+are lazy: their atom table is parsed on the host only when something (a ``Hit``'s atoms, a TSV
+row) actually needs it.
+"""
+from __future__ import annotations
+
+import io
+from pathlib import Path
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _native, pyjess
+from ._vocab import VOCAB
+
+
+class LazyMolecule(pyjess.Molecule):
+    """A ``Molecule`` backed by PDB text; columns appear on first use."""
+
+    def __init__(self, text: bytes, id: Optional[str], n_atoms: int, min_bfactor: float, ignore_endmdl: bool):
+        self._text = text
+        self.id = id
+        self._n = int(n_atoms)
+        self._min_bfactor = float(min_bfactor)
+        self._ignore_endmdl = bool(ignore_endmdl)
+        self._loaded = None
+        self._atoms = None
+        self._enc = None
+        import threading
+        self._lock = threading.Lock()
+
+    def _materialise(self) -> pyjess.Molecule:
+        if self._loaded is None:
+            mol = pyjess.Molecule.load(io.StringIO(self._text.decode("ascii", "replace")), id=self.id,
+                                       ignore_endmdl=self._ignore_endmdl)
+            if self._min_bfactor > 0:
+                mol = mol.conserved(self._min_bfactor)
+            if len(mol) != self._n:
+                raise RuntimeError(f"host and device parsers disagree on {self.id!r}: {len(mol)} vs {self._n} atoms")
+            self._loaded = mol
+        return self._loaded
+
+    _cols = property(lambda self: self._materialise()._cols)
+    _xyz = property(lambda self: self._materialise()._xyz)
+
+    def __len__(self):
+        return self._n
+
+    def __bool__(self):
+        return self._n > 0
+
+
+class PdbBatch:
+    """PDB files resident in HBM, ready for ``Jess.query_batch(..., batch=pdb_batch)``."""
+
+    def __init__(self, texts: Sequence[bytes], ids: Sequence[Optional[str]], device: Optional[int] = None,
+                 conservation_cutoff: float = 0.0, ignore_endmdl: bool = False):
+        self.device = pyjess.default_device() if device is None else int(device)
+        tables = VOCAB.native_tables()
+        self.vocab_version = tables[-1]
+        self.native = _native.Batch.from_pdb(self.device, list(texts), tables, min_bfactor=conservation_cutoff,
+                                             ignore_endmdl=ignore_endmdl)
+        self.native.vocab_version = self.vocab_version
+        counts = np.diff(self.native.atom_offsets)
+        self.molecules: List[LazyMolecule] = [
+            LazyMolecule(t, i, n, conservation_cutoff, ignore_endmdl) for t, i, n in zip(texts, ids, counts)]
+
+    @classmethod
+    def from_paths(cls, paths: Sequence, **kw) -> "PdbBatch":
+        """Same id rule as load_molecules: the file stem, with _2, _3 ... for repeated stems."""
+        import collections
+        seen = collections.Counter()
+        texts, ids = [], []
+        for p in paths:
+            stem = Path(p).stem
+            seen[stem] += 1
+            ids.append(stem if seen[stem] == 1 else f"{stem}_{seen[stem]}")
+            texts.append(Path(p).read_bytes())
+        return cls(texts, ids, **kw)
+
+    def __len__(self):
+        return len(self.molecules)
+
+    def close(self):
+        self.native.close()

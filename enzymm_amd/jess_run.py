@@ -362,7 +362,13 @@ class Matcher:
         return [Match(hit=h, pairwise_distance=distance_cutoff) for h in query]
 
     def run(self, molecules: List[pyjess.Molecule]) -> Dict[pyjess.Molecule, List[Match]]:
-        """Search all molecules; larger templates first, sizes < 3 skipped unless match_small_templates."""
+        """Search all molecules; larger templates first, sizes < 3 skipped unless match_small_templates.
+
+        ``molecules`` may also be an ``enzymm_amd.ingest.PdbBatch`` (PDB files parsed on the GPU); the
+        result is then keyed by its lazy ``Molecule`` objects."""
+        device_batch = None
+        if hasattr(molecules, "native") and hasattr(molecules, "molecules"):  # an ingest.PdbBatch
+            device_batch, molecules = molecules, molecules.molecules
         sizes = [s for s in self.template_effective_sizes if s >= 3 or self.match_small_templates]
         searched: List[Template] = []
         rmsd, dist, dyn, bucket_of = [], [], [], []
@@ -380,7 +386,7 @@ class Matcher:
             per_molecule = jess.query_batch(molecules, np.array(rmsd, float), np.array(dist, float),
                                             np.array(dyn, float), max_candidates=self.MAX_CANDIDATES,
                                             best_match=True, ignore_chain=True,
-                                            models=self._model_tables(searched, dist))
+                                            models=self._model_tables(searched, dist), batch=device_batch)
         position = {id(t): i for i, t in enumerate(searched)}
 
         processed: Dict[pyjess.Molecule, List[Match]] = collections.defaultdict(list)

@@ -538,13 +538,16 @@ def _packed(templates: Sequence[Template], device: int) -> _PackedLibrary:
 
 def make_batch(molecules: Sequence[Molecule], device: int) -> "_native.Batch":
     """Flatten molecules into one device-resident batch (``tm_batch_create``)."""
+    version = VOCAB.version
     enc = [m._encoded() for m in molecules]
     offsets = np.zeros(len(enc) + 1, dtype=np.uint32)
     for i, e in enumerate(enc):
         offsets[i + 1] = offsets[i] + len(e["residue"])
     cat = lambda k, dt: (np.concatenate([e[k] for e in enc]) if enc else np.zeros(0, dtype=dt)).astype(dt, copy=False)
-    return _native.Batch(device, offsets, cat("xyz", np.float64).reshape(-1, 3), cat("res_type", np.uint8),
-                         cat("name_id", np.uint8), cat("residue", np.uint32), cat("chain", np.uint8))
+    batch = _native.Batch(device, offsets, cat("xyz", np.float64).reshape(-1, 3), cat("res_type", np.uint8),
+                          cat("name_id", np.uint8), cat("residue", np.uint32), cat("chain", np.uint8))
+    batch.vocab_version = version  # ids are only meaningful against this state of the vocabulary
+    return batch
 
 
 # ---------------------------------------------------------------------------------- Hit / Query / Jess
@@ -640,6 +643,15 @@ class Jess:
             if not isinstance(t, Template):
                 raise TypeError(f"expected Template, found {type(t).__name__}")
         self._device = default_device() if device is None else int(device)
+        # every name the templates refer to gets its id now, so batches encoded after this line stay valid
+        for t in self._templates:
+            if getattr(t, "_vocab_version", None) is None:
+                for a in t._atoms:
+                    VOCAB.register_template_atom(a.match_mode, a._raw_names, a._raw_residues)
+                try:
+                    t._vocab_version = VOCAB.version
+                except AttributeError:
+                    pass
 
     def __len__(self):
         return len(self._templates)
@@ -673,6 +685,13 @@ class Jess:
         own_batch = batch is None
         if own_batch:
             batch = make_batch(molecules, self._device)
+        else:
+            batch = getattr(batch, "native", batch)  # an ingest.PdbBatch or a raw _native.Batch
+            if getattr(batch, "vocab_version", VOCAB.version) != VOCAB.version:
+                raise ValueError("this batch was encoded before new atom/residue names were registered by a "
+                                 "template; create the Jess (or its templates) first, then the batch")
+            if batch.n_structures != len(molecules):
+                raise ValueError("batch and molecule list differ in length")
         flags = _native.TM_FLAG_BEST_MATCH if best_match else 0
         if ignore_chain:
             flags |= _native.TM_FLAG_IGNORE_CHAIN

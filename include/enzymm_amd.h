@@ -103,6 +103,21 @@ typedef struct tm_batch_desc {
     const uint8_t *chain;         /* [n_atoms] chain ordinal within its structure */
 } tm_batch_desc;
 
+/* How raw PDB fields map to the ids of the host's vocabulary (tm_batch_create_from_pdb). */
+typedef struct tm_vocab {
+    uint32_t n_atom_names;
+    const char *atom_names;       /* [n * 4] raw 4-character name fields (cols 13-16) */
+    const uint8_t *atom_name_ids; /* [n] */
+    uint32_t n_elements;
+    const char *elements;         /* [n * 2] element columns (cols 13-14) for names not listed above */
+    const uint8_t *element_ids;   /* [n] */
+    uint32_t n_residues;
+    const char *residue_names;    /* [n * 3] raw residue-name fields (cols 18-20) */
+    const uint8_t *residue_ids;   /* [n] */
+} tm_vocab;
+
+enum { TM_PDB_IGNORE_ENDMDL = 1u };
+
 typedef struct tm_query_params {
     uint32_t n_selected;                /* templates to search */
     const uint32_t *template_index;     /* [n_selected] indices into the library */
@@ -148,6 +163,13 @@ int tm_library_create(int device, const tm_library_desc *desc, tm_library **out)
 void tm_library_destroy(tm_library *lib);
 
 int tm_batch_create(int device, const tm_batch_desc *desc, tm_batch **out);
+/* Device-side ingestion: raw PDB text is uploaded and parsed on the GPU (ATOM/HETATM records up to the first
+ * ENDMDL, optional temperature-factor cutoff) -- replaces pyjess.Molecule.load + Molecule.conserved for batches,
+ * enzymm/jess_run.py:538-545.  TM_E_UNSUPPORTED when a file is not residue-contiguous: use tm_batch_create. */
+int tm_batch_create_from_pdb(int device, uint32_t n_files, const char *const *text, const uint64_t *length,
+                             const tm_vocab *vocab, uint32_t flags, double min_bfactor, tm_batch **out);
+int tm_batch_atom_counts(tm_batch *batch, uint32_t *atom_offsets);            /* [n_structures + 1] */
+int tm_batch_line_offsets(tm_batch *batch, uint32_t *out, uint64_t n);        /* byte offset of each kept record in its file */
 void tm_batch_destroy(tm_batch *batch);
 
 /* Asynchronous on params->stream; the result owns the device-side hit table. */

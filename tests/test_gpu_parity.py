@@ -266,6 +266,62 @@ def test_fused_epilogue_matches_python_filter(amy, af):
     assert h.orientation == pytest.approx(G["G1"]["orientation"], abs=5e-8)
 
 
+def test_device_pdb_ingestion(amy, af, default_library):
+    """PDB text parsed on the GPU must give exactly the batch the host loader gives."""
+    from enzymm_amd import ingest
+    jess, olib, idx, cut = default_library
+    synth = synthetic.structures(12)
+    texts = [(helpers.GOLDEN / "1AMY.pdb").read_bytes(), (helpers.GOLDEN / "AF-P0DUB6-F1-model_v4.pdb").read_bytes()]
+    texts += [synthetic.to_pdb(m).encode() for m in synth]
+    ids = ["1AMY", "AF"] + [m.id for m in synth]
+    host_mols = [pyjess.Molecule.loads(t.decode(), id=i) for t, i in zip(texts, ids)]
+    assert [len(m) for m in host_mols[:2]] == [3339, 4079]
+    for cutoff in (0.0, 80.0):
+        pb = ingest.PdbBatch(texts, ids, device=jess._device, conservation_cutoff=cutoff)
+        want_mols = [m.conserved(cutoff) if cutoff else m for m in host_mols]
+        assert [len(m) for m in pb.molecules] == [len(m) for m in want_mols]
+        got = jess.query_batch(pb.molecules, 2.0, cut, cut, max_candidates=10000, ignore_chain=True,
+                               template_index=idx, batch=pb, return_raw=True)
+        want = jess.query_batch(want_mols, 2.0, cut, cut, max_candidates=10000, ignore_chain=True,
+                                template_index=idx, return_raw=True)
+        assert len(got) == len(want) > 0 and got.tobytes() == want.tobytes()
+        # the lazy molecules materialise to the same atoms the host loader produced
+        hits = jess.query_batch(pb.molecules, 2.0, cut, cut, max_candidates=10000, ignore_chain=True,
+                                template_index=idx, batch=pb)
+        h = next(h for per in hits for h in per)
+        assert [a.serial for a in h.atoms()] == [h._molecule._atom_list()[i].serial for i in h._atom_index]
+        # record offsets point at the kept ATOM/HETATM lines
+        offs, counts = pb.native.line_offsets(), pb.native.atom_offsets
+        for f in (0, 2):
+            first = int(offs[counts[f]])
+            assert texts[f][first:first + 6] in (b"ATOM  ", b"HETATM")
+        pb.close()
+    # the batch driver accepts the device-parsed batch directly
+    lib54 = list(template.load_templates(TPL / "5_residues")) + list(template.load_templates(TPL / "4_residues"))
+    pb = ingest.PdbBatch(texts[:2], ids[:2], device=jess._device)
+    via_device = jess_run.Matcher(lib54).run(pb)
+    via_host = jess_run.Matcher(lib54).run(host_mols[:2])
+    assert [[m.hit.template.id for m in v] for v in via_device.values()] == \
+           [[m.hit.template.id for m in v] for v in via_host.values()]
+    assert [m.query_residue_count for m in via_device[pb.molecules[0]]] == \
+           [m.query_residue_count for m in via_host[host_mols[0]]]
+    # ENDMDL handling: two models, only the first is read unless asked otherwise
+    model2 = b"".join(l[:20] + b" B" + l[22:] if l.startswith(b"ATOM") else l for l in texts[2].splitlines(keepends=True))
+    two = b"MODEL 1\n" + texts[2] + b"ENDMDL\nMODEL 2\n" + model2 + b"ENDMDL\n"
+    assert len(ingest.PdbBatch([two], ["x"]).molecules[0]) == len(synth[0])
+    assert len(ingest.PdbBatch([two], ["x"], ignore_endmdl=True).molecules[0]) == 2 * len(synth[0])
+    with pytest.raises(_native.NativeError):  # the same residues twice: not residue-contiguous
+        ingest.PdbBatch([b"MODEL 1\n" + texts[2] + b"ENDMDL\nMODEL 2\n" + texts[2]], ["x"], ignore_endmdl=True)
+    # a file whose residues are not contiguous is refused loudly (callers fall back to tm_batch_create)
+    lines = texts[2].decode().splitlines(keepends=True)
+    shuffled = "".join(lines[:3] + lines[40:43] + lines[3:40] + lines[43:]).encode()
+    with pytest.raises(_native.NativeError):
+        ingest.PdbBatch([shuffled], ["bad"])
+    with pytest.raises(_native.NativeError):
+        ingest.PdbBatch([b"ATOM      1  N   GLY A   1       0.000   x.000   0.000\n"], ["bad"])
+    assert len(ingest.PdbBatch([b"", b"END\n"], ["e1", "e2"]).molecules[0]) == 0
+
+
 def test_full_batch_properties(default_library):
     """configs[2] size (1000 structures x 6780 templates): properties that need no oracle."""
     jess, olib, idx, cut = default_library
