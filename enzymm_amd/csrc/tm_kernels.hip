@@ -382,8 +382,7 @@ __device__ __forceinline__ bool on_complete(const SearchCtx &C, WaveRegs &W, con
 // Returns false when the pair was cut short by max_candidates.
 __device__ __forceinline__ bool dfs(const SearchCtx &C, WaveRegs &W, const LibView &L, const double *qx,
                                     const QueryView &Q, const OutView &O, PairState &P, int floor) {
-    const int k = C.k;
-    if (floor >= k) return on_complete(C, W, L, qx, Q, O, P);
+    const int k = C.k;  // floor < k always: a template has at least 3 atoms per residue
     int level = floor;
     init_level(C, W, level);
     for (;;) {
@@ -445,11 +444,17 @@ __device__ __forceinline__ bool in_window(const float4 &p, const float4 &q, cons
 // (1, 0); surviving pairs are queued in LDS and, when the template has a third residue, the
 // cross product queue x list2 is tiled the same way against the constraints (2, 0) and (2, 1).
 // Only what survives that is searched depth-first (levels >= 3, or >= 2 for two-residue templates).
+//
+// Written as one resumable producer/consumer loop so that each stage -- pair tile, triple tile,
+// depth-first search -- exists exactly once in the instruction stream (the kernel must fit the
+// instruction cache): queue3 is refilled from the triple tiles, which pull from the pair queue,
+// which is refilled from the pair tiles.
 __device__ __forceinline__ bool joint_top_scan(const SearchCtx &C, WaveRegs &W, const LibView &L, const double *qx,
                                                const QueryView &Q, const OutView &O, PairState &P) {
     WaveScratch &S = *C.S;
     const int lane = C.lane;
-    const uint32_t n0 = RL(W.cnt, 0), n1 = RL(W.cnt, 1);
+    const bool single = C.n_groups < 2;  // one-residue template: plain depth-first search from level 0
+    const uint32_t n0 = single ? 0u : RL(W.cnt, 0), n1 = single ? 0u : RL(W.cnt, 1);
     const uint32_t lo0 = RL(W.lo, 0), lo1 = RL(W.lo, 1);
     const bool in_lds = n0 <= (uint32_t)kJointList && n1 <= (uint32_t)kJointList;
     const uint32_t n2 = C.n_groups >= 3 ? RL(W.cnt, 2) : 0u;
@@ -470,122 +475,105 @@ __device__ __forceinline__ bool joint_top_scan(const SearchCtx &C, WaveRegs &W, 
     const float2 b20 = S.bnd_lead[tri(2)], b21 = S.bnd_lead[tri(2) + 1];    // pairs (2, 0), (2, 1)
     const bool tc10 = RL(W.tchain, 0) == RL(W.tchain, 1);
     const bool tc20 = RL(W.tchain, 0) == RL(W.tchain, 2), tc21 = RL(W.tchain, 1) == RL(W.tchain, 2);
-    uint32_t nq = 0, nq3 = 0;  // queued survivors (uniform)
-    int floor = 3;             // levels already assigned by the queue3 entries
-    bool go_on = true;
+    const int floor = single ? 0 : tiled2 ? 3 : 2;  // levels the queue3 entries assign
 
-    // depth-first search below every queued partial assignment (the ONLY call site of dfs)
-    auto drain3 = [&]() {
-        for (uint32_t e = 0; e < nq3 && go_on; ++e) {
-            const uint32_t ab = uni(S.queue3[e][0]), c = uni(S.queue3[e][1]);
+    uint32_t i0 = 0, j0 = 0;        // next pair tile
+    bool pairs_done = single;
+    uint32_t nq = 0, e0 = 0, c0 = 0;  // pair queue fill, next triple tile (entry base, list2 base)
+    uint32_t sh2 = 6;               // triple tile shape for the current pair queue
+    uint32_t nq3 = 0;
+    bool single_pending = single;
+
+    for (;;) {
+        // ---- refill queue3 while it has room for a whole tile of survivors
+        if (single_pending) {
+            nq3 = 1;
+            single_pending = false;
+        } else {
+            while (nq3 + 64u <= (uint32_t)kJointQueue) {
+                if (e0 < nq) {
+                    if (tiled2) {  // one triple tile: TI2 queued pairs x TJ2 entries of list2
+                        const uint32_t TJ2 = 1u << sh2;
+                        const uint32_t e = e0 + ((uint32_t)lane >> sh2), j = c0 + ((uint32_t)lane & (TJ2 - 1));
+                        const bool ve = e < nq, vj = j < n2;
+                        const uint32_t ab = ve ? S.queue[e] : 0u;
+                        const uint32_t a = ab & 0xffffu, b = ab >> 16;
+                        const uint32_t c = vj ? (uint32_t)S.list2[j] : 0u;
+                        const float4 ra = C.rec[a], rb = C.rec[b], rc = C.rec[c];
+                        const uint32_t res_c = meta_res(__float_as_uint(rc.w));
+                        bool ok = ve && vj && in_window(rc, ra, b20) && in_window(rc, rb, b21) &&
+                                  res_c != meta_res(__float_as_uint(ra.w)) && res_c != meta_res(__float_as_uint(rb.w));
+                        if (!C.ignore_chain) {
+                            const uint8_t qc = C.qchain[c];
+                            ok = ok && ((qc == C.qchain[a]) == tc20) && ((qc == C.qchain[b]) == tc21);
+                        }
+                        const unsigned long long m = __ballot(ok);
+                        TM_STAT(2, 1);
+                        TM_STAT(24 + 2, __popcll(m));
+                        if (ok) {
+                            const uint32_t slot = nq3 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                            S.queue3[slot][0] = ab;
+                            S.queue3[slot][1] = c;
+                        }
+                        nq3 += (uint32_t)__popcll(m);
+                        c0 += TJ2;
+                        if (c0 >= n2) { c0 = 0; e0 += 64u >> sh2; }
+                    } else {  // two-residue template (or a very long list2): pairs go to the search as they are
+                        const uint32_t e = e0 + (uint32_t)lane;
+                        if (e < nq) S.queue3[nq3 + lane][0] = S.queue[e];
+                        nq3 += min(64u, nq - e0);
+                        e0 += 64u;
+                    }
+                    continue;
+                }
+                // the pair queue is used up: refill it from the pair tiles
+                if (pairs_done) break;
+                nq = 0; e0 = 0; c0 = 0;
+                wave_sync();
+                while (!pairs_done && nq + 64u <= (uint32_t)kJointQueue) {
+                    const uint32_t i = i0 + li, j = j0 + lj;
+                    const bool vi = i < n0, vj = j < n1;
+                    uint32_t a = 0, b = 0;
+                    if (vi) a = in_lds ? (uint32_t)S.list0[i] : (uint32_t)C.pool[lo0 + i];
+                    if (vj) b = in_lds ? (uint32_t)S.list1[j] : (uint32_t)C.pool[lo1 + j];
+                    const float4 ra = C.rec[a], rb = C.rec[b];
+                    bool ok = vi && vj && in_window(ra, rb, b10) &&
+                              meta_res(__float_as_uint(ra.w)) != meta_res(__float_as_uint(rb.w));
+                    if (!C.ignore_chain) ok = ok && ((C.qchain[a] == C.qchain[b]) == tc10);
+                    const unsigned long long m = __ballot(ok);
+                    TM_STAT(52, 1);
+                    TM_STAT(53, __popcll(m));
+                    if (ok) S.queue[nq + __popcll(m & ((1ull << lane) - 1ull))] = a | (b << 16);
+                    nq += (uint32_t)__popcll(m);
+                    j0 += TJ;
+                    if (j0 >= n1) { j0 = 0; i0 += TI; }
+                    if (i0 >= n0) pairs_done = true;
+                }
+                wave_sync();
+#if defined(TM_STATS) || defined(TM_ABLATE)
+                if (Q.flags & 0x100u) nq = 0;
+#endif
+                sh2 = best_tile_shift(nq, n2);
+            }
+            wave_sync();
+        }
+        if (nq3 == 0) return true;  // every tile evaluated, nothing left to search
+        // ---- depth-first search below every queued partial assignment (the only dfs call site)
+#if defined(TM_STATS) || defined(TM_ABLATE)
+        if (Q.flags & 0x400u) nq3 = 0;
+#endif
+        for (uint32_t e = 0; e < nq3; ++e) {
             if (floor >= 2) {
+                const uint32_t ab = uni(S.queue3[e][0]);
                 assign_level(C, W, 0, ab & 0xffffu);
                 assign_level(C, W, 1, ab >> 16);
             }
-            if (floor >= 3) assign_level(C, W, 2, c);
-            go_on = dfs(C, W, L, qx, Q, O, P, floor);
+            if (floor >= 3) assign_level(C, W, 2, uni(S.queue3[e][1]));
+            if (!dfs(C, W, L, qx, Q, O, P, floor)) return false;
         }
         nq3 = 0;
-    };
-
-    if (C.n_groups < 2) {  // single-residue template: plain depth-first search from level 0
-        floor = 0;
-        nq3 = 1;
-        drain3();
-        return go_on;
-    }
-
-    // queued pairs -> tiled scan against list2, or straight to the depth-first search
-    auto drain = [&]() {
-#if defined(TM_STATS) || defined(TM_ABLATE)
-        if (Q.flags & 0x100u) { nq = 0; return; }
-#endif
-        if (!tiled2) {  // the pairs go to the depth-first search as they are
-            floor = 2;
-            if (lane < (int)nq) S.queue3[lane][0] = S.queue[lane];
-            if (lane + 64 < (int)nq) S.queue3[lane + 64][0] = S.queue[lane + 64];
-            wave_sync();
-            nq3 = nq;
-            drain3();
-            nq = 0;
-            return;
-        }
-        const uint32_t sh = best_tile_shift(nq, n2);
-        const uint32_t TJ2 = 1u << sh, TI2 = 64u >> sh;
-        const uint32_t le = (uint32_t)lane >> sh, lc = (uint32_t)lane & (TJ2 - 1);
-        for (uint32_t e0 = 0; e0 < nq && go_on; e0 += TI2) {
-            const uint32_t e = e0 + le;
-            const bool ve = e < nq;
-            const uint32_t ab = ve ? S.queue[e] : 0u;
-            const uint32_t a = ab & 0xffffu, b = ab >> 16;
-            const float4 ra = C.rec[a], rb = C.rec[b];
-            const uint32_t res_a = meta_res(__float_as_uint(ra.w)), res_b = meta_res(__float_as_uint(rb.w));
-            for (uint32_t j0 = 0; j0 < n2; j0 += TJ2) {
-                const uint32_t j = j0 + lc;
-                const bool vj = j < n2;
-                const uint32_t c = vj ? (uint32_t)S.list2[j] : 0u;
-                const float4 rc = C.rec[c];
-                const uint32_t res_c = meta_res(__float_as_uint(rc.w));
-                bool ok = ve && vj && in_window(rc, ra, b20) && in_window(rc, rb, b21) && res_c != res_a && res_c != res_b;
-                if (!C.ignore_chain) {
-                    const uint8_t qc = C.qchain[c];
-                    ok = ok && ((qc == C.qchain[a]) == tc20) && ((qc == C.qchain[b]) == tc21);
-                }
-                const unsigned long long m = __ballot(ok);
-                TM_STAT(2, 1);
-                TM_STAT(24 + 2, __popcll(m));
-                if (m) {
-                    const uint32_t cntm = (uint32_t)__popcll(m);
-                    if (nq3 + cntm > (uint32_t)kJointQueue) {
-                        wave_sync();
-                        drain3();
-                    }
-                    if (ok) {
-                        const uint32_t slot = nq3 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                        S.queue3[slot][0] = ab;
-                        S.queue3[slot][1] = c;
-                    }
-                    nq3 += cntm;
-                }
-            }
-        }
         wave_sync();
-        if (go_on) drain3();
-        nq = 0;
-    };
-
-    for (uint32_t i0 = 0; i0 < n0 && go_on; i0 += TI) {
-        const uint32_t i = i0 + li;
-        const bool vi = i < n0;
-        uint32_t a = 0;
-        if (vi) a = in_lds ? (uint32_t)S.list0[i] : (uint32_t)C.pool[lo0 + i];
-        const float4 ra = C.rec[a];
-        for (uint32_t j0 = 0; j0 < n1; j0 += TJ) {
-            const uint32_t j = j0 + lj;
-            const bool vj = j < n1;
-            uint32_t b = 0;
-            if (vj) b = in_lds ? (uint32_t)S.list1[j] : (uint32_t)C.pool[lo1 + j];
-            const float4 rb = C.rec[b];
-            bool ok = vi && vj && in_window(ra, rb, b10) &&
-                      meta_res(__float_as_uint(ra.w)) != meta_res(__float_as_uint(rb.w));
-            if (!C.ignore_chain) ok = ok && ((C.qchain[a] == C.qchain[b]) == tc10);
-            const unsigned long long m = __ballot(ok);
-            TM_STAT(52, 1);
-            TM_STAT(53, __popcll(m));
-            if (m) {
-                const uint32_t cntm = (uint32_t)__popcll(m);
-                if (nq + cntm > (uint32_t)kJointQueue) {  // make room first (uniform branch)
-                    wave_sync();
-                    drain();
-                }
-                if (ok) S.queue[nq + __popcll(m & ((1ull << lane) - 1ull))] = a | (b << 16);
-                nq += cntm;
-            }
-        }
     }
-    wave_sync();
-    if (go_on) drain();
-    return go_on;
 }
 
 template <bool kLds>
