@@ -453,16 +453,15 @@ __device__ __forceinline__ bool joint_top_scan(const SearchCtx &C, WaveRegs &W, 
                                                const QueryView &Q, const OutView &O, PairState &P) {
     WaveScratch &S = *C.S;
     const int lane = C.lane;
-    const bool single = C.n_groups < 2;  // one-residue template: plain depth-first search from level 0
+    // plain depth-first search from level 0 for one-residue templates and for the rare template whose
+    // two most selective lead lists do not fit the LDS staging area (e.g. "any residue" backbone atoms)
+    const bool single = C.n_groups < 2 || RL(W.cnt, 0) > (uint32_t)kJointList || RL(W.cnt, 1) > (uint32_t)kJointList;
     const uint32_t n0 = single ? 0u : RL(W.cnt, 0), n1 = single ? 0u : RL(W.cnt, 1);
     const uint32_t lo0 = RL(W.lo, 0), lo1 = RL(W.lo, 1);
-    const bool in_lds = n0 <= (uint32_t)kJointList && n1 <= (uint32_t)kJointList;
     const uint32_t n2 = C.n_groups >= 3 ? RL(W.cnt, 2) : 0u;
-    const bool tiled2 = C.n_groups >= 3 && n2 <= (uint32_t)kJointList;  // third lead scanned by tiles too
-    if (in_lds) {
-        for (uint32_t i = lane; i < n0; i += 64) S.list0[i] = C.pool[lo0 + i];
-        for (uint32_t i = lane; i < n1; i += 64) S.list1[i] = C.pool[lo1 + i];
-    }
+    const bool tiled2 = !single && C.n_groups >= 3 && n2 <= (uint32_t)kJointList;  // third lead scanned by tiles too
+    for (uint32_t i = lane; i < n0; i += 64) S.list0[i] = C.pool[lo0 + i];
+    for (uint32_t i = lane; i < n1; i += 64) S.list1[i] = C.pool[lo1 + i];
     if (tiled2) {
         const uint32_t lo2 = RL(W.lo, 2);
         for (uint32_t i = lane; i < n2; i += 64) S.list2[i] = C.pool[lo2 + i];
@@ -496,9 +495,9 @@ __device__ __forceinline__ bool joint_top_scan(const SearchCtx &C, WaveRegs &W, 
                         const uint32_t TJ2 = 1u << sh2;
                         const uint32_t e = e0 + ((uint32_t)lane >> sh2), j = c0 + ((uint32_t)lane & (TJ2 - 1));
                         const bool ve = e < nq, vj = j < n2;
-                        const uint32_t ab = ve ? S.queue[e] : 0u;
+                        const uint32_t ab = S.queue[min(e, nq - 1)];  // clamped, branch-free; masked by ve / vj
                         const uint32_t a = ab & 0xffffu, b = ab >> 16;
-                        const uint32_t c = vj ? (uint32_t)S.list2[j] : 0u;
+                        const uint32_t c = (uint32_t)S.list2[min(j, n2 - 1)];
                         const float4 ra = C.rec[a], rb = C.rec[b], rc = C.rec[c];
                         const uint32_t res_c = meta_res(__float_as_uint(rc.w));
                         bool ok = ve && vj && in_window(rc, ra, b20) && in_window(rc, rb, b21) &&
@@ -533,9 +532,8 @@ __device__ __forceinline__ bool joint_top_scan(const SearchCtx &C, WaveRegs &W, 
                 while (!pairs_done && nq + 64u <= (uint32_t)kJointQueue) {
                     const uint32_t i = i0 + li, j = j0 + lj;
                     const bool vi = i < n0, vj = j < n1;
-                    uint32_t a = 0, b = 0;
-                    if (vi) a = in_lds ? (uint32_t)S.list0[i] : (uint32_t)C.pool[lo0 + i];
-                    if (vj) b = in_lds ? (uint32_t)S.list1[j] : (uint32_t)C.pool[lo1 + j];
+                    const uint32_t ic = min(i, n0 - 1), jc = min(j, n1 - 1);  // clamped, branch-free
+                    const uint32_t a = S.list0[ic], b = S.list1[jc];
                     const float4 ra = C.rec[a], rb = C.rec[b];
                     bool ok = vi && vj && in_window(ra, rb, b10) &&
                               meta_res(__float_as_uint(ra.w)) != meta_res(__float_as_uint(rb.w));
