@@ -455,6 +455,13 @@ class _PackedLibrary:
     """Host tables + device handle of a list of templates (what ``Jess(templates)`` builds)."""
 
     def __init__(self, templates: Sequence[Template], device: int):
+        if hasattr(templates, "device_tables"):  # a library_pack.PackedTemplates: flat arrays, no per-atom objects
+            tables = templates.device_tables(VOCAB)
+            self.vocab_version = VOCAB.version
+            self.offsets = np.ascontiguousarray(tables[0], dtype=np.uint32)
+            self.native = _native.Library(device, *tables[:8], orientation=tables[8])
+            self.device = device
+            return
         for t in templates:
             if len(t._atoms) == 0:
                 raise ValueError("cannot search an empty template")
@@ -523,14 +530,16 @@ _PACK_CACHE_SIZE = 32
 def _packed(templates: Sequence[Template], device: int) -> _PackedLibrary:
     """enzymm rebuilds ``Jess(templates)`` for every (molecule, size) call (jess_run.py:800);
     the device copy of a template list is therefore cached by identity of its members."""
-    key = (device, tuple(id(t) for t in templates))
+    key = (device, "pack", id(templates)) if hasattr(templates, "device_tables") \
+        else (device, tuple(id(t) for t in templates))
     with _pack_lock:
         hit = _pack_cache.get(key)
         if hit is not None and hit[1].vocab_version == VOCAB.version:
             _pack_cache.move_to_end(key)
             return hit[1]
         packed = _PackedLibrary(templates, device)
-        _pack_cache[key] = (tuple(templates), packed)  # keeps the templates alive: ids stay unique
+        keep_alive = templates if hasattr(templates, "device_tables") else tuple(templates)
+        _pack_cache[key] = (keep_alive, packed)  # keeps the templates alive: ids stay unique
         while len(_pack_cache) > _PACK_CACHE_SIZE:
             _pack_cache.popitem(last=False)
         return packed
@@ -597,8 +606,9 @@ class Hit:
 
     def atoms(self, transform: bool = False) -> List[Atom]:
         """Matched target atoms in template-atom order; ``transform`` maps them into the template frame."""
-        mol_atoms = self._molecule._atom_list()
-        picked = [mol_atoms[i] for i in self._atom_index]
+        mol = self._molecule
+        # only the matched atoms are materialised (a full atom list would cost far more than the query)
+        picked = [mol._atoms[i] if mol._atoms is not None else mol._atom(i) for i in self._atom_index]
         return [self._transform(a) for a in picked] if transform else [a.copy() for a in picked]
 
     def molecule(self, transform: bool = False) -> Molecule:
@@ -638,11 +648,16 @@ class Jess:
     """A set of templates to search structures with (device-resident once constructed)."""
 
     def __init__(self, templates: Iterable[Template] = (), device: Optional[int] = None):
+        self._device = default_device() if device is None else int(device)
+        if hasattr(templates, "device_tables"):
+            # library_pack.PackedTemplates: a lazy sequence; Template objects appear only for hits
+            self._templates = templates
+            _packed(templates, self._device)  # registers the library's vocabulary
+            return
         self._templates = tuple(templates)
         for t in self._templates:
             if not isinstance(t, Template):
                 raise TypeError(f"expected Template, found {type(t).__name__}")
-        self._device = default_device() if device is None else int(device)
         # every name the templates refer to gets its id now, so batches encoded after this line stay valid
         for t in self._templates:
             if getattr(t, "_vocab_version", None) is None:

@@ -322,6 +322,28 @@ def test_device_pdb_ingestion(amy, af, default_library):
     assert len(ingest.PdbBatch([b"", b"END\n"], ["e1", "e2"]).molecules[0]) == 0
 
 
+def test_packed_library_same_hits(amy, af, tmp_path):
+    """querying through the memory-mapped pack == querying through Template objects."""
+    from enzymm_amd import library_pack
+    lib = template.load_packed_library()
+    path = tmp_path / "lib.pack"
+    library_pack.write_pack(lib, path)
+    P = library_pack.PackedTemplates(path)
+    eff = P.effective_size
+    idx = np.nonzero(eff >= 3)[0]
+    cut = np.array([helpers.DEFAULT_DISTANCE[min(int(e), 8)] for e in eff[idx]])
+    mols = [amy, af] + synthetic.structures(6)
+    a = pyjess.Jess(P).query_batch(mols, 2.0, cut, cut, max_candidates=10000, ignore_chain=True, template_index=idx,
+                                   return_raw=True)
+    b = pyjess.Jess(lib).query_batch(mols, 2.0, cut, cut, max_candidates=10000, ignore_chain=True,
+                                     template_index=idx, return_raw=True)
+    assert len(a) > 20 and a.tobytes() == b.tobytes()
+    hits = pyjess.Jess(P).query_batch([amy], 2.0, cut, cut, max_candidates=10000, ignore_chain=True,
+                                      template_index=idx)[0]
+    assert all(isinstance(h.template, template.Template) for h in hits)
+    assert len(P._cache) == len({id(h.template) for h in hits})  # only templates with hits were materialised
+
+
 def test_full_batch_properties(default_library):
     """configs[2] size (1000 structures x 6780 templates): properties that need no oracle."""
     jess, olib, idx, cut = default_library

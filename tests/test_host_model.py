@@ -210,3 +210,34 @@ def test_load_molecules(tmp_path):
                                         tmp_path / "empty.pdb"], conservation_cutoff=80, warn=True)
     assert [m.id for m in mols] == ["1AMY", "1AMY_2"]
     assert len(mols[0]) == 3339  # the reference discards conserved()'s result (jess_run.py:541-545)
+
+
+def test_library_pack_round_trip(tmp_path, monkeypatch):
+    """the one-file pack reproduces the tables and the Template objects of the text library."""
+    from enzymm_amd import library_pack
+    lib = template.load_packed_library()[::9]
+    path = tmp_path / "lib.pack"
+    library_pack.write_pack(lib, path)
+    P = library_pack.PackedTemplates(path)
+    assert len(P) == len(lib) and list(P.effective_size) == [t.effective_size for t in lib]
+    for i in (0, 17, len(lib) - 1):
+        assert P[i] == lib[i] and hash(P[i]) == hash(lib[i]) and P[i] is P[i]
+        assert [r.orientation_vector for r in P[i].residues] == [r.orientation_vector for r in lib[i].residues]
+        assert (P[i].ec, P[i].cath, P[i].cluster, P[i].relative_order) == \
+               (lib[i].ec, lib[i].cath, lib[i].cluster, lib[i].relative_order)
+    captured = {}
+
+    class FakeLibrary:  # capture what would go to tm_library_create (no GPU here)
+        def __init__(self, device, *args, orientation=None):
+            captured["args"], captured["orientation"] = args, orientation
+
+    monkeypatch.setattr(_native, "Library", FakeLibrary)
+    pyjess._PackedLibrary(lib, 0)
+    want = dict(captured)
+    pyjess._PackedLibrary(P, 0)
+    for a, b in zip(want["args"], captured["args"]):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+    for a, b in zip(want["orientation"], captured["orientation"]):
+        assert np.array_equal(np.asarray(a), np.asarray(b).reshape(np.asarray(a).shape))
+    with pytest.raises(ValueError):
+        library_pack.PackedTemplates(helpers.GOLDEN / "1AMY.pdb")

@@ -153,3 +153,22 @@ def test_missing_logistic_model_raises(amy):
                        pairwise_distance=0.55)
     with pytest.raises(KeyError):
         m.predicted_correct
+
+
+def test_report_writers_match_the_cli_layout(amy, af, tmp_path):
+    """_cli.py:266-316: '# Version' line, header once, 1-based match_index per query, one PDB per query."""
+    from enzymm_amd import report
+    load = lambda d: list(template.load_templates(TPL / d))
+    t54 = load("5_residues/results/csa3d_0285") + load("4_residues/results/csa3d_0285")
+    processed = _matcher(t54).run([amy, af])
+    n = report.write_tsv(processed, tmp_path / "sub" / "out.tsv", version="x")
+    lines = (tmp_path / "sub" / "out.tsv").read_text().splitlines()
+    assert n == 4 and lines[0] == "# Version x" and lines[1].startswith("query_id\t") and len(lines) == 6
+    assert [l.split("\t")[0] for l in lines[2:]] == ["1AMY", "1AMY", "AF-P0DUB6-F1-model_v4", "AF-P0DUB6-F1-model_v4"]
+    assert [l.split("\t")[2] for l in lines[2:]] == ["1", "2", "1", "2"]
+    files = report.write_pdbs(processed, tmp_path / "pdbs", include_query=True)
+    assert [f.name for f in files] == ["1AMY_matches.pdb", "AF-P0DUB6-F1-model_v4_matches.pdb"]
+    text = files[0].read_text()
+    assert text.count("HEADER MOLECULE_ID 1AMY") == 1 and text.count("REMARK MATCH INDEX") == 2
+    with pytest.raises(FileExistsError):
+        report.write_pdbs(processed, tmp_path / "pdbs")
