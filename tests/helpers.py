@@ -112,3 +112,52 @@ class OracleJess:
                                 max_candidates=max_candidates, ignore_chain=ignore_chain, best_match=best_match)
         return pyjess.Query(self, molecule, rmsd_threshold, distance_cutoff, max_dynamic_distance, max_candidates,
                             ignore_chain, best_match, hits[0])
+
+
+def implant_templates(mol, templates, rng, max_templates=200, radius=14.0):
+    """Re-seat library templates on residues of ``mol``: every template atom takes the coordinates of the
+    same-named atom of a randomly chosen residue of an admissible type, residues picked within ``radius`` of the
+    first one.  The result is a list of pyjess.Template that are guaranteed to hit ``mol`` (RMSD 0 plus all
+    the symmetric alternatives) -- a dense parity workload, unlike the sparse hits of real templates."""
+    from enzymm_amd import pyjess
+    c = mol._cols
+    names = np.char.strip(c["name"].astype("U4"))
+    resn = np.char.strip(c["residue_name"].astype("U3"))
+    keys = list(zip(c["chain_id"].tolist(), c["residue_number"].tolist(), c["insertion_code"].tolist()))
+    by_res = {}
+    for i, k in enumerate(keys):
+        by_res.setdefault(k, []).append(i)
+    residues = [(k, resn[idx[0]], {names[i]: i for i in idx}, mol._xyz[idx].mean(0)) for k, idx in by_res.items()]
+    out = []
+    order = rng.permutation(len(templates))
+    for ti in order:
+        if len(out) >= max_templates:
+            break
+        tpl = templates[ti]
+        groups = {}
+        for a in tpl:
+            groups.setdefault((a.chain_id, a.residue_number), []).append(a)
+        chosen, used, centre, ok = {}, set(), None, True
+        for g, atoms in groups.items():
+            allowed = set(atoms[0].residue_names)
+            cands = [r for r in residues if r[0] not in used and (atoms[0].match_mode >= 100 or r[1] in allowed)
+                     and all(a.atom_names[0] in r[2] for a in atoms)
+                     and (centre is None or np.linalg.norm(r[3] - centre) < radius)]
+            if not cands:
+                ok = False
+                break
+            r = cands[int(rng.integers(len(cands)))]
+            chosen[g] = r
+            used.add(r[0])
+            centre = r[3] if centre is None else centre
+        if not ok:
+            continue
+        new_atoms = []
+        for a in tpl:
+            r = chosen[(a.chain_id, a.residue_number)]
+            x, y, z = mol._xyz[r[2][a.atom_names[0]]]
+            b = a.copy()
+            b.x, b.y, b.z = float(x), float(y), float(z)
+            new_atoms.append(b)
+        out.append(pyjess.Template(new_atoms, id=f"implant_{ti}"))
+    return out

@@ -100,6 +100,62 @@ def test_synthetic_batch_vs_oracle(default_library):
         compare(table, cands, s, r, olib)
 
 
+def test_implanted_templates_dense_hits(amy, af):
+    """Library templates re-seated on residues of the query: every one of them hits (RMSD 0) and has symmetric
+    alternatives (OD1/OD2 swaps, ring flips) -- exercises best-hit selection, ties and deep levels."""
+    rng = np.random.default_rng(7)
+    lib = helpers.product_library_templates()
+    big = [t for t in lib if len(t) >= 15]
+    for mol in (amy, af, synthetic.structure(5)):
+        tpls = helpers.implant_templates(mol, lib, rng, max_templates=150) + \
+               helpers.implant_templates(mol, big, rng, max_templates=50)
+        assert len(tpls) > 120
+        jess, olib = pyjess.Jess(tpls), oracle.OracleLibrary([helpers.to_oracle_template(t) for t in tpls])
+        for cutoff in (0.9, 2.0):
+            table, cands = jess.query_batch([mol], 2.0, cutoff, cutoff, max_candidates=10000, ignore_chain=True,
+                                            count_candidates=True, return_raw=True)
+            r = oracle.query_library(helpers.to_oracle_molecule(mol), olib, 2.0, cutoff, cutoff,
+                                     max_candidates=10000, ignore_chain=True)
+            n = compare(table, cands, 0, r, olib)
+            assert n == len(tpls) - int(r["truncated"].sum())  # every implanted template hits
+            assert (r["rmsd"][r["hit"] == 1] < 1e-6).sum() >= 0.9 * n
+
+
+def test_pdb_corner_cases(default_library):
+    """Insertion codes, alternate locations, negative residue numbers: the oracle's parser, the host loader
+    and the device-side ingestion must agree atom for atom, and the searches must agree hit for hit."""
+    from enzymm_amd import ingest
+    from oracle import parse
+    jess, olib, idx, cut = default_library
+    out = []
+    for line in (helpers.GOLDEN / "1AMY.pdb").read_text().splitlines(keepends=True):
+        if line.startswith("ATOM"):
+            resseq = int(line[22:26])
+            if resseq == 204:    # whole residue gets an insertion code
+                line = line[:26] + "A" + line[27:]
+            if resseq <= 10:     # negative numbering
+                line = line[:22] + "%4d" % (resseq - 11) + line[26:]
+            if resseq == 179:    # alternate location B, slightly displaced, after the A record
+                a = line[:16] + "A" + line[17:]
+                b = line[:16] + "B" + line[17:30] + "%8.3f" % (float(line[30:38]) + 0.3) + line[38:]
+                out += [a, b]
+                continue
+        out.append(line)
+    text = "".join(out)
+    om = parse.parse_molecule(text)
+    mol = pyjess.Molecule.loads(text, id="corner")
+    assert len(om) == len(mol) and np.array_equal(om.xyz, mol._xyz)
+    assert mol[0].residue_number == -10 and any(a.insertion_code == "A" for a in mol) and any(a.altloc == "B" for a in mol)
+    r = oracle.query_library(om, olib, 2.0, cut, cut, max_candidates=10000, ignore_chain=True)
+    table, cands = jess.query_batch([mol], 2.0, cut, cut, max_candidates=10000, ignore_chain=True,
+                                    template_index=idx, count_candidates=True, return_raw=True)
+    assert compare(table, cands, 0, r, olib) > 5
+    pb = ingest.PdbBatch([text.encode()], ["corner"], device=jess._device)
+    dev = jess.query_batch(pb.molecules, 2.0, cut, cut, max_candidates=10000, ignore_chain=True, template_index=idx,
+                           batch=pb, return_raw=True)
+    assert dev.tobytes() == table.tobytes()
+
+
 def _subset(n_per_size=40):
     """A few templates of every effective size 3..8 (library order)."""
     otpl = helpers.oracle_library_templates()
