@@ -121,6 +121,119 @@ _MOL_COLUMNS = (
 )
 
 
+_POW10 = (10.0 ** np.arange(19)).astype(np.float64)  # exact up to 1e18 < 2^63... as doubles exact up to 1e22
+
+
+def _fixed_decimals(fields: np.ndarray, blank_ok: np.ndarray, integer: np.ndarray):
+    """Decimal text fields [m, w] (uint8) -> (int64 mantissa with sign, digits after the point, ok flags).
+
+    One pass over the w columns with whole-array operations: [spaces][sign]digits[.digits][spaces].  The
+    value is mantissa / 10^frac; both are exact, so the quotient is the correctly rounded double --
+    exactly float(text)."""
+    m, w = fields.shape
+    mant = np.zeros(m, np.int64)
+    frac = np.zeros(m, np.int64)
+    ndig = np.zeros(m, np.int64)
+    seen_dot = np.zeros(m, bool)
+    started = np.zeros(m, bool)
+    ended = np.zeros(m, bool)
+    neg = np.zeros(m, bool)
+    bad = np.zeros(m, bool)
+    for k in range(w):
+        c = fields[:, k]
+        is_d = (c >= 48) & (c <= 57)
+        is_dot = c == 46
+        is_sign = (c == 45) | (c == 43)
+        is_sp = c == 32
+        bad |= ~(is_d | is_dot | is_sign | is_sp)
+        bad |= ended & ~is_sp          # something after the trailing blanks
+        bad |= is_sign & started       # a sign in the middle
+        bad |= is_dot & seen_dot       # a second point
+        ended |= started & is_sp
+        mant = np.where(is_d, mant * 10 + (c.astype(np.int64) - 48), mant)
+        frac += is_d & seen_dot
+        ndig += is_d
+        neg |= c == 45
+        seen_dot |= is_dot
+        started |= is_d | is_dot | is_sign
+    ok = ~bad & (ndig <= 18) & ((ndig > 0) | (~started & blank_ok)) & ~(integer & seen_dot)
+    return np.where(neg, -mant, mant), frac, ok
+
+
+def _parse_pdb_bytes(data: bytes, ignore_endmdl: bool):
+    """Vectorised fixed-column parse of the ATOM/HETATM records of a PDB file (up to the first ENDMDL).
+
+    Returns (columns, xyz, HEADER idCode).  Same fields and error behaviour as a line-by-line parse, but
+    the text is viewed as one byte matrix [records, 80] and every column is converted in one numpy call."""
+    buf = np.frombuffer(data, dtype=np.uint8)
+    if len(buf) and buf[-1] != 10:
+        buf = np.concatenate([buf, np.array([10], np.uint8)])
+    ends = np.flatnonzero(buf == 10)
+    starts = np.concatenate([[0], ends[:-1] + 1]) if len(ends) else np.zeros(0, np.int64)
+    lens = ends - starts
+    if len(lens):
+        lens = lens - (buf[np.maximum(ends - 1, 0)] == 13) * (lens > 0)  # drop a trailing \r
+    # first six bytes of every line (short lines padded with spaces)
+    if len(starts):
+        pos6 = starts[:, None] + np.arange(6)[None, :]
+        six = np.where(np.arange(6)[None, :] < lens[:, None], buf[np.minimum(pos6, len(buf) - 1)], 32).astype(np.uint8)
+        tag = np.ascontiguousarray(six).view("S6").ravel()
+    else:
+        tag = np.zeros(0, "S6")
+    is_atom = (tag == b"ATOM  ") | (tag == b"HETATM")
+    if not ignore_endmdl:
+        endm = np.flatnonzero(tag == b"ENDMDL")
+        if len(endm):
+            is_atom[endm[0]:] = False
+    header_id = None
+    head = np.flatnonzero(tag == b"HEADER")
+    if len(head):
+        h = head[0]
+        if lens[h] >= 66:
+            header_id = bytes(buf[starts[h] + 62: starts[h] + 66]).decode("ascii", "replace").strip() or None
+    rows_idx = np.flatnonzero(is_atom)
+    n = len(rows_idx)
+    cols = {k: np.zeros(n, dtype=dt) for k, dt in _MOL_COLUMNS}
+    xyz = np.zeros((n, 3), dtype=np.float64)
+    if n == 0:
+        return cols, xyz, header_id
+    st, ln = starts[rows_idx], lens[rows_idx]
+    pos = st[:, None] + np.arange(80)[None, :]
+    mat = np.where(np.arange(80)[None, :] < ln[:, None], buf[np.minimum(pos, len(buf) - 1)], 32).astype(np.uint8)
+    if (ln < 54).any():
+        bad = int(np.flatnonzero(ln < 54)[0])
+        raise ValueError(f"malformed PDB record: {bytes(mat[bad]).decode('ascii', 'replace').rstrip()!r}")
+    # the seven numeric fields of every record in ONE pass: stacked as [7 * n, 8] (narrower fields space-padded)
+    spans = ((6, 11), (22, 26), (30, 38), (38, 46), (46, 54), (54, 60), (60, 66))
+    stack = np.full((7 * n, 8), 32, np.uint8)
+    for f, (lo, hi) in enumerate(spans):
+        stack[f * n:(f + 1) * n, : hi - lo] = mat[:, lo:hi]
+    blank_ok = np.repeat(np.array([0, 0, 0, 0, 0, 1, 1], bool), n)
+    integer = np.repeat(np.array([1, 1, 0, 0, 0, 0, 0], bool), n)
+    mant, frac, ok = _fixed_decimals(stack, blank_ok, integer)
+    if not ok.all():
+        bad = int(np.flatnonzero(~ok)[0]) % n
+        raise ValueError(f"malformed PDB record: {bytes(mat[bad]).decode('ascii', 'replace').rstrip()!r}")
+    value = mant.astype(np.float64) / _POW10[frac]
+    cols["serial"][:] = mant[:n]
+    cols["residue_number"][:] = mant[n:2 * n]
+    xyz[:, 0], xyz[:, 1], xyz[:, 2] = value[2 * n:3 * n], value[3 * n:4 * n], value[4 * n:5 * n]
+    cols["occupancy"][:] = value[5 * n:6 * n]
+    cols["temperature_factor"][:] = value[6 * n:]
+    take = lambda lo, hi: np.ascontiguousarray(mat[:, lo:hi]).view(f"S{hi - lo}").ravel()  # noqa: E731
+    cols["name"][:] = take(12, 16)
+    cols["altloc"][:] = take(16, 17)
+    cols["residue_name"][:] = take(17, 20)
+    cols["chain_id"][:] = take(20, 22)
+    cols["insertion_code"][:] = take(26, 27)
+    cols["segment"][:] = np.char.strip(take(72, 76))
+    cols["element"][:] = np.char.strip(take(76, 78))
+    digit, sign = mat[:, 78], mat[:, 79]
+    is_digit = (digit >= 48) & (digit <= 57)
+    cols["charge"][:] = np.where(is_digit, (digit.astype(np.int16) - 48) * np.where(sign == 45, -1, 1), 0)
+    return cols, xyz, header_id
+
+
 class Molecule:
     """Atom table of one target structure.
 
@@ -191,43 +304,13 @@ class Molecule:
         explicit ``id`` the HEADER record's idCode is used (tests/test_jess_run.py:34-35, 62).
         """
         if hasattr(file, "read"):
-            lines = file.read().splitlines()
+            data = file.read()
         else:
-            with open(os.fspath(file)) as handle:
-                lines = handle.read().splitlines()
-        rows = []
-        header_id = None
-        for line in lines:
-            rec = line[:6]
-            if rec in ("ATOM  ", "HETATM"):
-                rows.append(line.ljust(80))
-            elif rec == "ENDMDL" and not ignore_endmdl:
-                break
-            elif rec == "HEADER" and header_id is None and len(line) >= 66:
-                header_id = line[62:66].strip() or None
-        n = len(rows)
-        cols = {k: np.zeros(n, dtype=dt) for k, dt in _MOL_COLUMNS}
-        xyz = np.zeros((n, 3), dtype=np.float64)
-        for i, line in enumerate(rows):
-            try:
-                cols["serial"][i] = int(line[6:11])
-                cols["residue_number"][i] = int(line[22:26])
-                xyz[i] = (float(line[30:38]), float(line[38:46]), float(line[46:54]))
-                occ, bfac = line[54:60].strip(), line[60:66].strip()
-                cols["occupancy"][i] = float(occ) if occ else 0.0
-                cols["temperature_factor"][i] = float(bfac) if bfac else 0.0
-            except ValueError as exc:
-                raise ValueError(f"malformed PDB record: {line.rstrip()!r}") from exc
-            cols["name"][i] = line[12:16].encode("ascii", "replace")
-            cols["altloc"][i] = line[16].encode("ascii", "replace")
-            cols["residue_name"][i] = line[17:20].encode("ascii", "replace")
-            cols["chain_id"][i] = line[20:22].encode("ascii", "replace")
-            cols["insertion_code"][i] = line[26].encode("ascii", "replace")
-            cols["segment"][i] = line[72:76].strip().encode("ascii", "replace")
-            cols["element"][i] = line[76:78].strip().encode("ascii", "replace")
-            chg = line[78:80].strip()
-            if chg and chg[0].isdigit():
-                cols["charge"][i] = int(chg[0]) * (-1 if chg[1:2] == "-" else 1)
+            with open(os.fspath(file), "rb") as handle:
+                data = handle.read()
+        if isinstance(data, str):
+            data = data.encode("ascii", "replace")
+        cols, xyz, header_id = _parse_pdb_bytes(data, ignore_endmdl)
         mol = cls.__new__(cls)
         mol._init_columns(cols, xyz, id if id is not None else header_id)
         return mol
