@@ -421,16 +421,18 @@ int tm_batch_create_from_pdb(int device, uint32_t n_files, const char *const *te
     }
     const uint64_t n_bytes = (file_off[n_files] + 15) & ~15ull;
     if (n_bytes >= (1ull << 36)) return fail(TM_E_UNSUPPORTED, "more than 64 GiB of PDB text in one batch");
-    std::vector<char> host(n_bytes + 16, ' ');
-    for (uint32_t f = 0; f < n_files; ++f) {
-        if (length[f]) std::memcpy(host.data() + file_off[f], text[f], length[f]);
-        if (file_off[f + 1] - file_off[f] != length[f]) host[file_off[f + 1] - 1] = '\n';
-    }
+    // every file goes straight from the caller's buffer to its place in HBM (no host-side concatenation)
     DevBuf<char> d_text;
     DevBuf<uint64_t> d_file_off, d_nl;
     DevBuf<uint32_t> d_counts, d_rank, d_sums, d_total, d_line_file, d_first_end, d_keep, d_atom_rank, d_bad;
     DevBuf<uint8_t> d_kind;
-    HIP_TRY(d_text.upload(host));
+    HIP_TRY(d_text.alloc(n_bytes + 16));
+    HIP_TRY(hipMemsetAsync(d_text.p + file_off[n_files], ' ', n_bytes + 16 - file_off[n_files], stream));
+    for (uint32_t f = 0; f < n_files; ++f) {
+        if (length[f]) HIP_TRY(hipMemcpyAsync(d_text.p + file_off[f], text[f], length[f], hipMemcpyHostToDevice, stream));
+        if (file_off[f + 1] - file_off[f] != length[f])
+            HIP_TRY(hipMemsetAsync(d_text.p + file_off[f + 1] - 1, '\n', 1, stream));
+    }
     HIP_TRY(d_file_off.upload(file_off));
     const uint64_t n_gran = n_bytes / 16;
     HIP_TRY(d_counts.alloc(n_gran)); HIP_TRY(d_rank.alloc(n_gran)); HIP_TRY(d_total.alloc(2)); HIP_TRY(d_bad.alloc(1));

@@ -311,6 +311,7 @@ class Matcher:
         if self.cpus <= 0:
             self.cpus = max(1, _default_cpus() + self.cpus)
         self.verbose_print(f"PyJess Version: {pyjess.__version__}")
+        pyjess.register_vocabulary(templates)  # device batches created from now on match these templates
 
         self.templates_by_effective_size: Dict[int, List[Template]] = collections.defaultdict(list)
         for t in templates:

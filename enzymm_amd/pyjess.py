@@ -727,6 +727,19 @@ class Query(collections.abc.Iterator):
         return next(self._hits)
 
 
+def register_vocabulary(templates) -> None:
+    """Give every atom/residue name the templates refer to its id now, so that batches encoded after
+    this call stay valid for queries with these templates."""
+    for t in templates:
+        if getattr(t, "_vocab_version", None) is None:
+            for a in t._atoms:
+                VOCAB.register_template_atom(a.match_mode, a._raw_names, a._raw_residues)
+            try:
+                t._vocab_version = VOCAB.version
+            except AttributeError:
+                pass
+
+
 class Jess:
     """A set of templates to search structures with (device-resident once constructed)."""
 
@@ -741,15 +754,7 @@ class Jess:
         for t in self._templates:
             if not isinstance(t, Template):
                 raise TypeError(f"expected Template, found {type(t).__name__}")
-        # every name the templates refer to gets its id now, so batches encoded after this line stay valid
-        for t in self._templates:
-            if getattr(t, "_vocab_version", None) is None:
-                for a in t._atoms:
-                    VOCAB.register_template_atom(a.match_mode, a._raw_names, a._raw_residues)
-                try:
-                    t._vocab_version = VOCAB.version
-                except AttributeError:
-                    pass
+        register_vocabulary(self._templates)
 
     def __len__(self):
         return len(self._templates)

@@ -19,7 +19,7 @@ for rep in range(3):
     pb = ingest.PdbBatch(texts, ids)
     dt = time.perf_counter() - t0
     print(f"PdbBatch: {n} files, {total / 1e6:.1f} MB in {dt * 1e3:.1f} ms = {total / dt / 1e9:.2f} GB/s "
-          f"({n / dt:.0f} files/s) incl. host concatenation + H2D", flush=True)
+          f"({n / dt:.0f} files/s) incl. the H2D copies", flush=True)
     pb.close()
 t0 = time.perf_counter()
 mols = [pyjess.Molecule.loads(t.decode()) for t in texts[:50]]
