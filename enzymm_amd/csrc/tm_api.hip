@@ -686,19 +686,21 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
         n_chunks = (n_sel + chunk_size - 1) / chunk_size;
         const uint32_t grid = ((b->n_structs + 7) / 8) * 8 * n_chunks;
         const size_t scratch = search_scratch_bytes();
-        const size_t res_bytes = (((size_t)b->max_res + 1) * sizeof(uint16_t) + 15) & ~size_t(15);
-        const size_t lds_full = scratch + (size_t)b->max_atoms * sizeof(float4) + res_bytes;
+        const size_t base = scratch + (size_t)b->max_atoms * sizeof(float4) + search_res_bytes(b->max_res) +
+                            search_kl_words(lib->view().n_lead) * sizeof(uint32_t);
         const size_t lds_limit = 160 * 1024 - 64;
-        if (lds_full <= lds_limit) {
+        if (base <= lds_limit) {
+            // whatever LDS is left holds the structure's kind lists (one workgroup per CU either way)
+            const uint32_t pool_cap = (uint32_t)((lds_limit - base) / sizeof(uint16_t));
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_search<true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full));
-            hipLaunchKernelGGL(k_search<true>, dim3(grid), dim3(kSearchBlock), lds_full, stream, lib->view(), b->view(),
-                               Q, O, n_chunks, chunk_size, b->max_atoms, b->max_res);
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
+            hipLaunchKernelGGL(k_search<true>, dim3(grid), dim3(kSearchBlock), lds_limit, stream,
+                               SearchArgs{lib->view(), b->view(), Q, O, n_chunks, chunk_size, b->max_atoms, b->max_res, pool_cap});
         } else {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_search<false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)scratch));
-            hipLaunchKernelGGL(k_search<false>, dim3(grid), dim3(kSearchBlock), scratch, stream, lib->view(), b->view(),
-                               Q, O, n_chunks, chunk_size, b->max_atoms, b->max_res);
+            hipLaunchKernelGGL(k_search<false>, dim3(grid), dim3(kSearchBlock), scratch, stream,
+                               SearchArgs{lib->view(), b->view(), Q, O, n_chunks, chunk_size, b->max_atoms, b->max_res, 0u});
         }
         HIP_TRY(hipGetLastError());
     }

@@ -13,8 +13,8 @@ constexpr int kMaxPairs = kMaxK * (kMaxK - 1) / 2;  // 276 pair constraints
 constexpr int kWave = 64;
 constexpr int kSearchWaves = 16;  // waves per search workgroup (one structure copy in LDS serves all)
 constexpr int kSearchBlock = kWave * kSearchWaves;
-constexpr int kJointQueue = 128;  // joint-scan survivors buffered per wave before their subtrees are searched
-constexpr int kJointList = 256;   // lead lists up to this length are staged in LDS for the joint top-level scan
+constexpr int kJointQueue = 128;  // pair-scan survivors buffered per wave (power of two)
+constexpr int kJointQueue3 = 64;  // triple-scan survivors buffered per wave before their subtrees are searched
 
 // fp32 prefilter slack (Angstrom) added to every pair threshold.  Centred fp32
 // coordinates of a <= 300 A structure carry < 4e-5 A of rounding; anything the

@@ -32,6 +32,10 @@ __device__ unsigned long long g_stats[64];
 // ------------------------------------------------------------------ wave helpers
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+// number of set bits of `m` below this lane (v_mbcnt_lo + v_mbcnt_hi)
+__device__ __forceinline__ uint32_t rank_in(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -179,7 +183,7 @@ __global__ __launch_bounds__(256) void k_kind_lists(LibView L, BatchView B, uint
                 ok = ((nm >> meta_name(m)) & 1ull) && (any || ((rm >> meta_rtype(m)) & 1u));
             }
             const unsigned long long mask = __ballot(ok);
-            if (ok) kl_pool[w + __popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)i;
+            if (ok) kl_pool[w + rank_in(mask)] = (uint16_t)i;
             w += __popcll(mask);
         }
     }
@@ -191,9 +195,10 @@ __global__ __launch_bounds__(256) void k_kind_lists(LibView L, BatchView B, uint
 struct __align__(16) WaveScratch {
     float2 bnd_lead[kMaxG * (kMaxG - 1) / 2];  // pair bounds among lead atoms (search positions < n_groups)
     uint16_t surv[kMaxG][64];                  // per template residue: one 64-entry chunk of its lead list
-    uint16_t list0[kJointList], list1[kJointList], list2[kJointList];  // the top lead lists, staged for the tiled scans
-    uint32_t queue[kJointQueue];               // pair-scan survivors (a | b << 16)
-    uint32_t queue3[kJointQueue][2];           // triple-scan survivors ((a | b << 16), c) waiting for their subtree
+    float4 rec0[64], rec1[64], rec2[64];       // atom records of the current 64-entry blocks of the top lead lists
+    uint16_t id0[64], id1[64], id2[64];        // and their atom indices
+    uint32_t queue[kJointQueue];               // pair-scan survivors (position in block 0 | position in block 1 << 8)
+    uint32_t queue3[kJointQueue3][2];          // triple-scan survivors ((a | b << 16), c) waiting for their subtree
 };
 
 // Search state of one wave, held in VGPRs and indexed BY LANE: lane L holds the entry of search
@@ -314,20 +319,43 @@ __device__ __forceinline__ void assign_level(const SearchCtx &C, WaveRegs &W, in
     if (!C.ignore_chain) WL(W.achain, level, uni((uint32_t)C.qchain[cand]));
 }
 
+// All arguments of k_search as one kernel-argument struct.  Code that runs rarely (a complete
+// assignment, a pair with candidates) re-reads what it needs from the kernel-argument segment
+// through cold_args() instead of keeping two dozen pointers in scalar registers for the whole
+// search: the search loop is short of SGPRs, and every spilled SGPR costs VALU instructions.
+struct SearchArgs {
+    LibView L;
+    BatchView B;
+    QueryView Q;
+    OutView O;
+    uint32_t n_chunks, chunk_size, max_atoms, max_res, pool_cap;
+};
+typedef const __attribute__((address_space(4))) SearchArgs *ColdArgsPtr;
+__device__ __forceinline__ ColdArgsPtr cold_args() {
+    ColdArgsPtr p = (ColdArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));  // opaque: loads through p stay where they are written
+    return p;
+}
+
 // Everything the wave needs to know about the (structure, template) pair it is searching.
 struct PairState {
-    uint32_t s, ti, off;      // structure, selected-template index, template atom offset in the library
+    uint32_t s, ti;           // structure, selected-template index
     uint32_t ncand, prev;     // verified candidates so far, last emitted candidate slot
     bool truncated;
-    double cut, mx;
 };
 
 // A complete assignment passed the fp32 prefilter: re-check every pair in fp64
 // (| |q_i - q_j| - |t_i - t_j| | <= thr_ij exactly as the oracle does) and append it to the
 // candidate buffer.  Returns false when the search must stop (max_candidates reached).
-__device__ __forceinline__ bool on_complete(const SearchCtx &C, WaveRegs &W, const LibView &L, const double *qx,
-                                            const QueryView &Q, const OutView &O, PairState &P) {
+__device__ __forceinline__ bool on_complete(const SearchCtx &C, WaveRegs &W, PairState &P) {
     const int lane = C.lane, k = C.k, npairs = tri(k);
+    // completions are rare: everything but the assignment itself is fetched here, not per search
+    ColdArgsPtr A = cold_args();
+    const uint32_t max_candidates = A->Q.max_candidates;
+    const uint32_t off = A->L.t_off[A->Q.sel[P.ti]];
+    const double *a_xyz = A->L.a_xyz, *a_w = A->L.a_w;
+    const double cut = A->Q.cutoff[P.ti], mx = A->Q.maxdyn[P.ti];
+    const double *qx = A->B.q_xyz + 3 * (size_t)A->B.s_off[P.s];
     bool bad = false;
     for (int p0 = 0; p0 < npairs; p0 += 64) {  // uniform trip count: the shuffles below need every lane
         const int p = p0 + lane;
@@ -336,13 +364,13 @@ __device__ __forceinline__ bool on_complete(const SearchCtx &C, WaveRegs &W, con
         const uint32_t ai = (uint32_t)__shfl((int)W.aidx, i), aj = (uint32_t)__shfl((int)W.aidx, j);
         if (p < npairs) {
             const double *qa = qx + 3 * (size_t)ai, *qb = qx + 3 * (size_t)aj;
-            const double *ta = L.a_xyz + 3 * (size_t)(P.off + i), *tb = L.a_xyz + 3 * (size_t)(P.off + j);
+            const double *ta = a_xyz + 3 * (size_t)(off + i), *tb = a_xyz + 3 * (size_t)(off + j);
             double dx = qa[0] - qb[0], dy = qa[1] - qb[1], dz = qa[2] - qb[2];
             const double dq = sqrt(dx * dx + dy * dy + dz * dz);
             dx = ta[0] - tb[0]; dy = ta[1] - tb[1]; dz = ta[2] - tb[2];
             const double dt = sqrt(dx * dx + dy * dy + dz * dz);
-            double thr = P.cut + L.a_w[P.off + i] + L.a_w[P.off + j];
-            thr = thr < P.mx ? thr : P.mx;
+            double thr = cut + a_w[off + i] + a_w[off + j];
+            thr = thr < mx ? thr : mx;
             if (fabs(dq - dt) > thr) bad = true;
         }
     }
@@ -351,19 +379,19 @@ __device__ __forceinline__ bool on_complete(const SearchCtx &C, WaveRegs &W, con
         TM_STAT(51, 1);
         return true;
     }
-    if (P.ncand >= Q.max_candidates) {
+    if (P.ncand >= max_candidates) {
         P.truncated = true;
         return false;
     }
     ++P.ncand;
     unsigned long long slot = 0;
-    if (lane == 0) slot = atomicAdd(O.n_cands, 1ull);
+    if (lane == 0) slot = atomicAdd(A->O.n_cands, 1ull);
     slot = uni64(slot);
-    if (slot >= O.cand_capacity) {
-        if (lane == 0) atomicOr(O.overflow, 1u);
+    if (slot >= A->O.cand_capacity) {
+        if (lane == 0) atomicOr(A->O.overflow, 1u);
         return true;
     }
-    Cand *c = O.cands + slot;
+    Cand *c = A->O.cands + slot;
     if (lane == 0) {
         c->s = P.s;
         c->ti = P.ti;
@@ -380,8 +408,7 @@ __device__ __forceinline__ bool on_complete(const SearchCtx &C, WaveRegs &W, con
 
 // Depth-first search over levels >= floor (levels < floor are already assigned).
 // Returns false when the pair was cut short by max_candidates.
-__device__ __forceinline__ bool dfs(const SearchCtx &C, WaveRegs &W, const LibView &L, const double *qx,
-                                    const QueryView &Q, const OutView &O, PairState &P, int floor) {
+__device__ __forceinline__ bool dfs(const SearchCtx &C, WaveRegs &W, PairState &P, int floor) {
     const int k = C.k;  // floor < k always: a template has at least 3 atoms per residue
     int level = floor;
     init_level(C, W, level);
@@ -419,7 +446,7 @@ __device__ __forceinline__ bool dfs(const SearchCtx &C, WaveRegs &W, const LibVi
             init_level(C, W, level);
             continue;
         }
-        if (!on_complete(C, W, L, qx, Q, O, P)) return false;
+        if (!on_complete(C, W, P)) return false;
     }
 }
 
@@ -433,11 +460,17 @@ __device__ __forceinline__ uint32_t best_tile_shift(uint32_t n_i, uint32_t n_j) 
     return shift;
 }
 
+// fp32 prefilter of one pair constraint; the bounds carry kPrefilterSlack, which also covers the
+// fused multiply-adds (the exact test is repeated in fp64 before a candidate is emitted)
 __device__ __forceinline__ bool in_window(const float4 &p, const float4 &q, const float2 &b) {
     const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
-    const float d2 = dx * dx + dy * dy + dz * dz;
+    const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
     return d2 >= b.x && d2 <= b.y;
 }
+
+// Padding records for unused slots of a staged block: far away from every atom and from each
+// other, so that any pair involving a padding slot fails its distance window by itself.
+constexpr float kPadFar = 3.0e18f;
 
 // The lead atoms of the first two (three) template residues are matched by tiled scans: the
 // wave lays the cross product list0 x list1 over its 64 lanes and tests the pair constraint
@@ -445,41 +478,48 @@ __device__ __forceinline__ bool in_window(const float4 &p, const float4 &q, cons
 // cross product queue x list2 is tiled the same way against the constraints (2, 0) and (2, 1).
 // Only what survives that is searched depth-first (levels >= 3, or >= 2 for two-residue templates).
 //
+// The lists are walked in blocks of 64 entries whose atom records are copied into a compact
+// per-wave LDS array once (one scattered gather per list entry); every tile then reads its
+// operands at consecutive or broadcast addresses, free of bank conflicts, and lists of any
+// length are handled.
+//
 // Written as one resumable producer/consumer loop so that each stage -- pair tile, triple tile,
 // depth-first search -- exists exactly once in the instruction stream (the kernel must fit the
 // instruction cache): queue3 is refilled from the triple tiles, which pull from the pair queue,
 // which is refilled from the pair tiles.
-__device__ __forceinline__ bool joint_top_scan(const SearchCtx &C, WaveRegs &W, const LibView &L, const double *qx,
-                                               const QueryView &Q, const OutView &O, PairState &P) {
+__device__ __forceinline__ bool joint_top_scan(const SearchCtx &C, WaveRegs &W, PairState &P, uint32_t flags) {
     WaveScratch &S = *C.S;
     const int lane = C.lane;
-    // plain depth-first search from level 0 for one-residue templates and for the rare template whose
-    // two most selective lead lists do not fit the LDS staging area (e.g. "any residue" backbone atoms)
-    const bool single = C.n_groups < 2 || RL(W.cnt, 0) > (uint32_t)kJointList || RL(W.cnt, 1) > (uint32_t)kJointList;
+    const bool single = C.n_groups < 2;  // one-residue template: plain depth-first search from level 0
+    const bool tiled2 = C.n_groups >= 3;
     const uint32_t n0 = single ? 0u : RL(W.cnt, 0), n1 = single ? 0u : RL(W.cnt, 1);
-    const uint32_t lo0 = RL(W.lo, 0), lo1 = RL(W.lo, 1);
-    const uint32_t n2 = C.n_groups >= 3 ? RL(W.cnt, 2) : 0u;
-    const bool tiled2 = !single && C.n_groups >= 3 && n2 <= (uint32_t)kJointList;  // third lead scanned by tiles too
-    for (uint32_t i = lane; i < n0; i += 64) S.list0[i] = C.pool[lo0 + i];
-    for (uint32_t i = lane; i < n1; i += 64) S.list1[i] = C.pool[lo1 + i];
-    if (tiled2) {
-        const uint32_t lo2 = RL(W.lo, 2);
-        for (uint32_t i = lane; i < n2; i += 64) S.list2[i] = C.pool[lo2 + i];
-    }
-    wave_sync();
-    const uint32_t tj_shift = best_tile_shift(n0, n1);
-    const uint32_t TJ = 1u << tj_shift, TI = 64u >> tj_shift;
-    const uint32_t li = (uint32_t)lane >> tj_shift, lj = (uint32_t)lane & (TJ - 1);
+    const uint32_t n2 = tiled2 ? RL(W.cnt, 2) : 0u;
+    const uint32_t lo0 = RL(W.lo, 0), lo1 = RL(W.lo, 1), lo2 = RL(W.lo, 2);
     const float2 b10 = S.bnd_lead[0];                                       // pair (1, 0)
     const float2 b20 = S.bnd_lead[tri(2)], b21 = S.bnd_lead[tri(2) + 1];    // pairs (2, 0), (2, 1)
     const bool tc10 = RL(W.tchain, 0) == RL(W.tchain, 1);
     const bool tc20 = RL(W.tchain, 0) == RL(W.tchain, 2), tc21 = RL(W.tchain, 1) == RL(W.tchain, 2);
     const int floor = single ? 0 : tiled2 ? 3 : 2;  // levels the queue3 entries assign
 
-    uint32_t i0 = 0, j0 = 0;        // next pair tile
+    // copies block `base` of a lead list (ids from the kind-list pool, records from the structure) into LDS;
+    // slots past the end get the padding record `pad`, so tiles may read any of the 64 slots unmasked
+    auto stage_block = [&](float4 *rec, uint16_t *id, uint32_t lo, uint32_t base, uint32_t cnt, float pad_x, float pad_y) {
+        const uint32_t a = C.pool[lo + base + min((uint32_t)lane, cnt - 1u)];
+        id[lane] = (uint16_t)a;
+        float4 r = C.rec[a];
+        if ((uint32_t)lane >= cnt) { r.x = pad_x; r.y = pad_y; }
+        rec[lane] = r;
+    };
+
+    uint32_t ib = 0, jb = 0;                    // blocks of list0 / list1 being paired
+    uint32_t ib_st = 0xffffffffu, jb_st = 0xffffffffu, cb_st = 0xffffffffu;  // blocks present in LDS
+    uint32_t cn0 = 0, cn1 = 0, cn2 = 0;         // entries in them
+    uint32_t i0 = 0, j0 = 0, tj_shift = 3;      // next pair tile inside the blocks, tile shape
+    bool fresh = true;                          // the block pair was not started yet
     bool pairs_done = single;
-    uint32_t nq = 0, e0 = 0, c0 = 0;  // pair queue fill, next triple tile (entry base, list2 base)
-    uint32_t sh2 = 6;               // triple tile shape for the current pair queue
+    uint32_t nq = 0;                            // pair queue fill
+    bool consuming = false, fresh2 = false;     // the pair queue is being crossed with list2 (or copied)
+    uint32_t e0 = 0, c0 = 0, cb = 0, sh2 = 6;   // next triple tile (queue entry base, position in block cb), shape
     uint32_t nq3 = 0;
     bool single_pending = single;
 
@@ -489,76 +529,117 @@ __device__ __forceinline__ bool joint_top_scan(const SearchCtx &C, WaveRegs &W, 
             nq3 = 1;
             single_pending = false;
         } else {
-            while (nq3 + 64u <= (uint32_t)kJointQueue) {
-                if (e0 < nq) {
-                    if (tiled2) {  // one triple tile: TI2 queued pairs x TJ2 entries of list2
+            while (nq3 + 64u <= (uint32_t)kJointQueue3) {
+                if (consuming) {
+                    if (tiled2) {  // one triple tile: TI2 queued pairs x TJ2 entries of the list2 block
+                        if (fresh2) {
+                            if (cb_st != cb) {
+                                wave_sync();
+                                cn2 = min(64u, n2 - cb);
+                                stage_block(S.rec2, S.id2, lo2, cb, cn2, 0.f, kPadFar);
+                                cb_st = cb;
+                                wave_sync();
+                            }
+                            sh2 = best_tile_shift(nq, cn2);
+                            fresh2 = false;
+                        }
                         const uint32_t TJ2 = 1u << sh2;
                         const uint32_t e = e0 + ((uint32_t)lane >> sh2), j = c0 + ((uint32_t)lane & (TJ2 - 1));
-                        const bool ve = e < nq, vj = j < n2;
-                        const uint32_t ab = S.queue[min(e, nq - 1)];  // clamped, branch-free; masked by ve / vj
-                        const uint32_t a = ab & 0xffffu, b = ab >> 16;
-                        const uint32_t c = (uint32_t)S.list2[min(j, n2 - 1)];
-                        const float4 ra = C.rec[a], rb = C.rec[b], rc = C.rec[c];
+                        const uint32_t pos = S.queue[e & (uint32_t)(kJointQueue - 1)];  // masked by `e < nq` below
+                        const uint32_t ip = pos & 63u, jp = (pos >> 8) & 63u;
+                        const float4 ra = S.rec0[ip], rb = S.rec1[jp], rc = S.rec2[j & 63u];
                         const uint32_t res_c = meta_res(__float_as_uint(rc.w));
-                        bool ok = ve && vj && in_window(rc, ra, b20) && in_window(rc, rb, b21) &&
+                        bool ok = e < nq && in_window(rc, ra, b20) && in_window(rc, rb, b21) &&  // padding fails the windows
                                   res_c != meta_res(__float_as_uint(ra.w)) && res_c != meta_res(__float_as_uint(rb.w));
+                        const uint32_t ab = (uint32_t)S.id0[ip] | ((uint32_t)S.id1[jp] << 16), c = S.id2[j & 63u];
                         if (!C.ignore_chain) {
                             const uint8_t qc = C.qchain[c];
-                            ok = ok && ((qc == C.qchain[a]) == tc20) && ((qc == C.qchain[b]) == tc21);
+                            ok = ok && ((qc == C.qchain[ab & 0xffffu]) == tc20) && ((qc == C.qchain[ab >> 16]) == tc21);
                         }
                         const unsigned long long m = __ballot(ok);
                         TM_STAT(2, 1);
                         TM_STAT(24 + 2, __popcll(m));
                         if (ok) {
-                            const uint32_t slot = nq3 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                            const uint32_t slot = nq3 + rank_in(m);
                             S.queue3[slot][0] = ab;
                             S.queue3[slot][1] = c;
                         }
                         nq3 += (uint32_t)__popcll(m);
                         c0 += TJ2;
-                        if (c0 >= n2) { c0 = 0; e0 += 64u >> sh2; }
-                    } else {  // two-residue template (or a very long list2): pairs go to the search as they are
+                        if (c0 >= cn2) {
+                            c0 = 0;
+                            e0 += 64u >> sh2;
+                            if (e0 >= nq) {  // the queue met this block of list2: next block, or done
+                                e0 = 0;
+                                cb += 64u;
+                                fresh2 = true;
+                                if (cb >= n2) { cb = 0; consuming = false; nq = 0; }
+                            }
+                        }
+                    } else {  // two-residue template: pairs go to the search as they are
                         const uint32_t e = e0 + (uint32_t)lane;
-                        if (e < nq) S.queue3[nq3 + lane][0] = S.queue[e];
+                        if (e < nq) {
+                            const uint32_t pos = S.queue[e];
+                            S.queue3[nq3 + lane][0] = (uint32_t)S.id0[pos & 63u] | ((uint32_t)S.id1[(pos >> 8) & 63u] << 16);
+                        }
                         nq3 += min(64u, nq - e0);
                         e0 += 64u;
+                        if (e0 >= nq) { e0 = 0; consuming = false; nq = 0; }
                     }
                     continue;
                 }
-                // the pair queue is used up: refill it from the pair tiles
+                // the pair queue is empty: refill it from the pair tiles of the current block pair
                 if (pairs_done) break;
-                nq = 0; e0 = 0; c0 = 0;
+                if (fresh) {
+                    wave_sync();
+                    if (ib_st != ib) { cn0 = min(64u, n0 - ib); stage_block(S.rec0, S.id0, lo0, ib, cn0, kPadFar, 0.f); ib_st = ib; }
+                    if (jb_st != jb) { cn1 = min(64u, n1 - jb); stage_block(S.rec1, S.id1, lo1, jb, cn1, -kPadFar, 0.f); jb_st = jb; }
+                    tj_shift = best_tile_shift(cn0, cn1);
+                    i0 = j0 = 0;
+                    fresh = false;
+                }
                 wave_sync();
-                while (!pairs_done && nq + 64u <= (uint32_t)kJointQueue) {
-                    const uint32_t i = i0 + li, j = j0 + lj;
-                    const bool vi = i < n0, vj = j < n1;
-                    const uint32_t ic = min(i, n0 - 1), jc = min(j, n1 - 1);  // clamped, branch-free
-                    const uint32_t a = S.list0[ic], b = S.list1[jc];
-                    const float4 ra = C.rec[a], rb = C.rec[b];
-                    bool ok = vi && vj && in_window(ra, rb, b10) &&
-                              meta_res(__float_as_uint(ra.w)) != meta_res(__float_as_uint(rb.w));
-                    if (!C.ignore_chain) ok = ok && ((C.qchain[a] == C.qchain[b]) == tc10);
-                    const unsigned long long m = __ballot(ok);
-                    TM_STAT(52, 1);
-                    TM_STAT(53, __popcll(m));
-                    if (ok) S.queue[nq + __popcll(m & ((1ull << lane) - 1ull))] = a | (b << 16);
-                    nq += (uint32_t)__popcll(m);
-                    j0 += TJ;
-                    if (j0 >= n1) { j0 = 0; i0 += TI; }
-                    if (i0 >= n0) pairs_done = true;
+                {
+                    const uint32_t TJ = 1u << tj_shift, TI = 64u >> tj_shift;
+                    const uint32_t li = (uint32_t)lane >> tj_shift, lj = (uint32_t)lane & (TJ - 1);
+                    const float4 *pa = S.rec0 + li, *pb = S.rec1 + lj;
+                    const uint32_t lpos = li | (lj << 8);
+                    while (!fresh && nq + 64u <= (uint32_t)kJointQueue) {
+                        const float4 ra = pa[i0], rb = pb[j0];  // slots < 64: tiles never leave the block
+                        bool ok = in_window(ra, rb, b10) &&      // padding slots fail here
+                                  meta_res(__float_as_uint(ra.w)) != meta_res(__float_as_uint(rb.w));
+                        if (!C.ignore_chain) ok = ok && ((C.qchain[S.id0[i0 + li]] == C.qchain[S.id1[j0 + lj]]) == tc10);
+                        const unsigned long long m = __ballot(ok);
+                        TM_STAT(52, 1);
+                        TM_STAT(53, __popcll(m));
+                        if (ok) S.queue[nq + rank_in(m)] = lpos + (i0 | (j0 << 8));
+                        nq += (uint32_t)__popcll(m);
+                        j0 += TJ;
+                        if (j0 >= cn1) {
+                            j0 = 0;
+                            i0 += TI;
+                            if (i0 >= cn0) fresh = true;  // block pair finished
+                        }
+                    }
+                }
+                if (fresh) {
+                    jb += 64u;
+                    if (jb >= n1) { jb = 0; ib += 64u; }
+                    if (ib >= n0) pairs_done = true;
                 }
                 wave_sync();
 #if defined(TM_STATS) || defined(TM_ABLATE)
-                if (Q.flags & 0x100u) nq = 0;
+                if (flags & 0x100u) nq = 0;
 #endif
-                sh2 = best_tile_shift(nq, n2);
+                // the queue refers to positions in the blocks now in LDS: it is used up before they change
+                if (nq) { consuming = true; fresh2 = true; e0 = 0; c0 = 0; cb = 0; }
             }
             wave_sync();
         }
         if (nq3 == 0) return true;  // every tile evaluated, nothing left to search
         // ---- depth-first search below every queued partial assignment (the only dfs call site)
 #if defined(TM_STATS) || defined(TM_ABLATE)
-        if (Q.flags & 0x400u) nq3 = 0;
+        if (flags & 0x400u) nq3 = 0;
 #endif
         for (uint32_t e = 0; e < nq3; ++e) {
             if (floor >= 2) {
@@ -567,22 +648,61 @@ __device__ __forceinline__ bool joint_top_scan(const SearchCtx &C, WaveRegs &W, 
                 assign_level(C, W, 1, ab >> 16);
             }
             if (floor >= 3) assign_level(C, W, 2, uni(S.queue3[e][1]));
-            if (!dfs(C, W, L, qx, Q, O, P, floor)) return false;
+            if (!dfs(C, W, P, floor)) return false;
         }
         nq3 = 0;
         wave_sync();
     }
 }
 
+__host__ __device__ inline size_t search_res_bytes(uint32_t max_res) {
+    return (((size_t)max_res + 1) * sizeof(uint16_t) + 15) & ~size_t(15);
+}
+__host__ __device__ inline size_t search_kl_words(uint32_t n_lead) { return ((size_t)n_lead + 1 + 3) & ~size_t(3); }
+
+// One template's per-level constants as loaded by lane L for level L (plus one lead-pair bound).
+// Held in registers one template ahead of the search, so that the global-memory latency of the
+// next template overlaps the current search.
+struct TemplateRegs {
+    uint32_t group, ref, tchain, orig, any, resmask, nm_lo, nm_hi, li;
+    float2 lead_bound;
+    uint32_t k, n_groups;
+};
+
+__device__ __forceinline__ void load_template(const QueryView &Q, uint32_t ti, int lane, TemplateRegs &R) {
+    const Staged &T = Q.staged[ti];
+    const int l = lane < kMaxK ? lane : kMaxK - 1;  // every lane loads: no dependence on k
+    const unsigned long long nm = T.namemask[l];
+    R.group = T.group[l];
+    R.ref = T.ref[l];
+    R.tchain = T.tchain[l];
+    R.orig = T.orig[l];
+    R.any = T.any[l];
+    R.resmask = T.resmask[l];
+    R.nm_lo = (uint32_t)nm;
+    R.nm_hi = (uint32_t)(nm >> 32);
+    R.li = T.lead_li[l];
+    R.lead_bound = Q.bounds[(size_t)ti * kMaxPairs + (lane < tri(kMaxG) ? lane : 0)];
+    R.k = T.k;
+    R.n_groups = T.n_groups;
+}
+
 template <bool kLds>
-__global__ __launch_bounds__(kSearchBlock) void k_search(LibView L, BatchView B, QueryView Q, OutView O,
-                                                          uint32_t n_chunks, uint32_t chunk_size,
-                                                          uint32_t max_atoms, uint32_t max_res) {
+__global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
+    const LibView &L = A.L;
+    const BatchView &B = A.B;
+    const QueryView &Q = A.Q;
+    const uint32_t n_chunks = A.n_chunks, chunk_size = A.chunk_size, max_atoms = A.max_atoms, max_res = A.max_res,
+                   pool_cap = A.pool_cap;
     extern __shared__ __align__(16) unsigned char smem[];
     // [WaveScratch x kSearchWaves][rec float4 x max_atoms][res_start u16 x (max_res+1)]
+    // [kind-list offsets u32 x (n_lead+1)][kind-list pool u16 x pool_cap]
     WaveScratch *scratch = reinterpret_cast<WaveScratch *>(smem);
     float4 *s_rec = reinterpret_cast<float4 *>(smem + sizeof(WaveScratch) * kSearchWaves);
     uint16_t *s_res = reinterpret_cast<uint16_t *>(s_rec + (kLds ? max_atoms : 0));
+    uint32_t *s_kl = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(s_res) +
+                                                  (kLds ? search_res_bytes(max_res) : 0));
+    uint16_t *s_pool = reinterpret_cast<uint16_t *>(s_kl + (kLds ? search_kl_words(L.n_lead) : 0));
     __shared__ uint32_t s_next;
 
     // all chunks of a structure land on one XCD (blocks b and b+8 share an XCD): its kind
@@ -595,58 +715,70 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(LibView L, BatchView B,
 
     const uint32_t a0 = B.s_off[s], n = B.s_off[s + 1] - a0;
     const uint32_t r0 = B.s_roff[s], nres1 = B.s_roff[s + 1] - r0;  // n_res + 1 entries
+    const uint32_t *kl_off = B.kl_off + (size_t)s * (L.n_lead + 1);
+    bool pool_in_lds = false;
     if (kLds) {
+        // the structure's atom records, residue starts, kind-list offsets and (when it fits) the
+        // kind lists themselves: after this the search reads global memory only for template data
+        const uint32_t p0 = kl_off[0], plen = kl_off[L.n_lead] - p0;
+        pool_in_lds = plen <= pool_cap;
+        const uint32_t rebase = pool_in_lds ? p0 : 0u;
         for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) s_rec[i] = B.q_rec[a0 + i];
         for (uint32_t i = threadIdx.x; i < nres1; i += blockDim.x) s_res[i] = B.res_start[r0 + i];
+        for (uint32_t i = threadIdx.x; i <= L.n_lead; i += blockDim.x) s_kl[i] = kl_off[i] - rebase;
+        if (pool_in_lds)
+            for (uint32_t i = threadIdx.x; i < plen; i += blockDim.x) s_pool[i] = B.kl_pool[p0 + i];
     }
     if (threadIdx.x == 0) s_next = chunk * chunk_size;
+    TM_STAT(55, threadIdx.x == 0 ? 1 : 0);
+    TM_STAT(56, threadIdx.x == 0 && pool_in_lds ? 1 : 0);
+    TM_STAT(57, threadIdx.x == 0 ? kl_off[L.n_lead] - kl_off[0] : 0);
     __syncthreads();
     const uint32_t t_end = min((chunk + 1) * chunk_size, Q.n_sel);
 
     SearchCtx C;
     C.rec = kLds ? s_rec : B.q_rec + a0;
     C.res_start = kLds ? s_res : B.res_start + r0;
-    C.pool = B.kl_pool;
+    C.pool = pool_in_lds ? s_pool : B.kl_pool;
     C.qchain = B.q_chain + a0;
     C.S = scratch + (threadIdx.x >> 6);
     C.lane = lane_id();
     C.ignore_chain = (Q.flags & TM_FLAG_IGNORE_CHAIN) != 0;
+    const bool count_candidates = A.O.candidates != nullptr;
     WaveScratch &S = *C.S;
     const int lane = C.lane;
-    const uint32_t *kl_off = B.kl_off + (size_t)s * (L.n_lead + 1);
-    const double *qx = B.q_xyz + 3 * (size_t)a0;
+    const uint32_t *kl = kLds ? s_kl : kl_off;
 
-    for (;;) {
-        uint32_t ti = 0;
-        if (lane == 0) ti = atomicAdd(&s_next, 1u);
-        ti = uni(ti);
-        if (ti >= t_end) break;
-        const Staged &T = Q.staged[ti];
-        const int k = (int)T.k;
-        const int G = (int)T.n_groups;
+    uint32_t ti = 0;
+    if (lane == 0) ti = atomicAdd(&s_next, 1u);
+    ti = uni(ti);
+    TemplateRegs R;
+    load_template(Q, min(ti, Q.n_sel - 1u), lane, R);
+
+    while (ti < t_end) {
+        const int k = (int)uni(R.k);
+        const int G = (int)uni(R.n_groups);
         C.k = k;
         C.n_groups = G;
         C.bnd = Q.bounds + (size_t)ti * kMaxPairs;
         TM_STAT(49, 1);
 
-        // ---- stage the template: lane L < k takes level L's constants straight into registers
+        // ---- lane L < k takes level L's constants
         WaveRegs W = {};
         W.surv_base = 0xffffffffu;
         bool empty = false;
         if (lane < k) {
-            const uint16_t li = T.lead_li[lane];
-            const unsigned long long nm = T.namemask[lane];
-            W.group = T.group[lane];
-            W.ref = T.ref[lane];
-            W.tchain = T.tchain[lane];
-            W.orig = T.orig[lane];
-            W.any = T.any[lane];
-            W.resmask = T.resmask[lane];
-            W.nm_lo = (uint32_t)nm;
-            W.nm_hi = (uint32_t)(nm >> 32);
-            W.lead = li != 0xffffu ? 1u : 0u;
+            W.group = R.group;
+            W.ref = R.ref;
+            W.tchain = R.tchain;
+            W.orig = R.orig;
+            W.any = R.any;
+            W.resmask = R.resmask;
+            W.nm_lo = R.nm_lo;
+            W.nm_hi = R.nm_hi;
+            W.lead = R.li != 0xffffu ? 1u : 0u;
             if (W.lead) {
-                const uint32_t o0 = kl_off[li], o1 = kl_off[li + 1];
+                const uint32_t o0 = kl[R.li], o1 = kl[R.li + 1];
                 W.lo = o0;
                 W.cnt = o1 - o0;
                 empty = o1 == o0;
@@ -654,35 +786,41 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(LibView L, BatchView B,
         }
         const bool feasible = __ballot(empty) == 0ull;  // an empty lead list: no assignment exists
         bool feasible_override = true;
-        if (lane < tri(G)) S.bnd_lead[lane] = C.bnd[lane];  // leads are search positions 0..G-1
+        if (lane < tri(G)) S.bnd_lead[lane] = R.lead_bound;  // leads are search positions 0..G-1
         wave_sync();
 
+        // ---- claim the next template and start loading it
+        const uint32_t ti_cur = ti;
+        if (lane == 0) ti = atomicAdd(&s_next, 1u);
+        ti = uni(ti);
+        load_template(Q, min(ti, Q.n_sel - 1u), lane, R);
+
         PairState P;
-        P.s = s; P.ti = ti; P.off = L.t_off[Q.sel[ti]];
+        P.s = s; P.ti = ti_cur;
         P.ncand = 0; P.prev = 0xffffffffu; P.truncated = false;
-        P.cut = Q.cutoff[ti]; P.mx = Q.maxdyn[ti];
 
 #if defined(TM_STATS) || defined(TM_ABLATE)
         if (Q.flags & 0x200u) feasible_override = false;
 #endif
         if (feasible && feasible_override) {
-            joint_top_scan(C, W, L, qx, Q, O, P);
+            joint_top_scan(C, W, P, Q.flags);
         }
 
         // ---- the pair's outcome
         const uint32_t packed = P.ncand | (P.truncated ? 0x80000000u : 0u);
-        if (O.candidates && lane == 0) O.candidates[(size_t)s * Q.n_sel + ti] = packed;
+        if (count_candidates && lane == 0) cold_args()->O.candidates[(size_t)s * Q.n_sel + ti_cur] = packed;
         if (packed != 0u && lane == 0) {
-            const unsigned long long slot = atomicAdd(O.n_pairs, 1ull);
-            if (slot >= O.pair_capacity) atomicOr(O.overflow, 2u);
-            else O.pairs[slot] = PairEntry{s, ti, P.prev, packed};
+            ColdArgsPtr cold = cold_args();
+            const unsigned long long slot = atomicAdd(cold->O.n_pairs, 1ull);
+            if (slot >= cold->O.pair_capacity) atomicOr(cold->O.overflow, 2u);
+            else cold->O.pairs[slot] = PairEntry{s, ti_cur, P.prev, packed};
         }
         wave_sync();
     }
 }
 
-template __global__ void k_search<true>(LibView, BatchView, QueryView, OutView, uint32_t, uint32_t, uint32_t, uint32_t);
-template __global__ void k_search<false>(LibView, BatchView, QueryView, OutView, uint32_t, uint32_t, uint32_t, uint32_t);
+template __global__ void k_search<true>(SearchArgs);
+template __global__ void k_search<false>(SearchArgs);
 
 size_t search_scratch_bytes() { return sizeof(WaveScratch) * kSearchWaves; }
 
