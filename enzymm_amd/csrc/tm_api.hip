@@ -689,19 +689,17 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
         const size_t base = scratch + (size_t)b->max_atoms * sizeof(float4) + search_res_bytes(b->max_res) +
                             search_kl_words(lib->view().n_lead) * sizeof(uint32_t);
         const size_t lds_limit = 160 * 1024 - 64;
-        if (base <= lds_limit) {
-            // whatever LDS is left holds the structure's kind lists (one workgroup per CU either way)
-            const uint32_t pool_cap = (uint32_t)((lds_limit - base) / sizeof(uint16_t));
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_search<true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
-            hipLaunchKernelGGL(k_search<true>, dim3(grid), dim3(kSearchBlock), lds_limit, stream,
-                               SearchArgs{lib->view(), b->view(), Q, O, n_chunks, chunk_size, b->max_atoms, b->max_res, pool_cap});
-        } else {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_search<false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)scratch));
-            hipLaunchKernelGGL(k_search<false>, dim3(grid), dim3(kSearchBlock), scratch, stream,
-                               SearchArgs{lib->view(), b->view(), Q, O, n_chunks, chunk_size, b->max_atoms, b->max_res, 0u});
-        }
+        const bool lds_path = base <= lds_limit;
+        // whatever LDS is left holds the structure's kind lists (one workgroup per CU either way)
+        const uint32_t pool_cap = lds_path ? (uint32_t)((lds_limit - base) / sizeof(uint16_t)) : 0u;
+        const size_t lds_bytes = lds_path ? lds_limit : scratch;
+        const bool ic = (p->flags & TM_FLAG_IGNORE_CHAIN) != 0;
+        void (*kernel)(SearchArgs) = lds_path ? (ic ? k_search<true, true> : k_search<true, false>)
+                                              : (ic ? k_search<false, true> : k_search<false, false>);
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds_bytes));
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(kSearchBlock), lds_bytes, stream,
+                           SearchArgs{lib->view(), b->view(), Q, O, n_chunks, chunk_size, b->max_atoms, b->max_res, pool_cap});
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(r->ev[2], stream));

@@ -32,6 +32,8 @@ __device__ unsigned long long g_stats[64];
 // ------------------------------------------------------------------ wave helpers
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+// wave-wide vote straight into an SGPR pair (HIP's __ballot goes through an integer compare)
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 // number of set bits of `m` below this lane (v_mbcnt_lo + v_mbcnt_hi)
 __device__ __forceinline__ uint32_t rank_in(unsigned long long m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(256) void k_kind_lists(LibView L, BatchView B, uint
                 const uint32_t m = __float_as_uint(rec[i].w);
                 ok = ((nm >> meta_name(m)) & 1ull) && (any || ((rm >> meta_rtype(m)) & 1u));
             }
-            c += __popcll(__ballot(ok));
+            c += __popcll(ballot64(ok));
         }
         if (lane == 0) s_cnt[li] = c;
     }
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(256) void k_kind_lists(LibView L, BatchView B, uint
                 const uint32_t m = __float_as_uint(rec[i].w);
                 ok = ((nm >> meta_name(m)) & 1ull) && (any || ((rm >> meta_rtype(m)) & 1u));
             }
-            const unsigned long long mask = __ballot(ok);
+            const unsigned long long mask = ballot64(ok);
             if (ok) kl_pool[w + rank_in(mask)] = (uint16_t)i;
             w += __popcll(mask);
         }
@@ -226,6 +228,9 @@ __device__ __forceinline__ float RLf(float v, int lane) {
 __device__ __forceinline__ void WL(uint32_t &v, int lane, uint32_t x) { v = lane_id() == lane ? x : v; }
 __device__ __forceinline__ void WLf(float &v, int lane, float x) { v = lane_id() == lane ? x : v; }
 
+// kIgnoreChain is a compile-time property of the launch: the default (ignore_chain=True in enzymm) drops
+// every chain test from the instruction stream.
+template <bool kIgnoreChain>
 struct SearchCtx {
     const float4 *rec;          // structure atom records (LDS or global)
     const uint16_t *res_start;  // residue -> first atom (LDS or global)
@@ -234,11 +239,12 @@ struct SearchCtx {
     const float2 *bnd;          // this template's pair bounds (global)
     WaveScratch *S;
     int lane, k, n_groups;
-    bool ignore_chain;
+    static constexpr bool ignore_chain = kIgnoreChain;
 };
 
 // Tests up to 64 candidates for `level`; returns the survivor mask.
-__device__ __forceinline__ unsigned long long eval_chunk(const SearchCtx &C, WaveRegs &W, int level, uint32_t base) {
+template <class Ctx>
+__device__ __forceinline__ unsigned long long eval_chunk(const Ctx &C, WaveRegs &W, int level, uint32_t base) {
     WaveScratch &S = *C.S;
     const int lane = C.lane;
     const uint32_t cnt = RL(W.cnt, level), lo = RL(W.lo, level);
@@ -275,7 +281,7 @@ __device__ __forceinline__ unsigned long long eval_chunk(const SearchCtx &C, Wav
         mychain = RL(W.tchain, level);
     }
     TM_STAT(level, 1);
-    unsigned long long alive = __ballot(ok);
+    unsigned long long alive = ballot64(ok);
     for (int j = 0; j < level && alive; ++j) {
         const float dx = r.x - RLf(W.ax, j), dy = r.y - RLf(W.ay, j), dz = r.z - RLf(W.az, j);
         const float d2 = dx * dx + dy * dy + dz * dz;
@@ -289,14 +295,15 @@ __device__ __forceinline__ unsigned long long eval_chunk(const SearchCtx &C, Wav
             ok = ok && (tc == qc);
         }
         TM_STAT(50, 1);
-        alive = __ballot(ok);
+        alive = ballot64(ok);
     }
     TM_STAT(24 + level, __popcll(alive));
     return alive;
 }
 
 // Prepares `level` after levels < level were assigned.
-__device__ __forceinline__ void init_level(const SearchCtx &C, WaveRegs &W, int level) {
+template <class Ctx>
+__device__ __forceinline__ void init_level(const Ctx &C, WaveRegs &W, int level) {
     WL(W.cur, level, 0u);
     WL(W.pend_lo, level, 0u);
     WL(W.pend_hi, level, 0u);
@@ -309,7 +316,8 @@ __device__ __forceinline__ void init_level(const SearchCtx &C, WaveRegs &W, int 
     }
 }
 
-__device__ __forceinline__ void assign_level(const SearchCtx &C, WaveRegs &W, int level, uint32_t cand) {
+template <class Ctx>
+__device__ __forceinline__ void assign_level(const Ctx &C, WaveRegs &W, int level, uint32_t cand) {
     const float4 r = C.rec[cand];  // uniform address
     WL(W.aidx, level, cand);
     WLf(W.ax, level, __uint_as_float(uni(__float_as_uint(r.x))));
@@ -347,7 +355,8 @@ struct PairState {
 // A complete assignment passed the fp32 prefilter: re-check every pair in fp64
 // (| |q_i - q_j| - |t_i - t_j| | <= thr_ij exactly as the oracle does) and append it to the
 // candidate buffer.  Returns false when the search must stop (max_candidates reached).
-__device__ __forceinline__ bool on_complete(const SearchCtx &C, WaveRegs &W, PairState &P) {
+template <class Ctx>
+__device__ __forceinline__ bool on_complete(const Ctx &C, WaveRegs &W, PairState &P) {
     const int lane = C.lane, k = C.k, npairs = tri(k);
     // completions are rare: everything but the assignment itself is fetched here, not per search
     ColdArgsPtr A = cold_args();
@@ -375,7 +384,7 @@ __device__ __forceinline__ bool on_complete(const SearchCtx &C, WaveRegs &W, Pai
         }
     }
     TM_STAT(48, 1);
-    if (__ballot(bad)) {  // fp32 prefilter false positive
+    if (ballot64(bad)) {  // fp32 prefilter false positive
         TM_STAT(51, 1);
         return true;
     }
@@ -408,7 +417,8 @@ __device__ __forceinline__ bool on_complete(const SearchCtx &C, WaveRegs &W, Pai
 
 // Depth-first search over levels >= floor (levels < floor are already assigned).
 // Returns false when the pair was cut short by max_candidates.
-__device__ __forceinline__ bool dfs(const SearchCtx &C, WaveRegs &W, PairState &P, int floor) {
+template <class Ctx>
+__device__ __forceinline__ bool dfs(const Ctx &C, WaveRegs &W, PairState &P, int floor) {
     const int k = C.k;  // floor < k always: a template has at least 3 atoms per residue
     int level = floor;
     init_level(C, W, level);
@@ -465,7 +475,7 @@ __device__ __forceinline__ uint32_t best_tile_shift(uint32_t n_i, uint32_t n_j) 
 __device__ __forceinline__ bool in_window(const float4 &p, const float4 &q, const float2 &b) {
     const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
     const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-    return d2 >= b.x && d2 <= b.y;
+    return (d2 >= b.x) & (d2 <= b.y);
 }
 
 // Padding records for unused slots of a staged block: far away from every atom and from each
@@ -487,7 +497,8 @@ constexpr float kPadFar = 3.0e18f;
 // depth-first search -- exists exactly once in the instruction stream (the kernel must fit the
 // instruction cache): queue3 is refilled from the triple tiles, which pull from the pair queue,
 // which is refilled from the pair tiles.
-__device__ __forceinline__ bool joint_top_scan(const SearchCtx &C, WaveRegs &W, PairState &P, uint32_t flags) {
+template <class Ctx>
+__device__ __forceinline__ bool joint_top_scan(const Ctx &C, WaveRegs &W, PairState &P, uint32_t flags) {
     WaveScratch &S = *C.S;
     const int lane = C.lane;
     const bool single = C.n_groups < 2;  // one-residue template: plain depth-first search from level 0
@@ -543,29 +554,35 @@ __device__ __forceinline__ bool joint_top_scan(const SearchCtx &C, WaveRegs &W, 
                             sh2 = best_tile_shift(nq, cn2);
                             fresh2 = false;
                         }
-                        const uint32_t TJ2 = 1u << sh2;
-                        const uint32_t e = e0 + ((uint32_t)lane >> sh2), j = c0 + ((uint32_t)lane & (TJ2 - 1));
+                        // one row of tiles: TI2 queued pairs (fixed) against the block of list2, TJ2 entries at a time
+                        const uint32_t TJ2 = 1u << sh2, lj2 = (uint32_t)lane & (TJ2 - 1);
+                        const uint32_t e = e0 + ((uint32_t)lane >> sh2);
                         const uint32_t pos = S.queue[e & (uint32_t)(kJointQueue - 1)];  // masked by `e < nq` below
                         const uint32_t ip = pos & 63u, jp = (pos >> 8) & 63u;
-                        const float4 ra = S.rec0[ip], rb = S.rec1[jp], rc = S.rec2[j & 63u];
-                        const uint32_t res_c = meta_res(__float_as_uint(rc.w));
-                        bool ok = e < nq && in_window(rc, ra, b20) && in_window(rc, rb, b21) &&  // padding fails the windows
-                                  res_c != meta_res(__float_as_uint(ra.w)) && res_c != meta_res(__float_as_uint(rb.w));
-                        const uint32_t ab = (uint32_t)S.id0[ip] | ((uint32_t)S.id1[jp] << 16), c = S.id2[j & 63u];
-                        if (!C.ignore_chain) {
-                            const uint8_t qc = C.qchain[c];
-                            ok = ok && ((qc == C.qchain[ab & 0xffffu]) == tc20) && ((qc == C.qchain[ab >> 16]) == tc21);
-                        }
-                        const unsigned long long m = __ballot(ok);
-                        TM_STAT(2, 1);
-                        TM_STAT(24 + 2, __popcll(m));
-                        if (ok) {
-                            const uint32_t slot = nq3 + rank_in(m);
-                            S.queue3[slot][0] = ab;
-                            S.queue3[slot][1] = c;
-                        }
-                        nq3 += (uint32_t)__popcll(m);
-                        c0 += TJ2;
+                        const float4 ra = S.rec0[ip], rb = S.rec1[jp];
+                        const uint32_t res_a = meta_res(__float_as_uint(ra.w)), res_b = meta_res(__float_as_uint(rb.w));
+                        const bool ve = e < nq;
+                        const float4 *pc = S.rec2 + lj2;
+                        do {
+                            const float4 rc = pc[c0];  // slot < 64: padding records fail the windows
+                            const uint32_t res_c = meta_res(__float_as_uint(rc.w));
+                            // every test is evaluated unconditionally: no divergent short-circuit branches
+                            bool ok = ve & in_window(rc, ra, b20) & in_window(rc, rb, b21) & (res_c != res_a) & (res_c != res_b);
+                            if (!C.ignore_chain) {
+                                const uint8_t qc = C.qchain[S.id2[c0 + lj2]];
+                                ok = ok && ((qc == C.qchain[S.id0[ip]]) == tc20) && ((qc == C.qchain[S.id1[jp]]) == tc21);
+                            }
+                            const unsigned long long m = ballot64(ok);
+                            TM_STAT(2, 1);
+                            TM_STAT(24 + 2, __popcll(m));
+                            if (ok) {
+                                const uint32_t slot = nq3 + rank_in(m);
+                                S.queue3[slot][0] = (uint32_t)S.id0[ip] | ((uint32_t)S.id1[jp] << 16);
+                                S.queue3[slot][1] = S.id2[c0 + lj2];
+                            }
+                            nq3 += (uint32_t)__popcll(m);
+                            c0 += TJ2;
+                        } while (c0 < cn2 && nq3 + 64u <= (uint32_t)kJointQueue3);
                         if (c0 >= cn2) {
                             c0 = 0;
                             e0 += 64u >> sh2;
@@ -605,16 +622,20 @@ __device__ __forceinline__ bool joint_top_scan(const SearchCtx &C, WaveRegs &W, 
                     const float4 *pa = S.rec0 + li, *pb = S.rec1 + lj;
                     const uint32_t lpos = li | (lj << 8);
                     while (!fresh && nq + 64u <= (uint32_t)kJointQueue) {
-                        const float4 ra = pa[i0], rb = pb[j0];  // slots < 64: tiles never leave the block
-                        bool ok = in_window(ra, rb, b10) &&      // padding slots fail here
-                                  meta_res(__float_as_uint(ra.w)) != meta_res(__float_as_uint(rb.w));
-                        if (!C.ignore_chain) ok = ok && ((C.qchain[S.id0[i0 + li]] == C.qchain[S.id1[j0 + lj]]) == tc10);
-                        const unsigned long long m = __ballot(ok);
-                        TM_STAT(52, 1);
-                        TM_STAT(53, __popcll(m));
-                        if (ok) S.queue[nq + rank_in(m)] = lpos + (i0 | (j0 << 8));
-                        nq += (uint32_t)__popcll(m);
-                        j0 += TJ;
+                        // one row of tiles: TI entries of block 0 (fixed) against block 1, TJ entries at a time
+                        const float4 ra = pa[i0];  // slots < 64: tiles never leave the block
+                        const uint32_t res_a = meta_res(__float_as_uint(ra.w));
+                        do {
+                            const float4 rb = pb[j0];
+                            bool ok = in_window(ra, rb, b10) & (res_a != meta_res(__float_as_uint(rb.w)));  // padding fails
+                            if (!C.ignore_chain) ok = ok && ((C.qchain[S.id0[i0 + li]] == C.qchain[S.id1[j0 + lj]]) == tc10);
+                            const unsigned long long m = ballot64(ok);
+                            TM_STAT(52, 1);
+                            TM_STAT(53, __popcll(m));
+                            if (ok) S.queue[nq + rank_in(m)] = lpos + (i0 | (j0 << 8));
+                            nq += (uint32_t)__popcll(m);
+                            j0 += TJ;
+                        } while (j0 < cn1 && nq + 64u <= (uint32_t)kJointQueue);
                         if (j0 >= cn1) {
                             j0 = 0;
                             i0 += TI;
@@ -687,7 +708,7 @@ __device__ __forceinline__ void load_template(const QueryView &Q, uint32_t ti, i
     R.n_groups = T.n_groups;
 }
 
-template <bool kLds>
+template <bool kLds, bool kIgnoreChain>
 __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
     const LibView &L = A.L;
     const BatchView &B = A.B;
@@ -736,14 +757,13 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
     __syncthreads();
     const uint32_t t_end = min((chunk + 1) * chunk_size, Q.n_sel);
 
-    SearchCtx C;
+    SearchCtx<kIgnoreChain> C;
     C.rec = kLds ? s_rec : B.q_rec + a0;
     C.res_start = kLds ? s_res : B.res_start + r0;
     C.pool = pool_in_lds ? s_pool : B.kl_pool;
     C.qchain = B.q_chain + a0;
     C.S = scratch + (threadIdx.x >> 6);
     C.lane = lane_id();
-    C.ignore_chain = (Q.flags & TM_FLAG_IGNORE_CHAIN) != 0;
     const bool count_candidates = A.O.candidates != nullptr;
     WaveScratch &S = *C.S;
     const int lane = C.lane;
@@ -784,7 +804,7 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
                 empty = o1 == o0;
             }
         }
-        const bool feasible = __ballot(empty) == 0ull;  // an empty lead list: no assignment exists
+        const bool feasible = ballot64(empty) == 0ull;  // an empty lead list: no assignment exists
         bool feasible_override = true;
         if (lane < tri(G)) S.bnd_lead[lane] = R.lead_bound;  // leads are search positions 0..G-1
         wave_sync();
@@ -819,8 +839,10 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
     }
 }
 
-template __global__ void k_search<true>(SearchArgs);
-template __global__ void k_search<false>(SearchArgs);
+template __global__ void k_search<true, true>(SearchArgs);
+template __global__ void k_search<true, false>(SearchArgs);
+template __global__ void k_search<false, true>(SearchArgs);
+template __global__ void k_search<false, false>(SearchArgs);
 
 size_t search_scratch_bytes() { return sizeof(WaveScratch) * kSearchWaves; }
 
