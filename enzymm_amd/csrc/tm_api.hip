@@ -338,7 +338,9 @@ int tm_batch_create(int device, const tm_batch_desc *d, tm_batch **out) {
                                               " atoms; limit " + std::to_string(TM_MAX_STRUCTURE_ATOMS));
         uint32_t nres = 0;
         for (uint32_t i = 0; i < n; ++i) nres = std::max(nres, d->residue[o + i] + 1);
-        if (nres > 65535) return fail(TM_E_UNSUPPORTED, "structure " + std::to_string(s) + " has too many residues");
+        if (nres > TM_MAX_STRUCTURE_RESIDUES)
+            return fail(TM_E_UNSUPPORTED, "structure " + std::to_string(s) + " has more than " +
+                                              std::to_string(TM_MAX_STRUCTURE_RESIDUES) + " residues");
         // counting sort by residue ordinal: atoms of a residue become contiguous, file order kept inside
         count.assign(nres + 1, 0);
         for (uint32_t i = 0; i < n; ++i) count[d->residue[o + i] + 1]++;

@@ -200,7 +200,7 @@ struct __align__(16) WaveScratch {
     float4 rec0[64], rec1[64], rec2[64];       // atom records of the current 64-entry blocks of the top lead lists
     uint16_t id0[64], id1[64], id2[64];        // and their atom indices
     uint32_t queue[kJointQueue];               // pair-scan survivors (position in block 0 | position in block 1 << 8)
-    uint32_t queue3[kJointQueue3][2];          // triple-scan survivors ((a | b << 16), c) waiting for their subtree
+    uint32_t queue3[kJointQueue3][2];          // survivors of one triple tile ((a | b << 16), c) waiting for their subtree
 };
 
 // Search state of one wave, held in VGPRs and indexed BY LANE: lane L holds the entry of search
@@ -481,199 +481,174 @@ __device__ __forceinline__ bool in_window(const float4 &p, const float4 &q, cons
 // Padding records for unused slots of a staged block: far away from every atom and from each
 // other, so that any pair involving a padding slot fails its distance window by itself.
 constexpr float kPadFar = 3.0e18f;
+// Upper bound (squared distance) of the pass-everything window used with wildcard lists: above any
+// real squared distance (PDB coordinates stay below 1e4 A), below kPadFar squared.
+constexpr float kWildWindow = 1.0e30f;
 
-// The lead atoms of the first two (three) template residues are matched by tiled scans: the
-// wave lays the cross product list0 x list1 over its 64 lanes and tests the pair constraint
-// (1, 0); surviving pairs are queued in LDS and, when the template has a third residue, the
-// cross product queue x list2 is tiled the same way against the constraints (2, 0) and (2, 1).
-// Only what survives that is searched depth-first (levels >= 3, or >= 2 for two-residue templates).
+// The lead atoms of the first three template residues are matched by tiled scans: the wave lays
+// the cross product list0 x list1 over its 64 lanes and tests the pair constraint (1, 0);
+// surviving pairs are queued in LDS and the cross product queue x list2 is tiled the same way
+// against the constraints (2, 0) and (2, 1).  Only what survives that is searched depth-first
+// (levels >= 3).  A template with fewer than three residues gets one-entry "wildcard" lists for
+// the missing ones, which pass every test, so that all templates run the same code.
 //
 // The lists are walked in blocks of 64 entries whose atom records are copied into a compact
 // per-wave LDS array once (one scattered gather per list entry); every tile then reads its
 // operands at consecutive or broadcast addresses, free of bank conflicts, and lists of any
 // length are handled.
 //
-// Written as one resumable producer/consumer loop so that each stage -- pair tile, triple tile,
-// depth-first search -- exists exactly once in the instruction stream (the kernel must fit the
-// instruction cache): queue3 is refilled from the triple tiles, which pull from the pair queue,
-// which is refilled from the pair tiles.
+// Plain nested loops; each stage -- pair tile, triple tile, depth-first search -- exists exactly
+// once in the instruction stream (the kernel must fit the instruction cache).  The pair queue is
+// consumed whenever it may not take another tile; the triple queue holds one tile of survivors
+// and is searched as soon as it is not empty.
 template <class Ctx>
 __device__ __forceinline__ bool joint_top_scan(const Ctx &C, WaveRegs &W, PairState &P, uint32_t flags) {
     WaveScratch &S = *C.S;
     const int lane = C.lane;
-    const bool single = C.n_groups < 2;  // one-residue template: plain depth-first search from level 0
-    const bool tiled2 = C.n_groups >= 3;
-    const uint32_t n0 = single ? 0u : RL(W.cnt, 0), n1 = single ? 0u : RL(W.cnt, 1);
-    const uint32_t n2 = tiled2 ? RL(W.cnt, 2) : 0u;
+    const bool real1 = C.n_groups >= 2, real2 = C.n_groups >= 3;
+    const int floor = real2 ? 3 : C.n_groups;  // levels the queue3 entries assign
+    const uint32_t n0 = RL(W.cnt, 0), n1 = real1 ? RL(W.cnt, 1) : 1u, n2 = real2 ? RL(W.cnt, 2) : 1u;
     const uint32_t lo0 = RL(W.lo, 0), lo1 = RL(W.lo, 1), lo2 = RL(W.lo, 2);
-    const float2 b10 = S.bnd_lead[0];                                       // pair (1, 0)
-    const float2 b20 = S.bnd_lead[tri(2)], b21 = S.bnd_lead[tri(2) + 1];    // pairs (2, 0), (2, 1)
+    const float2 pass_all = make_float2(-1.f, kWildWindow);
+    const float2 b10 = real1 ? S.bnd_lead[0] : pass_all;                       // pair (1, 0)
+    const float2 b20 = real2 ? S.bnd_lead[tri(2)] : pass_all;                  // pairs (2, 0), (2, 1)
+    const float2 b21 = real2 ? S.bnd_lead[tri(2) + 1] : pass_all;
     const bool tc10 = RL(W.tchain, 0) == RL(W.tchain, 1);
     const bool tc20 = RL(W.tchain, 0) == RL(W.tchain, 2), tc21 = RL(W.tchain, 1) == RL(W.tchain, 2);
-    const int floor = single ? 0 : tiled2 ? 3 : 2;  // levels the queue3 entries assign
 
     // copies block `base` of a lead list (ids from the kind-list pool, records from the structure) into LDS;
-    // slots past the end get the padding record `pad`, so tiles may read any of the 64 slots unmasked
-    auto stage_block = [&](float4 *rec, uint16_t *id, uint32_t lo, uint32_t base, uint32_t cnt, float pad_x, float pad_y) {
-        const uint32_t a = C.pool[lo + base + min((uint32_t)lane, cnt - 1u)];
-        id[lane] = (uint16_t)a;
-        float4 r = C.rec[a];
+    // slots past the end get a padding record, so tiles may read any of the 64 slots unmasked.
+    // A wildcard list is one record at the origin with a residue number no atom has.
+    auto stage_block = [&](float4 *rec, uint16_t *id, bool real, uint32_t lo, uint32_t base, uint32_t cnt, float pad_x,
+                           float pad_y, uint32_t wild_res) {
+        float4 r = make_float4(0.f, 0.f, 0.f, __uint_as_float(wild_res));
+        uint32_t a = 0;
+        if (real) {
+            a = C.pool[lo + base + min((uint32_t)lane, cnt - 1u)];
+            r = C.rec[a];
+        }
         if ((uint32_t)lane >= cnt) { r.x = pad_x; r.y = pad_y; }
+        id[lane] = (uint16_t)a;
         rec[lane] = r;
     };
 
-    uint32_t ib = 0, jb = 0;                    // blocks of list0 / list1 being paired
-    uint32_t ib_st = 0xffffffffu, jb_st = 0xffffffffu, cb_st = 0xffffffffu;  // blocks present in LDS
-    uint32_t cn0 = 0, cn1 = 0, cn2 = 0;         // entries in them
-    uint32_t i0 = 0, j0 = 0, tj_shift = 3;      // next pair tile inside the blocks, tile shape
-    bool fresh = true;                          // the block pair was not started yet
-    bool pairs_done = single;
-    uint32_t nq = 0;                            // pair queue fill
-    bool consuming = false, fresh2 = false;     // the pair queue is being crossed with list2 (or copied)
-    uint32_t e0 = 0, c0 = 0, cb = 0, sh2 = 6;   // next triple tile (queue entry base, position in block cb), shape
-    uint32_t nq3 = 0;
-    bool single_pending = single;
-
-    for (;;) {
-        // ---- refill queue3 while it has room for a whole tile of survivors
-        if (single_pending) {
-            nq3 = 1;
-            single_pending = false;
-        } else {
-            while (nq3 + 64u <= (uint32_t)kJointQueue3) {
-                if (consuming) {
-                    if (tiled2) {  // one triple tile: TI2 queued pairs x TJ2 entries of the list2 block
-                        if (fresh2) {
-                            if (cb_st != cb) {
-                                wave_sync();
-                                cn2 = min(64u, n2 - cb);
-                                stage_block(S.rec2, S.id2, lo2, cb, cn2, 0.f, kPadFar);
-                                cb_st = cb;
-                                wave_sync();
-                            }
-                            sh2 = best_tile_shift(nq, cn2);
-                            fresh2 = false;
-                        }
-                        // one row of tiles: TI2 queued pairs (fixed) against the block of list2, TJ2 entries at a time
-                        const uint32_t TJ2 = 1u << sh2, lj2 = (uint32_t)lane & (TJ2 - 1);
-                        const uint32_t e = e0 + ((uint32_t)lane >> sh2);
-                        const uint32_t pos = S.queue[e & (uint32_t)(kJointQueue - 1)];  // masked by `e < nq` below
-                        const uint32_t ip = pos & 63u, jp = (pos >> 8) & 63u;
-                        const float4 ra = S.rec0[ip], rb = S.rec1[jp];
-                        const uint32_t res_a = meta_res(__float_as_uint(ra.w)), res_b = meta_res(__float_as_uint(rb.w));
-                        const bool ve = e < nq;
-                        const float4 *pc = S.rec2 + lj2;
-                        do {
-                            const float4 rc = pc[c0];  // slot < 64: padding records fail the windows
-                            const uint32_t res_c = meta_res(__float_as_uint(rc.w));
-                            // every test is evaluated unconditionally: no divergent short-circuit branches
-                            bool ok = ve & in_window(rc, ra, b20) & in_window(rc, rb, b21) & (res_c != res_a) & (res_c != res_b);
-                            if (!C.ignore_chain) {
-                                const uint8_t qc = C.qchain[S.id2[c0 + lj2]];
-                                ok = ok && ((qc == C.qchain[S.id0[ip]]) == tc20) && ((qc == C.qchain[S.id1[jp]]) == tc21);
-                            }
-                            const unsigned long long m = ballot64(ok);
-                            TM_STAT(2, 1);
-                            TM_STAT(24 + 2, __popcll(m));
-                            if (ok) {
-                                const uint32_t slot = nq3 + rank_in(m);
-                                S.queue3[slot][0] = (uint32_t)S.id0[ip] | ((uint32_t)S.id1[jp] << 16);
-                                S.queue3[slot][1] = S.id2[c0 + lj2];
-                            }
-                            nq3 += (uint32_t)__popcll(m);
-                            c0 += TJ2;
-                        } while (c0 < cn2 && nq3 + 64u <= (uint32_t)kJointQueue3);
-                        if (c0 >= cn2) {
-                            c0 = 0;
-                            e0 += 64u >> sh2;
-                            if (e0 >= nq) {  // the queue met this block of list2: next block, or done
-                                e0 = 0;
-                                cb += 64u;
-                                fresh2 = true;
-                                if (cb >= n2) { cb = 0; consuming = false; nq = 0; }
-                            }
-                        }
-                    } else {  // two-residue template: pairs go to the search as they are
-                        const uint32_t e = e0 + (uint32_t)lane;
-                        if (e < nq) {
-                            const uint32_t pos = S.queue[e];
-                            S.queue3[nq3 + lane][0] = (uint32_t)S.id0[pos & 63u] | ((uint32_t)S.id1[(pos >> 8) & 63u] << 16);
-                        }
-                        nq3 += min(64u, nq - e0);
-                        e0 += 64u;
-                        if (e0 >= nq) { e0 = 0; consuming = false; nq = 0; }
-                    }
-                    continue;
-                }
-                // the pair queue is empty: refill it from the pair tiles of the current block pair
-                if (pairs_done) break;
-                if (fresh) {
-                    wave_sync();
-                    if (ib_st != ib) { cn0 = min(64u, n0 - ib); stage_block(S.rec0, S.id0, lo0, ib, cn0, kPadFar, 0.f); ib_st = ib; }
-                    if (jb_st != jb) { cn1 = min(64u, n1 - jb); stage_block(S.rec1, S.id1, lo1, jb, cn1, -kPadFar, 0.f); jb_st = jb; }
-                    tj_shift = best_tile_shift(cn0, cn1);
-                    i0 = j0 = 0;
-                    fresh = false;
-                }
+    uint32_t jb_st = 0xffffffffu, cb_st = 0xffffffffu;  // blocks of list1 / list2 present in LDS
+    wave_sync();
+    if (n2 <= 64u) {  // the usual case: list2 is one block, staged together with the others
+        stage_block(S.rec2, S.id2, real2, lo2, 0u, n2, 0.f, kPadFar, 0xfffdu);
+        cb_st = 0;
+    }
+    for (uint32_t ib = 0; ib < n0; ib += 64u) {
+        const uint32_t cn0 = min(64u, n0 - ib);
+        wave_sync();
+        stage_block(S.rec0, S.id0, true, lo0, ib, cn0, kPadFar, 0.f, 0u);
+        for (uint32_t jb = 0; jb < n1; jb += 64u) {
+            const uint32_t cn1 = min(64u, n1 - jb);
+            if (jb_st != jb) {
                 wave_sync();
-                {
-                    const uint32_t TJ = 1u << tj_shift, TI = 64u >> tj_shift;
-                    const uint32_t li = (uint32_t)lane >> tj_shift, lj = (uint32_t)lane & (TJ - 1);
-                    const float4 *pa = S.rec0 + li, *pb = S.rec1 + lj;
-                    const uint32_t lpos = li | (lj << 8);
-                    while (!fresh && nq + 64u <= (uint32_t)kJointQueue) {
-                        // one row of tiles: TI entries of block 0 (fixed) against block 1, TJ entries at a time
-                        const float4 ra = pa[i0];  // slots < 64: tiles never leave the block
-                        const uint32_t res_a = meta_res(__float_as_uint(ra.w));
-                        do {
-                            const float4 rb = pb[j0];
-                            bool ok = in_window(ra, rb, b10) & (res_a != meta_res(__float_as_uint(rb.w)));  // padding fails
-                            if (!C.ignore_chain) ok = ok && ((C.qchain[S.id0[i0 + li]] == C.qchain[S.id1[j0 + lj]]) == tc10);
-                            const unsigned long long m = ballot64(ok);
-                            TM_STAT(52, 1);
-                            TM_STAT(53, __popcll(m));
-                            if (ok) S.queue[nq + rank_in(m)] = lpos + (i0 | (j0 << 8));
-                            nq += (uint32_t)__popcll(m);
-                            j0 += TJ;
-                        } while (j0 < cn1 && nq + 64u <= (uint32_t)kJointQueue);
-                        if (j0 >= cn1) {
-                            j0 = 0;
-                            i0 += TI;
-                            if (i0 >= cn0) fresh = true;  // block pair finished
-                        }
+                stage_block(S.rec1, S.id1, real1, lo1, jb, cn1, -kPadFar, 0.f, 0xfffeu);
+                jb_st = jb;
+            }
+            wave_sync();
+            const uint32_t tj_shift = best_tile_shift(cn0, cn1);
+            const uint32_t TJ = 1u << tj_shift, TI = 64u >> tj_shift;
+            const uint32_t li = (uint32_t)lane >> tj_shift, lj = (uint32_t)lane & (TJ - 1);
+            const float4 *pa = S.rec0 + li, *pb = S.rec1 + lj;
+            const uint32_t lpos = li | (lj << 8);
+            uint32_t i0 = 0, j0 = 0;
+            while (i0 < cn0) {
+                // ---- pair tiles until the queue may not take another one (or the block pair is done)
+                uint32_t nq = 0;
+                do {
+                    // one row of tiles: TI entries of block 0 (fixed) against block 1, TJ entries at a time
+                    const float4 ra = pa[i0];  // slots < 64: tiles never leave the block
+                    const uint32_t res_a = meta_res(__float_as_uint(ra.w));
+                    do {
+                        const float4 rb = pb[j0];
+                        bool ok = in_window(ra, rb, b10) & (res_a != meta_res(__float_as_uint(rb.w)));  // padding fails
+                        if (!C.ignore_chain && real1)
+                            ok = ok && ((C.qchain[S.id0[i0 + li]] == C.qchain[S.id1[j0 + lj]]) == tc10);
+                        const unsigned long long m = ballot64(ok);
+                        TM_STAT(52, 1);
+                        TM_STAT(53, __popcll(m));
+                        if (ok) S.queue[nq + rank_in(m)] = lpos + (i0 | (j0 << 8));
+                        nq += (uint32_t)__popcll(m);
+                        j0 += TJ;
+                    } while (j0 < cn1 && nq + 64u <= (uint32_t)kJointQueue);
+                    if (j0 >= cn1) {
+                        j0 = 0;
+                        i0 += TI;
                     }
-                }
-                if (fresh) {
-                    jb += 64u;
-                    if (jb >= n1) { jb = 0; ib += 64u; }
-                    if (ib >= n0) pairs_done = true;
-                }
-                wave_sync();
+                } while (i0 < cn0 && nq + 64u <= (uint32_t)kJointQueue);
 #if defined(TM_STATS) || defined(TM_ABLATE)
                 if (flags & 0x100u) nq = 0;
 #endif
-                // the queue refers to positions in the blocks now in LDS: it is used up before they change
-                if (nq) { consuming = true; fresh2 = true; e0 = 0; c0 = 0; cb = 0; }
-            }
-            wave_sync();
-        }
-        if (nq3 == 0) return true;  // every tile evaluated, nothing left to search
-        // ---- depth-first search below every queued partial assignment (the only dfs call site)
+                if (nq == 0) continue;
+                wave_sync();
+                // ---- the queued pairs against list2, block by block
+                for (uint32_t cb = 0; cb < n2; cb += 64u) {
+                    const uint32_t cn2 = min(64u, n2 - cb);
+                    if (cb_st != cb) {
+                        wave_sync();
+                        stage_block(S.rec2, S.id2, real2, lo2, cb, cn2, 0.f, kPadFar, 0xfffdu);
+                        cb_st = cb;
+                        wave_sync();
+                    }
+                    const uint32_t sh2 = best_tile_shift(nq, cn2);
+                    const uint32_t TJ2 = 1u << sh2, TI2 = 64u >> sh2, lj2 = (uint32_t)lane & (TJ2 - 1);
+                    const float4 *pc = S.rec2 + lj2;
+                    for (uint32_t e0 = 0; e0 < nq; e0 += TI2) {
+                        uint32_t c0 = 0;
+                        while (c0 < cn2) {
+                            // one row of tiles: TI2 queued pairs (fixed) against the block of list2, TJ2 entries at a time
+                            const uint32_t e = e0 + ((uint32_t)lane >> sh2);
+                            const uint32_t pos = S.queue[e & (uint32_t)(kJointQueue - 1)];  // masked by `e < nq` below
+                            const uint32_t ip = pos & 63u, jp = (pos >> 8) & 63u;
+                            const float4 ra = S.rec0[ip], rb = S.rec1[jp];
+                            const uint32_t res_a = meta_res(__float_as_uint(ra.w)), res_b = meta_res(__float_as_uint(rb.w));
+                            const bool ve = e < nq;
+                            uint32_t nq3 = 0;
+                            do {
+                                const float4 rc = pc[c0];  // slot < 64: padding records fail the windows
+                                const uint32_t res_c = meta_res(__float_as_uint(rc.w));
+                                // every test is evaluated unconditionally: no divergent short-circuit branches
+                                bool ok = ve & in_window(rc, ra, b20) & in_window(rc, rb, b21) & (res_c != res_a) & (res_c != res_b);
+                                if (!C.ignore_chain && real2) {
+                                    const uint8_t qc = C.qchain[S.id2[c0 + lj2]];
+                                    ok = ok && ((qc == C.qchain[S.id0[ip]]) == tc20) && ((qc == C.qchain[S.id1[jp]]) == tc21);
+                                }
+                                const unsigned long long m = ballot64(ok);
+                                TM_STAT(2, 1);
+                                TM_STAT(24 + 2, __popcll(m));
+                                if (ok) {
+                                    const uint32_t slot = rank_in(m);
+                                    S.queue3[slot][0] = (uint32_t)S.id0[ip] | ((uint32_t)S.id1[jp] << 16);
+                                    S.queue3[slot][1] = S.id2[c0 + lj2];
+                                }
+                                nq3 = (uint32_t)__popcll(m);
+                                c0 += TJ2;
+                            } while (c0 < cn2 && nq3 == 0);
+                            if (nq3 == 0) break;
+                            // ---- depth-first search below every surviving triple (the only dfs call site)
+                            wave_sync();
 #if defined(TM_STATS) || defined(TM_ABLATE)
-        if (flags & 0x400u) nq3 = 0;
+                            if (flags & 0x400u) nq3 = 0;
 #endif
-        for (uint32_t e = 0; e < nq3; ++e) {
-            if (floor >= 2) {
-                const uint32_t ab = uni(S.queue3[e][0]);
-                assign_level(C, W, 0, ab & 0xffffu);
-                assign_level(C, W, 1, ab >> 16);
+                            for (uint32_t q = 0; q < nq3; ++q) {
+                                const uint32_t ab = uni(S.queue3[q][0]);
+                                assign_level(C, W, 0, ab & 0xffffu);
+                                if (floor >= 2) assign_level(C, W, 1, ab >> 16);
+                                if (floor >= 3) assign_level(C, W, 2, uni(S.queue3[q][1]));
+                                if (!dfs(C, W, P, floor)) return false;
+                            }
+                            wave_sync();
+                        }
+                    }
+                }
             }
-            if (floor >= 3) assign_level(C, W, 2, uni(S.queue3[e][1]));
-            if (!dfs(C, W, P, floor)) return false;
         }
-        nq3 = 0;
-        wave_sync();
     }
+    return true;
 }
 
 __host__ __device__ inline size_t search_res_bytes(uint32_t max_res) {

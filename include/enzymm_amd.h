@@ -41,6 +41,7 @@ extern "C" {
 #define TM_MAX_TEMPLATE_ATOMS 24   /* 8 residues x 3 atoms: enzymm's largest size bucket (jess_run.py:564-571) */
 #define TM_MAX_TEMPLATE_GROUPS 8   /* template residues */
 #define TM_MAX_STRUCTURE_ATOMS 65535
+#define TM_MAX_STRUCTURE_RESIDUES 65533  /* residue numbers 0xfffd..0xffff are reserved by the search kernel */
 #define TM_RES_OTHER 31            /* residue-type id of "not in the vocabulary" */
 #define TM_NAME_OTHER 63           /* atom-name id of "not in the vocabulary" */
 

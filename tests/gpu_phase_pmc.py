@@ -1,24 +1,28 @@
-"""Per-phase instruction counters: parse a rocprofv3 --pmc run of tests/gpu_ablate.py. Not a test.
+"""Per-phase instruction counters: summarise a rocprofv3 --pmc run of tests/gpu_ablate.py. Not a test.
 
-usage: gpu_phase_pmc.py <dir with counter csv> [searches]
+usage: gpu_phase_pmc.py <dir with the rocpd .db> [searches per launch]
 gpu_ablate.py launches k_search 4x per mode in the order full / no dfs / no subtrees / staging only."""
 import collections
-import csv
 import glob
+import sqlite3
 import sys
 
 d = sys.argv[1]
 searches = float(sys.argv[2]) if len(sys.argv) > 2 else 6.78e6
 rows = collections.defaultdict(dict)
-for f in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
-    for r in csv.DictReader(open(f)):
-        if "k_search" in r["Kernel_Name"]:
-            key = int(r["Dispatch_Id"])
-            rows[key][r["Counter_Name"]] = rows[key].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+for f in glob.glob(f"{d}/**/*.db", recursive=True):
+    cur = sqlite3.connect(f).cursor()
+    for did, name, cn, cv in cur.execute("select dispatch_id, name, counter_name, counter_value from pmc_events"):
+        if "k_search" in name:
+            rows[did][cn] = rows[did].get(cn, 0.0) + cv
 ids = sorted(rows)
 labels = ["full", "no dfs", "no subtrees", "staging only"]
 per = len(ids) // 4
-for m, label in enumerate(labels):
+prev = None
+for m, label in reversed(list(enumerate(labels))):
     sel = ids[m * per:(m + 1) * per]
-    names = sorted(rows[sel[0]])
-    print(label, {n: round(sum(rows[i][n] for i in sel) / len(sel) / searches, 2) for n in names})
+    cur = {n: sum(rows[i][n] for i in sel) / len(sel) / searches for n in sorted(rows[sel[0]])}
+    delta = {n: round(cur[n] - (prev[n] if prev else 0.0), 1) for n in cur}
+    print("%-13s total %s" % (label, {n: round(v, 1) for n, v in cur.items()}))
+    print("%-13s added %s" % ("", delta))
+    prev = cur

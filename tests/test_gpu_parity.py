@@ -121,6 +121,30 @@ def test_implanted_templates_dense_hits(amy, af):
             assert (r["rmsd"][r["hit"] == 1] < 1e-6).sum() >= 0.9 * n
 
 
+def test_one_and_two_residue_templates(amy):
+    """Templates cut down to their first one / two residues: the tiled scans run with wildcard lists for the
+    missing residues (and long lead lists span several 64-entry blocks), with and without chain tests."""
+    lib = helpers.product_library_templates()
+    rng = np.random.default_rng(11)
+    tpls = []
+    for ti in rng.permutation(len(lib))[:60]:
+        groups = {}
+        for a in lib[ti]:
+            groups.setdefault((a.chain_id, a.residue_number), []).append(a)
+        keys = list(groups)
+        for n_res in (1, 2):
+            atoms = [a.copy() for g in keys[:n_res] for a in groups[g]]
+            tpls.append(pyjess.Template(atoms, id=f"{lib[ti].id}_first{n_res}"))
+    jess, olib = pyjess.Jess(tpls), oracle.OracleLibrary([helpers.to_oracle_template(t) for t in tpls])
+    dimer = _multichain(amy, 2, shift=38.0)
+    for mol, ignore in ((amy, True), (dimer, False), (dimer, True)):
+        table, cands = jess.query_batch([mol], 2.0, 1.0, 1.0, max_candidates=100000, ignore_chain=ignore,
+                                        count_candidates=True, return_raw=True)
+        r = oracle.query_library(helpers.to_oracle_molecule(mol), olib, 2.0, 1.0, 1.0, max_candidates=100000,
+                                 ignore_chain=ignore)
+        assert compare(table, cands, 0, r, olib) >= 80
+
+
 def test_pdb_corner_cases(default_library):
     """Insertion codes, alternate locations, negative residue numbers: the oracle's parser, the host loader
     and the device-side ingestion must agree atom for atom, and the searches must agree hit for hit."""
