@@ -194,8 +194,12 @@ __global__ __launch_bounds__(256) void k_kind_lists(LibView L, BatchView B, uint
 // ------------------------------------------------------------------ k_search
 
 // Per-wave LDS: only what lanes exchange.  All search state lives in registers (see WaveRegs).
+// Pair-bound rows 1..kBoundRowsLds (row L = bounds of level L against levels 0..L-1, at tri(L)) are kept in LDS.
+constexpr int kBoundRowsLds = 11;
+constexpr int kBoundsLds = kBoundRowsLds * (kBoundRowsLds + 1) / 2;  // 66 entries
+
 struct __align__(16) WaveScratch {
-    float2 bnd_lead[kMaxG * (kMaxG - 1) / 2];  // pair bounds among lead atoms (search positions < n_groups)
+    float2 bnd[kBoundsLds];                    // the first rows of the template's pair bounds (all of them for k <= 12)
     uint16_t surv[kMaxG][64];                  // per template residue: one 64-entry chunk of its lead list
     float4 rec0[64], rec1[64], rec2[64];       // atom records of the current 64-entry blocks of the top lead lists
     uint16_t id0[64], id1[64], id2[64];        // and their atom indices
@@ -243,6 +247,14 @@ struct SearchCtx {
 };
 
 // Tests up to 64 candidates for `level`; returns the survivor mask.
+//
+// A lead level takes its candidates from a kind list: lane = candidate, and the constraints
+// against the levels already assigned are tested one level at a time (their atoms are broadcast
+// from the lane-indexed registers).
+// Any other level takes the atoms of one target residue, of which the name/residue-type masks
+// usually leave one or two: those are tested TRANSPOSED -- lane j holds assigned level j, its own
+// bound (level, j) and its own group, the candidate is broadcast -- so the cost is per surviving
+// candidate, not per assigned level.
 template <class Ctx>
 __device__ __forceinline__ unsigned long long eval_chunk(const Ctx &C, WaveRegs &W, int level, uint32_t base) {
     WaveScratch &S = *C.S;
@@ -252,7 +264,7 @@ __device__ __forceinline__ unsigned long long eval_chunk(const Ctx &C, WaveRegs 
     const uint32_t mygroup = RL(W.group, level);
     // this level's row of pair bounds, one entry per lane j < level, loaded before the candidate gather
     float2 brow = make_float2(0.f, 0.f);
-    if (lane < level) brow = level < C.n_groups ? S.bnd_lead[tri(level) + lane] : C.bnd[tri(level) + lane];
+    if (lane < level) brow = level <= kBoundRowsLds ? S.bnd[tri(level) + lane] : C.bnd[tri(level) + lane];
     const uint32_t idx = base + lane;
     bool ok = idx < cnt;
     uint32_t cand;
@@ -268,34 +280,50 @@ __device__ __forceinline__ unsigned long long eval_chunk(const Ctx &C, WaveRegs 
     }
     const float4 r = C.rec[cand];
     const uint32_t m = __float_as_uint(r.w);
-    if (!lead) {
-        const unsigned long long nm = ((unsigned long long)RL(W.nm_hi, level) << 32) | RL(W.nm_lo, level);
-        const uint32_t rm = RL(W.resmask, level);
-        const bool any = RL(W.any, level) != 0;
-        ok = ok && ((nm >> meta_name(m)) & 1ull) && (any || ((rm >> meta_rtype(m)) & 1u));
-    }
-    const uint32_t cres = meta_res(m);
     uint32_t cchain = 0, mychain = 0;
     if (!C.ignore_chain) {
         cchain = C.qchain[cand];
         mychain = RL(W.tchain, level);
     }
     TM_STAT(level, 1);
-    unsigned long long alive = ballot64(ok);
-    for (int j = 0; j < level && alive; ++j) {
-        const float dx = r.x - RLf(W.ax, j), dy = r.y - RLf(W.ay, j), dz = r.z - RLf(W.az, j);
-        const float d2 = dx * dx + dy * dy + dz * dz;
-        const float blo = RLf(brow.x, j), bhi = RLf(brow.y, j);
-        const bool same_t = RL(W.group, j) == mygroup;
-        const bool same_q = meta_res(RL(W.ameta, j)) == cres;
-        ok = ok && (d2 >= blo) && (d2 <= bhi) && (same_t == same_q) && (cand != RL(W.aidx, j));
-        if (!C.ignore_chain) {
-            const bool tc = RL(W.tchain, j) == mychain;
-            const bool qc = RL(W.achain, j) == cchain;
-            ok = ok && (tc == qc);
-        }
-        TM_STAT(50, 1);
+    unsigned long long alive;
+    if (lead) {
+        const uint32_t cres = meta_res(m);
         alive = ballot64(ok);
+        for (int j = 0; j < level && alive; ++j) {
+            const float dx = r.x - RLf(W.ax, j), dy = r.y - RLf(W.ay, j), dz = r.z - RLf(W.az, j);
+            const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            const float blo = RLf(brow.x, j), bhi = RLf(brow.y, j);
+            const bool same_t = RL(W.group, j) == mygroup;
+            const bool same_q = meta_res(RL(W.ameta, j)) == cres;
+            ok = ok & (d2 >= blo) & (d2 <= bhi) & (same_t == same_q) & (cand != RL(W.aidx, j));
+            if (!C.ignore_chain) {
+                const bool tc = RL(W.tchain, j) == mychain;
+                const bool qc = RL(W.achain, j) == cchain;
+                ok = ok & (tc == qc);
+            }
+            TM_STAT(50, 1);
+            alive = ballot64(ok);
+        }
+    } else {
+        const unsigned long long nm = ((unsigned long long)RL(W.nm_hi, level) << 32) | RL(W.nm_lo, level);
+        const uint32_t rm = RL(W.resmask, level);
+        const bool any = RL(W.any, level) != 0;
+        ok = ok & (((nm >> meta_name(m)) & 1ull) != 0ull) & (any | (((rm >> meta_rtype(m)) & 1u) != 0u));
+        alive = 0ull;
+        const bool active = lane < level;
+        const bool same_t = W.group == mygroup;
+        const bool tc = W.tchain == mychain;
+        for (unsigned long long todo = ballot64(ok); todo; todo &= todo - 1ull) {
+            const int b = __ffsll((long long)todo) - 1;
+            const float dx = RLf(r.x, b) - W.ax, dy = RLf(r.y, b) - W.ay, dz = RLf(r.z, b) - W.az;
+            const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            const bool same_q = meta_res(W.ameta) == meta_res(RL(m, b));
+            bool good = (d2 >= brow.x) & (d2 <= brow.y) & (same_t == same_q) & (W.aidx != lo + base + (uint32_t)b);
+            if (!C.ignore_chain) good = good & (tc == (W.achain == RL(cchain, b)));
+            TM_STAT(50, 1);
+            if (ballot64(active & !good) == 0ull) alive |= 1ull << b;
+        }
     }
     TM_STAT(24 + level, __popcll(alive));
     return alive;
@@ -310,7 +338,7 @@ __device__ __forceinline__ void init_level(const Ctx &C, WaveRegs &W, int level)
     if (RL(W.lead, level) == 0) {
         // same template residue as an already placed lead atom: scan the atoms of that target residue
         const uint32_t res = meta_res(RL(W.ameta, (int)RL(W.ref, level)));
-        const uint32_t s0 = uni((uint32_t)C.res_start[res]), s1 = uni((uint32_t)C.res_start[res + 1]);
+        const uint32_t s0 = C.res_start[res], s1 = C.res_start[res + 1];  // uniform address: same value in every lane
         WL(W.lo, level, s0);
         WL(W.cnt, level, s1 - s0);
     }
@@ -318,13 +346,13 @@ __device__ __forceinline__ void init_level(const Ctx &C, WaveRegs &W, int level)
 
 template <class Ctx>
 __device__ __forceinline__ void assign_level(const Ctx &C, WaveRegs &W, int level, uint32_t cand) {
-    const float4 r = C.rec[cand];  // uniform address
+    const float4 r = C.rec[cand];  // uniform address: every lane receives the same record
     WL(W.aidx, level, cand);
-    WLf(W.ax, level, __uint_as_float(uni(__float_as_uint(r.x))));
-    WLf(W.ay, level, __uint_as_float(uni(__float_as_uint(r.y))));
-    WLf(W.az, level, __uint_as_float(uni(__float_as_uint(r.z))));
-    WL(W.ameta, level, uni(__float_as_uint(r.w)));
-    if (!C.ignore_chain) WL(W.achain, level, uni((uint32_t)C.qchain[cand]));
+    WLf(W.ax, level, r.x);
+    WLf(W.ay, level, r.y);
+    WLf(W.az, level, r.z);
+    WL(W.ameta, level, __float_as_uint(r.w));
+    if (!C.ignore_chain) WL(W.achain, level, (uint32_t)C.qchain[cand]);
 }
 
 // All arguments of k_search as one kernel-argument struct.  Code that runs rarely (a complete
@@ -510,9 +538,9 @@ __device__ __forceinline__ bool joint_top_scan(const Ctx &C, WaveRegs &W, PairSt
     const uint32_t n0 = RL(W.cnt, 0), n1 = real1 ? RL(W.cnt, 1) : 1u, n2 = real2 ? RL(W.cnt, 2) : 1u;
     const uint32_t lo0 = RL(W.lo, 0), lo1 = RL(W.lo, 1), lo2 = RL(W.lo, 2);
     const float2 pass_all = make_float2(-1.f, kWildWindow);
-    const float2 b10 = real1 ? S.bnd_lead[0] : pass_all;                       // pair (1, 0)
-    const float2 b20 = real2 ? S.bnd_lead[tri(2)] : pass_all;                  // pairs (2, 0), (2, 1)
-    const float2 b21 = real2 ? S.bnd_lead[tri(2) + 1] : pass_all;
+    const float2 b10 = real1 ? S.bnd[0] : pass_all;                       // pair (1, 0)
+    const float2 b20 = real2 ? S.bnd[tri(2)] : pass_all;                  // pairs (2, 0), (2, 1)
+    const float2 b21 = real2 ? S.bnd[tri(2) + 1] : pass_all;
     const bool tc10 = RL(W.tchain, 0) == RL(W.tchain, 1);
     const bool tc20 = RL(W.tchain, 0) == RL(W.tchain, 2), tc21 = RL(W.tchain, 1) == RL(W.tchain, 2);
 
@@ -661,7 +689,7 @@ __host__ __device__ inline size_t search_kl_words(uint32_t n_lead) { return ((si
 // next template overlaps the current search.
 struct TemplateRegs {
     uint32_t group, ref, tchain, orig, any, resmask, nm_lo, nm_hi, li;
-    float2 lead_bound;
+    float2 bound0, bound1;  // bounds[lane], bounds[64 + (lane & 1)]
     uint32_t k, n_groups;
 };
 
@@ -678,7 +706,8 @@ __device__ __forceinline__ void load_template(const QueryView &Q, uint32_t ti, i
     R.nm_lo = (uint32_t)nm;
     R.nm_hi = (uint32_t)(nm >> 32);
     R.li = T.lead_li[l];
-    R.lead_bound = Q.bounds[(size_t)ti * kMaxPairs + (lane < tri(kMaxG) ? lane : 0)];
+    R.bound0 = Q.bounds[(size_t)ti * kMaxPairs + lane];
+    R.bound1 = Q.bounds[(size_t)ti * kMaxPairs + 64 + (lane & 1)];
     R.k = T.k;
     R.n_groups = T.n_groups;
 }
@@ -781,7 +810,8 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
         }
         const bool feasible = ballot64(empty) == 0ull;  // an empty lead list: no assignment exists
         bool feasible_override = true;
-        if (lane < tri(G)) S.bnd_lead[lane] = R.lead_bound;  // leads are search positions 0..G-1
+        S.bnd[lane] = R.bound0;
+        if (lane < kBoundsLds - 64) S.bnd[64 + lane] = R.bound1;
         wave_sync();
 
         // ---- claim the next template and start loading it
