@@ -6,6 +6,8 @@
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <new>
 #include <numeric>
 #include <string>
@@ -32,25 +34,104 @@ int fail(int code, const std::string &msg) {
         if (e_ != hipSuccess) return fail(TM_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-// Owning device buffer.
+// Device memory is recycled through a process-wide cache: a query allocates a dozen buffers, and
+// hipMalloc / hipFree (which synchronises the device) would otherwise cost more than a millisecond
+// per call.  Blocks are rounded up to size classes and handed back on release; a block is only
+// released once the work that used it has completed (tm_result_destroy waits for the stream,
+// tm_batch_destroy / tm_library_destroy for the device).
+class DevicePool {
+  public:
+    static DevicePool &get() {
+        static DevicePool *pool = new DevicePool;  // never destroyed: the HIP runtime may be gone at exit
+        return *pool;
+    }
+    static size_t size_class(size_t bytes) {
+        size_t c = 256;
+        while (c < bytes && c < (size_t(1) << 20)) c <<= 1;
+        if (c >= bytes) return c;
+        const size_t mib = size_t(1) << 20;
+        return (bytes + mib - 1) / mib * mib;
+    }
+    hipError_t acquire(size_t bytes, void **p, size_t *granted) {
+        int device = 0;
+        hipError_t e = hipGetDevice(&device);
+        if (e != hipSuccess) return e;
+        const size_t c = size_class(bytes);
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            auto it = free_.find({device, c});
+            if (it != free_.end()) {
+                *p = it->second;
+                *granted = c;
+                free_.erase(it);
+                cached_ -= c;
+                return hipSuccess;
+            }
+        }
+        e = hipMalloc(p, c);
+        if (e != hipSuccess) {  // give cached blocks back to the driver and retry once
+            trim(device);
+            e = hipMalloc(p, c);
+        }
+        *granted = c;
+        return e;
+    }
+    void release(void *p, size_t c) {
+        int device = 0;
+        if (hipGetDevice(&device) != hipSuccess) return;
+        std::lock_guard<std::mutex> lock(mu_);
+        if (cached_ + c > kMaxCached) {
+            (void)hipFree(p);
+            return;
+        }
+        free_.insert({{device, c}, p});
+        cached_ += c;
+    }
+    void trim(int device) {
+        std::lock_guard<std::mutex> lock(mu_);
+        for (auto it = free_.begin(); it != free_.end();) {
+            if (it->first.first == device) {
+                (void)hipFree(it->second);
+                cached_ -= it->first.second;
+                it = free_.erase(it);
+            } else {
+                ++it;
+            }
+        }
+    }
+
+  private:
+    static constexpr size_t kMaxCached = size_t(16) << 30;  // of 288 GB HBM
+    std::mutex mu_;
+    std::multimap<std::pair<int, size_t>, void *> free_;
+    size_t cached_ = 0;
+};
+
+// Owning device buffer (memory from DevicePool; the current device must be the owning one on release).
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
+    size_t bytes = 0;  // granted size class
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { release(); }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) DevicePool::get().release(p, bytes);
         p = nullptr;
         n = 0;
+        bytes = 0;
     }
     hipError_t alloc(size_t count) {
+        const size_t need = std::max<size_t>(count, 1) * sizeof(T);
+        if (p && bytes >= need && bytes <= 2 * DevicePool::size_class(need)) {  // keep a block that still fits
+            n = count;
+            return hipSuccess;
+        }
         release();
         n = count;
-        if (count == 0) count = 1;
-        return hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
+        return DevicePool::get().acquire(need, reinterpret_cast<void **>(&p), &bytes);
     }
     hipError_t upload(const std::vector<T> &v) {
         hipError_t e = alloc(v.size());
@@ -59,9 +140,27 @@ struct DevBuf {
     }
 };
 
+// A template selection with its thresholds, staged for the search kernel (k_stage_templates).
+// Batches are normally queried with the same selection over and over: the library keeps the last
+// one and tm_query reuses it when the arguments are identical.
+struct StagedSelection {
+    std::vector<uint32_t> sel;
+    std::vector<double> rmsd, cut, maxdyn;
+    DevBuf<uint32_t> d_sel;
+    DevBuf<double> d_rmsd, d_cut, d_maxdyn;
+    DevBuf<float2> d_bounds;
+    DevBuf<Staged> d_staged;
+    hipEvent_t ready = nullptr;  // recorded after k_stage_templates
+    ~StagedSelection() {
+        if (ready) (void)hipEventDestroy(ready);
+    }
+};
+
 }  // namespace
 
 struct tm_library {
+    mutable std::mutex sel_mu;
+    mutable std::shared_ptr<StagedSelection> last_selection;
     int device = 0;
     uint32_t n_templates = 0, n_atoms = 0, n_kinds = 0, n_lead = 0;
     std::vector<uint32_t> t_off;
@@ -118,12 +217,11 @@ struct tm_result {
     DevBuf<Cand> d_cands;
     DevBuf<PairEntry> d_pairs;
     DevBuf<unsigned long long> d_counters;  // [0] hits, [1] candidates, [2] pairs
-    DevBuf<uint32_t> d_overflow, d_candidates, d_sel;
-    DevBuf<double> d_rmsd, d_cut, d_maxdyn, d_cand_rmsd, d_models;
+    std::shared_ptr<StagedSelection> selection;
+    DevBuf<uint32_t> d_overflow, d_candidates;
+    DevBuf<double> d_cand_rmsd, d_models;
     DevBuf<int32_t> d_model_set;
     DevBuf<uint32_t> d_model_offsets, d_model_votes;
-    DevBuf<float2> d_bounds;
-    DevBuf<Staged> d_staged;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool waited = false;
     uint32_t overflow = 0;
@@ -312,6 +410,7 @@ int tm_library_create(int device, const tm_library_desc *d, tm_library **out) {
 void tm_library_destroy(tm_library *lib) {
     if (!lib) return;
     (void)hipSetDevice(lib->device);
+    (void)hipDeviceSynchronize();  // its buffers go back to the allocation cache: nothing may still read them
     delete lib;
 }
 
@@ -570,6 +669,7 @@ int tm_batch_line_offsets(tm_batch *b, uint32_t *out, uint64_t n) {
 void tm_batch_destroy(tm_batch *b) {
     if (!b) return;
     (void)hipSetDevice(b->device);
+    (void)hipDeviceSynchronize();  // its buffers go back to the allocation cache: nothing may still read them
     delete b;
 }
 
@@ -587,9 +687,12 @@ static int build_index(const tm_library *lib, tm_batch *b, hipStream_t stream) {
         HIP_TRY(hipMemsetAsync(b->d_cursor.p, 0, sizeof(unsigned long long), stream));
         HIP_TRY(hipMemsetAsync(b->d_overflow.p, 0, sizeof(uint32_t), stream));
         if (b->n_structs && lib->n_lead) {
-            hipLaunchKernelGGL(k_kind_lists, dim3(b->n_structs), dim3(256), (lib->n_lead + 1) * sizeof(uint32_t), stream,
+            // LDS for the per-name atom buckets: structures above the cap scan all atoms for every lead kind
+            const uint32_t bucket_cap = 12288;
+            const size_t lds = ((size_t)lib->n_lead + 1 + std::min<uint32_t>(b->max_atoms, bucket_cap)) * sizeof(uint32_t);
+            hipLaunchKernelGGL(k_kind_lists, dim3(b->n_structs), dim3(256), lds, stream,
                                lib->view(), b->view(), b->d_kl_off.p, b->d_kl_pool.p, b->d_cursor.p, cap,
-                               b->d_overflow.p);
+                               b->d_overflow.p, bucket_cap);
             HIP_TRY(hipGetLastError());
         }
         unsigned long long used = 0;
@@ -623,12 +726,41 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
     const uint32_t n_sel = p->n_selected;
     for (auto &e : r->ev) HIP_TRY(hipEventCreate(&e));
 
-    std::vector<uint32_t> sel(p->template_index, p->template_index + n_sel);
-    std::vector<double> rm(p->rmsd_threshold, p->rmsd_threshold + n_sel), cu(p->distance_cutoff, p->distance_cutoff + n_sel),
-        md(p->max_dynamic_distance, p->max_dynamic_distance + n_sel);
-    HIP_TRY(r->d_sel.upload(sel)); HIP_TRY(r->d_rmsd.upload(rm)); HIP_TRY(r->d_cut.upload(cu)); HIP_TRY(r->d_maxdyn.upload(md));
-    HIP_TRY(r->d_bounds.alloc((size_t)n_sel * kMaxPairs));
-    HIP_TRY(r->d_staged.alloc(n_sel));
+    // the staged selection: reused when this library was last queried with identical arguments
+    std::shared_ptr<StagedSelection> S;
+    bool stage_now = false;
+    {
+        std::lock_guard<std::mutex> lock(lib->sel_mu);
+        const auto &last = lib->last_selection;
+        if (last && last->sel.size() == n_sel &&
+            std::equal(last->sel.begin(), last->sel.end(), p->template_index) &&
+            std::equal(last->rmsd.begin(), last->rmsd.end(), p->rmsd_threshold) &&
+            std::equal(last->cut.begin(), last->cut.end(), p->distance_cutoff) &&
+            std::equal(last->maxdyn.begin(), last->maxdyn.end(), p->max_dynamic_distance)) {
+            S = last;
+        } else {
+            S = std::make_shared<StagedSelection>();
+            S->sel.assign(p->template_index, p->template_index + n_sel);
+            S->rmsd.assign(p->rmsd_threshold, p->rmsd_threshold + n_sel);
+            S->cut.assign(p->distance_cutoff, p->distance_cutoff + n_sel);
+            S->maxdyn.assign(p->max_dynamic_distance, p->max_dynamic_distance + n_sel);
+            HIP_TRY(S->d_sel.upload(S->sel)); HIP_TRY(S->d_rmsd.upload(S->rmsd));
+            HIP_TRY(S->d_cut.upload(S->cut)); HIP_TRY(S->d_maxdyn.upload(S->maxdyn));
+            HIP_TRY(S->d_bounds.alloc((size_t)n_sel * kMaxPairs));
+            HIP_TRY(S->d_staged.alloc(n_sel));
+            HIP_TRY(hipEventCreateWithFlags(&S->ready, hipEventDisableTiming));
+            if (n_sel) {
+                hipLaunchKernelGGL(k_stage_templates, dim3(n_sel), dim3(64), 0, stream, lib->view(), n_sel, S->d_sel.p,
+                                   S->d_cut.p, S->d_maxdyn.p, S->d_staged.p, S->d_bounds.p);
+                HIP_TRY(hipGetLastError());
+            }
+            HIP_TRY(hipEventRecord(S->ready, stream));
+            lib->last_selection = S;
+            stage_now = true;
+        }
+    }
+    if (!stage_now) HIP_TRY(hipStreamWaitEvent(stream, S->ready, 0));  // staged on another stream, possibly
+    r->selection = S;
     unsigned long long hcap = p->hit_capacity, ccap = p->candidate_capacity;
     if (!hcap) hcap = std::max<unsigned long long>(4096, 64ull * b->n_structs);
     if (!ccap) ccap = std::max<unsigned long long>(65536, 256ull * b->n_structs);
@@ -652,16 +784,11 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
         int rc = build_index(lib, b, stream);
         if (rc != TM_OK) return rc;
     }
-    if (n_sel) {
-        hipLaunchKernelGGL(k_stage_templates, dim3(n_sel), dim3(64), 0, stream, lib->view(), n_sel, r->d_sel.p,
-                           r->d_cut.p, r->d_maxdyn.p, r->d_staged.p, r->d_bounds.p);
-        HIP_TRY(hipGetLastError());
-    }
     HIP_TRY(hipEventRecord(r->ev[1], stream));
 
     QueryView Q;
-    Q.n_sel = n_sel; Q.sel = r->d_sel.p; Q.rmsd_thr = r->d_rmsd.p; Q.cutoff = r->d_cut.p; Q.maxdyn = r->d_maxdyn.p;
-    Q.staged = r->d_staged.p; Q.bounds = r->d_bounds.p; Q.max_candidates = p->max_candidates; Q.flags = p->flags;
+    Q.n_sel = n_sel; Q.sel = S->d_sel.p; Q.rmsd_thr = S->d_rmsd.p; Q.cutoff = S->d_cut.p; Q.maxdyn = S->d_maxdyn.p;
+    Q.staged = S->d_staged.p; Q.bounds = S->d_bounds.p; Q.max_candidates = p->max_candidates; Q.flags = p->flags;
     Q.model_set = nullptr; Q.model_offsets = nullptr; Q.model_votes = nullptr; Q.models = nullptr;
     if (p->model_set && p->n_model_sets && p->model_offsets && p->model_votes && p->models) {
         const uint32_t ns = p->n_model_sets, nm = p->model_offsets[ns];

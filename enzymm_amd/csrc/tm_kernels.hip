@@ -118,34 +118,96 @@ __global__ __launch_bounds__(64) void k_stage_templates(LibView L, uint32_t n_se
 
 // ------------------------------------------------------------------ k_kind_lists
 
-// One workgroup per structure.  Pass A counts the admissible atoms of every lead kind, a
-// bump allocation reserves the structure's slice of the pool, pass B writes the lists.
+// One workgroup per structure.  The atoms are first bucketed by atom-name id (ascending atom index
+// inside a bucket); a lead kind that accepts a single name -- nearly all of them -- then only scans
+// that bucket for its residue types instead of the whole structure.  Pass A counts the admissible
+// atoms of every lead kind, a bump allocation reserves the structure's slice of the pool, pass B
+// writes the lists (ascending atom index).
+//
+// Dynamic LDS: [n_lead + 1] counts/offsets, then (when n <= bucket_cap) one u32 per atom:
+// atom index | residue-type id << 16, grouped by name id.
 __global__ __launch_bounds__(256) void k_kind_lists(LibView L, BatchView B, uint32_t *__restrict__ kl_off,
                                                      uint16_t *__restrict__ kl_pool,
                                                      unsigned long long *__restrict__ cursor,
-                                                     unsigned long long capacity, uint32_t *__restrict__ overflow) {
-    extern __shared__ uint32_t s_cnt[];  // [n_lead + 1]
+                                                     unsigned long long capacity, uint32_t *__restrict__ overflow,
+                                                     uint32_t bucket_cap) {
+    extern __shared__ uint32_t s_dyn[];
+    uint32_t *s_cnt = s_dyn;                      // [n_lead + 1]
+    uint32_t *s_bucket = s_dyn + L.n_lead + 1;    // [n] when bucketed
     __shared__ unsigned long long s_base;
+    __shared__ uint32_t s_noff[65];               // bucket of name id i: [s_noff[i], s_noff[i + 1])
     const uint32_t s = blockIdx.x;
     const uint32_t a0 = B.s_off[s], n = B.s_off[s + 1] - a0;
     const int lane = lane_id(), wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const float4 *rec = B.q_rec + a0;
+    const bool bucketed = n <= bucket_cap;
 
-    for (uint32_t li = wave; li < L.n_lead; li += nwaves) {
+    if (bucketed) {
+        if (threadIdx.x < 65) s_noff[threadIdx.x] = 0;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x)
+            atomicAdd(&s_noff[meta_name(__float_as_uint(rec[i].w)) + 1], 1u);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t run = 0;
+            for (int i = 1; i <= 64; ++i) { run += s_noff[i]; s_noff[i] = run; }
+        }
+        __syncthreads();
+        // every wave takes the names w, w + nwaves, ...: ordered compaction of the atoms carrying that name
+        for (uint32_t name = wave; name < 64; name += nwaves) {
+            uint32_t w = s_noff[name];
+            if (s_noff[name + 1] == w) continue;
+            for (uint32_t b0 = 0; b0 < n; b0 += 64) {
+                const uint32_t i = b0 + lane;
+                uint32_t m = 0;
+                bool ok = false;
+                if (i < n) {
+                    m = __float_as_uint(rec[i].w);
+                    ok = meta_name(m) == name;
+                }
+                const unsigned long long mask = ballot64(ok);
+                if (ok) s_bucket[w + rank_in(mask)] = i | (meta_rtype(m) << 16);
+                w += __popcll(mask);
+            }
+        }
+        __syncthreads();
+    }
+
+    // admissible atoms of lead kind li, in ascending order, handed to `emit(mask, ok, atom)` 64 at a time
+    auto scan_kind = [&](uint32_t li, auto emit) {
         const uint32_t kind = L.lead_kind[li];
         const uint32_t rm = L.k_resmask[kind];
         const uint64_t nm = L.k_namemask[kind];
         const bool any = L.k_any[kind] != 0;
-        uint32_t c = 0;
-        for (uint32_t b = 0; b < n; b += 64) {
-            const uint32_t i = b + lane;
-            bool ok = false;
-            if (i < n) {
-                const uint32_t m = __float_as_uint(rec[i].w);
-                ok = ((nm >> meta_name(m)) & 1ull) && (any || ((rm >> meta_rtype(m)) & 1u));
+        if (bucketed && (nm & (nm - 1)) == 0ull && nm != 0ull) {
+            const uint32_t name = (uint32_t)__ffsll((long long)nm) - 1u;
+            const uint32_t e1 = s_noff[name + 1];
+            for (uint32_t e0 = s_noff[name]; e0 < e1; e0 += 64) {
+                const uint32_t e = e0 + lane;
+                uint32_t v = 0;
+                bool ok = false;
+                if (e < e1) {
+                    v = s_bucket[e];
+                    ok = any || ((rm >> (v >> 16)) & 1u);
+                }
+                emit(ballot64(ok), ok, v & 0xffffu);
             }
-            c += __popcll(ballot64(ok));
+        } else {
+            for (uint32_t b0 = 0; b0 < n; b0 += 64) {
+                const uint32_t i = b0 + lane;
+                bool ok = false;
+                if (i < n) {
+                    const uint32_t m = __float_as_uint(rec[i].w);
+                    ok = ((nm >> meta_name(m)) & 1ull) && (any || ((rm >> meta_rtype(m)) & 1u));
+                }
+                emit(ballot64(ok), ok, i);
+            }
         }
+    };
+
+    for (uint32_t li = wave; li < L.n_lead; li += nwaves) {
+        uint32_t c = 0;
+        scan_kind(li, [&](unsigned long long mask, bool, uint32_t) { c += __popcll(mask); });
         if (lane == 0) s_cnt[li] = c;
     }
     __syncthreads();
@@ -172,22 +234,11 @@ __global__ __launch_bounds__(256) void k_kind_lists(LibView L, BatchView B, uint
     if (base == ~0ull) return;
 
     for (uint32_t li = wave; li < L.n_lead; li += nwaves) {
-        const uint32_t kind = L.lead_kind[li];
-        const uint32_t rm = L.k_resmask[kind];
-        const uint64_t nm = L.k_namemask[kind];
-        const bool any = L.k_any[kind] != 0;
         unsigned long long w = base + s_cnt[li];
-        for (uint32_t b = 0; b < n; b += 64) {
-            const uint32_t i = b + lane;
-            bool ok = false;
-            if (i < n) {
-                const uint32_t m = __float_as_uint(rec[i].w);
-                ok = ((nm >> meta_name(m)) & 1ull) && (any || ((rm >> meta_rtype(m)) & 1u));
-            }
-            const unsigned long long mask = ballot64(ok);
-            if (ok) kl_pool[w + rank_in(mask)] = (uint16_t)i;
+        scan_kind(li, [&](unsigned long long mask, bool ok, uint32_t atom) {
+            if (ok) kl_pool[w + rank_in(mask)] = (uint16_t)atom;
             w += __popcll(mask);
-        }
+        });
     }
 }
 
