@@ -540,6 +540,7 @@ __device__ __forceinline__ bool dfs(const Ctx &C, WaveRegs &W, PairState &P, int
 }
 
 // tile shape TI x TJ = 64 lanes (TJ = 1 << shift) that covers an n_i x n_j cross product with the fewest tiles
+// (a cheaper "narrowest TJ spanning n_j" rule costs 20 % more pair tiles than the comparisons here)
 __device__ __forceinline__ uint32_t best_tile_shift(uint32_t n_i, uint32_t n_j) {
     uint32_t shift = 3, best = 0xffffffffu;
     for (uint32_t sh = 3; sh <= 6; ++sh) {
@@ -642,7 +643,7 @@ __device__ __forceinline__ bool joint_top_scan(const Ctx &C, WaveRegs &W, PairSt
                     // one row of tiles: TI entries of block 0 (fixed) against block 1, TJ entries at a time
                     const float4 ra = pa[i0];  // slots < 64: tiles never leave the block
                     const uint32_t res_a = meta_res(__float_as_uint(ra.w));
-                    do {
+                    for (;;) {
                         const float4 rb = pb[j0];
                         bool ok = in_window(ra, rb, b10) & (res_a != meta_res(__float_as_uint(rb.w)));  // padding fails
                         if (!C.ignore_chain && real1)
@@ -650,10 +651,17 @@ __device__ __forceinline__ bool joint_top_scan(const Ctx &C, WaveRegs &W, PairSt
                         const unsigned long long m = ballot64(ok);
                         TM_STAT(52, 1);
                         TM_STAT(53, __popcll(m));
-                        if (ok) S.queue[nq + rank_in(m)] = lpos + (i0 | (j0 << 8));
-                        nq += (uint32_t)__popcll(m);
+                        if (m) {  // most tiles have no survivor: nothing to append, nothing to count
+                            if (ok) S.queue[nq + rank_in(m)] = lpos + (i0 | (j0 << 8));
+                            nq += (uint32_t)__popcll(m);
+                            if (nq + 64u > (uint32_t)kJointQueue) {  // the queue may not take another tile
+                                j0 += TJ;
+                                break;
+                            }
+                        }
                         j0 += TJ;
-                    } while (j0 < cn1 && nq + 64u <= (uint32_t)kJointQueue);
+                        if (j0 >= cn1) break;
+                    }
                     if (j0 >= cn1) {
                         j0 = 0;
                         i0 += TI;
