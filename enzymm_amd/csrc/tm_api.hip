@@ -807,13 +807,17 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
     O.hits = r->d_hits.p; O.n_hits = r->d_counters.p; O.hit_capacity = hcap; O.overflow = r->d_overflow.p;
     O.candidates = (p->flags & TM_FLAG_COUNT_CANDIDATES) ? r->d_candidates.p : nullptr;
     if (n_sel && b->n_structs) {
-        // enough workgroups to fill 256 CUs several times over; every chunk of a structure on one XCD
+        // enough workgroups to fill 256 CUs several times over
         const uint32_t min_chunk = 2 * kSearchWaves;
-        uint32_t n_chunks = (2048 + b->n_structs - 1) / b->n_structs;
-        n_chunks = std::max(1u, std::min(n_chunks, (n_sel + min_chunk - 1) / min_chunk));
-        const uint32_t chunk_size = (n_sel + n_chunks - 1) / n_chunks;
-        n_chunks = (n_sel + chunk_size - 1) / chunk_size;
-        const uint32_t grid = ((b->n_structs + 7) / 8) * 8 * n_chunks;
+        // template chunks: 2^cx of them spread over the XCDs (each XCD then touches 1/2^cx of the staged
+        // templates), times `rounds` more when the batch alone cannot fill the GPU
+        uint32_t cx = 2;
+        if (b->n_structs * 4u < 2048u) cx = 3;
+        while (cx > 0 && (n_sel >> cx) < min_chunk) --cx;
+        uint32_t rounds = 1;
+        while ((unsigned long long)b->n_structs * (rounds << cx) < 2048ull && n_sel / ((rounds + 1) << cx) >= min_chunk) ++rounds;
+        const uint32_t per_group = 8u >> cx;  // structures per group of 8 consecutive workgroups
+        const uint32_t grid = (b->n_structs + per_group - 1) / per_group * 8u * rounds;
         const size_t scratch = search_scratch_bytes();
         const size_t base = scratch + (size_t)b->max_atoms * sizeof(float4) + search_res_bytes(b->max_res) +
                             search_kl_words(lib->view().n_lead) * sizeof(uint32_t);
@@ -828,7 +832,7 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds_bytes));
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(kSearchBlock), lds_bytes, stream,
-                           SearchArgs{lib->view(), b->view(), Q, O, n_chunks, chunk_size, b->max_atoms, b->max_res, pool_cap});
+                           SearchArgs{lib->view(), b->view(), Q, O, cx, rounds, b->max_atoms, b->max_res, pool_cap});
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(r->ev[2], stream));

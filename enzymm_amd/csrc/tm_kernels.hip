@@ -415,7 +415,8 @@ struct SearchArgs {
     BatchView B;
     QueryView Q;
     OutView O;
-    uint32_t n_chunks, chunk_size, max_atoms, max_res, pool_cap;
+    uint32_t chunk_xcd_shift, chunk_rounds;  // template chunks: (1 << chunk_xcd_shift) per XCD group x rounds
+    uint32_t max_atoms, max_res, pool_cap;
 };
 typedef const __attribute__((address_space(4))) SearchArgs *ColdArgsPtr;
 __device__ __forceinline__ ColdArgsPtr cold_args() {
@@ -776,7 +777,7 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
     const LibView &L = A.L;
     const BatchView &B = A.B;
     const QueryView &Q = A.Q;
-    const uint32_t n_chunks = A.n_chunks, chunk_size = A.chunk_size, max_atoms = A.max_atoms, max_res = A.max_res,
+    const uint32_t max_atoms = A.max_atoms, max_res = A.max_res,
                    pool_cap = A.pool_cap;
     extern __shared__ __align__(16) unsigned char smem[];
     // [WaveScratch x kSearchWaves][rec float4 x max_atoms][res_start u16 x (max_res+1)]
@@ -789,13 +790,19 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
     uint16_t *s_pool = reinterpret_cast<uint16_t *>(s_kl + (kLds ? search_kl_words(L.n_lead) : 0));
     __shared__ uint32_t s_next;
 
-    // all chunks of a structure land on one XCD (blocks b and b+8 share an XCD): its kind
-    // lists and records are then served by a single L2.
+    // Workgroups b and b + 8 share an XCD.  The template selection is cut into chunks and every XCD only
+    // ever works on 1 / (1 << chunk_xcd_shift) of them, so that its share of the staged template table
+    // (about 1 KB per template) stays resident in its own 4 MB L2; the structure a workgroup searches is
+    // copied into LDS once, so it does not matter which XCD that is.
     const uint32_t bid = blockIdx.x;
     const uint32_t xcd = bid & 7u, q = bid >> 3;
-    const uint32_t chunk = q % n_chunks;
-    const uint32_t s = (q / n_chunks) * 8u + xcd;
-    if (s >= B.n_structs) return;
+    const uint32_t cx = A.chunk_xcd_shift;
+    const uint32_t chunk = (q % A.chunk_rounds << cx) + (xcd & ((1u << cx) - 1u));
+    const uint32_t s = (q / A.chunk_rounds << (3u - cx)) + (xcd >> cx);
+    // chunk c holds the selected templates c, c + n_chunks, c + 2 n_chunks, ...: interleaved, so that every
+    // chunk (hence every XCD) gets the same mix of cheap and expensive templates
+    const uint32_t n_chunks = A.chunk_rounds << cx;
+    if (s >= B.n_structs || chunk >= Q.n_sel) return;
 
     const uint32_t a0 = B.s_off[s], n = B.s_off[s + 1] - a0;
     const uint32_t r0 = B.s_roff[s], nres1 = B.s_roff[s + 1] - r0;  // n_res + 1 entries
@@ -813,12 +820,12 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
         if (pool_in_lds)
             for (uint32_t i = threadIdx.x; i < plen; i += blockDim.x) s_pool[i] = B.kl_pool[p0 + i];
     }
-    if (threadIdx.x == 0) s_next = chunk * chunk_size;
+    if (threadIdx.x == 0) s_next = chunk;
     TM_STAT(55, threadIdx.x == 0 ? 1 : 0);
     TM_STAT(56, threadIdx.x == 0 && pool_in_lds ? 1 : 0);
     TM_STAT(57, threadIdx.x == 0 ? kl_off[L.n_lead] - kl_off[0] : 0);
     __syncthreads();
-    const uint32_t t_end = min((chunk + 1) * chunk_size, Q.n_sel);
+    const uint32_t t_end = Q.n_sel;
 
     SearchCtx<kIgnoreChain> C;
     C.rec = kLds ? s_rec : B.q_rec + a0;
@@ -833,7 +840,7 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
     const uint32_t *kl = kLds ? s_kl : kl_off;
 
     uint32_t ti = 0;
-    if (lane == 0) ti = atomicAdd(&s_next, 1u);
+    if (lane == 0) ti = atomicAdd(&s_next, n_chunks);
     ti = uni(ti);
     TemplateRegs R;
     load_template(Q, min(ti, Q.n_sel - 1u), lane, R);
@@ -875,7 +882,7 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
 
         // ---- claim the next template and start loading it
         const uint32_t ti_cur = ti;
-        if (lane == 0) ti = atomicAdd(&s_next, 1u);
+        if (lane == 0) ti = atomicAdd(&s_next, n_chunks);
         ti = uni(ti);
         load_template(Q, min(ti, Q.n_sel - 1u), lane, R);
 
