@@ -197,6 +197,9 @@ struct tm_batch {
     DevBuf<unsigned long long> d_cursor;
     DevBuf<uint32_t> d_overflow;
     DevBuf<uint32_t> d_line_off;  // device-parsed batches: byte offset of every atom record in its file
+    // search work items (structure, round), cached for the (cx, n_sel) they were planned for
+    DevBuf<WorkItem> d_work;
+    uint32_t work_items = 0, work_cx = 0xffffffffu, work_n_sel = 0;
     uint64_t index_for = 0;  // serial of the library the candidate index was built for
     unsigned long long pool_capacity = 0;
     BatchView view() const {
@@ -814,10 +817,34 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
         uint32_t cx = 2;
         if (b->n_structs * 4u < 2048u) cx = 3;
         while (cx > 0 && (n_sel >> cx) < min_chunk) --cx;
-        uint32_t rounds = 1;
-        while ((unsigned long long)b->n_structs * (rounds << cx) < 2048ull && n_sel / ((rounds + 1) << cx) >= min_chunk) ++rounds;
-        const uint32_t per_group = 8u >> cx;  // structures per group of 8 consecutive workgroups
-        const uint32_t grid = (b->n_structs + per_group - 1) / per_group * 8u * rounds;
+        // work items: every structure gets rounds ~ its share of the estimated cost (pair tests grow with the
+        // square of the atom count), at least one; heaviest structures first
+        if (b->work_cx != cx || b->work_n_sel != n_sel) {
+            const uint32_t ns = b->n_structs;
+            const uint32_t per_class_target = std::max<uint32_t>(ns, 2048u >> cx);
+            const uint32_t max_rounds = std::min<uint32_t>(std::max<uint32_t>(1u, n_sel / (min_chunk << cx)), 0xffffu);
+            std::vector<double> cost(ns);
+            double total = 0.0;
+            for (uint32_t s = 0; s < ns; ++s) {
+                const double n = std::max<double>(64.0, (double)(b->s_off[s + 1] - b->s_off[s]));
+                total += cost[s] = n * n;
+            }
+            std::vector<uint32_t> order(ns);
+            std::iota(order.begin(), order.end(), 0u);
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return cost[x] > cost[y]; });
+            std::vector<WorkItem> items;
+            items.reserve(ns);
+            for (uint32_t s : order) {
+                const double share = cost[s] * (double)per_class_target / total;
+                const uint32_t rounds = (uint32_t)std::min<double>(max_rounds, std::max<double>(1.0, std::floor(share + 0.5)));
+                for (uint32_t r = 0; r < rounds; ++r) items.push_back(WorkItem{s, (uint16_t)r, (uint16_t)rounds});
+            }
+            HIP_TRY(hipStreamSynchronize(stream));  // a previous query may still read the old list
+            HIP_TRY(b->d_work.upload(items));
+            b->work_items = (uint32_t)items.size(); b->work_cx = cx; b->work_n_sel = n_sel;
+        }
+        const uint32_t per_group = 8u >> cx;  // work items per group of 8 consecutive workgroups
+        const uint32_t grid = (b->work_items + per_group - 1) / per_group * 8u;
         const size_t scratch = search_scratch_bytes();
         const size_t base = scratch + (size_t)b->max_atoms * sizeof(float4) + search_res_bytes(b->max_res) +
                             search_kl_words(lib->view().n_lead) * sizeof(uint32_t);
@@ -832,7 +859,7 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds_bytes));
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(kSearchBlock), lds_bytes, stream,
-                           SearchArgs{lib->view(), b->view(), Q, O, cx, rounds, b->max_atoms, b->max_res, pool_cap});
+                           SearchArgs{lib->view(), b->view(), Q, O, b->d_work.p, b->work_items, cx, b->max_atoms, b->max_res, pool_cap});
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(r->ev[2], stream));

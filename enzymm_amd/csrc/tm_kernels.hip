@@ -410,12 +410,20 @@ __device__ __forceinline__ void assign_level(const Ctx &C, WaveRegs &W, int leve
 // assignment, a pair with candidates) re-reads what it needs from the kernel-argument segment
 // through cold_args() instead of keeping two dozen pointers in scalar registers for the whole
 // search: the search loop is short of SGPRs, and every spilled SGPR costs VALU instructions.
+// One (structure, round) work item; with the XCD class of the workgroup it names a template chunk.
+struct WorkItem {
+    uint32_t s;
+    uint16_t round, rounds;
+};
+
 struct SearchArgs {
     LibView L;
     BatchView B;
     QueryView Q;
     OutView O;
-    uint32_t chunk_xcd_shift, chunk_rounds;  // template chunks: (1 << chunk_xcd_shift) per XCD group x rounds
+    const WorkItem *work;      // (structure, round) items, heaviest structures first
+    uint32_t n_items;
+    uint32_t chunk_xcd_shift;  // template chunks of an item: (1 << chunk_xcd_shift) spread over the XCDs x item.rounds
     uint32_t max_atoms, max_res, pool_cap;
 };
 typedef const __attribute__((address_space(4))) SearchArgs *ColdArgsPtr;
@@ -790,19 +798,23 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
     uint16_t *s_pool = reinterpret_cast<uint16_t *>(s_kl + (kLds ? search_kl_words(L.n_lead) : 0));
     __shared__ uint32_t s_next;
 
-    // Workgroups b and b + 8 share an XCD.  The template selection is cut into chunks and every XCD only
-    // ever works on 1 / (1 << chunk_xcd_shift) of them, so that its share of the staged template table
-    // (about 1 KB per template) stays resident in its own 4 MB L2; the structure a workgroup searches is
-    // copied into LDS once, so it does not matter which XCD that is.
+    // Workgroups b and b + 8 share an XCD.  The template selection of a work item is cut into
+    // (rounds << cx) interleaved chunks -- chunk c holds the selected templates c, c + n_chunks, ..., so every
+    // chunk gets the same mix of cheap and expensive templates -- and an XCD only ever works on the chunks
+    // whose low cx bits equal its own: its share of the staged template table (about 1 KB per template) stays
+    // resident in its own 4 MB L2.  The structure a workgroup searches is copied into LDS once, so it does not
+    // matter which XCD that is.  Work items are ordered heaviest structure first, and heavy structures are cut
+    // into more rounds (host side), so that a few large structures in a batch do not become the tail.
     const uint32_t bid = blockIdx.x;
-    const uint32_t xcd = bid & 7u, q = bid >> 3;
+    const uint32_t xcd = bid & 7u;
     const uint32_t cx = A.chunk_xcd_shift;
-    const uint32_t chunk = (q % A.chunk_rounds << cx) + (xcd & ((1u << cx) - 1u));
-    const uint32_t s = (q / A.chunk_rounds << (3u - cx)) + (xcd >> cx);
-    // chunk c holds the selected templates c, c + n_chunks, c + 2 n_chunks, ...: interleaved, so that every
-    // chunk (hence every XCD) gets the same mix of cheap and expensive templates
-    const uint32_t n_chunks = A.chunk_rounds << cx;
-    if (s >= B.n_structs || chunk >= Q.n_sel) return;
+    const uint32_t item_index = ((bid >> 3) << (3u - cx)) + (xcd >> cx);
+    if (item_index >= A.n_items) return;
+    const WorkItem item = A.work[item_index];
+    const uint32_t s = item.s;
+    const uint32_t chunk = ((uint32_t)item.round << cx) + (xcd & ((1u << cx) - 1u));
+    const uint32_t n_chunks = (uint32_t)item.rounds << cx;
+    if (chunk >= Q.n_sel) return;
 
     const uint32_t a0 = B.s_off[s], n = B.s_off[s + 1] - a0;
     const uint32_t r0 = B.s_roff[s], nres1 = B.s_roff[s + 1] - r0;  // n_res + 1 entries
