@@ -145,6 +145,37 @@ def test_one_and_two_residue_templates(amy):
         assert compare(table, cands, 0, r, olib) >= 80
 
 
+def test_randomised_parameters_vs_oracle(amy, af):
+    """Seeded random draws of everything a caller can vary: template subset, per-template thresholds
+    (max_dynamic_distance above and below the cutoff), ignore_chain, max_candidates small enough to truncate,
+    and a batch mixing real, synthetic, multi-chain and empty structures."""
+    rng = np.random.default_rng(2024)
+    ptpl, otpl = helpers.product_library_templates(), helpers.oracle_library_templates()
+    dimer = _multichain(amy, 2, shift=38.0)
+    pool = [amy, af, dimer, pyjess.Molecule()] + synthetic.structures(6)
+    checked = truncated = 0
+    for trial in range(6):
+        idx = np.sort(rng.choice(len(ptpl), size=120, replace=False))
+        jess, olib = pyjess.Jess([ptpl[i] for i in idx]), oracle.OracleLibrary([otpl[i] for i in idx])
+        rmsd = rng.uniform(0.8, 3.0, size=len(idx))
+        cutoff = rng.uniform(0.6, 2.4, size=len(idx))
+        maxdyn = cutoff + rng.uniform(-0.4, 0.6, size=len(idx))
+        ignore = bool(trial % 2)
+        cap = int(rng.choice([3, 40, 10000]))
+        mols = [pool[i] for i in rng.choice(len(pool), size=4, replace=False)]
+        table, cands = jess.query_batch(mols, rmsd, cutoff, maxdyn, max_candidates=cap, ignore_chain=ignore,
+                                        count_candidates=True, return_raw=True)
+        for s, mol in enumerate(mols):
+            r = oracle.query_library(helpers.to_oracle_molecule(mol), olib, rmsd, cutoff, maxdyn, max_candidates=cap,
+                                     ignore_chain=ignore)
+            cut_short = r["truncated"].astype(bool)
+            assert np.array_equal((cands[s] >> 31).astype(bool), cut_short)
+            assert np.array_equal((cands[s] & 0x7FFFFFFF)[~cut_short], r["candidates"][~cut_short])
+            checked += compare(table, cands, s, r, olib, check_candidates=False)
+            truncated += int(cut_short.sum())
+    assert checked > 10 and truncated > 0
+
+
 def test_pdb_corner_cases(default_library):
     """Insertion codes, alternate locations, negative residue numbers: the oracle's parser, the host loader
     and the device-side ingestion must agree atom for atom, and the searches must agree hit for hit."""
