@@ -289,7 +289,11 @@ template <bool kIgnoreChain>
 struct SearchCtx {
     const float4 *rec;          // structure atom records (LDS or global)
     const uint16_t *res_start;  // residue -> first atom (LDS or global)
-    const uint16_t *pool;       // kind-list pool
+    const uint16_t *pool_lds;   // kind lists of this structure in LDS (when they fit) ...
+    const uint16_t *pool_glb;   // ... or the batch-wide pool in global memory; offsets are rebased accordingly
+    bool pool_in_lds;
+    // two explicit loads instead of one through a generic pointer: ds_read is much cheaper than flat_load
+    __device__ __forceinline__ uint32_t pool_at(uint32_t i) const { return pool_in_lds ? pool_lds[i] : pool_glb[i]; }
     const uint8_t *qchain;      // global, per atom of this structure
     const float2 *bnd;          // this template's pair bounds (global)
     WaveScratch *S;
@@ -321,7 +325,7 @@ __device__ __forceinline__ unsigned long long eval_chunk(const Ctx &C, WaveRegs 
     uint32_t cand;
     if (lead) {
         if (RL(W.surv_base, (int)mygroup) != base) {  // the chunk is not the one cached in LDS
-            S.surv[mygroup][lane] = ok ? C.pool[lo + idx] : (uint16_t)0;
+            S.surv[mygroup][lane] = ok ? (uint16_t)C.pool_at(lo + idx) : (uint16_t)0;
             WL(W.surv_base, (int)mygroup, base);
             wave_sync();
         }
@@ -605,37 +609,53 @@ __device__ __forceinline__ bool joint_top_scan(const Ctx &C, WaveRegs &W, PairSt
     const bool tc10 = RL(W.tchain, 0) == RL(W.tchain, 1);
     const bool tc20 = RL(W.tchain, 0) == RL(W.tchain, 2), tc21 = RL(W.tchain, 1) == RL(W.tchain, 2);
 
-    // copies block `base` of a lead list (ids from the kind-list pool, records from the structure) into LDS;
-    // slots past the end get a padding record, so tiles may read any of the 64 slots unmasked.
-    // A wildcard list is one record at the origin with a residue number no atom has.
-    auto stage_block = [&](float4 *rec, uint16_t *id, bool real, uint32_t lo, uint32_t base, uint32_t cnt, float pad_x,
-                           float pad_y, uint32_t wild_res) {
-        float4 r = make_float4(0.f, 0.f, 0.f, __uint_as_float(wild_res));
-        uint32_t a = 0;
+    // A block of a lead list is copied into LDS in two steps -- fetch (ids from the kind-list pool, records from
+    // the structure) and store -- so that the fetches of several blocks overlap.  Slots past the end get a
+    // padding record, so tiles may read any of the 64 slots unmasked.  A wildcard list is one record at the
+    // origin with a residue number no atom has.
+    struct Block { float4 r; uint32_t a; };
+    auto fetch_block = [&](bool real, uint32_t lo, uint32_t base, uint32_t cnt, float pad_x, float pad_y,
+                           uint32_t wild_res) {
+        Block b;
+        b.r = make_float4(0.f, 0.f, 0.f, __uint_as_float(wild_res));
+        b.a = 0;
         if (real) {
-            a = C.pool[lo + base + min((uint32_t)lane, cnt - 1u)];
-            r = C.rec[a];
+            b.a = C.pool_at(lo + base + min((uint32_t)lane, cnt - 1u));
+            b.r = C.rec[b.a];
         }
-        if ((uint32_t)lane >= cnt) { r.x = pad_x; r.y = pad_y; }
-        id[lane] = (uint16_t)a;
-        rec[lane] = r;
+        if ((uint32_t)lane >= cnt) { b.r.x = pad_x; b.r.y = pad_y; }
+        return b;
+    };
+    auto store_block = [&](float4 *rec, uint16_t *id, const Block &b) {
+        id[lane] = (uint16_t)b.a;
+        rec[lane] = b.r;
     };
 
-    uint32_t jb_st = 0xffffffffu, cb_st = 0xffffffffu;  // blocks of list1 / list2 present in LDS
+    // the first block of each list (usually the only one) is staged in one go
+    uint32_t jb_st = 0, cb_st = 0xffffffffu;  // blocks of list1 / list2 present in LDS
     wave_sync();
-    if (n2 <= 64u) {  // the usual case: list2 is one block, staged together with the others
-        stage_block(S.rec2, S.id2, real2, lo2, 0u, n2, 0.f, kPadFar, 0xfffdu);
-        cb_st = 0;
+    {
+        const Block f0 = fetch_block(true, lo0, 0u, min(64u, n0), kPadFar, 0.f, 0u);
+        const Block f1 = fetch_block(real1, lo1, 0u, min(64u, n1), -kPadFar, 0.f, 0xfffeu);
+        if (n2 <= 64u) {
+            const Block f2 = fetch_block(real2, lo2, 0u, n2, 0.f, kPadFar, 0xfffdu);
+            store_block(S.rec2, S.id2, f2);
+            cb_st = 0;
+        }
+        store_block(S.rec0, S.id0, f0);
+        store_block(S.rec1, S.id1, f1);
     }
     for (uint32_t ib = 0; ib < n0; ib += 64u) {
         const uint32_t cn0 = min(64u, n0 - ib);
-        wave_sync();
-        stage_block(S.rec0, S.id0, true, lo0, ib, cn0, kPadFar, 0.f, 0u);
+        if (ib != 0u) {
+            wave_sync();
+            store_block(S.rec0, S.id0, fetch_block(true, lo0, ib, cn0, kPadFar, 0.f, 0u));
+        }
         for (uint32_t jb = 0; jb < n1; jb += 64u) {
             const uint32_t cn1 = min(64u, n1 - jb);
             if (jb_st != jb) {
                 wave_sync();
-                stage_block(S.rec1, S.id1, real1, lo1, jb, cn1, -kPadFar, 0.f, 0xfffeu);
+                store_block(S.rec1, S.id1, fetch_block(real1, lo1, jb, cn1, -kPadFar, 0.f, 0xfffeu));
                 jb_st = jb;
             }
             wave_sync();
@@ -686,7 +706,7 @@ __device__ __forceinline__ bool joint_top_scan(const Ctx &C, WaveRegs &W, PairSt
                     const uint32_t cn2 = min(64u, n2 - cb);
                     if (cb_st != cb) {
                         wave_sync();
-                        stage_block(S.rec2, S.id2, real2, lo2, cb, cn2, 0.f, kPadFar, 0xfffdu);
+                        store_block(S.rec2, S.id2, fetch_block(real2, lo2, cb, cn2, 0.f, kPadFar, 0xfffdu));
                         cb_st = cb;
                         wave_sync();
                     }
@@ -842,7 +862,9 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
     SearchCtx<kIgnoreChain> C;
     C.rec = kLds ? s_rec : B.q_rec + a0;
     C.res_start = kLds ? s_res : B.res_start + r0;
-    C.pool = pool_in_lds ? s_pool : B.kl_pool;
+    C.pool_lds = s_pool;
+    C.pool_glb = B.kl_pool;
+    C.pool_in_lds = pool_in_lds;
     C.qchain = B.q_chain + a0;
     C.S = scratch + (threadIdx.x >> 6);
     C.lane = lane_id();
