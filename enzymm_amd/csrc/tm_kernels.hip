@@ -319,7 +319,11 @@ __device__ __forceinline__ unsigned long long eval_chunk(const Ctx &C, WaveRegs 
     const uint32_t mygroup = RL(W.group, level);
     // this level's row of pair bounds, one entry per lane j < level, loaded before the candidate gather
     float2 brow = make_float2(0.f, 0.f);
-    if (lane < level) brow = level <= kBoundRowsLds ? S.bnd[tri(level) + lane] : C.bnd[tri(level) + lane];
+    if (level <= kBoundRowsLds) {  // two explicit loads: a pointer select would turn both into flat loads
+        if (lane < level) brow = S.bnd[tri(level) + lane];
+    } else {
+        if (lane < level) brow = C.bnd[tri(level) + lane];
+    }
     const uint32_t idx = base + lane;
     bool ok = idx < cnt;
     uint32_t cand;
@@ -400,14 +404,18 @@ __device__ __forceinline__ void init_level(const Ctx &C, WaveRegs &W, int level)
 }
 
 template <class Ctx>
-__device__ __forceinline__ void assign_level(const Ctx &C, WaveRegs &W, int level, uint32_t cand) {
-    const float4 r = C.rec[cand];  // uniform address: every lane receives the same record
+__device__ __forceinline__ void assign_record(const Ctx &C, WaveRegs &W, int level, uint32_t cand, const float4 &r) {
     WL(W.aidx, level, cand);
     WLf(W.ax, level, r.x);
     WLf(W.ay, level, r.y);
     WLf(W.az, level, r.z);
     WL(W.ameta, level, __float_as_uint(r.w));
     if (!C.ignore_chain) WL(W.achain, level, (uint32_t)C.qchain[cand]);
+}
+
+template <class Ctx>
+__device__ __forceinline__ void assign_level(const Ctx &C, WaveRegs &W, int level, uint32_t cand) {
+    assign_record(C, W, level, cand, C.rec[cand]);  // uniform address: every lane receives the same record
 }
 
 // All arguments of k_search as one kernel-argument struct.  Code that runs rarely (a complete
@@ -751,10 +759,15 @@ __device__ __forceinline__ bool joint_top_scan(const Ctx &C, WaveRegs &W, PairSt
                             if (flags & 0x400u) nq3 = 0;
 #endif
                             for (uint32_t q = 0; q < nq3; ++q) {
-                                const uint32_t ab = uni(S.queue3[q][0]);
-                                assign_level(C, W, 0, ab & 0xffffu);
-                                if (floor >= 2) assign_level(C, W, 1, ab >> 16);
-                                if (floor >= 3) assign_level(C, W, 2, uni(S.queue3[q][1]));
+                                // all three records are fetched at once; for templates with fewer than three
+                                // residues the wildcard entries name atom 0, and the levels they are written to
+                                // are re-assigned by the search before anything reads them
+                                const uint32_t ab = uni(S.queue3[q][0]), c = uni(S.queue3[q][1]);
+                                const uint32_t a0 = ab & 0xffffu, a1 = ab >> 16;
+                                const float4 r0 = C.rec[a0], r1 = C.rec[a1], r2 = C.rec[c];
+                                assign_record(C, W, 0, a0, r0);
+                                assign_record(C, W, 1, a1, r1);
+                                assign_record(C, W, 2, c, r2);
                                 if (!dfs(C, W, P, floor)) return false;
                             }
                             wave_sync();
