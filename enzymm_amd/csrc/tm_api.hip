@@ -133,10 +133,14 @@ struct DevBuf {
         n = count;
         return DevicePool::get().acquire(need, reinterpret_cast<void **>(&p), &bytes);
     }
-    hipError_t upload(const std::vector<T> &v) {
+    // With a stream the copy is ordered on (and waited for on) that stream only; a plain hipMemcpy goes through
+    // the null stream and would wait for whatever other blocking streams are running.
+    hipError_t upload(const std::vector<T> &v, hipStream_t stream = nullptr) {
         hipError_t e = alloc(v.size());
         if (e != hipSuccess || v.empty()) return e;
-        return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+        if (!stream) return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+        e = hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, stream);
+        return e != hipSuccess ? e : hipStreamSynchronize(stream);
     }
 };
 
@@ -200,6 +204,8 @@ struct tm_batch {
     // search work items (structure, round), cached for the (cx, n_sel) they were planned for
     DevBuf<WorkItem> d_work;
     uint32_t work_items = 0, work_cx = 0xffffffffu, work_n_sel = 0;
+    hipStream_t last_stream = nullptr;  // stream of the last query that read this batch
+    bool queried = false;
     uint64_t index_for = 0;  // serial of the library the candidate index was built for
     unsigned long long pool_capacity = 0;
     BatchView view() const {
@@ -510,12 +516,28 @@ static int device_scan(const uint32_t *in, uint64_t n, uint32_t *out, uint32_t *
     return TM_OK;
 }
 
+// Ingestion runs on a private non-blocking stream (one per host thread and device), so that a caller can parse
+// the next batch on one thread while a query of the previous batch runs on another stream.
+static hipError_t ingest_stream(int device, hipStream_t *out) {
+    thread_local std::map<int, hipStream_t> streams;
+    auto it = streams.find(device);
+    if (it == streams.end()) {
+        hipStream_t st = nullptr;
+        hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        if (e != hipSuccess) return e;
+        it = streams.emplace(device, st).first;
+    }
+    *out = it->second;
+    return hipSuccess;
+}
+
 int tm_batch_create_from_pdb(int device, uint32_t n_files, const char *const *text, const uint64_t *length,
                              const tm_vocab *vocab, uint32_t flags, double min_bfactor, tm_batch **out) {
     if (!out || !vocab || (n_files && (!text || !length))) return fail(TM_E_INVALID, "tm_batch_create_from_pdb: NULL argument");
     *out = nullptr;
     HIP_TRY(hipSetDevice(device));
     hipStream_t stream = nullptr;
+    HIP_TRY(ingest_stream(device, &stream));
 
     // ---- one contiguous text buffer, every file newline-terminated, padded to 16-byte granules
     std::vector<uint64_t> file_off(n_files + 1, 0);
@@ -537,7 +559,7 @@ int tm_batch_create_from_pdb(int device, uint32_t n_files, const char *const *te
         if (file_off[f + 1] - file_off[f] != length[f])
             HIP_TRY(hipMemsetAsync(d_text.p + file_off[f + 1] - 1, '\n', 1, stream));
     }
-    HIP_TRY(d_file_off.upload(file_off));
+    HIP_TRY(d_file_off.upload(file_off, stream));
     const uint64_t n_gran = n_bytes / 16;
     HIP_TRY(d_counts.alloc(n_gran)); HIP_TRY(d_rank.alloc(n_gran)); HIP_TRY(d_total.alloc(2)); HIP_TRY(d_bad.alloc(1));
     HIP_TRY(hipMemsetAsync(d_bad.p, 0, sizeof(uint32_t), stream));
@@ -553,7 +575,7 @@ int tm_batch_create_from_pdb(int device, uint32_t n_files, const char *const *te
     HIP_TRY(d_nl.alloc(n_lines)); HIP_TRY(d_line_file.alloc(n_lines)); HIP_TRY(d_kind.alloc(n_lines));
     HIP_TRY(d_keep.alloc(n_lines)); HIP_TRY(d_atom_rank.alloc(n_lines));
     std::vector<uint32_t> first_end(std::max<uint32_t>(n_files, 1), 0xffffffffu);
-    HIP_TRY(d_first_end.upload(first_end));
+    HIP_TRY(d_first_end.upload(first_end, stream));
     DevBuf<uint32_t> d_s_off_tmp;
     HIP_TRY(d_s_off_tmp.alloc(n_files + 1));
     if (n_lines) {
@@ -593,10 +615,10 @@ int tm_batch_create_from_pdb(int device, uint32_t n_files, const char *const *te
     DevBuf<uint32_t> dv_names, dv_res;
     DevBuf<uint16_t> dv_el;
     DevBuf<uint8_t> dv_name_ids, dv_el_ids, dv_res_ids;
-    HIP_TRY(dv_names.upload(v_names)); HIP_TRY(dv_res.upload(v_res)); HIP_TRY(dv_el.upload(v_el));
-    HIP_TRY(dv_name_ids.upload(std::vector<uint8_t>(vocab->atom_name_ids, vocab->atom_name_ids + vocab->n_atom_names)));
-    HIP_TRY(dv_el_ids.upload(std::vector<uint8_t>(vocab->element_ids, vocab->element_ids + vocab->n_elements)));
-    HIP_TRY(dv_res_ids.upload(std::vector<uint8_t>(vocab->residue_ids, vocab->residue_ids + vocab->n_residues)));
+    HIP_TRY(dv_names.upload(v_names, stream)); HIP_TRY(dv_res.upload(v_res, stream)); HIP_TRY(dv_el.upload(v_el, stream));
+    HIP_TRY(dv_name_ids.upload(std::vector<uint8_t>(vocab->atom_name_ids, vocab->atom_name_ids + vocab->n_atom_names), stream));
+    HIP_TRY(dv_el_ids.upload(std::vector<uint8_t>(vocab->element_ids, vocab->element_ids + vocab->n_elements), stream));
+    HIP_TRY(dv_res_ids.upload(std::vector<uint8_t>(vocab->residue_ids, vocab->residue_ids + vocab->n_residues), stream));
     VocabView V{vocab->n_atom_names, vocab->n_elements, vocab->n_residues, dv_names.p, dv_name_ids.p,
                 dv_el.p, dv_el_ids.p, dv_res.p, dv_res_ids.p};
 
@@ -639,7 +661,7 @@ int tm_batch_create_from_pdb(int device, uint32_t n_files, const char *const *te
         max_res = std::max(max_res, runs[f]);
     }
     b->max_atoms = max_atoms; b->max_res = max_res; b->s_off = s_off;
-    HIP_TRY(b->d_s_off.upload(s_off)); HIP_TRY(b->d_s_roff.upload(s_roff));
+    HIP_TRY(b->d_s_off.upload(s_off, stream)); HIP_TRY(b->d_s_roff.upload(s_roff, stream));
     HIP_TRY(b->d_rec.alloc(n_atoms)); HIP_TRY(b->d_chain.alloc(n_atoms)); HIP_TRY(b->d_orig.alloc(n_atoms));
     HIP_TRY(b->d_res_start.alloc(s_roff[n_files]));
     HIP_TRY(b->d_cursor.alloc(1)); HIP_TRY(b->d_overflow.alloc(1));
@@ -672,7 +694,10 @@ int tm_batch_line_offsets(tm_batch *b, uint32_t *out, uint64_t n) {
 void tm_batch_destroy(tm_batch *b) {
     if (!b) return;
     (void)hipSetDevice(b->device);
-    (void)hipDeviceSynchronize();  // its buffers go back to the allocation cache: nothing may still read them
+    // its buffers go back to the allocation cache: nothing may still read them.  Only queries read a batch
+    // after its creation returned, so waiting for the last query's stream is enough (a device-wide wait would
+    // also wait for another thread's ingestion of the next batch).
+    if (b->queried) (void)hipStreamSynchronize(b->last_stream);
     delete b;
 }
 
@@ -782,6 +807,8 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
         HIP_TRY(hipMemsetAsync(r->d_candidates.p, 0, (size_t)b->n_structs * n_sel * sizeof(uint32_t), stream));
     }
 
+    if (b->queried && b->last_stream != stream) HIP_TRY(hipStreamSynchronize(b->last_stream));
+    b->last_stream = stream; b->queried = true;
     HIP_TRY(hipEventRecord(r->ev[0], stream));
     if (b->index_for != lib->serial || (p->flags & TM_FLAG_REBUILD_INDEX)) {
         int rc = build_index(lib, b, stream);

@@ -89,3 +89,47 @@ class PdbBatch:
 
     def close(self):
         self.native.close()
+
+
+def iter_batches(paths: Sequence, batch_size: int = 1000, prefetch: int = 1, **kw):
+    """Yield ``PdbBatch`` objects over ``paths`` in slices of ``batch_size`` files, built on a worker thread
+    ``prefetch`` batches ahead: reading, uploading and parsing batch i+1 overlaps the search of batch i
+    (ingestion runs on its own HIP stream, and the native calls release the GIL).  The consumer closes each
+    batch when it is done with it."""
+    import queue
+    import threading
+
+    paths = list(paths)
+    slices = [paths[i:i + batch_size] for i in range(0, len(paths), batch_size)]
+    q: "queue.Queue" = queue.Queue(maxsize=max(1, int(prefetch)))
+    stop = threading.Event()
+
+    def worker():
+        try:
+            for chunk in slices:
+                if stop.is_set():
+                    return
+                q.put(("ok", PdbBatch.from_paths(chunk, **kw)))
+            q.put(("done", None))
+        except BaseException as exc:  # handed to the consumer
+            q.put(("error", exc))
+
+    t = threading.Thread(target=worker, name="enzymm_amd-ingest", daemon=True)
+    t.start()
+    try:
+        while True:
+            kind, payload = q.get()
+            if kind == "done":
+                return
+            if kind == "error":
+                raise payload
+            yield payload
+    finally:
+        stop.set()
+        while t.is_alive():  # let a blocked put() through, closing what the consumer will not take
+            try:
+                kind, payload = q.get(timeout=0.05)
+                if kind == "ok":
+                    payload.close()
+            except queue.Empty:
+                pass

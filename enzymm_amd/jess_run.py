@@ -370,39 +370,36 @@ class Matcher:
         device_batch = None
         if hasattr(molecules, "native") and hasattr(molecules, "molecules"):  # an ingest.PdbBatch
             device_batch, molecules = molecules, molecules.molecules
-        sizes = [s for s in self.template_effective_sizes if s >= 3 or self.match_small_templates]
-        searched: List[Template] = []
-        rmsd, dist, dyn, bucket_of = [], [], [], []
-        for s in sizes:
-            r, d, m = self._get_jess_parameters(s)
-            for t in self.templates_by_effective_size[s]:
-                searched.append(t)
-                rmsd.append(r); dist.append(d); dyn.append(m); bucket_of.append(s)
+        sizes, searched, rmsd, dist, dyn, bucket_of, position, models, jess = self._plan()
 
         # ONE launch for every (molecule, template) pair of every bucket; the orientation angle and the
         # logistic filter are evaluated in the hit epilogue on the GPU (Hit.orientation, Hit.predicted)
         per_molecule: List[List[pyjess.Hit]] = [[] for _ in molecules]
         if searched and molecules:
-            jess = self._jess_factory(searched)
-            per_molecule = jess.query_batch(molecules, np.array(rmsd, float), np.array(dist, float),
-                                            np.array(dyn, float), max_candidates=self.MAX_CANDIDATES,
-                                            best_match=True, ignore_chain=True,
-                                            models=self._model_tables(searched, dist), batch=device_batch)
-        position = {id(t): i for i, t in enumerate(searched)}
+            per_molecule = jess.query_batch(molecules, rmsd, dist, dyn, max_candidates=self.MAX_CANDIDATES,
+                                            best_match=True, ignore_chain=True, models=models, batch=device_batch)
+
+        # hits bucketed by size once; only molecules that have hits are visited below
+        by_size: Dict[int, List[Tuple[int, List[pyjess.Hit]]]] = {s: [] for s in sizes}
+        for mi, hits in enumerate(per_molecule):
+            if not hits:
+                continue
+            groups: Dict[int, List[pyjess.Hit]] = {}
+            for h in hits:
+                groups.setdefault(bucket_of[position[id(h.template)]], []).append(h)
+            for s, hs in groups.items():
+                by_size[s].append((mi, hs))
 
         processed: Dict[pyjess.Molecule, List[Match]] = collections.defaultdict(list)
         for s in sizes:  # replay the reference's per-size loop on the hit table
             _, distance, _ = self._get_jess_parameters(s)
             self.verbose_print(f"Now matching query structure(s) to template of size {s}")
             total = 0
-            staged = []
-            for mol, hits in zip(molecules, per_molecule):
+            for mi, hits in by_size[s]:
+                mol = molecules[mi]
                 if self.skip_smaller_hits and mol in processed:
                     continue
-                matches = [Match(hit=h, pairwise_distance=distance) for h in hits
-                           if bucket_of[position[id(h.template)]] == s]
-                staged.append((mol, self._check_completeness(matches)))
-            for mol, matches in staged:
+                matches = self._check_completeness([Match(hit=h, pairwise_distance=distance) for h in hits])
                 if self.filter_matches:
                     for m in matches:
                         # the epilogue's verdict when it had a model set for this bucket; otherwise the
@@ -413,11 +410,33 @@ class Matcher:
                             processed[mol].append(m)
                             total += 1
                 else:
-                    if matches:
-                        processed[mol].extend(matches)
+                    processed[mol].extend(matches)
                     total += len(matches)
             self.verbose_print(f"{total} matches found!")
         return processed
+
+    def _plan(self):
+        """The flattened search plan (templates by descending size with their bucket's thresholds, the lookup
+        tables the per-size replay needs, the logistic model tables).  Depends only on the matcher's settings;
+        cached until one of them changes."""
+        key = (self.match_small_templates, tuple(self.template_effective_sizes),
+               tuple(sorted((k, tuple(sorted(v.items()))) for k, v in self.jess_params.items())))
+        cached = getattr(self, "_plan_cache", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        sizes = [s for s in self.template_effective_sizes if s >= 3 or self.match_small_templates]
+        searched: List[Template] = []
+        rmsd, dist, dyn, bucket_of = [], [], [], []
+        for s in sizes:
+            r, d, m = self._get_jess_parameters(s)
+            for t in self.templates_by_effective_size[s]:
+                searched.append(t)
+                rmsd.append(r); dist.append(d); dyn.append(m); bucket_of.append(s)
+        position = {id(t): i for i, t in enumerate(searched)}
+        plan = (sizes, searched, np.array(rmsd, float), np.array(dist, float), np.array(dyn, float), bucket_of,
+                position, self._model_tables(searched, dist), self._jess_factory(searched) if searched else None)
+        self._plan_cache = (key, plan)
+        return plan
 
     @staticmethod
     def _model_tables(templates: Sequence[Template], distances: Sequence[float]):
@@ -450,6 +469,20 @@ class Matcher:
             return None  # keep the pure-Python filter so the reference's KeyError behaviour is untouched
         return (np.array(index, np.int32), np.array(offsets, np.uint32), np.array(votes, np.uint32),
                 np.array(params, np.float64).reshape(-1, 4))
+
+    def run_files(self, paths, batch_size: int = 1000, **ingest_options) -> Dict[pyjess.Molecule, List[Match]]:
+        """``run`` over PDB files without host-side parsing: the files are read, uploaded and parsed on the GPU in
+        batches of ``batch_size`` on a worker thread while the previous batch is searched
+        (``enzymm_amd.ingest.iter_batches``).  ``ingest_options``: ``conservation_cutoff`` (default 0: like
+        ``load_molecules``, which computes the filtered molecule and drops it), ``ignore_endmdl``."""
+        from . import ingest
+        out: Dict[pyjess.Molecule, List[Match]] = {}
+        for batch in ingest.iter_batches(paths, batch_size=batch_size, **ingest_options):
+            try:
+                out.update(self.run(batch))
+            finally:
+                batch.close()
+        return out
 
     def run_single(self, molecule: pyjess.Molecule) -> List[Match]:
         return self.run([molecule])[molecule]

@@ -784,7 +784,11 @@ class Jess:
             else np.ascontiguousarray(template_index, dtype=np.uint32)
         if not len(self._templates) or not len(sel) or not molecules:
             return np.zeros(0, dtype=_native.HIT_DTYPE) if return_raw else [[] for _ in molecules]
-        packed = _packed(self._templates, self._device)
+        # the device copy is looked up by the identity of the templates; remembered on this object, so that a
+        # long-lived Jess does not rebuild the 6780-entry key for every batch
+        packed = getattr(self, "_packed_ref", None)
+        if packed is None or packed.vocab_version != VOCAB.version:
+            packed = self._packed_ref = _packed(self._templates, self._device)
         own_batch = batch is None
         if own_batch:
             batch = make_batch(molecules, self._device)
