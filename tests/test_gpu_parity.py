@@ -348,6 +348,30 @@ def test_matcher_end_to_end(amy, af):
     assert all(isinstance(m, jess_run.Match) for m in single)
 
 
+def test_run_files_equals_host_loader(tmp_path):
+    """Matcher.run_files (GPU ingestion, next batch prepared on a worker thread) gives the matches of
+    Matcher.run(load_molecules(paths)), in the same order, with the same TSV rows."""
+    import shutil
+    paths = []
+    for name in ("1AMY.pdb", "AF-P0DUB6-F1-model_v4.pdb"):
+        shutil.copy(helpers.GOLDEN / name, tmp_path / name)
+        paths.append(tmp_path / name)
+    for i, m in enumerate(synthetic.structures(5)):
+        p = tmp_path / f"synthetic_{i}.pdb"
+        p.write_text(synthetic.to_pdb(m))
+        paths.append(p)
+    load = lambda d: list(template.load_templates(TPL / d))
+    tpls = load("5_residues/results/csa3d_0285") + load("4_residues/results/csa3d_0285") + \
+        load("3_residues/results/csa3d_0344")
+    matcher = jess_run.Matcher(tpls, filter_matches=False)
+    host = matcher.run(jess_run.load_molecules(paths))
+    dev = matcher.run_files(paths, batch_size=3)  # three batches: 3 + 3 + 1 files
+    rows = lambda res: [(mol.id, m.hit.template.id, round(m.hit.rmsd, 9), m.hit._atom_index, m.complete)
+                        for mol, ms in res.items() for m in ms]
+    assert rows(dev) == rows(host) and len(rows(host)) >= 4
+    assert [m.dumps() for ms in dev.values() for m in ms] == [m.dumps() for ms in host.values() for m in ms]
+
+
 def test_fused_epilogue_matches_python_filter(amy, af):
     """orientation angle and logistic verdict computed in the hit epilogue on the GPU must
     equal what Match.orientation / Match.predicted_correct compute in Python (jess_run.py:298-346, 425-478)."""
