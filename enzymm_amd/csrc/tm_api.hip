@@ -154,6 +154,10 @@ struct StagedSelection {
     DevBuf<double> d_rmsd, d_cut, d_maxdyn;
     DevBuf<float2> d_bounds;
     DevBuf<Staged> d_staged;
+    // The device works on the selection sorted by descending estimated cost (every workgroup's dynamic queue
+    // then starts with the expensive templates and ends on the cheap ones); order[pos] is the caller's index.
+    std::vector<uint32_t> order;
+    DevBuf<uint32_t> d_order;
     hipEvent_t ready = nullptr;  // recorded after k_stage_templates
     ~StagedSelection() {
         if (ready) (void)hipEventDestroy(ready);
@@ -176,6 +180,9 @@ struct tm_library {
     DevBuf<uint64_t> d_k_namemask;
     DevBuf<int32_t> d_k_lead;
     uint64_t serial = 0;  // identity for the batch-side index cache
+    // per template: expected size of the cross product of its two top lead lists (residue types x atom names
+    // admitted by each) -- the estimate of search cost the selection is ordered by
+    std::vector<float> cost_weight;
     LibView view() const {
         LibView v;
         v.n_templates = n_templates; v.n_kinds = n_kinds; v.n_lead = n_lead;
@@ -334,6 +341,7 @@ int tm_library_create(int device, const tm_library_desc *d, tm_library **out) {
     std::vector<uint16_t> kind(na);
     std::vector<uint8_t> group(na), orig(na), chain(na), ref(na);
     std::map<std::tuple<uint8_t, uint32_t, uint64_t>, uint32_t> kinds;
+    std::vector<float> cost_weight(nt, 1.f);
     std::vector<uint32_t> k_resmask;
     std::vector<uint64_t> k_namemask;
     std::vector<uint8_t> k_any;
@@ -384,6 +392,14 @@ int tm_library_create(int device, const tm_library_desc *d, tm_library **out) {
                 lead_kind.push_back(it->second);
             }
         }
+        {
+            const int G = *std::max_element(p.group.begin(), p.group.end()) + 1;
+            auto expected = [&](uint32_t pos) {
+                const uint32_t kd = kind[o + pos];
+                return (double)(k_any[kd] ? 20 : __builtin_popcount(k_resmask[kd])) * (double)__builtin_popcountll(k_namemask[kd]);
+            };
+            cost_weight[t] = (float)(expected(0) * (G >= 2 ? expected(1) : 1.0));
+        }
     }
 
     tm_library *lib = new (std::nothrow) tm_library;
@@ -392,6 +408,7 @@ int tm_library_create(int device, const tm_library_desc *d, tm_library **out) {
     lib->n_templates = nt; lib->n_atoms = na;
     lib->n_kinds = (uint32_t)k_any.size(); lib->n_lead = (uint32_t)lead_kind.size();
     lib->t_off.assign(d->atom_offsets, d->atom_offsets + nt + 1);
+    lib->cost_weight = std::move(cost_weight);
     lib->serial = ++g_serial;
     hipError_t e = hipSuccess;
     auto up = [&](hipError_t r) { if (e == hipSuccess) e = r; };
@@ -772,8 +789,22 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
             S->rmsd.assign(p->rmsd_threshold, p->rmsd_threshold + n_sel);
             S->cut.assign(p->distance_cutoff, p->distance_cutoff + n_sel);
             S->maxdyn.assign(p->max_dynamic_distance, p->max_dynamic_distance + n_sel);
-            HIP_TRY(S->d_sel.upload(S->sel)); HIP_TRY(S->d_rmsd.upload(S->rmsd));
-            HIP_TRY(S->d_cut.upload(S->cut)); HIP_TRY(S->d_maxdyn.upload(S->maxdyn));
+            S->order.resize(n_sel);
+            std::iota(S->order.begin(), S->order.end(), 0u);
+            std::stable_sort(S->order.begin(), S->order.end(), [&](uint32_t x, uint32_t y) {
+                return lib->cost_weight[S->sel[x]] > lib->cost_weight[S->sel[y]];
+            });
+            {
+                std::vector<uint32_t> sel(n_sel);
+                std::vector<double> rm(n_sel), cu(n_sel), md(n_sel);
+                for (uint32_t i = 0; i < n_sel; ++i) {
+                    const uint32_t o = S->order[i];
+                    sel[i] = S->sel[o]; rm[i] = S->rmsd[o]; cu[i] = S->cut[o]; md[i] = S->maxdyn[o];
+                }
+                HIP_TRY(S->d_sel.upload(sel)); HIP_TRY(S->d_rmsd.upload(rm));
+                HIP_TRY(S->d_cut.upload(cu)); HIP_TRY(S->d_maxdyn.upload(md));
+                HIP_TRY(S->d_order.upload(S->order));
+            }
             HIP_TRY(S->d_bounds.alloc((size_t)n_sel * kMaxPairs));
             HIP_TRY(S->d_staged.alloc(n_sel));
             HIP_TRY(hipEventCreateWithFlags(&S->ready, hipEventDisableTiming));
@@ -818,13 +849,17 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
 
     QueryView Q;
     Q.n_sel = n_sel; Q.sel = S->d_sel.p; Q.rmsd_thr = S->d_rmsd.p; Q.cutoff = S->d_cut.p; Q.maxdyn = S->d_maxdyn.p;
-    Q.staged = S->d_staged.p; Q.bounds = S->d_bounds.p; Q.max_candidates = p->max_candidates; Q.flags = p->flags;
+    Q.staged = S->d_staged.p; Q.bounds = S->d_bounds.p; Q.order = S->d_order.p; Q.max_candidates = p->max_candidates; Q.flags = p->flags;
     Q.model_set = nullptr; Q.model_offsets = nullptr; Q.model_votes = nullptr; Q.models = nullptr;
     if (p->model_set && p->n_model_sets && p->model_offsets && p->model_votes && p->models) {
         const uint32_t ns = p->n_model_sets, nm = p->model_offsets[ns];
         for (uint32_t i = 0; i < n_sel; ++i)
             if (p->model_set[i] >= (int32_t)ns) return fail(TM_E_INVALID, "model_set index out of range");
-        HIP_TRY(r->d_model_set.upload(std::vector<int32_t>(p->model_set, p->model_set + n_sel)));
+        {
+            std::vector<int32_t> ms(n_sel);
+            for (uint32_t i = 0; i < n_sel; ++i) ms[i] = p->model_set[S->order[i]];
+            HIP_TRY(r->d_model_set.upload(ms));
+        }
         HIP_TRY(r->d_model_offsets.upload(std::vector<uint32_t>(p->model_offsets, p->model_offsets + ns + 1)));
         HIP_TRY(r->d_model_votes.upload(std::vector<uint32_t>(p->model_votes, p->model_votes + ns)));
         HIP_TRY(r->d_models.upload(std::vector<double>(p->models, p->models + 4 * (size_t)nm)));

@@ -88,6 +88,8 @@ struct QueryView {
     const double *maxdyn;       // [n_sel]
     const Staged *staged;       // [n_sel]
     const float2 *bounds;       // [n_sel*kMaxPairs] (lo^2, hi^2) fp32 prefilter bounds, search order
+    const uint32_t *order;      // [n_sel] every per-selection array above is sorted by descending estimated cost;
+                                // order[pos] = the caller's selection index (reported in tm_hit / candidate counts)
     uint32_t max_candidates;
     uint32_t flags;
     // optional logistic filter

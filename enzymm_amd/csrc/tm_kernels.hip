@@ -946,7 +946,10 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
 
         // ---- the pair's outcome
         const uint32_t packed = P.ncand | (P.truncated ? 0x80000000u : 0u);
-        if (count_candidates && lane == 0) cold_args()->O.candidates[(size_t)s * Q.n_sel + ti_cur] = packed;
+        if (count_candidates && lane == 0) {
+            ColdArgsPtr cold = cold_args();
+            cold->O.candidates[(size_t)s * Q.n_sel + cold->Q.order[ti_cur]] = packed;
+        }
         if (packed != 0u && lane == 0) {
             ColdArgsPtr cold = cold_args();
             const unsigned long long slot = atomicAdd(cold->O.n_pairs, 1ull);
@@ -1109,7 +1112,7 @@ __device__ void emit_hit(const LibView &L, const BatchView &B, const QueryView &
     for (int a = 0; a < 9; ++a) h->rot[a] = R[a];
     for (int a = 0; a < 3; ++a) h->trans[a] = T[a];
     h->structure = pe.s;
-    h->template_sel = pe.ti;
+    h->template_sel = Q.order[pe.ti];
     h->n_candidates = pe.count & 0x7fffffffu;
     h->flags = (pe.count >> 31) ? TM_HIT_TRUNCATED : 0u;
     h->n_atoms = (uint32_t)k;
