@@ -60,6 +60,7 @@ class _Vocab(C.Structure):
         ("n_atom_names", C.c_uint32), ("atom_names", C.c_void_p), ("atom_name_ids", C.c_void_p),
         ("n_elements", C.c_uint32), ("elements", C.c_void_p), ("element_ids", C.c_void_p),
         ("n_residues", C.c_uint32), ("residue_names", C.c_void_p), ("residue_ids", C.c_void_p),
+        ("n_counted_residues", C.c_uint32), ("counted_residue_names", C.c_void_p),
     ]
 
 
@@ -79,6 +80,7 @@ class _QueryParams(C.Structure):
 EXPORTS = (
     "tm_abi_version", "tm_last_error", "tm_device_count", "tm_library_create", "tm_library_destroy",
     "tm_batch_create", "tm_batch_create_from_pdb", "tm_batch_atom_counts", "tm_batch_line_offsets",
+    "tm_batch_residue_counts",
     "tm_batch_destroy", "tm_query", "tm_result_wait", "tm_result_needed", "tm_result_hit_count",
     "tm_result_copy_hits", "tm_result_copy_candidates", "tm_result_timing", "tm_result_device_hits",
     "tm_result_destroy",
@@ -182,8 +184,10 @@ class Batch:
         self.device = device
 
     @classmethod
-    def from_pdb(cls, device, texts, vocab_tables, min_bfactor: float = 0.0, ignore_endmdl: bool = False) -> "Batch":
-        """Upload raw PDB texts (bytes) and parse them on the GPU (``tm_batch_create_from_pdb``)."""
+    def from_pdb(cls, device, texts, vocab_tables, min_bfactor: float = 0.0, ignore_endmdl: bool = False,
+                 counted_residues=()) -> "Batch":
+        """Upload raw PDB texts (bytes) and parse them on the GPU (``tm_batch_create_from_pdb``).
+        ``counted_residues``: residue names (3 characters) whose distinct residue numbers are counted per file."""
         lib = load()
         self = cls.__new__(cls)
         self._h = C.c_void_p()
@@ -191,8 +195,10 @@ class Batch:
         names, name_ids, els, el_ids, res, res_ids, _ = vocab_tables
         keep = [_arr(names, "S4"), _arr(name_ids, np.uint8), _arr(els, "S2"), _arr(el_ids, np.uint8),
                 _arr(res, "S3"), _arr(res_ids, np.uint8)]
+        keep.append(_arr(np.array([str(r).rjust(3)[:3].encode() for r in counted_residues], dtype="S3"), "S3"))
         vocab = _Vocab(len(keep[0]), _ptr(keep[0]), _ptr(keep[1]), len(keep[2]), _ptr(keep[2]), _ptr(keep[3]),
-                       len(keep[4]), _ptr(keep[4]), _ptr(keep[5]))
+                       len(keep[4]), _ptr(keep[4]), _ptr(keep[5]), len(keep[6]), _ptr(keep[6]) if len(keep[6]) else None)
+        self.has_residue_counts = len(keep[6]) > 0
         ptrs = (C.c_char_p * max(1, len(texts)))(*texts)
         lens = (C.c_uint64 * max(1, len(texts)))(*[len(t) for t in texts])
         _check(lib.tm_batch_create_from_pdb(C.c_int(device), C.c_uint32(len(texts)), ptrs, lens, C.byref(vocab),
@@ -207,6 +213,12 @@ class Batch:
         """Byte offset of every kept ATOM/HETATM record inside its file (device-parsed batches)."""
         out = np.zeros(int(self.atom_offsets[-1]), dtype=np.uint32)
         _check(load().tm_batch_line_offsets(self._h, _ptr(out), C.c_uint64(out.size)))
+        return out
+
+    def residue_counts(self) -> np.ndarray:
+        """Per file: distinct residue numbers among the atoms of the counted residue names."""
+        out = np.zeros(self.n_structures, dtype=np.uint32)
+        _check(load().tm_batch_residue_counts(self._h, _ptr(out)))
         return out
 
     def close(self):

@@ -208,6 +208,8 @@ struct tm_batch {
     DevBuf<unsigned long long> d_cursor;
     DevBuf<uint32_t> d_overflow;
     DevBuf<uint32_t> d_line_off;  // device-parsed batches: byte offset of every atom record in its file
+    DevBuf<uint32_t> d_residue_count;  // device-parsed batches with counted residue names: distinct residue numbers
+    bool has_residue_count = false;
     // search work items (structure, round), cached for the (cx, n_sel) they were planned for
     DevBuf<WorkItem> d_work;
     uint32_t work_items = 0, work_cx = 0xffffffffu, work_n_sel = 0;
@@ -636,8 +638,13 @@ int tm_batch_create_from_pdb(int device, uint32_t n_files, const char *const *te
     HIP_TRY(dv_name_ids.upload(std::vector<uint8_t>(vocab->atom_name_ids, vocab->atom_name_ids + vocab->n_atom_names), stream));
     HIP_TRY(dv_el_ids.upload(std::vector<uint8_t>(vocab->element_ids, vocab->element_ids + vocab->n_elements), stream));
     HIP_TRY(dv_res_ids.upload(std::vector<uint8_t>(vocab->residue_ids, vocab->residue_ids + vocab->n_residues), stream));
+    const uint32_t n_counted = vocab->counted_residue_names ? vocab->n_counted_residues : 0u;
+    std::vector<uint32_t> v_counted(n_counted, 0u);
+    for (uint32_t i = 0; i < n_counted; ++i) std::memcpy(&v_counted[i], vocab->counted_residue_names + 3 * i, 3);
+    DevBuf<uint32_t> dv_counted;
+    HIP_TRY(dv_counted.upload(v_counted, stream));
     VocabView V{vocab->n_atom_names, vocab->n_elements, vocab->n_residues, dv_names.p, dv_name_ids.p,
-                dv_el.p, dv_el_ids.p, dv_res.p, dv_res_ids.p};
+                dv_el.p, dv_el_ids.p, dv_res.p, dv_res_ids.p, n_counted, dv_counted.p};
 
     hipLaunchKernelGGL(k_pdb_file_offsets, dim3((n_files + 256) / 256), dim3(256), 0, stream, d_nl.p, n_lines,
                        d_file_off.p, n_files, d_atom_rank.p, d_total.p + 1, d_s_off_tmp.p);
@@ -682,9 +689,11 @@ int tm_batch_create_from_pdb(int device, uint32_t n_files, const char *const *te
     HIP_TRY(b->d_rec.alloc(n_atoms)); HIP_TRY(b->d_chain.alloc(n_atoms)); HIP_TRY(b->d_orig.alloc(n_atoms));
     HIP_TRY(b->d_res_start.alloc(s_roff[n_files]));
     HIP_TRY(b->d_cursor.alloc(1)); HIP_TRY(b->d_overflow.alloc(1));
+    HIP_TRY(b->d_residue_count.alloc(n_files));
+    b->has_residue_count = n_counted != 0;
     if (n_files) {
         hipLaunchKernelGGL(k_pdb_finalize, dim3(n_files), dim3(256), 0, stream, b->d_s_off.p, b->d_s_roff.p, P,
-                           b->d_rec.p, b->d_chain.p, b->d_orig.p, b->d_res_start.p);
+                           b->d_rec.p, b->d_chain.p, b->d_orig.p, b->d_res_start.p, b->d_residue_count.p);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipStreamSynchronize(stream));
@@ -705,6 +714,16 @@ int tm_batch_line_offsets(tm_batch *b, uint32_t *out, uint64_t n) {
     if (n < b->n_atoms) return fail(TM_E_INVALID, "output buffer too small");
     HIP_TRY(hipSetDevice(b->device));
     if (b->n_atoms) HIP_TRY(hipMemcpy(out, b->d_line_off.p, b->n_atoms * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return TM_OK;
+}
+
+int tm_batch_residue_counts(tm_batch *b, uint32_t *out) {
+    if (!b || (!out && b->n_structs)) return fail(TM_E_INVALID, "NULL argument");
+    if (!b->has_residue_count)
+        return fail(TM_E_UNSUPPORTED, "batch was not created from PDB text with tm_vocab.counted_residue_names");
+    HIP_TRY(hipSetDevice(b->device));
+    if (b->n_structs)
+        HIP_TRY(hipMemcpy(out, b->d_residue_count.p, b->n_structs * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return TM_OK;
 }
 

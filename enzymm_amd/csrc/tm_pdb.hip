@@ -28,7 +28,11 @@ struct VocabView {
     const uint8_t *element_ids;
     const uint32_t *res;        // raw 3-char residue names in the low 24 bits
     const uint8_t *res_ids;
+    uint32_t n_counted;         // residue names whose residue numbers are counted per structure
+    const uint32_t *counted;
 };
+
+constexpr uint32_t kMetaCounted = 1u << 27;  // ParsedAtoms::meta flag: residue name is one of the counted ones
 
 // ------------------------------------------------------------------ generic exclusive scan (u32)
 
@@ -290,7 +294,10 @@ __global__ __launch_bounds__(256) void k_pdb_parse(const uint8_t *__restrict__ t
     uint32_t rtype = TM_RES_OTHER;
     for (uint32_t n = 0; n < V.n_res; ++n)
         if (V.res[n] == res) { rtype = V.res_ids[n]; break; }
-    out.meta[a] = (name_id << 16) | (rtype << 22);
+    uint32_t counted = 0;
+    for (uint32_t n = 0; n < V.n_counted; ++n)
+        if (V.counted[n] == res) { counted = kMetaCounted; break; }
+    out.meta[a] = (name_id << 16) | (rtype << 22) | counted;
     out.key[a] = ((uint64_t)p[20] << 48) | ((uint64_t)p[21] << 40) | ((uint64_t)(uint32_t)(resseq + (1 << 24)) << 8) | p[26];
     out.line_off[a] = (uint32_t)(start - file_off[line_file[i]]);
 }
@@ -346,8 +353,15 @@ __global__ __launch_bounds__(256) void k_pdb_residues(const uint32_t *__restrict
 // per structure: residue ordinals (= run index), res_start, chain ordinals, centroid, packed records
 __global__ __launch_bounds__(256) void k_pdb_finalize(const uint32_t *__restrict__ s_off, const uint32_t *__restrict__ s_roff,
                                                        ParsedAtoms P, float4 *__restrict__ rec, uint8_t *__restrict__ chain,
-                                                       uint32_t *__restrict__ orig, uint16_t *__restrict__ res_start) {
+                                                       uint32_t *__restrict__ orig, uint16_t *__restrict__ res_start,
+                                                       uint32_t *__restrict__ residue_count) {
     __shared__ uint32_t s_wave[4];
+    // distinct residue NUMBERS among atoms whose residue name is counted (enzymm's query_residue_count ignores
+    // chains and insertion codes): one bit per value of the 4-column resSeq field, -999 .. 9999
+    __shared__ uint32_t s_seen[(11000 + 31) / 32];
+    __shared__ uint32_t s_distinct;
+    for (uint32_t i = threadIdx.x; i < (11000 + 31) / 32; i += blockDim.x) s_seen[i] = 0;
+    if (threadIdx.x == 0) s_distinct = 0;
     __shared__ uint32_t s_carry;
     __shared__ double s_sum[3][4];
     __shared__ uint16_t s_chains[256];
@@ -404,15 +418,26 @@ __global__ __launch_bounds__(256) void k_pdb_finalize(const uint32_t *__restrict
             r.x = (float)(P.xyz[3 * (size_t)(a0 + i) + 0] - c[0]);
             r.y = (float)(P.xyz[3 * (size_t)(a0 + i) + 1] - c[1]);
             r.z = (float)(P.xyz[3 * (size_t)(a0 + i) + 2] - c[2]);
-            r.w = __uint_as_float((ord & 0xffffu) | P.meta[a0 + i]);
+            const uint32_t m = P.meta[a0 + i];
+            r.w = __uint_as_float((ord & 0xffffu) | (m & ~kMetaCounted));
             rec[a0 + i] = r;
             orig[a0 + i] = i;
+            if (m & kMetaCounted) {
+                const uint32_t v = (uint32_t)((P.key[a0 + i] >> 8) & 0xffffffffull) - (1u << 24) + 999u;  // resSeq + 999
+                if (v < 11000u) atomicOr(&s_seen[v >> 5], 1u << (v & 31));
+            }
         }
         __syncthreads();
         if (threadIdx.x == 0) s_carry += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
         __syncthreads();
     }
     if (threadIdx.x == 0) res_start[r0 + s_carry] = (uint16_t)n;
+    __syncthreads();
+    uint32_t bits = 0;
+    for (uint32_t i = threadIdx.x; i < (11000 + 31) / 32; i += blockDim.x) bits += __popc(s_seen[i]);
+    if (bits) atomicAdd(&s_distinct, bits);
+    __syncthreads();
+    if (threadIdx.x == 0) residue_count[s] = s_distinct;
 }
 
 }  // namespace tmx

@@ -34,6 +34,30 @@ class LazyMolecule(pyjess.Molecule):
         self._enc = None
         import threading
         self._lock = threading.Lock()
+        #: filled by PdbBatch.annotate(): byte offset of every kept record in the text, and the number of
+        #: distinct residue numbers among the counted residue names (what a TSV row needs) -- with those a
+        #: match is reported without parsing the whole file on the host
+        self._line_off = None
+        self._residue_count = None
+        self._picked: dict = {}
+
+    def _atoms_at(self, indices) -> List[pyjess.Atom]:
+        """The atoms with these (kept-record) indices; only their lines are parsed."""
+        if self._loaded is not None or self._line_off is None:
+            return [self._materialise()._atom(int(i)) for i in indices]
+        missing = [int(i) for i in indices if int(i) not in self._picked]
+        if missing:
+            lines = []
+            for i in missing:
+                lo = int(self._line_off[i])
+                hi = self._text.find(b"\n", lo)
+                lines.append(self._text[lo: hi if hi >= 0 else len(self._text)])
+            cols, xyz, _ = pyjess._parse_pdb_bytes(b"\n".join(lines) + b"\n", True)
+            part = pyjess.Molecule.__new__(pyjess.Molecule)
+            part._init_columns(cols, xyz, self.id)
+            for j, i in enumerate(missing):
+                self._picked[i] = part._atom(j)
+        return [self._picked[int(i)] for i in indices]
 
     def _materialise(self) -> pyjess.Molecule:
         if self._loaded is None:
@@ -64,12 +88,32 @@ class PdbBatch:
         self.device = pyjess.default_device() if device is None else int(device)
         tables = VOCAB.native_tables()
         self.vocab_version = tables[-1]
+        from .jess_run import _COUNTED_RESIDUES
         self.native = _native.Batch.from_pdb(self.device, list(texts), tables, min_bfactor=conservation_cutoff,
-                                             ignore_endmdl=ignore_endmdl)
+                                             ignore_endmdl=ignore_endmdl, counted_residues=sorted(_COUNTED_RESIDUES))
         self.native.vocab_version = self.vocab_version
         counts = np.diff(self.native.atom_offsets)
         self.molecules: List[LazyMolecule] = [
             LazyMolecule(t, i, n, conservation_cutoff, ignore_endmdl) for t, i, n in zip(texts, ids, counts)]
+        self._annotated = False
+
+    def annotate(self, indices) -> None:
+        """Give the molecules at ``indices`` (the ones with matches) what a report row needs from the device --
+        record offsets for parsing only the matched atoms, and the counted-residue total -- while the batch is
+        still alive.  One device-to-host copy per batch."""
+        indices = list(indices)
+        if not indices:
+            return
+        if not self._annotated:
+            self._line_off = self.native.line_offsets()
+            self._res_counts = self.native.residue_counts() if self.native.has_residue_counts else None
+            self._annotated = True
+        off = self.native.atom_offsets
+        for i in indices:
+            mol = self.molecules[i]
+            mol._line_off = self._line_off[int(off[i]): int(off[i + 1])].copy()
+            if self._res_counts is not None:
+                mol._residue_count = int(self._res_counts[i])
 
     @classmethod
     def from_paths(cls, paths: Sequence, **kw) -> "PdbBatch":

@@ -159,6 +159,9 @@ class Match:
     @property
     def query_residue_count(self) -> int:
         mol = self.hit.molecule()
+        counted = getattr(mol, "_residue_count", None)  # counted on the GPU during ingestion (ingest.PdbBatch)
+        if counted is not None:
+            return counted
         names = np.char.strip(mol._cols["residue_name"].astype("U3"))
         keep = np.isin(names, list(_COUNTED_RESIDUES))
         return len(set(mol._cols["residue_number"][keep].tolist()))
@@ -378,6 +381,9 @@ class Matcher:
         if searched and molecules:
             per_molecule = jess.query_batch(molecules, rmsd, dist, dyn, max_candidates=self.MAX_CANDIDATES,
                                             best_match=True, ignore_chain=True, models=models, batch=device_batch)
+
+        if device_batch is not None and hasattr(device_batch, "annotate"):
+            device_batch.annotate(mi for mi, hits in enumerate(per_molecule) if hits)
 
         # hits bucketed by size once; only molecules that have hits are visited below
         by_size: Dict[int, List[Tuple[int, List[pyjess.Hit]]]] = {s: [] for s in sizes}

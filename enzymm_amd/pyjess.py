@@ -691,7 +691,10 @@ class Hit:
         """Matched target atoms in template-atom order; ``transform`` maps them into the template frame."""
         mol = self._molecule
         # only the matched atoms are materialised (a full atom list would cost far more than the query)
-        picked = [mol._atoms[i] if mol._atoms is not None else mol._atom(i) for i in self._atom_index]
+        if mol._atoms is None and hasattr(mol, "_atoms_at"):  # a lazily parsed molecule: only the matched lines
+            picked = mol._atoms_at(self._atom_index)
+        else:
+            picked = [mol._atoms[i] if mol._atoms is not None else mol._atom(i) for i in self._atom_index]
         return [self._transform(a) for a in picked] if transform else [a.copy() for a in picked]
 
     def molecule(self, transform: bool = False) -> Molecule:

@@ -115,6 +115,10 @@ typedef struct tm_vocab {
     uint32_t n_residues;
     const char *residue_names;    /* [n * 3] raw residue-name fields (cols 18-20) */
     const uint8_t *residue_ids;   /* [n] */
+    /* Optional: residue names whose distinct residue numbers are counted per structure during ingestion
+     * (enzymm's Match.query_residue_count, jess_run.py:488-497); 0 / NULL: tm_batch_residue_counts is unavailable. */
+    uint32_t n_counted_residues;
+    const char *counted_residue_names; /* [n * 3] */
 } tm_vocab;
 
 enum { TM_PDB_IGNORE_ENDMDL = 1u };
@@ -171,6 +175,7 @@ int tm_batch_create_from_pdb(int device, uint32_t n_files, const char *const *te
                              const tm_vocab *vocab, uint32_t flags, double min_bfactor, tm_batch **out);
 int tm_batch_atom_counts(tm_batch *batch, uint32_t *atom_offsets);            /* [n_structures + 1] */
 int tm_batch_line_offsets(tm_batch *batch, uint32_t *out, uint64_t n);        /* byte offset of each kept record in its file */
+int tm_batch_residue_counts(tm_batch *batch, uint32_t *out);                  /* [n_structures]; TM_E_UNSUPPORTED without tm_vocab.counted_residue_names */
 void tm_batch_destroy(tm_batch *batch);
 
 /* Asynchronous on params->stream; the result owns the device-side hit table. */

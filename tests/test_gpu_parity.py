@@ -370,6 +370,14 @@ def test_run_files_equals_host_loader(tmp_path):
                         for mol, ms in res.items() for m in ms]
     assert rows(dev) == rows(host) and len(rows(host)) >= 4
     assert [m.dumps() for ms in dev.values() for m in ms] == [m.dumps() for ms in host.values() for m in ms]
+    # the rows came from the device's residue counts and the matched atoms' lines alone: no file was parsed whole
+    assert all(mol._loaded is None and mol._residue_count is not None for mol in dev)
+    buf_dev, buf_host = io.StringIO(), io.StringIO()
+    for ms_d, ms_h in zip(dev.values(), host.values()):
+        for m_d, m_h in zip(ms_d, ms_h):
+            m_d.dump2pdb(buf_dev, transform=True)
+            m_h.dump2pdb(buf_host, transform=True)
+    assert buf_dev.getvalue() == buf_host.getvalue()
 
 
 def test_fused_epilogue_matches_python_filter(amy, af):
