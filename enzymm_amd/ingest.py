@@ -119,13 +119,20 @@ class PdbBatch:
     def from_paths(cls, paths: Sequence, **kw) -> "PdbBatch":
         """Same id rule as load_molecules: the file stem, with _2, _3 ... for repeated stems."""
         import collections
+        import os
+
+        def read(p):
+            with open(p, "rb") as f:
+                return f.read()
+
+        paths = [os.fspath(p) for p in paths]
         seen = collections.Counter()
-        texts, ids = [], []
+        ids = []
         for p in paths:
-            stem = Path(p).stem
+            stem = os.path.splitext(os.path.basename(p))[0]
             seen[stem] += 1
             ids.append(stem if seen[stem] == 1 else f"{stem}_{seen[stem]}")
-            texts.append(Path(p).read_bytes())
+        texts = [read(p) for p in paths]  # (a thread pool for the reads halves the rate: the files are small)
         return cls(texts, ids, **kw)
 
     def __len__(self):
