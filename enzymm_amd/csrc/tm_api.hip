@@ -11,6 +11,7 @@
 #include <new>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <vector>
 
@@ -133,6 +134,11 @@ struct DevBuf {
         n = count;
         return DevicePool::get().acquire(need, reinterpret_cast<void **>(&p), &bytes);
     }
+    hipError_t upload_async(const T *src, size_t count, hipStream_t stream) {  // caller synchronises the stream
+        hipError_t e = alloc(count);
+        if (e != hipSuccess || count == 0) return e;
+        return hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, stream);
+    }
     // With a stream the copy is ordered on (and waited for on) that stream only; a plain hipMemcpy goes through
     // the null stream and would wait for whatever other blocking streams are running.
     hipError_t upload(const std::vector<T> &v, hipStream_t stream = nullptr) {
@@ -142,6 +148,66 @@ struct DevBuf {
         e = hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, stream);
         return e != hipSuccess ? e : hipStreamSynchronize(stream);
     }
+};
+
+// Page-locked host staging memory, recycled like device memory: tm_batch_create flattens >100 MB per thousand
+// structures, and fresh pageable vectors cost more in page faults and staged DMA than the flattening itself.
+class PinnedPool {
+  public:
+    static PinnedPool &get() {
+        static PinnedPool *pool = new PinnedPool;  // never destroyed: the HIP runtime may be gone at exit
+        return *pool;
+    }
+    hipError_t acquire(size_t bytes, void **p, size_t *granted) {
+        const size_t c = DevicePool::size_class(bytes);
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            auto it = free_.find(c);
+            if (it != free_.end()) {
+                *p = it->second;
+                *granted = c;
+                free_.erase(it);
+                cached_ -= c;
+                return hipSuccess;
+            }
+        }
+        *granted = c;
+        return hipHostMalloc(p, c, hipHostMallocDefault);
+    }
+    void release(void *p, size_t c) {
+        std::lock_guard<std::mutex> lock(mu_);
+        if (cached_ + c > kMaxCached) {
+            (void)hipHostFree(p);
+            return;
+        }
+        free_.insert({c, p});
+        cached_ += c;
+    }
+
+  private:
+    static constexpr size_t kMaxCached = size_t(2) << 30;
+    std::mutex mu_;
+    std::multimap<size_t, void *> free_;
+    size_t cached_ = 0;
+};
+
+// Owning page-locked host array (contents uninitialised).
+template <typename T>
+struct PinnedBuf {
+    T *p = nullptr;
+    size_t n = 0, bytes = 0;
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf &) = delete;
+    PinnedBuf &operator=(const PinnedBuf &) = delete;
+    ~PinnedBuf() {
+        if (p) PinnedPool::get().release(p, bytes);
+    }
+    hipError_t alloc(size_t count) {
+        n = count;
+        return PinnedPool::get().acquire(std::max<size_t>(count, 1) * sizeof(T), reinterpret_cast<void **>(&p), &bytes);
+    }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
 };
 
 // A template selection with its thresholds, staged for the search kernel (k_stage_templates).
@@ -442,6 +508,8 @@ void tm_library_destroy(tm_library *lib) {
     delete lib;
 }
 
+static hipError_t ingest_stream(int device, hipStream_t *out);
+
 int tm_batch_create(int device, const tm_batch_desc *d, tm_batch **out) {
     if (!d || !out || !d->atom_offsets ||
         (d->n_structures && d->atom_offsets[d->n_structures] && (!d->xyz || !d->res_type || !d->name_id || !d->residue)))
@@ -450,14 +518,16 @@ int tm_batch_create(int device, const tm_batch_desc *d, tm_batch **out) {
     HIP_TRY(hipSetDevice(device));
     const uint32_t ns = d->n_structures;
     const uint32_t na = d->atom_offsets[ns];
-    std::vector<double> xyz(3 * (size_t)na);
-    std::vector<float4> rec(na);
-    std::vector<uint8_t> chain(na);
-    std::vector<uint32_t> orig(na), s_roff(ns + 1, 0);
-    std::vector<uint16_t> res_start;
+    PinnedBuf<double> xyz;
+    PinnedBuf<float4> rec;
+    PinnedBuf<uint8_t> chain;
+    PinnedBuf<uint32_t> orig;
+    PinnedBuf<uint16_t> res_start;
+    HIP_TRY(xyz.alloc(3 * (size_t)na)); HIP_TRY(rec.alloc(na)); HIP_TRY(chain.alloc(na)); HIP_TRY(orig.alloc(na));
+    std::vector<uint32_t> s_roff(ns + 1, 0), nres_of(ns, 0);
     uint32_t max_atoms = 0, max_res = 0;
-    std::vector<uint32_t> count, perm;
 
+    // pass 1: limits and residue counts (they fix where every structure's residue table starts)
     for (uint32_t s = 0; s < ns; ++s) {
         const uint32_t o = d->atom_offsets[s], n = d->atom_offsets[s + 1] - o;
         if (n > TM_MAX_STRUCTURE_ATOMS)
@@ -468,41 +538,67 @@ int tm_batch_create(int device, const tm_batch_desc *d, tm_batch **out) {
         if (nres > TM_MAX_STRUCTURE_RESIDUES)
             return fail(TM_E_UNSUPPORTED, "structure " + std::to_string(s) + " has more than " +
                                               std::to_string(TM_MAX_STRUCTURE_RESIDUES) + " residues");
-        // counting sort by residue ordinal: atoms of a residue become contiguous, file order kept inside
-        count.assign(nres + 1, 0);
-        for (uint32_t i = 0; i < n; ++i) count[d->residue[o + i] + 1]++;
-        for (uint32_t r = 0; r < nres; ++r) count[r + 1] += count[r];
-        s_roff[s] = (uint32_t)res_start.size();
-        for (uint32_t r = 0; r <= nres; ++r) res_start.push_back((uint16_t)count[r]);
-        perm.assign(n, 0);
-        {
-            std::vector<uint32_t> fill(count.begin(), count.end() - 1);
-            for (uint32_t i = 0; i < n; ++i) perm[fill[d->residue[o + i]]++] = i;
-        }
-        double c[3] = {0, 0, 0};
-        for (uint32_t i = 0; i < n; ++i)
-            for (int a = 0; a < 3; ++a) c[a] += d->xyz[3 * (size_t)(o + i) + a];
-        if (n)
-            for (int a = 0; a < 3; ++a) c[a] /= (double)n;
-        for (uint32_t j = 0; j < n; ++j) {
-            const uint32_t src = o + perm[j], dst = o + j;
-            for (int a = 0; a < 3; ++a) xyz[3 * (size_t)dst + a] = d->xyz[3 * (size_t)src + a];
-            float4 r;
-            r.x = (float)(d->xyz[3 * (size_t)src] - c[0]);
-            r.y = (float)(d->xyz[3 * (size_t)src + 1] - c[1]);
-            r.z = (float)(d->xyz[3 * (size_t)src + 2] - c[2]);
-            const uint32_t nm = std::min<uint32_t>(d->name_id[src], TM_NAME_OTHER);
-            const uint32_t rt = std::min<uint32_t>(d->res_type[src], TM_RES_OTHER);
-            const uint32_t m = meta_pack(d->residue[src], nm, rt);
-            std::memcpy(&r.w, &m, 4);
-            rec[dst] = r;
-            chain[dst] = d->chain ? d->chain[src] : 0;
-            orig[dst] = perm[j];
-        }
+        nres_of[s] = nres;
+        s_roff[s + 1] = s_roff[s] + nres + 1;
         max_atoms = std::max(max_atoms, n);
         max_res = std::max(max_res, nres);
     }
-    s_roff[ns] = (uint32_t)res_start.size();
+    HIP_TRY(res_start.alloc(s_roff[ns]));
+
+    // pass 2: the structures are independent; a small team of threads flattens them
+    auto flatten = [&](uint32_t s_begin, uint32_t s_end) {
+        std::vector<uint32_t> count, perm, fill;
+        for (uint32_t s = s_begin; s < s_end; ++s) {
+            const uint32_t o = d->atom_offsets[s], n = d->atom_offsets[s + 1] - o, nres = nres_of[s];
+            // counting sort by residue ordinal: atoms of a residue become contiguous, file order kept inside
+            count.assign(nres + 1, 0);
+            for (uint32_t i = 0; i < n; ++i) count[d->residue[o + i] + 1]++;
+            for (uint32_t r = 0; r < nres; ++r) count[r + 1] += count[r];
+            for (uint32_t r = 0; r <= nres; ++r) res_start[s_roff[s] + r] = (uint16_t)count[r];
+            perm.assign(n, 0);
+            fill.assign(count.begin(), count.end() - 1);
+            for (uint32_t i = 0; i < n; ++i) perm[fill[d->residue[o + i]]++] = i;
+            double c[3] = {0, 0, 0};
+            for (uint32_t i = 0; i < n; ++i)
+                for (int a = 0; a < 3; ++a) c[a] += d->xyz[3 * (size_t)(o + i) + a];
+            if (n)
+                for (int a = 0; a < 3; ++a) c[a] /= (double)n;
+            for (uint32_t j = 0; j < n; ++j) {
+                const uint32_t src = o + perm[j], dst = o + j;
+                for (int a = 0; a < 3; ++a) xyz[3 * (size_t)dst + a] = d->xyz[3 * (size_t)src + a];
+                float4 r;
+                r.x = (float)(d->xyz[3 * (size_t)src] - c[0]);
+                r.y = (float)(d->xyz[3 * (size_t)src + 1] - c[1]);
+                r.z = (float)(d->xyz[3 * (size_t)src + 2] - c[2]);
+                const uint32_t nm = std::min<uint32_t>(d->name_id[src], TM_NAME_OTHER);
+                const uint32_t rt = std::min<uint32_t>(d->res_type[src], TM_RES_OTHER);
+                const uint32_t m = meta_pack(d->residue[src], nm, rt);
+                std::memcpy(&r.w, &m, 4);
+                rec[dst] = r;
+                chain[dst] = d->chain ? d->chain[src] : 0;
+                orig[dst] = perm[j];
+            }
+        }
+    };
+    {
+        const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
+        const uint32_t team = std::min<uint32_t>({hw, 16u, std::max(1u, na / 65536u)});  // ~64 k atoms per thread at least
+        if (team <= 1) {
+            flatten(0, ns);
+        } else {
+            // contiguous slices of structures with about the same number of atoms each
+            std::vector<std::thread> workers;
+            uint32_t s0 = 0;
+            for (uint32_t t = 0; t < team; ++t) {
+                const uint64_t target = (uint64_t)na * (t + 1) / team;
+                uint32_t s1 = s0;
+                while (s1 < ns && (t + 1 == team || d->atom_offsets[s1 + 1] <= target)) ++s1;
+                if (s1 > s0) workers.emplace_back(flatten, s0, s1);
+                s0 = s1;
+            }
+            for (auto &w : workers) w.join();
+        }
+    }
 
     tm_batch *b = new (std::nothrow) tm_batch;
     if (!b) return fail(TM_E_NOMEM, "out of host memory");
@@ -511,9 +607,14 @@ int tm_batch_create(int device, const tm_batch_desc *d, tm_batch **out) {
     b->s_off.assign(d->atom_offsets, d->atom_offsets + ns + 1);
     hipError_t e = hipSuccess;
     auto up = [&](hipError_t r) { if (e == hipSuccess) e = r; };
-    up(b->d_s_off.upload(b->s_off)); up(b->d_s_roff.upload(s_roff)); up(b->d_xyz.upload(xyz));
-    up(b->d_rec.upload(rec)); up(b->d_chain.upload(chain)); up(b->d_orig.upload(orig));
-    up(b->d_res_start.upload(res_start)); up(b->d_cursor.alloc(1)); up(b->d_overflow.alloc(1));
+    hipStream_t stream = nullptr;
+    up(ingest_stream(device, &stream));
+    up(b->d_xyz.upload_async(xyz.p, xyz.n, stream)); up(b->d_rec.upload_async(rec.p, rec.n, stream));
+    up(b->d_chain.upload_async(chain.p, chain.n, stream)); up(b->d_orig.upload_async(orig.p, orig.n, stream));
+    up(b->d_res_start.upload_async(res_start.p, res_start.n, stream));
+    up(b->d_s_off.upload(b->s_off, stream)); up(b->d_s_roff.upload(s_roff, stream));  // these also wait for the stream
+    up(b->d_cursor.alloc(1)); up(b->d_overflow.alloc(1));
+    if (e == hipSuccess && stream) up(hipStreamSynchronize(stream));
     if (e != hipSuccess) {
         delete b;
         return fail(TM_E_DEVICE, std::string("tm_batch_create upload: ") + hipGetErrorString(e));
