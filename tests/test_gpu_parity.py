@@ -280,6 +280,34 @@ def test_large_structure_global_memory_path(af, default_library):
     compare(table, cands, 0, r, sub)
 
 
+def test_structure_near_the_atom_limit(af, default_library):
+    """16 copies of a 4079-atom chain = 65 264 atoms, just under TM_MAX_STRUCTURE_ATOMS: u16 atom indices and
+    residue tables at their upper end, kind lists of thousands of entries, work items cut into many rounds."""
+    jess, olib, idx, cut = default_library
+    cols = {k: np.concatenate([v] * 16) for k, v in af._cols.items()}
+    xyz = np.concatenate([af._xyz + np.array([70.0 * (c % 4), 70.0 * (c // 4), 0.0]) for c in range(16)])
+    cols["chain_id"] = np.concatenate([np.full(len(af), (" " + "ABCDEFGHIJKLMNOP"[c]).encode(), dtype="S2")
+                                       for c in range(16)])
+    big = pyjess.Molecule.__new__(pyjess.Molecule)
+    big._init_columns(cols, xyz, "AFx16")
+    assert len(big) == 16 * 4079 <= _native.TM_MAX_STRUCTURE_ATOMS
+    sel = np.arange(3, len(idx), 41)
+    sub = oracle.OracleLibrary([olib.templates[i] for i in sel])
+    small = synthetic.structure(3)
+    table, cands = jess.query_batch([small, big], 2.0, cut[sel], cut[sel], max_candidates=10000, ignore_chain=True,
+                                    template_index=idx[sel], count_candidates=True, return_raw=True)
+    for s, mol in enumerate((small, big)):
+        r = oracle.query_library(helpers.to_oracle_molecule(mol), sub, 2.0, cut[sel], cut[sel], max_candidates=10000,
+                                 ignore_chain=True)
+        n = compare(table, cands, s, r, sub)
+    assert n >= 1
+    with pytest.raises(_native.NativeError):  # one atom too many is refused, not truncated
+        extra = {k: np.concatenate([v, v[: 65536 - len(big)]]) for k, v in cols.items()}
+        over = pyjess.Molecule.__new__(pyjess.Molecule)
+        over._init_columns(extra, np.concatenate([xyz, xyz[: 65536 - len(big)]]), "too_big")
+        jess.query_batch([over], 2.0, cut[sel], cut[sel], template_index=idx[sel])
+
+
 def test_edge_cases(amy):
     tpl = template.Template.load(TPL / G["G1"]["template"])
     jess = pyjess.Jess([tpl])
