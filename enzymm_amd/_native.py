@@ -83,7 +83,7 @@ EXPORTS = (
     "tm_batch_residue_counts",
     "tm_batch_destroy", "tm_query", "tm_result_wait", "tm_result_needed", "tm_result_hit_count",
     "tm_result_copy_hits", "tm_result_copy_candidates", "tm_result_timing", "tm_result_device_hits",
-    "tm_result_destroy",
+    "tm_result_destroy", "tm_pdb_count_host", "tm_pdb_parse_host",
 )
 
 _lock = threading.Lock()
@@ -128,6 +128,46 @@ def _ptr(a):
 
 def _arr(a, dtype):
     return np.ascontiguousarray(a, dtype=dtype)
+
+
+class _PdbColumns(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "serial", "name", "altloc", "residue_name", "chain_id", "residue_number", "insertion_code", "xyz",
+        "occupancy", "temperature_factor", "segment", "element", "charge")]
+
+
+_PDB_COLUMN_DTYPES = (
+    ("serial", "<i4"), ("name", "S4"), ("altloc", "S1"), ("residue_name", "S3"), ("chain_id", "S2"),
+    ("residue_number", "<i4"), ("insertion_code", "S1"), ("occupancy", "<f8"), ("temperature_factor", "<f8"),
+    ("segment", "S4"), ("element", "S2"), ("charge", "i1"),
+)
+
+
+def parse_pdb_host(data: bytes, ignore_endmdl: bool = False):
+    """One PDB file -> (columns, xyz, HEADER idCode) with the native host reader (``tm_pdb_parse_host``).
+    Raises ValueError quoting the offending record, like a line-by-line parse would."""
+    lib = load()
+    flags = C.c_uint32(TM_PDB_IGNORE_ENDMDL if ignore_endmdl else 0)
+    n = C.c_uint64(0)
+    head = C.create_string_buffer(4)
+    has_head = C.c_int(0)
+    _check(lib.tm_pdb_count_host(data, C.c_uint64(len(data)), flags, C.byref(n), head, C.byref(has_head)))
+    n = n.value
+    cols = {k: np.zeros(n, dtype=dt) for k, dt in _PDB_COLUMN_DTYPES}
+    xyz = np.zeros((n, 3), dtype=np.float64)
+    header_id = None
+    if has_head.value:
+        header_id = head.raw.decode("ascii", "replace").strip() or None
+    if n:
+        out = _PdbColumns(**{k: _ptr(cols[k]) for k, _ in _PDB_COLUMN_DTYPES}, xyz=_ptr(xyz))
+        bad_begin, bad_len = C.c_uint64(0), C.c_uint64(0)
+        rc = lib.tm_pdb_parse_host(data, C.c_uint64(len(data)), flags, C.c_uint64(n), C.byref(out),
+                                   C.byref(bad_begin), C.byref(bad_len))
+        if rc == TM_E_INVALID and (lib.tm_last_error() or b"") == b"malformed PDB record":
+            line = data[bad_begin.value: bad_begin.value + min(bad_len.value, 80)]
+            raise ValueError(f"malformed PDB record: {line.decode('ascii', 'replace').rstrip()!r}")
+        _check(rc)
+    return cols, xyz, header_id
 
 
 def device_count() -> int:

@@ -1154,3 +1154,159 @@ void tm_result_destroy(tm_result *r) {
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------- host-side PDB reader
+
+namespace {
+
+struct PdbLine {
+    const char *p;   // start of the line
+    uint32_t len;    // without the line terminator(s)
+};
+
+// Calls f(line) for every line; stops when f returns false.
+template <class F>
+void for_each_line(const char *text, uint64_t length, F &&f) {
+    uint64_t i = 0;
+    while (i < length) {
+        const char *nl = static_cast<const char *>(std::memchr(text + i, '\n', length - i));
+        const uint64_t end = nl ? (uint64_t)(nl - text) : length;
+        uint64_t len = end - i;
+        if (len > 0 && text[end - 1] == '\r') --len;
+        if (!f(PdbLine{text + i, (uint32_t)std::min<uint64_t>(len, 0xffffffffu)})) return;
+        i = end + 1;
+    }
+}
+
+inline bool tag_is(const PdbLine &l, const char *tag6) {
+    for (int k = 0; k < 6; ++k) {
+        const char c = (uint32_t)k < l.len ? l.p[k] : ' ';
+        if (c != tag6[k]) return false;
+    }
+    return true;
+}
+
+// One decimal field of `width` <= 8 columns starting at column `lo` (columns past the end of the line are
+// blanks): [spaces][sign]digits[.digits][spaces].  value = mantissa / 10^frac, both exact, so the quotient
+// is the correctly rounded double.
+inline bool parse_field(const PdbLine &l, int lo, int width, bool blank_ok, bool integer, long long *mant_out,
+                        int *frac_out) {
+    long long mant = 0;
+    int frac = 0, ndig = 0;
+    bool seen_dot = false, started = false, ended = false, neg = false, bad = false;
+    for (int k = 0; k < width; ++k) {
+        const unsigned char c = (uint32_t)(lo + k) < l.len ? (unsigned char)l.p[lo + k] : ' ';
+        const bool is_d = c >= '0' && c <= '9', is_dot = c == '.', is_sign = c == '-' || c == '+', is_sp = c == ' ';
+        bad |= !(is_d || is_dot || is_sign || is_sp);
+        bad |= ended && !is_sp;
+        bad |= is_sign && started;
+        bad |= is_dot && seen_dot;
+        ended |= started && is_sp;
+        if (is_d) {
+            mant = (long long)((unsigned long long)mant * 10ull + (unsigned long long)(c - '0'));
+            frac += seen_dot ? 1 : 0;
+            ++ndig;
+        }
+        neg |= c == '-';
+        seen_dot |= is_dot;
+        started |= is_d || is_dot || is_sign;
+    }
+    *mant_out = neg ? -mant : mant;
+    *frac_out = frac;
+    return !bad && ndig <= 18 && (ndig > 0 || (!started && blank_ok)) && !(integer && seen_dot);
+}
+
+const double kPow10[19] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16,
+                           1e17, 1e18};
+
+inline char col(const PdbLine &l, int k) { return (uint32_t)k < l.len ? l.p[k] : ' '; }
+
+inline bool is_strip_space(char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f'; }
+
+// columns [lo, hi) stripped of surrounding whitespace, left-aligned, NUL padded (numpy.char.strip into an S field)
+inline void stripped(const PdbLine &l, int lo, int hi, char *out) {
+    int a = lo, b = hi;
+    while (a < b && is_strip_space(col(l, a))) ++a;
+    while (b > a && is_strip_space(col(l, b - 1))) --b;
+    int n = 0;
+    for (int k = a; k < b; ++k) out[n++] = col(l, k);
+    for (; n < hi - lo; ++n) out[n] = '\0';
+}
+
+}  // namespace
+
+extern "C" {
+
+int tm_pdb_count_host(const char *text, uint64_t length, uint32_t flags, uint64_t *n_atoms, char header_id[4],
+                      int *has_header) {
+    if ((!text && length) || !n_atoms) return fail(TM_E_INVALID, "tm_pdb_count_host: NULL argument");
+    uint64_t n = 0;
+    bool open = true, header = false;
+    for_each_line(text, length, [&](const PdbLine &l) {
+        if (open && (tag_is(l, "ATOM  ") || tag_is(l, "HETATM"))) ++n;
+        else if (open && !(flags & TM_PDB_IGNORE_ENDMDL) && tag_is(l, "ENDMDL")) open = false;
+        else if (!header && tag_is(l, "HEADER")) {
+            header = true;
+            if (has_header) *has_header = l.len >= 66 ? 1 : 0;
+            if (header_id && l.len >= 66) std::memcpy(header_id, l.p + 62, 4);
+        }
+        return open || !header;  // nothing left to learn once the model is closed and the header seen
+    });
+    if (!header && has_header) *has_header = 0;
+    *n_atoms = n;
+    return TM_OK;
+}
+
+int tm_pdb_parse_host(const char *text, uint64_t length, uint32_t flags, uint64_t capacity, const tm_pdb_columns *out,
+                      uint64_t *bad_begin, uint64_t *bad_length) {
+    if ((!text && length) || !out) return fail(TM_E_INVALID, "tm_pdb_parse_host: NULL argument");
+    // error precedence of the vectorised reference implementation: the first record shorter than 54 columns;
+    // otherwise, field by field (serial, resSeq, x, y, z, occupancy, tempFactor), the first record whose field
+    // is malformed
+    const PdbLine none{nullptr, 0};
+    PdbLine short_line = none, bad_field[7] = {none, none, none, none, none, none, none};
+    static const int lo[7] = {6, 22, 30, 38, 46, 54, 60}, width[7] = {5, 4, 8, 8, 8, 6, 6};
+    uint64_t n = 0;
+    bool overflow = false;
+    for_each_line(text, length, [&](const PdbLine &l) {
+        if (!(flags & TM_PDB_IGNORE_ENDMDL) && tag_is(l, "ENDMDL")) return false;
+        if (!(tag_is(l, "ATOM  ") || tag_is(l, "HETATM"))) return true;
+        if (n >= capacity) { overflow = true; return false; }
+        if (l.len < 54) {
+            if (!short_line.p) short_line = l;
+            ++n;
+            return true;
+        }
+        long long mant[7];
+        int frac[7];
+        for (int f = 0; f < 7; ++f)
+            if (!parse_field(l, lo[f], width[f], f >= 5, f < 2, &mant[f], &frac[f]) && !bad_field[f].p) bad_field[f] = l;
+        out->serial[n] = (int32_t)mant[0];
+        out->residue_number[n] = (int32_t)mant[1];
+        for (int a = 0; a < 3; ++a) out->xyz[3 * n + a] = (double)mant[2 + a] / kPow10[std::min(frac[2 + a], 18)];
+        out->occupancy[n] = (double)mant[5] / kPow10[std::min(frac[5], 18)];
+        out->temperature_factor[n] = (double)mant[6] / kPow10[std::min(frac[6], 18)];
+        for (int k = 0; k < 4; ++k) out->name[4 * n + k] = col(l, 12 + k);
+        out->altloc[n] = col(l, 16);
+        for (int k = 0; k < 3; ++k) out->residue_name[3 * n + k] = col(l, 17 + k);
+        for (int k = 0; k < 2; ++k) out->chain_id[2 * n + k] = col(l, 20 + k);
+        out->insertion_code[n] = col(l, 26);
+        stripped(l, 72, 76, out->segment + 4 * n);
+        stripped(l, 76, 78, out->element + 2 * n);
+        const char digit = col(l, 78), sign = col(l, 79);
+        out->charge[n] = (digit >= '0' && digit <= '9') ? (int8_t)((digit - '0') * (sign == '-' ? -1 : 1)) : (int8_t)0;
+        ++n;
+        return true;
+    });
+    if (overflow) return fail(TM_E_INVALID, "tm_pdb_parse_host: more records than capacity");
+    PdbLine bad = short_line;
+    for (int f = 0; f < 7 && !bad.p; ++f) bad = bad_field[f];
+    if (bad.p) {
+        if (bad_begin) *bad_begin = (uint64_t)(bad.p - text);
+        if (bad_length) *bad_length = bad.len;
+        return fail(TM_E_INVALID, "malformed PDB record");
+    }
+    return TM_OK;
+}
+
+}  // extern "C"

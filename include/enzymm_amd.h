@@ -190,6 +190,32 @@ int tm_result_timing(tm_result *res, float *index_ms, float *search_ms, float *f
 const void *tm_result_device_hits(tm_result *res);           /* device pointer to the unsorted tm_hit table */
 void tm_result_destroy(tm_result *res);
 
+/* ---- host-side PDB reader (no GPU involved) -----------------------------------------------------------
+ * The atom table pyjess.Molecule.load builds for ONE file (enzymm/jess_run.py:538): ATOM/HETATM records up to
+ * the first ENDMDL, fixed columns, decimal fields converted exactly.  Two calls: count, then fill the caller's
+ * arrays.  A malformed record (shorter than 54 columns, or a numeric field that is not [spaces][sign]digits
+ * [.digits][spaces]) gives TM_E_INVALID with the offending line's byte range in *bad_begin / *bad_length. */
+typedef struct tm_pdb_columns {
+    int32_t *serial;            /* [n] */
+    char *name;                 /* [n * 4] cols 13-16, raw */
+    char *altloc;               /* [n] */
+    char *residue_name;         /* [n * 3] */
+    char *chain_id;             /* [n * 2] cols 21-22 */
+    int32_t *residue_number;    /* [n] */
+    char *insertion_code;       /* [n] */
+    double *xyz;                /* [n * 3] */
+    double *occupancy;          /* [n] blank = 0 */
+    double *temperature_factor; /* [n] blank = 0 */
+    char *segment;              /* [n * 4] cols 73-76, stripped, NUL padded */
+    char *element;              /* [n * 2] cols 77-78, stripped, NUL padded */
+    int8_t *charge;             /* [n] cols 79-80 */
+} tm_pdb_columns;
+
+int tm_pdb_count_host(const char *text, uint64_t length, uint32_t flags, uint64_t *n_atoms, char header_id[4],
+                      int *has_header);
+int tm_pdb_parse_host(const char *text, uint64_t length, uint32_t flags, uint64_t capacity, const tm_pdb_columns *out,
+                      uint64_t *bad_begin, uint64_t *bad_length);
+
 #ifdef __cplusplus
 }
 #endif

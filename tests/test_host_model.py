@@ -241,3 +241,53 @@ def test_library_pack_round_trip(tmp_path, monkeypatch):
         assert np.array_equal(np.asarray(a), np.asarray(b).reshape(np.asarray(a).shape))
     with pytest.raises(ValueError):
         library_pack.PackedTemplates(helpers.GOLDEN / "1AMY.pdb")
+
+
+def test_native_pdb_reader_equals_numpy_reference():
+    """tm_pdb_parse_host against the vectorised numpy reader it replaced: same columns on the fixtures, and on
+    randomly damaged records either the same table or the same ValueError (same offending line quoted)."""
+    import numpy as np
+    from enzymm_amd import pyjess
+
+    def outcome(fn, data, ignore):
+        try:
+            cols, xyz, head = fn(data, ignore)
+        except ValueError as exc:
+            return ("error", str(exc))
+        return ("ok", head, xyz.tobytes(), tuple((k, v.dtype.str, v.tobytes()) for k, v in cols.items()))
+
+    base = (helpers.GOLDEN / "1AMY.pdb").read_bytes()
+    for ignore in (False, True):
+        assert outcome(pyjess._parse_pdb_bytes, base, ignore) == outcome(pyjess._parse_pdb_bytes_numpy, base, ignore)
+    lines = base.split(b"\n")
+    atom_rows = [i for i, l in enumerate(lines) if l.startswith((b"ATOM", b"HETATM"))]
+    rng = np.random.default_rng(5)
+    alphabet = b" 0123456789.-+AxZ\t\r"
+    errors = 0
+    for trial in range(300):
+        work = list(lines[: atom_rows[0] + 300])  # header + a few hundred records: enough, and quick
+        for _ in range(int(rng.integers(1, 4))):
+            i = int(rng.choice([r for r in atom_rows if r < atom_rows[0] + 300]))
+            line = bytearray(work[i])
+            kind = int(rng.integers(0, 5))
+            if kind == 0 and line:      # overwrite a byte anywhere in the fixed columns
+                line[int(rng.integers(0, len(line)))] = alphabet[int(rng.integers(0, len(alphabet)))]
+            elif kind == 1:             # truncate
+                line = line[: int(rng.integers(0, 70))]
+            elif kind == 2:             # blank a numeric field
+                lo, hi = [(6, 11), (22, 26), (30, 38), (38, 46), (46, 54), (54, 60), (60, 66)][int(rng.integers(0, 7))]
+                line[lo:hi] = b" " * (hi - lo)
+            elif kind == 3:             # an ENDMDL / HEADER line in the middle
+                work.insert(i, [b"ENDMDL", b"HEADER    HYDROLASE" + b" " * 43 + b"9XYZ", b"HEADER short"][int(rng.integers(0, 3))])
+            else:                       # CRLF ending
+                line += b"\r"
+            if kind != 3:
+                work[i] = bytes(line)
+        data = b"\n".join(work) + (b"\n" if trial % 2 else b"")
+        for ignore in (False, True):
+            a, b = outcome(pyjess._parse_pdb_bytes, data, ignore), outcome(pyjess._parse_pdb_bytes_numpy, data, ignore)
+            assert a == b, (trial, ignore, a[:2], b[:2])
+            errors += a[0] == "error"
+    assert errors > 50  # the damage does produce malformed records
+    for data in (b"", b"\n", b"ATOM", b"END\n", b"HEADER" + b" " * 56 + b"1ABC\n"):
+        assert outcome(pyjess._parse_pdb_bytes, data, False) == outcome(pyjess._parse_pdb_bytes_numpy, data, False)
