@@ -44,6 +44,44 @@ def load_library():
     return templates, idx, cut
 
 
+def reference_baseline(molecules, idx, cut, target_seconds):
+    """PyJess itself, if this host happens to have it (it is not in the image this repo is built in): the
+    reference's own call, jess_run.py:800-811, one Jess per distinct threshold, threads over structures.
+    Returns None when PyJess is absent or its API is not what enzymm 's pyproject pins."""
+    try:
+        import importlib
+        from concurrent.futures import ThreadPoolExecutor
+        real = importlib.import_module("pyjess")
+        if "enzymm_amd" in (getattr(real, "__file__", "") or ""):
+            return None
+        from enzymm_amd import synthetic
+        from oracle import parse
+        texts = parse.read_packed_library(ROOT / "enzymm_amd" / "data" / "jess_templates_20230210.txt.gz")
+        by_cut = {}
+        for i, c in zip(idx, cut):
+            by_cut.setdefault(float(c), []).append(real.Template.loads(texts[i][1], id=str(i)))
+        engines = [(c, real.Jess(tpls)) for c, tpls in by_cut.items()]
+        cores = len(os.sched_getaffinity(0))
+
+        def one(mol):
+            m = real.Molecule.loads(synthetic.to_pdb(mol))
+            return sum(len(list(j.query(m, 2.0, c, c, max_candidates=10000, best_match=True, ignore_chain=True)))
+                       for c, j in engines)
+
+        done, t0 = 0, time.perf_counter()
+        with ThreadPoolExecutor(cores) as pool:
+            while done < len(molecules) and time.perf_counter() - t0 < target_seconds:
+                chunk = molecules[done: done + cores]
+                list(pool.map(one, chunk))
+                done += len(chunk)
+        dt = time.perf_counter() - t0
+        return dict(value=done / dt, unit="structures/s", cores=cores, kind="reference",
+                    sample=f"first {done} structures of the bench batch vs the same 6780 templates, "
+                           f"pyjess {getattr(real, '__version__', '?')} Jess.query on {cores} threads ({dt:.1f} s)")
+    except Exception:  # absent, or not the API of pyjess ~= 0.5
+        return None
+
+
 def cpu_baseline(molecules, idx, cut, target_seconds):
     """Oracle (CPU restatement, NOT PyJess) timed on this host's cores, bounded sample."""
     from enzymm_amd import synthetic
@@ -158,11 +196,11 @@ def main():
     if rank == 0:
         total_structs = args.structures * world
         ms_per_step = 1e3 * elapsed / args.steps
-        # algorithmic HBM bytes of ONE search launch on this rank (DESIGN.md "Measurement"):
-        # 16 B per target atom + 224 B per hit + the template library read once per batch
-        lib_atoms = int(packed.offsets[-1])
-        lib_bytes = lib_atoms * (24 + 8 + 2 + 3) + len(idx) * 276 * 8
-        algo_bytes = n_atoms * 16 + hit_total * 224 + lib_bytes
+        # algorithmic HBM bytes of ONE search launch on this rank, SURVEY.md 8(d)'s per-unit figure x the units of
+        # the launch: 16 B per target atom + 128 B per hit + the template library (98 808 atoms x 16 B + 659 760 pair
+        # distances x 4 B = 4.2 MB) read once per batch -- about 44 KB per 2 350-atom structure in a batch of 1000
+        lib_bytes = 98808 * 16 + 659760 * 4
+        algo_bytes = n_atoms * 16 + hit_total * 128 + lib_bytes
         k_ms = float(np.mean(search_ms))
         achieved = algo_bytes / (k_ms * 1e-3) / 1e9
         # HBM traffic of one k_search launch from the committed PMC passes of this workload (rocprofv3 cannot run
@@ -199,7 +237,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             base, oracle_results = cpu_baseline(molecules, idx, cut, args.cpu_baseline_seconds)
-            out["cpu_baseline"] = base
+            ref = reference_baseline(molecules, idx, cut, args.cpu_baseline_seconds)  # None: PyJess not on this host
+            out["cpu_baseline"] = ref if ref is not None else base
+            if ref is not None:
+                out["cpu_baseline_port"] = base
             # the sample doubles as a parity check of the timed GPU output
             mism = 0
             for s, r in enumerate(oracle_results):
