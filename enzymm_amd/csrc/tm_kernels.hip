@@ -20,11 +20,12 @@ namespace tmx {
 #ifdef TM_STATS
 // diagnostic build only: [0..23] chunk evaluations per level, [24..47] survivors per level,
 // [48] complete assignments, [49] searches, [50] pair tests (j-loop trips), [51] fp64 rejects,
-// [52] joint-scan tiles, [53] joint-scan survivors
+// [52] joint-scan tiles, [53] joint-scan survivors, [55] workgroups, [56] workgroups with their kind lists in LDS,
+// [57] kind-list entries of their structures
 __device__ unsigned long long g_stats[64];
 #define TM_STAT(i, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_stats[i], (unsigned long long)(v)); } while (0)
-// [54] searches with >= 1 joint-scan survivor.  Ablation (diagnostic build only): query flag bit 8 skips the
-// subtrees below the joint scan, bit 9 skips the joint scan too (template staging only).
+// Ablation (diagnostic and timing builds): query flag bit 8 (0x100) drops the pair-scan survivors, bit 9 (0x200)
+// skips the search after template staging, bit 10 (0x400) drops the triple-scan survivors.
 #else
 #define TM_STAT(i, v) do { } while (0)
 #endif
