@@ -83,7 +83,8 @@ EXPORTS = (
     "tm_batch_residue_counts",
     "tm_batch_destroy", "tm_query", "tm_result_wait", "tm_result_needed", "tm_result_hit_count",
     "tm_result_copy_hits", "tm_result_copy_candidates", "tm_result_timing", "tm_result_device_hits",
-    "tm_result_destroy", "tm_pdb_count_host", "tm_pdb_parse_host",
+    "tm_result_destroy", "tm_pdb_count_host", "tm_pdb_parse_host", "tm_pdb_count_host_many",
+    "tm_pdb_parse_host_many",
 )
 
 _lock = threading.Lock()
@@ -168,6 +169,45 @@ def parse_pdb_host(data: bytes, ignore_endmdl: bool = False):
             raise ValueError(f"malformed PDB record: {line.decode('ascii', 'replace').rstrip()!r}")
         _check(rc)
     return cols, xyz, header_id
+
+
+def parse_pdb_host_many(datas, ignore_endmdl: bool = False):
+    """Many PDB files -> [(columns, xyz, HEADER idCode), ...] in two native calls that parse on a team of host
+    threads (``tm_pdb_parse_host_many``); the per-file tables are views into shared arrays.  Raises the
+    ValueError of the first malformed file, like the sequential loop would."""
+    lib = load()
+    nf = len(datas)
+    if nf == 0:
+        return []
+    flags = C.c_uint32(TM_PDB_IGNORE_ENDMDL if ignore_endmdl else 0)
+    ptrs = (C.c_char_p * nf)(*datas)
+    lens = (C.c_uint64 * nf)(*[len(d) for d in datas])
+    counts = np.zeros(nf, dtype=np.uint64)
+    heads = np.zeros(nf, dtype="S4")
+    head_raw = C.create_string_buffer(4 * nf)
+    has_head = np.zeros(nf, dtype=np.int32)
+    _check(lib.tm_pdb_count_host_many(C.c_uint32(nf), ptrs, lens, flags, _ptr(counts), head_raw, _ptr(has_head)))
+    offsets = np.zeros(nf + 1, dtype=np.uint64)
+    np.cumsum(counts, out=offsets[1:])
+    n = int(offsets[-1])
+    cols = {k: np.zeros(n, dtype=dt) for k, dt in _PDB_COLUMN_DTYPES}
+    xyz = np.zeros((n, 3), dtype=np.float64)
+    out = _PdbColumns(**{k: _ptr(cols[k]) for k, _ in _PDB_COLUMN_DTYPES}, xyz=_ptr(xyz))
+    bad_file, bad_begin, bad_len = C.c_int64(-1), C.c_uint64(0), C.c_uint64(0)
+    rc = lib.tm_pdb_parse_host_many(C.c_uint32(nf), ptrs, lens, flags, _ptr(offsets), C.byref(out), C.byref(bad_file),
+                                    C.byref(bad_begin), C.byref(bad_len))
+    if rc == TM_E_INVALID and bad_file.value >= 0:
+        data = datas[bad_file.value]
+        line = data[bad_begin.value: bad_begin.value + min(bad_len.value, 80)]
+        raise ValueError(f"malformed PDB record: {line.decode('ascii', 'replace').rstrip()!r}")
+    _check(rc)
+    raw = head_raw.raw
+    result = []
+    for f in range(nf):
+        lo, hi = int(offsets[f]), int(offsets[f + 1])
+        header_id = (raw[4 * f: 4 * f + 4].decode("ascii", "replace").strip() or None) if has_head[f] else None
+        result.append(({k: v[lo:hi] for k, v in cols.items()}, xyz[lo:hi], header_id))
+    return result
 
 
 def device_count() -> int:

@@ -1310,3 +1310,72 @@ int tm_pdb_parse_host(const char *text, uint64_t length, uint32_t flags, uint64_
 }
 
 }  // extern "C"
+
+namespace {
+
+// Runs f(i) for i in [0, n) on a team of host threads (contiguous slices, at least `grain` items each).
+template <class F>
+void parallel_for(uint32_t n, uint32_t grain, F &&f) {
+    const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
+    const uint32_t team = std::min<uint32_t>({hw, 16u, std::max(1u, n / std::max(1u, grain))});
+    if (team <= 1) {
+        for (uint32_t i = 0; i < n; ++i) f(i);
+        return;
+    }
+    std::vector<std::thread> workers;
+    for (uint32_t t = 0; t < team; ++t) {
+        const uint32_t lo = (uint32_t)((uint64_t)n * t / team), hi = (uint32_t)((uint64_t)n * (t + 1) / team);
+        workers.emplace_back([&f, lo, hi] { for (uint32_t i = lo; i < hi; ++i) f(i); });
+    }
+    for (auto &w : workers) w.join();
+}
+
+tm_pdb_columns columns_at(const tm_pdb_columns &c, uint64_t o) {
+    tm_pdb_columns r;
+    r.serial = c.serial + o; r.name = c.name + 4 * o; r.altloc = c.altloc + o; r.residue_name = c.residue_name + 3 * o;
+    r.chain_id = c.chain_id + 2 * o; r.residue_number = c.residue_number + o; r.insertion_code = c.insertion_code + o;
+    r.xyz = c.xyz + 3 * o; r.occupancy = c.occupancy + o; r.temperature_factor = c.temperature_factor + o;
+    r.segment = c.segment + 4 * o; r.element = c.element + 2 * o; r.charge = c.charge + o;
+    return r;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tm_pdb_count_host_many(uint32_t n_files, const char *const *text, const uint64_t *length, uint32_t flags,
+                           uint64_t *n_atoms, char *header_ids, int *has_header) {
+    if (n_files && (!text || !length || !n_atoms || !header_ids || !has_header))
+        return fail(TM_E_INVALID, "tm_pdb_count_host_many: NULL argument");
+    std::atomic<int> rc{TM_OK};
+    parallel_for(n_files, 8, [&](uint32_t f) {
+        const int r = tm_pdb_count_host(text[f], length[f], flags, &n_atoms[f], header_ids + 4 * (size_t)f, &has_header[f]);
+        if (r != TM_OK) rc = r;
+    });
+    return rc == TM_OK ? TM_OK : fail(rc, "tm_pdb_count_host_many: invalid file");
+}
+
+int tm_pdb_parse_host_many(uint32_t n_files, const char *const *text, const uint64_t *length, uint32_t flags,
+                           const uint64_t *atom_offsets, const tm_pdb_columns *out, int64_t *bad_file,
+                           uint64_t *bad_begin, uint64_t *bad_length) {
+    if (n_files && (!text || !length || !atom_offsets || !out))
+        return fail(TM_E_INVALID, "tm_pdb_parse_host_many: NULL argument");
+    std::vector<uint64_t> begin(n_files, 0), len(n_files, 0);
+    std::vector<int> status(n_files, TM_OK);
+    parallel_for(n_files, 8, [&](uint32_t f) {
+        const tm_pdb_columns cols = columns_at(*out, atom_offsets[f]);
+        status[f] = tm_pdb_parse_host(text[f], length[f], flags, atom_offsets[f + 1] - atom_offsets[f], &cols, &begin[f],
+                                      &len[f]);
+    });
+    for (uint32_t f = 0; f < n_files; ++f)
+        if (status[f] != TM_OK) {
+            if (bad_file) *bad_file = f;
+            if (bad_begin) *bad_begin = begin[f];
+            if (bad_length) *bad_length = len[f];
+            return fail(status[f], "malformed PDB record");
+        }
+    if (bad_file) *bad_file = -1;
+    return TM_OK;
+}
+
+}  // extern "C"

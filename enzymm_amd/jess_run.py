@@ -258,12 +258,18 @@ class Match:
 
 def load_molecules(molecule_paths: List[Path], conservation_cutoff: float = 0, warn: bool = False
                    ) -> List[pyjess.Molecule]:
-    """Load query structures; duplicate file stems get ``_2``, ``_3`` ... suffixes."""
-    molecules, seen = [], collections.Counter()
+    """Load query structures; duplicate file stems get ``_2``, ``_3`` ... suffixes.  The files are parsed together
+    by the native reader on several host threads (``pyjess.Molecule.load_many``); order, ids, warnings and the
+    error for a malformed file are those of a file-by-file loop."""
+    seen: collections.Counter = collections.Counter()
+    paths, ids = [], []
     for path in molecule_paths:
         stem = Path(path).stem
         seen[stem] += 1
-        mol = pyjess.Molecule.load(str(path), id=stem if seen[stem] == 1 else f"{stem}_{seen[stem]}")
+        paths.append(str(path))
+        ids.append(stem if seen[stem] == 1 else f"{stem}_{seen[stem]}")
+    molecules = []
+    for path, mol in zip(paths, pyjess.Molecule.load_many(paths, ids)):
         if conservation_cutoff:
             # the reference computes the filtered molecule and drops it (jess_run.py:541-545); kept as is
             mol.conserved(conservation_cutoff)

@@ -321,6 +321,23 @@ class Molecule:
         mol._init_columns(cols, xyz, id if id is not None else header_id)
         return mol
 
+    @classmethod
+    def load_many(cls, files: Sequence, ids: Optional[Sequence[Optional[str]]] = None,
+                  ignore_endmdl: bool = False) -> List["Molecule"]:
+        """``load`` for many paths at once: the files are parsed on a team of native host threads
+        (``tm_pdb_parse_host_many``).  Same molecules, same error for the first malformed file."""
+        datas = []
+        for file in files:
+            with open(os.fspath(file), "rb") as handle:
+                datas.append(handle.read())
+        tables = _native.parse_pdb_host_many(datas, ignore_endmdl)
+        out = []
+        for i, (cols, xyz, header_id) in enumerate(tables):
+            mol = cls.__new__(cls)
+            mol._init_columns(cols, xyz, ids[i] if ids is not None and ids[i] is not None else header_id)
+            out.append(mol)
+        return out
+
     # -- container protocol -------------------------------------------------
     def _atom(self, i: int) -> Atom:
         c = self._cols

@@ -215,6 +215,14 @@ int tm_pdb_count_host(const char *text, uint64_t length, uint32_t flags, uint64_
                       int *has_header);
 int tm_pdb_parse_host(const char *text, uint64_t length, uint32_t flags, uint64_t capacity, const tm_pdb_columns *out,
                       uint64_t *bad_begin, uint64_t *bad_length);
+/* The same for many files at once, on a team of host threads (the loop of load_molecules, jess_run.py:523-556).
+ * count: n_atoms[f], header_ids[4 f .. 4 f + 3], has_header[f].  parse: file f fills rows atom_offsets[f] ..
+ * atom_offsets[f + 1] - 1 of the concatenated arrays; on a malformed record *bad_file is the FIRST such file. */
+int tm_pdb_count_host_many(uint32_t n_files, const char *const *text, const uint64_t *length, uint32_t flags,
+                           uint64_t *n_atoms, char *header_ids, int *has_header);
+int tm_pdb_parse_host_many(uint32_t n_files, const char *const *text, const uint64_t *length, uint32_t flags,
+                           const uint64_t *atom_offsets, const tm_pdb_columns *out, int64_t *bad_file,
+                           uint64_t *bad_begin, uint64_t *bad_length);
 
 #ifdef __cplusplus
 }

@@ -291,3 +291,40 @@ def test_native_pdb_reader_equals_numpy_reference():
     assert errors > 50  # the damage does produce malformed records
     for data in (b"", b"\n", b"ATOM", b"END\n", b"HEADER" + b" " * 56 + b"1ABC\n"):
         assert outcome(pyjess._parse_pdb_bytes, data, False) == outcome(pyjess._parse_pdb_bytes_numpy, data, False)
+
+
+def test_load_many_equals_per_file_load(tmp_path):
+    """Molecule.load_many / load_molecules (batched native reader on host threads) against file-by-file loads:
+    same tables, ids from the HEADER or the stems with _2 suffixes, and the first malformed file's error."""
+    import numpy as np
+    from enzymm_amd import jess_run, pyjess, synthetic
+
+    paths = []
+    for i, mol in enumerate(synthetic.structures(40)):
+        p = tmp_path / ("same.pdb" if i in (3, 7) else f"s{i}.pdb")
+        if i in (3, 7):
+            p = tmp_path / f"d{i}" / "same.pdb"
+            p.parent.mkdir()
+        p.write_text(synthetic.to_pdb(mol))
+        paths.append(p)
+    paths.append(helpers.GOLDEN / "1AMY.pdb")
+    many = pyjess.Molecule.load_many(paths)
+    for p, m in zip(paths, many):
+        one = pyjess.Molecule.load(p)
+        assert one.id == m.id and np.array_equal(one._xyz, m._xyz)
+        assert all(np.array_equal(one._cols[k], m._cols[k]) for k in one._cols)
+    assert many[-1].id == "1AMY"  # HEADER idCode
+    loaded = jess_run.load_molecules(paths)
+    assert [m.id for m in loaded][:8] == ["s0", "s1", "s2", "same", "s4", "s5", "s6", "same_2"]
+    # a malformed record in the middle of the batch: the error names that record, as the sequential loop would
+    bad = tmp_path / "bad.pdb"
+    lines = (helpers.GOLDEN / "1AMY.pdb").read_text().splitlines()
+    k = next(i for i, l in enumerate(lines) if l.startswith("ATOM"))
+    lines[k + 5] = lines[k + 5][:32] + "x" + lines[k + 5][33:]
+    bad.write_text("\n".join(lines))
+    with pytest.raises(ValueError) as many_err:
+        pyjess.Molecule.load_many(paths[:5] + [bad] + paths[5:])
+    with pytest.raises(ValueError) as one_err:
+        pyjess.Molecule.load(bad)
+    assert str(many_err.value) == str(one_err.value)
+    assert pyjess.Molecule.load_many([]) == []
