@@ -55,6 +55,14 @@ class _BatchDesc(C.Structure):
     ]
 
 
+class _ColumnsDesc(C.Structure):
+    _fields_ = [
+        ("n_structures", C.c_uint32), ("atom_offsets", C.c_void_p), ("xyz", C.c_void_p), ("name", C.c_void_p),
+        ("residue_name", C.c_void_p), ("chain_id", C.c_void_p), ("residue_number", C.c_void_p),
+        ("insertion_code", C.c_void_p),
+    ]
+
+
 class _Vocab(C.Structure):
     _fields_ = [
         ("n_atom_names", C.c_uint32), ("atom_names", C.c_void_p), ("atom_name_ids", C.c_void_p),
@@ -79,7 +87,7 @@ class _QueryParams(C.Structure):
 
 EXPORTS = (
     "tm_abi_version", "tm_last_error", "tm_device_count", "tm_library_create", "tm_library_destroy",
-    "tm_batch_create", "tm_batch_create_from_pdb", "tm_batch_atom_counts", "tm_batch_line_offsets",
+    "tm_batch_create", "tm_batch_create_from_columns", "tm_batch_create_from_pdb", "tm_batch_atom_counts", "tm_batch_line_offsets",
     "tm_batch_residue_counts",
     "tm_batch_destroy", "tm_query", "tm_result_wait", "tm_result_needed", "tm_result_hit_count",
     "tm_result_copy_hits", "tm_result_copy_candidates", "tm_result_timing", "tm_result_device_hits",
@@ -262,6 +270,29 @@ class Batch:
         desc = _BatchDesc(self.n_structures, *[_ptr(a) for a in keep])
         _check(lib.tm_batch_create(C.c_int(device), C.byref(desc), C.byref(self._h)))
         self.device = device
+
+    @classmethod
+    def from_columns(cls, device, atom_offsets, xyz, name, residue_name, chain_id, residue_number, insertion_code,
+                     vocab_tables) -> "Batch":
+        """Raw atom-table columns of many molecules (concatenated); vocabulary encoding, residue/chain ordinals and
+        flattening happen in the library on host threads (``tm_batch_create_from_columns``)."""
+        lib = load()
+        self = cls.__new__(cls)
+        self._h = C.c_void_p()
+        self.n_structures = len(atom_offsets) - 1
+        names, name_ids, els, el_ids, res, res_ids, _ = vocab_tables
+        vk = [_arr(names, "S4"), _arr(name_ids, np.uint8), _arr(els, "S2"), _arr(el_ids, np.uint8),
+              _arr(res, "S3"), _arr(res_ids, np.uint8)]
+        vocab = _Vocab(len(vk[0]), _ptr(vk[0]), _ptr(vk[1]), len(vk[2]), _ptr(vk[2]), _ptr(vk[3]),
+                       len(vk[4]), _ptr(vk[4]), _ptr(vk[5]), 0, None)
+        keep = [_arr(atom_offsets, np.uint32), _arr(xyz, np.float64), _arr(name, "S4"), _arr(residue_name, "S3"),
+                _arr(chain_id, "S2"), _arr(residue_number, np.int32), _arr(insertion_code, "S1")]
+        desc = _ColumnsDesc(self.n_structures, *[_ptr(a) for a in keep])
+        _check(lib.tm_batch_create_from_columns(C.c_int(device), C.byref(desc), C.byref(vocab), C.byref(self._h)))
+        self.device = device
+        self.atom_offsets = keep[0]
+        self.has_residue_counts = False
+        return self
 
     @classmethod
     def from_pdb(cls, device, texts, vocab_tables, min_bfactor: float = 0.0, ignore_endmdl: bool = False,

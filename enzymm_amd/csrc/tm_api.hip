@@ -623,6 +623,105 @@ int tm_batch_create(int device, const tm_batch_desc *d, tm_batch **out) {
     return TM_OK;
 }
 
+// Raw atom-table columns -> vocabulary ids and residue / chain ordinals (per structure, on host threads), then
+// tm_batch_create.  Ordinals are numbered by first appearance; only their equality matters.
+int tm_batch_create_from_columns(int device, const tm_columns_desc *d, const tm_vocab *vocab, tm_batch **out) {
+    if (!d || !vocab || !out || !d->atom_offsets)
+        return fail(TM_E_INVALID, "tm_batch_create_from_columns: NULL argument");
+    const uint32_t ns = d->n_structures;
+    const uint32_t na = d->atom_offsets[ns];
+    if (na && (!d->xyz || !d->name || !d->residue_name || !d->chain_id || !d->residue_number || !d->insertion_code))
+        return fail(TM_E_INVALID, "tm_batch_create_from_columns: NULL column");
+    std::vector<uint32_t> v_names(vocab->n_atom_names), v_res(vocab->n_residues, 0u);
+    std::vector<uint16_t> v_el(vocab->n_elements);
+    for (uint32_t i = 0; i < vocab->n_atom_names; ++i) std::memcpy(&v_names[i], vocab->atom_names + 4 * i, 4);
+    for (uint32_t i = 0; i < vocab->n_elements; ++i) std::memcpy(&v_el[i], vocab->elements + 2 * i, 2);
+    for (uint32_t i = 0; i < vocab->n_residues; ++i) std::memcpy(&v_res[i], vocab->residue_names + 3 * i, 3);
+    std::vector<uint8_t> res_type(na), name_id(na), chain(na);
+    std::vector<uint32_t> residue(na);
+    auto encode = [&](uint32_t s_begin, uint32_t s_end) {
+        std::vector<uint16_t> seen_chain;
+        for (uint32_t s = s_begin; s < s_end; ++s) {
+            const uint32_t o = d->atom_offsets[s], n = d->atom_offsets[s + 1] - o;
+            seen_chain.clear();
+            std::map<uint64_t, uint32_t> by_key;
+            uint64_t last_key = ~0ull;
+            uint32_t last_ord = 0;
+            uint32_t last_name = 0, last_name_id = TM_NAME_OTHER;
+            bool have_name = false;
+            uint32_t last_res = 0, last_res_id = TM_RES_OTHER;
+            bool have_res = false;
+            for (uint32_t i = 0; i < n; ++i) {
+                const size_t a = (size_t)o + i;
+                uint32_t nm = 0;
+                std::memcpy(&nm, d->name + 4 * a, 4);
+                if (!have_name || nm != last_name) {
+                    uint32_t id = TM_NAME_OTHER;
+                    for (uint32_t q = 0; q < vocab->n_atom_names; ++q)
+                        if (v_names[q] == nm) { id = vocab->atom_name_ids[q]; break; }
+                    if (id == TM_NAME_OTHER) {
+                        const uint16_t el = (uint16_t)(nm & 0xffffu);
+                        for (uint32_t q = 0; q < vocab->n_elements; ++q)
+                            if (v_el[q] == el) { id = vocab->element_ids[q]; break; }
+                    }
+                    last_name = nm; last_name_id = id; have_name = true;
+                }
+                name_id[a] = (uint8_t)last_name_id;
+                uint32_t rn = 0;
+                std::memcpy(&rn, d->residue_name + 3 * a, 3);
+                if (!have_res || rn != last_res) {
+                    uint32_t id = TM_RES_OTHER;
+                    for (uint32_t q = 0; q < vocab->n_residues; ++q)
+                        if (v_res[q] == rn) { id = vocab->residue_ids[q]; break; }
+                    last_res = rn; last_res_id = id; have_res = true;
+                }
+                res_type[a] = (uint8_t)last_res_id;
+                const uint16_t ch = (uint16_t)((uint8_t)d->chain_id[2 * a] << 8 | (uint8_t)d->chain_id[2 * a + 1]);
+                const uint64_t key = ((uint64_t)ch << 40) | ((uint64_t)(uint32_t)(d->residue_number[a] + (1 << 24)) << 8) |
+                                     (uint8_t)d->insertion_code[a];
+                if (key != last_key) {
+                    auto it = by_key.find(key);
+                    if (it == by_key.end()) it = by_key.emplace(key, (uint32_t)by_key.size()).first;
+                    last_key = key;
+                    last_ord = it->second;
+                }
+                residue[a] = last_ord;
+                uint32_t c = 0;
+                while (c < seen_chain.size() && seen_chain[c] != ch) ++c;
+                if (c == seen_chain.size()) seen_chain.push_back(ch);
+                chain[a] = (uint8_t)(c & 0xffu);
+            }
+        }
+    };
+    {
+        const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
+        const uint32_t team = std::min<uint32_t>({hw, 16u, std::max(1u, na / 65536u)});
+        if (team <= 1) {
+            encode(0, ns);
+        } else {
+            std::vector<std::thread> workers;
+            uint32_t s0 = 0;
+            for (uint32_t t = 0; t < team; ++t) {
+                const uint64_t target = (uint64_t)na * (t + 1) / team;
+                uint32_t s1 = s0;
+                while (s1 < ns && (t + 1 == team || d->atom_offsets[s1 + 1] <= target)) ++s1;
+                if (s1 > s0) workers.emplace_back(encode, s0, s1);
+                s0 = s1;
+            }
+            for (auto &w : workers) w.join();
+        }
+    }
+    tm_batch_desc enc;
+    enc.n_structures = ns;
+    enc.atom_offsets = d->atom_offsets;
+    enc.xyz = d->xyz;
+    enc.res_type = res_type.data();
+    enc.name_id = name_id.data();
+    enc.residue = residue.data();
+    enc.chain = chain.data();
+    return tm_batch_create(device, &enc, out);
+}
+
 // exclusive prefix sum of n u32 values on the device; *total (device) receives the sum
 static int device_scan(const uint32_t *in, uint64_t n, uint32_t *out, uint32_t *total, DevBuf<uint32_t> &block_sums,
                        hipStream_t stream) {

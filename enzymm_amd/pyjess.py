@@ -651,17 +651,43 @@ def _packed(templates: Sequence[Template], device: int) -> _PackedLibrary:
         return packed
 
 
+def _joined(parts: List[np.ndarray], dtype) -> np.ndarray:
+    """The arrays one after the other; without copying when they already are consecutive views of one array
+    (molecules that came out of ``Molecule.load_many`` together)."""
+    if not parts:
+        return np.zeros(0, dtype=dtype)
+    base = parts[0].base
+    if base is not None and isinstance(base, np.ndarray) and base.ndim == parts[0].ndim and base.flags.c_contiguous \
+            and len(base) and base.strides[0]:
+        step = base.strides[0]
+        start = (parts[0].__array_interface__["data"][0] - base.__array_interface__["data"][0])
+        addr, ok = parts[0].__array_interface__["data"][0], start % step == 0
+        for a in parts:
+            if not ok:
+                break
+            ok = a.base is base and a.dtype == base.dtype and a.flags.c_contiguous and \
+                a.__array_interface__["data"][0] == addr
+            addr += a.shape[0] * step
+        if ok:
+            first = start // step
+            return base[first: first + sum(len(a) for a in parts)]
+    return np.concatenate(parts).astype(dtype, copy=False)
+
+
 def make_batch(molecules: Sequence[Molecule], device: int) -> "_native.Batch":
-    """Flatten molecules into one device-resident batch (``tm_batch_create``)."""
-    version = VOCAB.version
-    enc = [m._encoded() for m in molecules]
-    offsets = np.zeros(len(enc) + 1, dtype=np.uint32)
-    for i, e in enumerate(enc):
-        offsets[i + 1] = offsets[i] + len(e["residue"])
-    cat = lambda k, dt: (np.concatenate([e[k] for e in enc]) if enc else np.zeros(0, dtype=dt)).astype(dt, copy=False)
-    batch = _native.Batch(device, offsets, cat("xyz", np.float64).reshape(-1, 3), cat("res_type", np.uint8),
-                          cat("name_id", np.uint8), cat("residue", np.uint32), cat("chain", np.uint8))
-    batch.vocab_version = version  # ids are only meaningful against this state of the vocabulary
+    """Flatten molecules into one device-resident batch.  The raw columns go to the library, which encodes them
+    with the vocabulary and packs them on host threads (``tm_batch_create_from_columns``)."""
+    tables = VOCAB.native_tables()
+    offsets = np.zeros(len(molecules) + 1, dtype=np.uint32)
+    for i, m in enumerate(molecules):
+        offsets[i + 1] = offsets[i] + len(m)
+    cols = [m._cols for m in molecules]
+    cat = lambda k, dt: _joined([c[k] for c in cols], dt)  # noqa: E731
+    xyz = _joined([m._xyz for m in molecules], np.float64).reshape(-1, 3)
+    batch = _native.Batch.from_columns(device, offsets, xyz, cat("name", "S4"), cat("residue_name", "S3"),
+                                       cat("chain_id", "S2"), cat("residue_number", np.int32),
+                                       cat("insertion_code", "S1"), tables)
+    batch.vocab_version = tables[-1]  # ids are only meaningful against this state of the vocabulary
     return batch
 
 

@@ -104,6 +104,19 @@ typedef struct tm_batch_desc {
     const uint8_t *chain;         /* [n_atoms] chain ordinal within its structure */
 } tm_batch_desc;
 
+/* Target structures as the raw columns of their atom tables (what Molecule.load yields); the library encodes them
+ * with the vocabulary, on a team of host threads (tm_batch_create_from_columns). */
+typedef struct tm_columns_desc {
+    uint32_t n_structures;
+    const uint32_t *atom_offsets;   /* [n_structures + 1] */
+    const double *xyz;              /* [n_atoms * 3] */
+    const char *name;               /* [n_atoms * 4] raw atom-name fields */
+    const char *residue_name;       /* [n_atoms * 3] */
+    const char *chain_id;           /* [n_atoms * 2] */
+    const int32_t *residue_number;  /* [n_atoms] */
+    const char *insertion_code;     /* [n_atoms] */
+} tm_columns_desc;
+
 /* How raw PDB fields map to the ids of the host's vocabulary (tm_batch_create_from_pdb). */
 typedef struct tm_vocab {
     uint32_t n_atom_names;
@@ -168,6 +181,8 @@ int tm_library_create(int device, const tm_library_desc *desc, tm_library **out)
 void tm_library_destroy(tm_library *lib);
 
 int tm_batch_create(int device, const tm_batch_desc *desc, tm_batch **out);
+struct tm_vocab;
+int tm_batch_create_from_columns(int device, const tm_columns_desc *desc, const struct tm_vocab *vocab, tm_batch **out);
 /* Device-side ingestion: raw PDB text is uploaded and parsed on the GPU (ATOM/HETATM records up to the first
  * ENDMDL, optional temperature-factor cutoff) -- replaces pyjess.Molecule.load + Molecule.conserved for batches,
  * enzymm/jess_run.py:538-545.  TM_E_UNSUPPORTED when a file is not residue-contiguous: use tm_batch_create. */
