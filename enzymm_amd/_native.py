@@ -92,7 +92,7 @@ EXPORTS = (
     "tm_batch_destroy", "tm_query", "tm_result_wait", "tm_result_needed", "tm_result_hit_count",
     "tm_result_copy_hits", "tm_result_copy_candidates", "tm_result_timing", "tm_result_device_hits",
     "tm_result_destroy", "tm_pdb_count_host", "tm_pdb_parse_host", "tm_pdb_count_host_many",
-    "tm_pdb_parse_host_many",
+    "tm_pdb_parse_host_many", "tm_files_sizes", "tm_files_read",
 )
 
 _lock = threading.Lock()
@@ -179,6 +179,57 @@ def parse_pdb_host(data: bytes, ignore_endmdl: bool = False):
     return cols, xyz, header_id
 
 
+class TextBlock:
+    """Many files' bytes in one buffer (``tm_files_read``): ``buffer`` uint8, file f at offsets[f]:offsets[f+1]."""
+
+    def __init__(self, buffer: np.ndarray, offsets: np.ndarray):
+        self.buffer, self.offsets = buffer, offsets
+
+    def __len__(self):
+        return len(self.offsets) - 1
+
+    def __getitem__(self, i) -> memoryview:
+        return memoryview(self.buffer)[int(self.offsets[i]): int(self.offsets[i + 1])]
+
+    @property
+    def pointers(self) -> np.ndarray:
+        return (np.uint64(self.buffer.ctypes.data) + self.offsets[:-1]).astype(np.uint64)
+
+    @property
+    def lengths(self) -> np.ndarray:
+        return np.diff(self.offsets).astype(np.uint64)
+
+    @classmethod
+    def from_bytes(cls, datas) -> "TextBlock":
+        offsets = np.zeros(len(datas) + 1, dtype=np.uint64)
+        np.cumsum([len(d) for d in datas], out=offsets[1:])
+        return cls(np.frombuffer(b"".join(datas), dtype=np.uint8), offsets)
+
+
+def read_files(paths) -> TextBlock:
+    """Read many files on a team of native host threads (``tm_files_sizes`` + ``tm_files_read``)."""
+    lib = load()
+    raw = [os.fsencode(p) for p in paths]
+    nf = len(raw)
+    offsets = np.zeros(nf + 1, dtype=np.uint64)
+    if nf == 0:
+        return TextBlock(np.zeros(0, np.uint8), offsets)
+    cpaths = (C.c_char_p * nf)(*raw)
+    sizes = np.zeros(nf, dtype=np.uint64)
+    bad = C.c_int64(-1)
+    rc = lib.tm_files_sizes(C.c_uint32(nf), cpaths, _ptr(sizes), C.byref(bad))
+    if rc == TM_OK:
+        np.cumsum(sizes, out=offsets[1:])
+        buffer = np.empty(int(offsets[-1]), dtype=np.uint8)
+        rc = lib.tm_files_read(C.c_uint32(nf), cpaths, _ptr(offsets), _ptr(buffer) if len(buffer) else None, C.byref(bad))
+        if rc == TM_OK:
+            return TextBlock(buffer, offsets)
+    if bad.value >= 0:
+        open(paths[bad.value], "rb").close()  # raises the ordinary OSError (FileNotFoundError, IsADirectoryError ...)
+    _check(rc)
+    raise OSError(f"cannot read {paths[max(bad.value, 0)]}")
+
+
 def parse_pdb_host_many(datas, ignore_endmdl: bool = False):
     """Many PDB files -> [(columns, xyz, HEADER idCode), ...] in two native calls that parse on a team of host
     threads (``tm_pdb_parse_host_many``); the per-file tables are views into shared arrays.  Raises the
@@ -187,9 +238,10 @@ def parse_pdb_host_many(datas, ignore_endmdl: bool = False):
     nf = len(datas)
     if nf == 0:
         return []
+    block = datas if isinstance(datas, TextBlock) else TextBlock.from_bytes(datas)
     flags = C.c_uint32(TM_PDB_IGNORE_ENDMDL if ignore_endmdl else 0)
-    ptrs = (C.c_char_p * nf)(*datas)
-    lens = (C.c_uint64 * nf)(*[len(d) for d in datas])
+    ptr_arr, len_arr = block.pointers, block.lengths
+    ptrs, lens = _ptr(ptr_arr), _ptr(len_arr)
     counts = np.zeros(nf, dtype=np.uint64)
     heads = np.zeros(nf, dtype="S4")
     head_raw = C.create_string_buffer(4 * nf)
@@ -205,7 +257,7 @@ def parse_pdb_host_many(datas, ignore_endmdl: bool = False):
     rc = lib.tm_pdb_parse_host_many(C.c_uint32(nf), ptrs, lens, flags, _ptr(offsets), C.byref(out), C.byref(bad_file),
                                     C.byref(bad_begin), C.byref(bad_len))
     if rc == TM_E_INVALID and bad_file.value >= 0:
-        data = datas[bad_file.value]
+        data = bytes(block[bad_file.value])
         line = data[bad_begin.value: bad_begin.value + min(bad_len.value, 80)]
         raise ValueError(f"malformed PDB record: {line.decode('ascii', 'replace').rstrip()!r}")
     _check(rc)
@@ -310,8 +362,12 @@ class Batch:
         vocab = _Vocab(len(keep[0]), _ptr(keep[0]), _ptr(keep[1]), len(keep[2]), _ptr(keep[2]), _ptr(keep[3]),
                        len(keep[4]), _ptr(keep[4]), _ptr(keep[5]), len(keep[6]), _ptr(keep[6]) if len(keep[6]) else None)
         self.has_residue_counts = len(keep[6]) > 0
-        ptrs = (C.c_char_p * max(1, len(texts)))(*texts)
-        lens = (C.c_uint64 * max(1, len(texts)))(*[len(t) for t in texts])
+        if isinstance(texts, TextBlock):
+            keep += [texts.pointers, texts.lengths, texts.buffer]
+            ptrs, lens = _ptr(keep[-3]), _ptr(keep[-2])
+        else:
+            ptrs = (C.c_char_p * max(1, len(texts)))(*texts)
+            lens = (C.c_uint64 * max(1, len(texts)))(*[len(t) for t in texts])
         _check(lib.tm_batch_create_from_pdb(C.c_int(device), C.c_uint32(len(texts)), ptrs, lens, C.byref(vocab),
                                             C.c_uint32(TM_PDB_IGNORE_ENDMDL if ignore_endmdl else 0),
                                             C.c_double(min_bfactor), C.byref(self._h)))

@@ -12,6 +12,10 @@
 #include <numeric>
 #include <string>
 #include <thread>
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <tuple>
 #include <vector>
 
@@ -1441,6 +1445,48 @@ tm_pdb_columns columns_at(const tm_pdb_columns &c, uint64_t o) {
 }  // namespace
 
 extern "C" {
+
+int tm_files_sizes(uint32_t n_files, const char *const *paths, uint64_t *sizes, int64_t *bad_file) {
+    if (n_files && (!paths || !sizes)) return fail(TM_E_INVALID, "tm_files_sizes: NULL argument");
+    std::vector<uint8_t> failed(n_files, 0);
+    parallel_for(n_files, 32, [&](uint32_t f) {
+        struct stat st;
+        if (::stat(paths[f], &st) != 0 || !S_ISREG(st.st_mode)) { failed[f] = 1; sizes[f] = 0; }
+        else sizes[f] = (uint64_t)st.st_size;
+    });
+    if (bad_file) *bad_file = -1;
+    for (uint32_t f = 0; f < n_files; ++f)
+        if (failed[f]) {
+            if (bad_file) *bad_file = f;
+            return fail(TM_E_INVALID, std::string("cannot stat ") + paths[f]);
+        }
+    return TM_OK;
+}
+
+int tm_files_read(uint32_t n_files, const char *const *paths, const uint64_t *offsets, char *buffer, int64_t *bad_file) {
+    if (n_files && (!paths || !offsets || !buffer)) return fail(TM_E_INVALID, "tm_files_read: NULL argument");
+    std::vector<uint8_t> failed(n_files, 0);
+    parallel_for(n_files, 16, [&](uint32_t f) {
+        const uint64_t want = offsets[f + 1] - offsets[f];
+        const int fd = ::open(paths[f], O_RDONLY | O_CLOEXEC);
+        if (fd < 0) { failed[f] = 1; return; }
+        uint64_t got = 0;
+        while (got < want) {
+            const ssize_t r = ::read(fd, buffer + offsets[f] + got, want - got);
+            if (r <= 0) break;
+            got += (uint64_t)r;
+        }
+        ::close(fd);
+        if (got != want) failed[f] = 1;  // the file changed size since tm_files_sizes
+    });
+    if (bad_file) *bad_file = -1;
+    for (uint32_t f = 0; f < n_files; ++f)
+        if (failed[f]) {
+            if (bad_file) *bad_file = f;
+            return fail(TM_E_INVALID, std::string("cannot read ") + paths[f]);
+        }
+    return TM_OK;
+}
 
 int tm_pdb_count_host_many(uint32_t n_files, const char *const *text, const uint64_t *length, uint32_t flags,
                            uint64_t *n_atoms, char *header_ids, int *has_header) {

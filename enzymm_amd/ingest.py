@@ -50,8 +50,9 @@ class LazyMolecule(pyjess.Molecule):
             lines = []
             for i in missing:
                 lo = int(self._line_off[i])
-                hi = self._text.find(b"\n", lo)
-                lines.append(self._text[lo: hi if hi >= 0 else len(self._text)])
+                piece = bytes(self._text[lo: lo + 96])  # a record is at most 80 columns + its line end
+                hi = piece.find(b"\n")
+                lines.append(piece if hi < 0 else piece[:hi])
             cols, xyz, _ = pyjess._parse_pdb_bytes(b"\n".join(lines) + b"\n", True)
             part = pyjess.Molecule.__new__(pyjess.Molecule)
             part._init_columns(cols, xyz, self.id)
@@ -61,7 +62,7 @@ class LazyMolecule(pyjess.Molecule):
 
     def _materialise(self) -> pyjess.Molecule:
         if self._loaded is None:
-            mol = pyjess.Molecule.load(io.StringIO(self._text.decode("ascii", "replace")), id=self.id,
+            mol = pyjess.Molecule.load(io.StringIO(bytes(self._text).decode("ascii", "replace")), id=self.id,
                                        ignore_endmdl=self._ignore_endmdl)
             if self._min_bfactor > 0:
                 mol = mol.conserved(self._min_bfactor)
@@ -89,12 +90,14 @@ class PdbBatch:
         tables = VOCAB.native_tables()
         self.vocab_version = tables[-1]
         from .jess_run import _COUNTED_RESIDUES
-        self.native = _native.Batch.from_pdb(self.device, list(texts), tables, min_bfactor=conservation_cutoff,
+        if not isinstance(texts, _native.TextBlock):
+            texts = list(texts)
+        self.native = _native.Batch.from_pdb(self.device, texts, tables, min_bfactor=conservation_cutoff,
                                              ignore_endmdl=ignore_endmdl, counted_residues=sorted(_COUNTED_RESIDUES))
         self.native.vocab_version = self.vocab_version
         counts = np.diff(self.native.atom_offsets)
         self.molecules: List[LazyMolecule] = [
-            LazyMolecule(t, i, n, conservation_cutoff, ignore_endmdl) for t, i, n in zip(texts, ids, counts)]
+            LazyMolecule(texts[k], i, n, conservation_cutoff, ignore_endmdl) for k, (i, n) in enumerate(zip(ids, counts))]
         self._annotated = False
 
     def annotate(self, indices) -> None:
@@ -121,10 +124,6 @@ class PdbBatch:
         import collections
         import os
 
-        def read(p):
-            with open(p, "rb") as f:
-                return f.read()
-
         paths = [os.fspath(p) for p in paths]
         seen = collections.Counter()
         ids = []
@@ -132,7 +131,7 @@ class PdbBatch:
             stem = os.path.splitext(os.path.basename(p))[0]
             seen[stem] += 1
             ids.append(stem if seen[stem] == 1 else f"{stem}_{seen[stem]}")
-        texts = [read(p) for p in paths]  # (a thread pool for the reads halves the rate: the files are small)
+        texts = _native.read_files(paths)  # one buffer for all files, read on native host threads
         return cls(texts, ids, **kw)
 
     def __len__(self):

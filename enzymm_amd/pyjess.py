@@ -326,11 +326,7 @@ class Molecule:
                   ignore_endmdl: bool = False) -> List["Molecule"]:
         """``load`` for many paths at once: the files are parsed on a team of native host threads
         (``tm_pdb_parse_host_many``).  Same molecules, same error for the first malformed file."""
-        datas = []
-        for file in files:
-            with open(os.fspath(file), "rb") as handle:
-                datas.append(handle.read())
-        tables = _native.parse_pdb_host_many(datas, ignore_endmdl)
+        tables = _native.parse_pdb_host_many(_native.read_files([os.fspath(f) for f in files]), ignore_endmdl)
         out = []
         for i, (cols, xyz, header_id) in enumerate(tables):
             mol = cls.__new__(cls)

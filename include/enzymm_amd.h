@@ -233,6 +233,11 @@ int tm_pdb_parse_host(const char *text, uint64_t length, uint32_t flags, uint64_
 /* The same for many files at once, on a team of host threads (the loop of load_molecules, jess_run.py:523-556).
  * count: n_atoms[f], header_ids[4 f .. 4 f + 3], has_header[f].  parse: file f fills rows atom_offsets[f] ..
  * atom_offsets[f + 1] - 1 of the concatenated arrays; on a malformed record *bad_file is the FIRST such file. */
+/* File reading for the two calls above and for tm_batch_create_from_pdb, on host threads: sizes first, then every
+ * file into its slice [offsets[f], offsets[f + 1]) of one caller-allocated buffer.  *bad_file = first file that
+ * could not be read (-1: none). */
+int tm_files_sizes(uint32_t n_files, const char *const *paths, uint64_t *sizes, int64_t *bad_file);
+int tm_files_read(uint32_t n_files, const char *const *paths, const uint64_t *offsets, char *buffer, int64_t *bad_file);
 int tm_pdb_count_host_many(uint32_t n_files, const char *const *text, const uint64_t *length, uint32_t flags,
                            uint64_t *n_atoms, char *header_ids, int *has_header);
 int tm_pdb_parse_host_many(uint32_t n_files, const char *const *text, const uint64_t *length, uint32_t flags,

@@ -18,15 +18,20 @@ with tempfile.TemporaryDirectory() as d:
         p = Path(d) / f"s{i:05d}.pdb"
         p.write_bytes(base[i % len(base)])
         paths.append(p)
-    for rep in range(2):
-        t0 = time.perf_counter()
+    def serial():
         hits = 0
         for i in range(0, n, bs):
             pb = ingest.PdbBatch.from_paths(paths[i:i + bs], conservation_cutoff=0)
             hits += sum(len(v) for v in matcher.run(pb).values())
             pb.close()
-        t1 = time.perf_counter()
-        out = matcher.run_files(paths, batch_size=bs)
-        t2 = time.perf_counter()
-        print(f"rep {rep}: serial {n / (t1 - t0):.0f} structures/s ({hits} matches), pipelined {n / (t2 - t1):.0f} "
-              f"structures/s ({sum(len(v) for v in out.values())} matches), files -> matches", flush=True)
+        return hits
+
+    def pipelined():
+        return sum(len(v) for v in matcher.run_files(paths, batch_size=bs).values())
+
+    for label, fn in (("one batch after the other", serial), ("next batch ingested on a worker thread", pipelined)):
+        for rep in range(3):
+            t0 = time.perf_counter()
+            hits = fn()
+            t1 = time.perf_counter()
+            print(f"{label}, rep {rep}: {n / (t1 - t0):.0f} structures/s ({hits} matches), files -> matches", flush=True)
