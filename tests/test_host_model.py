@@ -328,3 +328,8 @@ def test_load_many_equals_per_file_load(tmp_path):
         pyjess.Molecule.load(bad)
     assert str(many_err.value) == str(one_err.value)
     assert pyjess.Molecule.load_many([]) == []
+    with pytest.raises(FileNotFoundError):  # the ordinary error of open(), whichever file of the batch it is
+        pyjess.Molecule.load_many(paths[:3] + [tmp_path / "missing.pdb"])
+    from enzymm_amd import _native
+    block = _native.read_files(paths[:4])
+    assert [bytes(block[i]) for i in range(4)] == [p.read_bytes() for p in paths[:4]]
