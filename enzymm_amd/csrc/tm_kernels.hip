@@ -644,13 +644,27 @@ __device__ __forceinline__ bool joint_top_scan(const Ctx &C, WaveRegs &W, PairSt
     uint32_t jb_st = 0, cb_st = 0xffffffffu;  // blocks of list1 / list2 present in LDS
     wave_sync();
     {
-        const Block f0 = fetch_block(true, lo0, 0u, min(64u, n0), kPadFar, 0.f, 0u);
-        const Block f1 = fetch_block(real1, lo1, 0u, min(64u, n1), -kPadFar, 0.f, 0xfffeu);
-        if (n2 <= 64u) {
-            const Block f2 = fetch_block(real2, lo2, 0u, n2, 0.f, kPadFar, 0xfffdu);
-            store_block(S.rec2, S.id2, f2);
-            cb_st = 0;
-        }
+        // straight-line on purpose: three independent kind-list reads, then three independent record gathers, then
+        // the selects and stores -- two memory round trips for all three blocks instead of two per block.  A list
+        // that is a wildcard reads entry lo0 instead; the value is dropped.
+        const uint32_t c0 = min(64u, n0), c1 = min(64u, n1), c2 = min(64u, n2);
+        const uint32_t i0 = lo0 + min((uint32_t)lane, c0 - 1u);
+        const uint32_t i1 = real1 ? lo1 + min((uint32_t)lane, c1 - 1u) : i0;
+        const uint32_t i2 = real2 ? lo2 + min((uint32_t)lane, c2 - 1u) : i0;
+        const uint32_t a0 = C.pool_at(i0), a1 = C.pool_at(i1), a2 = C.pool_at(i2);
+        float4 r0 = C.rec[a0], r1 = C.rec[a1], r2 = C.rec[a2];
+        Block f0, f1, f2;
+        f0.a = a0;
+        f1.a = real1 ? a1 : 0u;
+        f2.a = real2 ? a2 : 0u;
+        if (!real1) r1 = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xfffeu));
+        if (!real2) r2 = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xfffdu));
+        if ((uint32_t)lane >= c0) { r0.x = kPadFar; r0.y = 0.f; }
+        if ((uint32_t)lane >= c1) { r1.x = -kPadFar; r1.y = 0.f; }
+        if ((uint32_t)lane >= c2) { r2.x = 0.f; r2.y = kPadFar; }
+        f0.r = r0; f1.r = r1; f2.r = r2;
+        store_block(S.rec2, S.id2, f2);  // block 0 of list2 whatever its length
+        cb_st = 0;
         store_block(S.rec0, S.id0, f0);
         store_block(S.rec1, S.id1, f1);
     }
