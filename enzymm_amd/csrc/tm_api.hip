@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -266,6 +267,12 @@ struct tm_library {
     }
 };
 
+// What a query result may have to tell its batch after the fact (it can outlive the batch, hence shared).
+struct IndexShared {
+    std::atomic<unsigned long long> pool_wanted{0};  // kind-list entries an overflowed build needed
+    std::atomic<bool> stale{false};                  // the index in the batch is incomplete: rebuild before use
+};
+
 struct tm_batch {
     int device = 0;
     uint32_t n_structs = 0, n_atoms = 0, max_atoms = 0, max_res = 0;
@@ -287,6 +294,10 @@ struct tm_batch {
     bool queried = false;
     uint64_t index_for = 0;  // serial of the library the candidate index was built for
     unsigned long long pool_capacity = 0;
+    // The index build is not waited for: a query whose build overflowed the kind-list pool finds out in
+    // tm_result_wait and leaves the size it needed here (shared with the results, which may outlive a batch);
+    // the next build starts from it.
+    std::shared_ptr<IndexShared> index_shared = std::make_shared<IndexShared>();
     BatchView view() const {
         BatchView v;
         v.n_structs = n_structs; v.s_off = d_s_off.p; v.s_roff = d_s_roff.p; v.q_xyz = d_xyz.p;
@@ -306,6 +317,9 @@ struct tm_result {
     DevBuf<PairEntry> d_pairs;
     DevBuf<unsigned long long> d_counters;  // [0] hits, [1] candidates, [2] pairs
     std::shared_ptr<StagedSelection> selection;
+    std::shared_ptr<IndexShared> index_shared;                      // the batch's (see tm_batch)
+    DevBuf<unsigned long long> d_pool_used;                         // kind-list entries the index build needed
+    unsigned long long pool_capacity = 0;
     DevBuf<uint32_t> d_overflow, d_candidates;
     DevBuf<double> d_cand_rmsd, d_models;
     DevBuf<int32_t> d_model_set;
@@ -941,38 +955,46 @@ void tm_batch_destroy(tm_batch *b) {
     delete b;
 }
 
-// (Re)builds the batch's candidate index for `lib`.  Synchronises the stream once to learn
-// whether the bump-allocated pool was large enough; grows it and retries otherwise.
-static int build_index(const tm_library *lib, tm_batch *b, hipStream_t stream) {
+// (Re)builds the batch's candidate index for `lib` on `stream` without waiting for it.  The kind-list pool is
+// sized generously (32 entries per atom; a protein needs about 3) or to what an earlier build reported; should it
+// overflow all the same, the structures that did not fit get empty lists, bit 3 of the query's overflow word is
+// set, and tm_result_wait reports TM_E_OVERFLOW so that the caller queries again (the pool then has the size the
+// failed build asked for).
+static int build_index(const tm_library *lib, tm_batch *b, tm_result *r, hipStream_t stream) {
     const size_t off_n = (size_t)b->n_structs * (lib->n_lead + 1);
     if (b->d_kl_off.n != off_n) HIP_TRY(b->d_kl_off.alloc(off_n));
     unsigned long long cap = b->pool_capacity ? b->pool_capacity : std::max<unsigned long long>(1024, 32ull * b->n_atoms);
-    for (int attempt = 0; attempt < 8; ++attempt) {
-        if (cap > 0xffffffffull)
-            return fail(TM_E_UNSUPPORTED, "candidate index needs more than 2^32 entries: split the batch");
-        if (b->d_kl_pool.n != cap) HIP_TRY(b->d_kl_pool.alloc(cap));
-        b->pool_capacity = cap;
-        HIP_TRY(hipMemsetAsync(b->d_cursor.p, 0, sizeof(unsigned long long), stream));
-        HIP_TRY(hipMemsetAsync(b->d_overflow.p, 0, sizeof(uint32_t), stream));
-        if (b->n_structs && lib->n_lead) {
-            // LDS for the per-name atom buckets: structures above the cap scan all atoms for every lead kind
-            const uint32_t bucket_cap = 12288;
-            const size_t lds = ((size_t)lib->n_lead + 1 + std::min<uint32_t>(b->max_atoms, bucket_cap)) * sizeof(uint32_t);
-            hipLaunchKernelGGL(k_kind_lists, dim3(b->n_structs), dim3(256), lds, stream,
-                               lib->view(), b->view(), b->d_kl_off.p, b->d_kl_pool.p, b->d_cursor.p, cap,
-                               b->d_overflow.p, bucket_cap);
-            HIP_TRY(hipGetLastError());
-        }
-        unsigned long long used = 0;
-        HIP_TRY(hipMemcpyAsync(&used, b->d_cursor.p, sizeof used, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-        if (used <= cap) {
-            b->index_for = lib->serial;
-            return TM_OK;
-        }
-        cap = used + used / 8 + 1024;
+    if (!b->pool_capacity)
+        if (const char *env = std::getenv("ENZYMM_AMD_INDEX_POOL"))  // test hook: start from a pool that is too small
+            cap = std::max<unsigned long long>(64, std::strtoull(env, nullptr, 10));
+    const unsigned long long wanted = b->index_shared->pool_wanted.load();
+    b->index_shared->stale = false;
+    if (wanted > cap) cap = wanted + wanted / 8 + 1024;
+    if (cap > 0xffffffffull)
+        return fail(TM_E_UNSUPPORTED, "candidate index needs more than 2^32 entries: split the batch");
+    if (b->d_kl_pool.n != cap) {
+        if (b->queried) HIP_TRY(hipStreamSynchronize(b->last_stream));  // an earlier query may still read the old pool
+        HIP_TRY(b->d_kl_pool.alloc(cap));
     }
-    return fail(TM_E_NOMEM, "candidate index did not fit");
+    b->pool_capacity = cap;
+    HIP_TRY(hipMemsetAsync(b->d_cursor.p, 0, sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(b->d_overflow.p, 0, sizeof(uint32_t), stream));
+    if (b->n_structs && lib->n_lead) {
+        // LDS for the per-name atom buckets: structures above the cap scan all atoms for every lead kind
+        const uint32_t bucket_cap = 12288;
+        const size_t lds = ((size_t)lib->n_lead + 1 + std::min<uint32_t>(b->max_atoms, bucket_cap)) * sizeof(uint32_t);
+        hipLaunchKernelGGL(k_kind_lists, dim3(b->n_structs), dim3(256), lds, stream,
+                           lib->view(), b->view(), b->d_kl_off.p, b->d_kl_pool.p, b->d_cursor.p, cap,
+                           b->d_overflow.p, bucket_cap);
+        HIP_TRY(hipGetLastError());
+    }
+    // the outcome travels with the query: pool entries needed, and the overflow bit
+    HIP_TRY(hipMemcpyAsync(r->d_pool_used.p, b->d_cursor.p, sizeof(unsigned long long), hipMemcpyDeviceToDevice, stream));
+    hipLaunchKernelGGL(k_flag_index_overflow, dim3(1), dim3(1), 0, stream, b->d_overflow.p, r->d_overflow.p);
+    HIP_TRY(hipGetLastError());
+    r->pool_capacity = cap;
+    b->index_for = lib->serial;
+    return TM_OK;
 }
 
 int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_result **out) {
@@ -1054,6 +1076,9 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
     HIP_TRY(r->d_cand_rmsd.alloc(ccap));
     HIP_TRY(r->d_counters.alloc(3));
     HIP_TRY(r->d_overflow.alloc(1));
+    HIP_TRY(r->d_pool_used.alloc(1));
+    HIP_TRY(hipMemsetAsync(r->d_pool_used.p, 0, sizeof(unsigned long long), stream));
+    r->index_shared = b->index_shared;
     HIP_TRY(hipMemsetAsync(r->d_counters.p, 0, 3 * sizeof(unsigned long long), stream));
     HIP_TRY(hipMemsetAsync(r->d_overflow.p, 0, sizeof(uint32_t), stream));
     if (p->flags & TM_FLAG_COUNT_CANDIDATES) {
@@ -1064,8 +1089,8 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
     if (b->queried && b->last_stream != stream) HIP_TRY(hipStreamSynchronize(b->last_stream));
     b->last_stream = stream; b->queried = true;
     HIP_TRY(hipEventRecord(r->ev[0], stream));
-    if (b->index_for != lib->serial || (p->flags & TM_FLAG_REBUILD_INDEX)) {
-        int rc = build_index(lib, b, stream);
+    if (b->index_for != lib->serial || (p->flags & TM_FLAG_REBUILD_INDEX) || b->index_shared->stale.load()) {
+        int rc = build_index(lib, b, r, stream);
         if (rc != TM_OK) return rc;
     }
     HIP_TRY(hipEventRecord(r->ev[1], stream));
@@ -1167,11 +1192,21 @@ int tm_result_wait(tm_result *r) {
         HIP_TRY(hipSetDevice(r->device));
         unsigned long long counters[3] = {0, 0, 0};
         HIP_TRY(hipMemcpyAsync(counters, r->d_counters.p, sizeof counters, hipMemcpyDeviceToHost, r->stream));
+        unsigned long long pool_used = 0;
         HIP_TRY(hipMemcpyAsync(&r->overflow, r->d_overflow.p, sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
+        HIP_TRY(hipMemcpyAsync(&pool_used, r->d_pool_used.p, sizeof pool_used, hipMemcpyDeviceToHost, r->stream));
         HIP_TRY(hipStreamSynchronize(r->stream));
         r->n_hits = counters[0]; r->n_cands = counters[1]; r->n_pairs = counters[2];
         r->waited = true;
+        if ((r->overflow & 8u) && r->index_shared) {  // the index build ran out of pool: remember what it needed
+            unsigned long long seen = r->index_shared->pool_wanted.load();
+            while (seen < pool_used && !r->index_shared->pool_wanted.compare_exchange_weak(seen, pool_used)) {}
+            r->index_shared->stale = true;
+        }
     }
+    if (r->overflow & 8u)
+        return fail(TM_E_OVERFLOW, "candidate index pool too small (" + std::to_string(r->pool_capacity) +
+                                       " entries): query again, the batch now reserves what this build needed");
     if (r->overflow)
         return fail(TM_E_OVERFLOW, "result tables too small: " + std::to_string(r->n_cands) + " candidates (capacity " +
                                        std::to_string(r->cand_capacity) + "), " + std::to_string(r->n_pairs) +

@@ -243,6 +243,11 @@ __global__ __launch_bounds__(256) void k_kind_lists(LibView L, BatchView B, uint
     }
 }
 
+// one thread: carries the index build's overflow flag into the query's overflow word (bit 3)
+__global__ void k_flag_index_overflow(const uint32_t *__restrict__ index_overflow, uint32_t *__restrict__ query_overflow) {
+    if (*index_overflow) atomicOr(query_overflow, 8u);
+}
+
 // ------------------------------------------------------------------ k_search
 
 // Per-wave LDS: only what lanes exchange.  All search state lives in registers (see WaveRegs).

@@ -308,6 +308,31 @@ def test_structure_near_the_atom_limit(af, default_library):
         jess.query_batch([over], 2.0, cut[sel], cut[sel], template_index=idx[sel])
 
 
+def test_index_pool_overflow_is_reported_and_retried(amy, af, monkeypatch):
+    """The candidate index is built without a host round trip; if its pool overflows, the query says so
+    (TM_E_OVERFLOW) and the next query of the batch has room.  ENZYMM_AMD_INDEX_POOL starts the pool too small."""
+    tpls = [template.Template.load(TPL / p) for p in G["A1"]["templates"]]
+    jess = pyjess.Jess(tpls)
+    want = jess.query_batch([amy, af], 2.0, 1.7, 1.7, max_candidates=10000, ignore_chain=True, return_raw=True)
+    monkeypatch.setenv("ENZYMM_AMD_INDEX_POOL", "256")
+    got = jess.query_batch([amy, af], 2.0, 1.7, 1.7, max_candidates=10000, ignore_chain=True, return_raw=True)
+    assert got.tobytes() == want.tobytes() and len(want) >= 4
+    # without the automatic retry the overflow surfaces as an error, and the same batch then succeeds
+    packed = pyjess._packed(jess._templates, jess._device)
+    batch = pyjess.make_batch([amy, af], jess._device)
+    idx = np.arange(len(tpls), dtype=np.uint32)
+    flags = _native.TM_FLAG_BEST_MATCH | _native.TM_FLAG_IGNORE_CHAIN
+    res = _native.query(packed.native, batch, idx, 2.0, 1.7, 1.7, 10000, flags, retry=False)
+    with pytest.raises(_native.NativeError) as err:
+        res.wait()
+    assert err.value.code == _native.TM_E_OVERFLOW
+    res.close()
+    res = _native.query(packed.native, batch, idx, 2.0, 1.7, 1.7, 10000, flags, retry=False)
+    assert res.hits().tobytes() == want.tobytes()
+    res.close()
+    batch.close()
+
+
 def test_edge_cases(amy):
     tpl = template.Template.load(TPL / G["G1"]["template"])
     jess = pyjess.Jess([tpl])
