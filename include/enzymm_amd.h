@@ -195,7 +195,8 @@ void tm_batch_destroy(tm_batch *batch);
 
 /* Asynchronous on params->stream; the result owns the device-side hit table. */
 int tm_query(const tm_library *lib, tm_batch *batch, const tm_query_params *params, tm_result **out);
-int tm_result_wait(tm_result *res);                          /* blocks; TM_E_OVERFLOW if a table filled up */
+int tm_result_wait(tm_result *res);                          /* blocks; TM_E_OVERFLOW if a result table or the batch's
+                                                                candidate-index pool filled up: query again */
 int tm_result_needed(tm_result *res, uint64_t *candidates, uint64_t *pairs); /* sizes a retry needs */
 int tm_result_hit_count(tm_result *res, uint64_t *n_hits);   /* implies wait */
 int tm_result_copy_hits(tm_result *res, tm_hit *out, uint64_t capacity); /* sorted by (structure, template_sel, atoms) */
