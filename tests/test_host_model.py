@@ -333,3 +333,39 @@ def test_load_many_equals_per_file_load(tmp_path):
     from enzymm_amd import _native
     block = _native.read_files(paths[:4])
     assert [bytes(block[i]) for i in range(4)] == [p.read_bytes() for p in paths[:4]]
+
+
+def test_iter_batches_order_errors_and_cleanup(monkeypatch):
+    """ingest.iter_batches without a GPU (PdbBatch.from_paths replaced): slices in order, an ingestion error
+    re-raised in the consumer, and batches the consumer never took closed when it stops early."""
+    from enzymm_amd import ingest
+
+    made, closed = [], []
+
+    class FakeBatch:
+        def __init__(self, chunk):
+            self.chunk = list(chunk)
+            made.append(self)
+
+        def close(self):
+            closed.append(self)
+
+    def fake_from_paths(chunk, **kw):
+        if "boom" in chunk:
+            raise RuntimeError("cannot ingest")
+        return FakeBatch(chunk)
+
+    monkeypatch.setattr(ingest.PdbBatch, "from_paths", staticmethod(fake_from_paths))
+    paths = [f"f{i}" for i in range(10)]
+    got = [b.chunk for b in ingest.iter_batches(paths, batch_size=4)]
+    assert got == [paths[0:4], paths[4:8], paths[8:10]]
+    with pytest.raises(RuntimeError, match="cannot ingest"):
+        for _ in ingest.iter_batches(paths[:4] + ["boom"] + paths[4:], batch_size=4):
+            pass
+    made.clear(); closed.clear()
+    gen = ingest.iter_batches(paths, batch_size=2, prefetch=2)
+    first = next(gen)
+    gen.close()  # the consumer walks away: whatever the worker had prepared is closed, nothing leaks
+    assert first in made and first not in closed
+    assert all(b in closed for b in made if b is not first)
+    assert list(ingest.iter_batches([], batch_size=4)) == []
