@@ -756,13 +756,21 @@ static int device_scan(const uint32_t *in, uint64_t n, uint32_t *out, uint32_t *
 // Ingestion runs on a private non-blocking stream (one per host thread and device), so that a caller can parse
 // the next batch on one thread while a query of the previous batch runs on another stream.
 static hipError_t ingest_stream(int device, hipStream_t *out) {
-    thread_local std::map<int, hipStream_t> streams;
-    auto it = streams.find(device);
-    if (it == streams.end()) {
+    struct Streams {  // destroyed with the host thread that used them
+        std::map<int, hipStream_t> by_device;
+        ~Streams() {
+            for (auto &kv : by_device) {
+                if (hipSetDevice(kv.first) == hipSuccess) (void)hipStreamDestroy(kv.second);
+            }
+        }
+    };
+    thread_local Streams streams;
+    auto it = streams.by_device.find(device);
+    if (it == streams.by_device.end()) {
         hipStream_t st = nullptr;
         hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
         if (e != hipSuccess) return e;
-        it = streams.emplace(device, st).first;
+        it = streams.by_device.emplace(device, st).first;
     }
     *out = it->second;
     return hipSuccess;
