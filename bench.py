@@ -112,18 +112,34 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--structures", type=int, default=1000, help="synthetic structures per GPU")
+    ap.add_argument("--generator", default="v2", choices=["v2", "v1", "real"],
+                    help="v2: natively packed synthetic globules (default); v1: the round-1 generator (under-dense, "
+                         "kept for side-by-side rates); real: rigid-transform copies of 1AMY / AF-P0DUB6 (density reference)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+
+    # this rank's shard of the synthetic proteome (weak scaling: fixed work per GPU), generated on worker
+    # processes BEFORE anything initialises the GPU
+    from enzymm_amd import distributed, synthetic
+    lo, hi = distributed.shard_range(args.structures * world, rank, world)
+    workers = max(1, min(32, len(os.sched_getaffinity(0)) // max(1, world)))
+    if args.generator == "real":
+        from enzymm_amd import pyjess as _pj
+        real = [_pj.Molecule.load(ROOT / "tests" / "golden" / f) for f in ("1AMY.pdb", "AF-P0DUB6-F1-model_v4.pdb")]
+        half = (hi - lo + 1) // 2
+        molecules = (synthetic.rigid_copies(real[0], half, seed=lo) + synthetic.rigid_copies(real[1], hi - lo - half, seed=lo + 1))
+    else:
+        molecules = synthetic.structures(hi - lo, start=lo, processes=workers, generator=args.generator)
+
+    import torch
+    import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
     # ENZYMM_AMD_BENCH_ONE_GPU=1: every rank on GPU 0 with a gloo group -- only to exercise the N > 1
@@ -140,15 +156,12 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     gather_device = "cpu" if one_gpu else f"cuda:{local_rank}"
 
-    from enzymm_amd import _native, distributed, pyjess, synthetic
+    from enzymm_amd import _native, pyjess
 
     templates, idx, cut = load_library()
     jess = pyjess.Jess(templates, device=local_rank)
     packed = pyjess._packed(jess._templates, local_rank)
 
-    # this rank's shard of the synthetic proteome (weak scaling: fixed work per GPU)
-    lo, hi = distributed.shard_range(args.structures * world, rank, world)
-    molecules = synthetic.structures(hi - lo, start=lo)
     n_atoms = sum(len(m) for m in molecules)
     batch = pyjess.make_batch(molecules, local_rank)  # upload: outside the timed region
     stream = torch.cuda.current_stream().cuda_stream
@@ -224,6 +237,7 @@ def main():
             "config": {
                 "workload": "batch of 1000 synthetic ~300-residue structures per GPU vs the 6780 default-eligible "
                             "templates of jess_templates_20230210 (BASELINE.json configs[2])",
+                "generator": args.generator,
                 "structures_per_gpu": args.structures, "templates": int(len(idx)),
                 "atoms_per_structure": n_atoms / max(1, len(molecules)),
                 "parallelism": f"structures sharded over {world} GPU(s), hit-table gather to rank 0",

@@ -1,31 +1,34 @@
 """Seeded synthetic query structures for benchmarks and parity tests.
 
 The reference ships no benchmark inputs, so the workload "batch of synthetic
-~300-residue structures" (BASELINE.json configs[2], [3]) is defined here:
+~300-residue structures" (BASELINE.json configs[2], [3]) is defined here; structure ``i`` uses seed
+``1234 + i`` and L ~ N(300, 30^2) residues clipped to [150, 450].
 
-* chain length L ~ N(300, 30^2), clipped to [150, 450] residues; structure ``i`` uses seed
-  ``1234 + i``;
-* the chain is assembled from backbone-contiguous fragments (8-20 residues, all heavy atoms) cut
-  from the two structures the reference's own tests use (1AMY and AF-P0DUB6, packed in
-  ``data/residue_pool.npz`` by tests/golden/make_fixtures.py).  Fragments are placed as rigid
-  bodies: local geometry (bond lengths, side-chain conformers, secondary structure) is therefore
-  real, the global fold is new, and the residue composition is that of the two sources;
-* growth is greedy and compact: each fragment tries 48 random poses whose first C-alpha sits 3.8 A
-  from the previous fragment's last C-alpha; the pose with no C-alpha closer than 4 A to the
-  existing chain and the smallest distance to the running centroid wins (radius of gyration comes
-  out near the 2.2 L^0.38 A of globular proteins);
-* coordinates are rounded to 3 decimals (PDB precision), B-factors are U(30, 100) per residue (pLDDT-like), residues are
-  renumbered 1..L on chain A.
+Two generators:
+
+* **v2 (default)**, ``_synth_core.py``: natively packed globules recombined from wedge-shaped cutouts of the
+  two structures the reference's own tests use; atom density and radius of gyration are those of globular
+  proteins (about 140 atoms within 10 A of an atom, Rg within a few per cent of 2.2 L^0.38 A; the band is
+  asserted in tests/test_host_model.py).  ``complex_structure`` builds multi-chain complexes of such globules
+  (BASELINE.json configs[4]).
+* **v1** (``generator="v1"``, round 1): backbone-contiguous fragments (8-20 residues) of the same sources placed
+  as rigid bodies by a greedy compact growth that only rejects C-alpha clashes.  Real local geometry, but 35 %
+  fewer atom pairs inside the templates' distance windows than a real protein (about 105 atoms within 10 A,
+  Rg 20 % above 2.2 L^0.38); kept so that rates measured on both can be put side by side.
+
+``rigid_copies`` gives the density reference asked for next to them: the real structures themselves under random
+rigid transforms.
 """
 from __future__ import annotations
 
 import functools
+import os
 from pathlib import Path
 from typing import List
 
 import numpy as np
 
-from . import pyjess
+from . import _synth_core, pyjess
 
 _POOL = Path(__file__).resolve().parent / "data" / "residue_pool.npz"
 BASE_SEED = 1234
@@ -61,9 +64,9 @@ def _random_rotations(rng, count: int) -> np.ndarray:
     return R
 
 
-def structure_columns(index: int, mean_residues: float = 300.0, sd_residues: float = 30.0,
-                      min_residues: int = 150, max_residues: int = 450):
-    """Columns (xyz, name, residue_name, residue_number, temperature_factor) of synthetic structure ``index``."""
+def structure_columns_v1(index: int, mean_residues: float = 300.0, sd_residues: float = 30.0,
+                         min_residues: int = 150, max_residues: int = 450):
+    """Generator v1: columns (xyz, name, residue_name, residue_number, temperature_factor) of structure ``index``."""
     P = _pool()
     rng = np.random.default_rng(BASE_SEED + int(index))
     length = int(np.clip(round(rng.normal(mean_residues, sd_residues)), min_residues, max_residues))
@@ -122,18 +125,89 @@ def structure_columns(index: int, mean_residues: float = 300.0, sd_residues: flo
     return dict(xyz=xyz, name=name, residue_name=res, residue_number=resnum, temperature_factor=bfac)
 
 
-def structure(index: int, **kw) -> pyjess.Molecule:
-    c = structure_columns(index, **kw)
+def _molecule(ident: str, c) -> pyjess.Molecule:
     n = len(c["residue_number"])
     element = np.array([nm[1:2] for nm in c["name"]], dtype="S2")
+    chain = c.get("chain_id")
     return pyjess.Molecule.from_columns(
-        id=f"synthetic_{index:06d}", xyz=c["xyz"], name=c["name"], residue_name=c["residue_name"],
-        chain_id=np.full(n, b" A", dtype="S2"), residue_number=c["residue_number"],
+        id=ident, xyz=c["xyz"], name=c["name"], residue_name=c["residue_name"],
+        chain_id=chain if chain is not None else np.full(n, b" A", dtype="S2"), residue_number=c["residue_number"],
         temperature_factor=c["temperature_factor"], occupancy=np.ones(n), element=element)
 
 
-def structures(count: int, start: int = 0, **kw) -> List[pyjess.Molecule]:
-    return [structure(start + i, **kw) for i in range(count)]
+def structure_columns(index: int, generator: str = "v2", **kw):
+    if generator == "v1":
+        return structure_columns_v1(index, **kw)
+    if generator != "v2":
+        raise ValueError(f"unknown generator {generator!r}")
+    return _synth_core.structure_columns(index, **kw)
+
+
+def structure(index: int, generator: str = "v2", **kw) -> pyjess.Molecule:
+    return _molecule(f"synthetic_{index:06d}", structure_columns(index, generator=generator, **kw))
+
+
+def _cache_file(kind: str, count: int, start: int, kw) -> "Path | None":
+    """ENZYMM_AMD_SYNTH_CACHE=<dir>: generated columns are kept there (profiling sessions run the same bench
+    several times on one box); unset = nothing is cached."""
+    root = os.environ.get("ENZYMM_AMD_SYNTH_CACHE")
+    if not root:
+        return None
+    tag = "_".join(f"{k}{v}" for k, v in sorted(kw.items()))
+    return Path(root) / f"synth_{kind}_{start}_{count}_{tag}.npz"
+
+
+def structures(count: int, start: int = 0, processes: int = 0, generator: str = "v2", **kw) -> List[pyjess.Molecule]:
+    """Structures ``start`` .. ``start + count - 1``.  ``processes`` > 1 generates them on forked worker
+    processes (numpy only; call it before this process initialises the GPU)."""
+    if generator == "v1":
+        return [structure(start + i, generator="v1", **kw) for i in range(count)]
+    cache = _cache_file("v2", count, start, kw)
+    cols = None
+    if cache is not None and cache.exists():
+        z = np.load(cache)
+        off = z["offsets"]
+        cols = [{k: z[k][off[i]:off[i + 1]] for k in _CACHE_KEYS} for i in range(count)]
+    if cols is None:
+        jobs = [("globule", start + i, kw) for i in range(count)]
+        if processes > 1 and count >= 4 * processes:
+            import multiprocessing
+            with multiprocessing.get_context("fork").Pool(processes) as pool:
+                cols = pool.map(_synth_core._columns_job, jobs, chunksize=max(1, count // (8 * processes)))
+        else:
+            cols = [_synth_core._columns_job(j) for j in jobs]
+        if cache is not None:
+            cache.parent.mkdir(parents=True, exist_ok=True)
+            off = np.concatenate([[0], np.cumsum([len(c["residue_number"]) for c in cols])])
+            tmp = cache.with_suffix(f".{os.getpid()}.tmp.npz")
+            np.savez(tmp, offsets=off, **{k: np.concatenate([c[k] for c in cols]) for k in _CACHE_KEYS})
+            os.replace(tmp, cache)
+    return [_molecule(f"synthetic_{start + i:06d}", c) for i, c in enumerate(cols)]
+
+
+_CACHE_KEYS = ("xyz", "name", "residue_name", "residue_number", "temperature_factor", "chain_id")
+
+
+def complex_structure(index: int, n_residues: int = 6000, **kw) -> pyjess.Molecule:
+    """A multi-chain complex of about ``n_residues`` residues (BASELINE.json configs[4])."""
+    return _molecule(f"complex_{index:06d}", _synth_core.complex_columns(index, n_residues=n_residues, **kw))
+
+
+def rigid_copies(mol: pyjess.Molecule, count: int, seed: int = 0) -> List[pyjess.Molecule]:
+    """``count`` copies of a real structure under random rigid transforms, coordinates rounded to PDB precision:
+    the density reference next to the synthetic batches."""
+    rng = np.random.default_rng(BASE_SEED + 9_000_000 + seed)
+    Rs = _random_rotations(rng, count)
+    shifts = rng.uniform(-50.0, 50.0, size=(count, 3))
+    centre = mol._xyz.mean(0)
+    out = []
+    for i in range(count):
+        c = {k: v for k, v in mol._cols.items()}
+        xyz = np.round((mol._xyz - centre) @ Rs[i].T + shifts[i], 3)
+        m = pyjess.Molecule.from_columns(id=f"{mol.id}_copy{i:04d}", xyz=xyz,
+                                         **{k: v for k, v in c.items() if k not in ("xyz",)})
+        out.append(m)
+    return out
 
 
 def to_pdb(mol: pyjess.Molecule) -> str:

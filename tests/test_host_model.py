@@ -369,3 +369,47 @@ def test_iter_batches_order_errors_and_cleanup(monkeypatch):
     assert first in made and first not in closed
     assert all(b in closed for b in made if b is not first)
     assert list(ingest.iter_batches([], batch_size=4)) == []
+
+
+def test_synthetic_generator_density_band():
+    """The synthetic workload must look like a globular protein to the search: neighbour
+    counts and radius of gyration against the two real structures the reference's tests use."""
+    import numpy as np
+    from scipy.spatial import cKDTree
+    from enzymm_amd import pyjess, synthetic
+
+    def density(xyz, radius):
+        return float((cKDTree(xyz).query_ball_point(xyz, radius, return_length=True) - 1).mean())
+
+    real = [density(pyjess.Molecule.load(helpers.GOLDEN / f)._xyz, 10.0)
+            for f in ("1AMY.pdb", "AF-P0DUB6-F1-model_v4.pdb")]
+    assert 155 < min(real) and max(real) < 170  # 164 / 161
+    n6, n10, rg_ratio, clash, lengths = [], [], [], [], []
+    for mol in synthetic.structures(24):
+        xyz = mol._xyz
+        res = mol._cols["residue_number"]
+        n_res = int(res.max())
+        lengths.append(n_res)
+        n6.append(density(xyz, 6.0))
+        n10.append(density(xyz, 10.0))
+        rg = float(np.sqrt(((xyz - xyz.mean(0)) ** 2).sum(1).mean()))
+        rg_ratio.append(rg / (2.2 * n_res ** 0.38))  # SURVEY.md 8d: compact radius of gyration ~ 2.2 L^0.38
+        pairs = cKDTree(xyz).query_pairs(2.0, output_type="ndarray")
+        clash.append(int((res[pairs[:, 0]] != res[pairs[:, 1]]).sum() - 0))
+    # per structure and on average: within 20 % of a real protein, never the 105 of generator v1
+    assert min(n10) > 125 and 132 < np.mean(n10) < 170, (min(n10), np.mean(n10))
+    assert 33 < np.mean(n6) < 44, np.mean(n6)
+    assert 0.92 < min(rg_ratio) and max(rg_ratio) < 1.08, (min(rg_ratio), max(rg_ratio))
+    assert 150 <= min(lengths) and max(lengths) <= 450 and 270 < np.mean(lengths) < 330
+    # heavy atoms of different residues closer than 2 A: only the peptide bonds of the source chains (1.33 A)
+    assert max(clash) <= max(lengths), clash
+    old = [density(synthetic.structure(i, generator="v1")._xyz, 10.0) for i in range(4)]
+    assert np.mean(old) < 120  # what the round-1 generator gave; kept for side-by-side rates
+    # worker processes give the same structures
+    again = synthetic.structures(8, processes=2)
+    assert all(np.array_equal(a._xyz, b._xyz) for a, b in zip(again, synthetic.structures(8)))
+    # multi-chain complexes for BASELINE.json configs[4]
+    big = synthetic.complex_structure(0, 6000)
+    keys = set(zip(big._cols["chain_id"].tolist(), big._cols["residue_number"].tolist()))
+    assert len(keys) > 5000 and len(set(big._cols["chain_id"].tolist())) >= 15 and len(big) <= 65535
+    assert 135 < density(big._xyz, 10.0) < 170
