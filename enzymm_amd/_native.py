@@ -115,6 +115,13 @@ def load() -> C.CDLL:
                     f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                     "or `make -C enzymm_amd/csrc`. There is no CPU fallback."
                 )
+            # PyTorch bundles its own HIP/HSA runtime; a process can only hold one.  Loading torch first makes this
+            # library bind to the runtime torch uses (same sonames) -- the other order leaves torch.distributed / RCCL
+            # with a second runtime that finds no device ("no ROCm-capable device is detected").
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
             lib = C.CDLL(str(LIB_PATH))
             lib.tm_last_error.restype = C.c_char_p
             lib.tm_result_device_hits.restype = C.c_void_p

@@ -17,7 +17,7 @@ offline, so density is inherited from them instead of being approximated:
   are kept, L ~ N(300, 30^2) clipped to [150, 450]: a compact globule with radius of gyration within a few per
   cent of 2.2 L^0.38 A;
 * residues are renumbered 1..L on chain A (wedge after wedge, source order inside a wedge), coordinates stay at
-  PDB precision, B-factors are U(30, 100) per residue (pLDDT-like).
+  PDB precision, B-factors are pLDDT-like per residue: confident core, less confident surface (``plddt_like``).
 
 What it is not: a single connected chain -- a wedge holds the chain segments of its source that pass through it.
 Nothing on the matching path looks at connectivity.
@@ -150,7 +150,13 @@ def globule(rng, length: int):
     sel &= present
     am = sel[RID]
     new_ord = np.cumsum(sel) - 1  # wedge after wedge, source order inside a wedge
-    return X[am], name[am], res[am], new_ord[RID[am]]
+    return X[am], name[am], res[am], new_ord[RID[am]], rad[sel] / max(float(rad[sel].max()), 1e-9)
+
+
+def plddt_like(rng, rel_radius):
+    """Per-residue temperature factors shaped like the pLDDT column of a predicted model: confident core, less
+    confident surface (100 - 55 r^2 + N(0, 6), clipped to [30, 100]; about 40 % of the residues reach 70)."""
+    return np.round(np.clip(100.0 - 55.0 * rel_radius ** 2 + rng.normal(scale=6.0, size=len(rel_radius)), 30.0, 100.0), 2)
 
 
 def draw_length(rng, mean_residues, sd_residues, min_residues, max_residues) -> int:
@@ -162,9 +168,8 @@ def structure_columns(index: int, mean_residues: float = 300.0, sd_residues: flo
     """Columns of synthetic structure ``index``: one globule on chain A."""
     rng = np.random.default_rng(BASE_SEED + int(index))
     length = draw_length(rng, mean_residues, sd_residues, min_residues, max_residues)
-    xyz, name, res, rord = globule(rng, length)
-    n_res = int(rord.max()) + 1 if len(rord) else 0
-    bfac = np.round(rng.uniform(30.0, 100.0, size=max(n_res, 1)), 2)[rord]
+    xyz, name, res, rord, rel = globule(rng, length)
+    bfac = plddt_like(rng, rel)[rord]
     return dict(xyz=np.round(xyz, 3), name=name, residue_name=res, residue_number=(rord + 1).astype(np.int32),
                 temperature_factor=bfac, chain_id=np.full(len(rord), b" A", dtype="S2"))
 
@@ -186,13 +191,14 @@ def complex_columns(index: int, n_residues: int = 6000, chain_mean: float = 300.
     pts = np.array([(i, j, k) for i in g for j in g for k in g if (i + j + k) % 2 == 0], dtype=np.float64)
     pts *= spacing / np.sqrt(2.0)
     pts = pts[np.argsort((pts ** 2).sum(1), kind="stable")][:n_chains]
-    xs, names, ress, rids, chain = [], [], [], [], []
+    xs, names, ress, rids, chain, bfs = [], [], [], [], [], []
     base = 0
     for c in range(n_chains):
-        x, name, res, rord = globule(rng, draw_length(rng, chain_mean, chain_sd, 150, 450))
+        x, name, res, rord, rel = globule(rng, draw_length(rng, chain_mean, chain_sd, 150, 450))
         xs.append(x + pts[c] + rng.normal(scale=0.5, size=3))
         names.append(name); ress.append(res)
         rids.append(rord + base)
+        bfs.append(plddt_like(rng, rel))
         n_c = int(rord.max()) + 1
         chain.append(np.full(n_c, c))
         base += n_c
@@ -209,8 +215,7 @@ def complex_columns(index: int, n_residues: int = 6000, chain_mean: float = 300.
         members = np.nonzero(present & (C == c))[0]
         first_of_chain[c] = new_ord[members[0]] if len(members) else 0
     resnum = (new_ord[RID] - first_of_chain[chain_of_atom] + 1).astype(np.int32)
-    n_res = int(present.sum())
-    bfac = np.round(rng.uniform(30.0, 100.0, size=max(n_res, 1)), 2)[new_ord[RID]]
+    bfac = np.concatenate(bfs)[np.nonzero(present)[0]][new_ord[RID]]
     chain_id = np.array([(" " + _CHAIN_LETTERS[c]).encode() for c in range(n_chains)], dtype="S2")[chain_of_atom]
     return dict(xyz=np.round(X, 3), name=name, residue_name=res, residue_number=resnum, temperature_factor=bfac,
                 chain_id=chain_id)

@@ -776,6 +776,131 @@ static hipError_t ingest_stream(int device, hipStream_t *out) {
     return hipSuccess;
 }
 
+}  // extern "C"
+
+namespace {
+
+// One PDB file laid out on the host exactly as k_pdb_parse / k_pdb_finalize lay out the others: used by
+// tm_batch_create_from_pdb for the files its device path cannot handle.
+struct HostFlattened {
+    uint32_t file = 0, n_res = 0, residue_count = 0;
+    std::vector<double> xyz;       // device (residue-contiguous) order
+    std::vector<float4> rec;
+    std::vector<uint8_t> chain;
+    std::vector<uint32_t> orig;    // device position -> kept-record index in file order
+    std::vector<uint16_t> res_start;
+};
+
+}  // namespace
+
+extern "C" int tm_pdb_count_host(const char *, uint64_t, uint32_t, uint64_t *, char[4], int *);
+extern "C" int tm_pdb_parse_host(const char *, uint64_t, uint32_t, uint64_t, const tm_pdb_columns *, uint64_t *, uint64_t *);
+
+static int flatten_pdb_on_host(const char *text, uint64_t length, uint32_t flags, double min_bfactor,
+                               const std::vector<uint32_t> &v_names, const uint8_t *name_ids,
+                               const std::vector<uint16_t> &v_el, const uint8_t *el_ids,
+                               const std::vector<uint32_t> &v_res, const uint8_t *res_ids,
+                               const std::vector<uint32_t> &v_counted, uint32_t expect_atoms, uint32_t file,
+                               HostFlattened *out) {
+    uint64_t total = 0;
+    int rc = tm_pdb_count_host(text, length, flags, &total, nullptr, nullptr);
+    if (rc != TM_OK) return rc;
+    std::vector<int32_t> serial(total), resnum(total);
+    std::vector<char> name(4 * total), altloc(total), resname(3 * total), chain_id(2 * total), icode(total),
+        segment(4 * total), element(2 * total);
+    std::vector<double> xyz(3 * total), occ(total), bfac(total);
+    std::vector<int8_t> charge(total);
+    tm_pdb_columns cols{serial.data(), name.data(), altloc.data(), resname.data(), chain_id.data(), resnum.data(),
+                        icode.data(), xyz.data(), occ.data(), bfac.data(), segment.data(), element.data(), charge.data()};
+    rc = tm_pdb_parse_host(text, length, flags, total, &cols, nullptr, nullptr);
+    if (rc != TM_OK) return rc;
+    // kept records in file order (Molecule.conserved: temperature factor >= cutoff)
+    std::vector<uint32_t> kept;
+    kept.reserve(total);
+    for (uint64_t i = 0; i < total; ++i)
+        if (!(min_bfactor > 0.0) || bfac[i] >= min_bfactor) kept.push_back((uint32_t)i);
+    const uint32_t n = (uint32_t)kept.size();
+    if (n != expect_atoms)
+        return fail(TM_E_INVALID, "structure " + std::to_string(file) + ": host and device readers disagree (" +
+                                      std::to_string(n) + " vs " + std::to_string(expect_atoms) + " atoms)");
+    // residue and chain ordinals by first appearance, vocabulary ids, counted residue numbers
+    std::map<uint64_t, uint32_t> by_key;
+    std::vector<uint16_t> seen_chain;
+    std::vector<uint32_t> residue(n);
+    std::vector<uint8_t> chain(n), name_id(n), res_type(n);
+    std::vector<bool> counted_seen(11000, false);
+    uint32_t distinct_counted = 0;
+    for (uint32_t j = 0; j < n; ++j) {
+        const size_t a = kept[j];
+        uint32_t nm = 0, rn = 0;
+        std::memcpy(&nm, &name[4 * a], 4);
+        std::memcpy(&rn, &resname[3 * a], 3);
+        uint32_t id = TM_NAME_OTHER;
+        for (size_t q = 0; q < v_names.size(); ++q)
+            if (v_names[q] == nm) { id = name_ids[q]; break; }
+        if (id == TM_NAME_OTHER) {
+            const uint16_t el = (uint16_t)(nm & 0xffffu);
+            for (size_t q = 0; q < v_el.size(); ++q)
+                if (v_el[q] == el) { id = el_ids[q]; break; }
+        }
+        name_id[j] = (uint8_t)id;
+        uint32_t rt = TM_RES_OTHER;
+        for (size_t q = 0; q < v_res.size(); ++q)
+            if (v_res[q] == rn) { rt = res_ids[q]; break; }
+        res_type[j] = (uint8_t)rt;
+        for (size_t q = 0; q < v_counted.size(); ++q)
+            if (v_counted[q] == rn) {
+                const uint32_t v = (uint32_t)(resnum[a] + 999);
+                if (v < 11000u && !counted_seen[v]) { counted_seen[v] = true; ++distinct_counted; }
+                break;
+            }
+        const uint16_t ch = (uint16_t)((uint8_t)chain_id[2 * a] << 8 | (uint8_t)chain_id[2 * a + 1]);
+        const uint64_t key = ((uint64_t)ch << 40) | ((uint64_t)(uint32_t)(resnum[a] + (1 << 24)) << 8) | (uint8_t)icode[a];
+        auto it = by_key.find(key);
+        if (it == by_key.end()) it = by_key.emplace(key, (uint32_t)by_key.size()).first;
+        residue[j] = it->second;
+        uint32_t c = 0;
+        while (c < seen_chain.size() && seen_chain[c] != ch) ++c;
+        if (c == seen_chain.size()) seen_chain.push_back(ch);
+        chain[j] = (uint8_t)(c & 0xffu);
+    }
+    const uint32_t nres = (uint32_t)by_key.size();
+    if (nres > TM_MAX_STRUCTURE_RESIDUES)
+        return fail(TM_E_UNSUPPORTED, "structure " + std::to_string(file) + " has more than " +
+                                          std::to_string(TM_MAX_STRUCTURE_RESIDUES) + " residues");
+    // stable counting sort by residue ordinal, centred fp32 records
+    std::vector<uint32_t> count(nres + 1, 0), fill;
+    for (uint32_t j = 0; j < n; ++j) count[residue[j] + 1]++;
+    for (uint32_t r = 0; r < nres; ++r) count[r + 1] += count[r];
+    out->n_res = nres;
+    out->residue_count = distinct_counted;
+    out->res_start.resize(nres + 1);
+    for (uint32_t r = 0; r <= nres; ++r) out->res_start[r] = (uint16_t)count[r];
+    fill.assign(count.begin(), count.end() - 1);
+    out->orig.resize(n);
+    for (uint32_t j = 0; j < n; ++j) out->orig[fill[residue[j]]++] = j;
+    double c[3] = {0, 0, 0};
+    for (uint32_t j = 0; j < n; ++j)
+        for (int a = 0; a < 3; ++a) c[a] += xyz[3 * (size_t)kept[j] + a];
+    if (n)
+        for (int a = 0; a < 3; ++a) c[a] /= (double)n;
+    out->xyz.resize(3 * (size_t)n); out->rec.resize(n); out->chain.resize(n);
+    for (uint32_t d = 0; d < n; ++d) {
+        const uint32_t j = out->orig[d];
+        const size_t a = kept[j];
+        for (int k = 0; k < 3; ++k) out->xyz[3 * (size_t)d + k] = xyz[3 * a + k];
+        float4 r;
+        r.x = (float)(xyz[3 * a] - c[0]); r.y = (float)(xyz[3 * a + 1] - c[1]); r.z = (float)(xyz[3 * a + 2] - c[2]);
+        const uint32_t m = meta_pack(residue[j], name_id[j], res_type[j]);
+        std::memcpy(&r.w, &m, 4);
+        out->rec[d] = r;
+        out->chain[d] = chain[j];
+    }
+    return TM_OK;
+}
+
+extern "C" {
+
 int tm_batch_create_from_pdb(int device, uint32_t n_files, const char *const *text, const uint64_t *length,
                              const tm_vocab *vocab, uint32_t flags, double min_bfactor, tm_batch **out) {
     if (!out || !vocab || (n_files && (!text || !length))) return fail(TM_E_INVALID, "tm_batch_create_from_pdb: NULL argument");
@@ -879,9 +1004,13 @@ int tm_batch_create_from_pdb(int device, uint32_t n_files, const char *const *te
                            reinterpret_cast<const uint8_t *>(d_text.p), d_nl.p, n_lines, d_keep.p, d_atom_rank.p,
                            d_line_file.p, d_file_off.p, V, P, d_bad.p);
     }
-    if (n_files)
-        hipLaunchKernelGGL(k_pdb_residues, dim3(n_files), dim3(256), 0, stream, d_s_off_tmp.p, d_key.p, d_runs.p,
+    if (n_files) {
+        const size_t key_lds = (size_t)kMaxSortedRuns * sizeof(uint64_t);
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pdb_residues),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)key_lds));
+        hipLaunchKernelGGL(k_pdb_residues, dim3(n_files), dim3(256), key_lds, stream, d_s_off_tmp.p, d_key.p, d_runs.p,
                            d_needs_host.p);
+    }
     HIP_TRY(hipGetLastError());
     std::vector<uint32_t> s_off(n_files + 1, 0), runs(n_files, 0), needs_host(n_files, 0);
     uint32_t bad = 0;
@@ -898,14 +1027,24 @@ int tm_batch_create_from_pdb(int device, uint32_t n_files, const char *const *te
     if (bad) return fail(TM_E_INVALID, "malformed ATOM/HETATM record in the PDB text");
     std::vector<uint32_t> s_roff(n_files + 1, 0);
     uint32_t max_atoms = 0, max_res = 0;
+    // Files the device path cannot lay out -- a residue whose records are not contiguous (its atoms have to be
+    // gathered), or more residue runs than k_pdb_residues can check -- are flattened on the host, one by one, and
+    // patched into the batch below; the rest of the batch stays on the device path.
+    std::vector<HostFlattened> host_files;
     for (uint32_t f = 0; f < n_files; ++f) {
         const uint32_t n = s_off[f + 1] - s_off[f];
         if (n > TM_MAX_STRUCTURE_ATOMS)
             return fail(TM_E_UNSUPPORTED, "structure " + std::to_string(f) + " has " + std::to_string(n) + " atoms; limit " +
                                               std::to_string(TM_MAX_STRUCTURE_ATOMS));
-        if (needs_host[f])
-            return fail(TM_E_UNSUPPORTED, "structure " + std::to_string(f) + " is not residue-contiguous (or has more than " +
-                                              std::to_string(kMaxSortedRuns) + " residues): use tm_batch_create");
+        if (needs_host[f]) {
+            host_files.emplace_back();
+            HostFlattened &h = host_files.back();
+            h.file = f;
+            int rc = flatten_pdb_on_host(text[f], length[f], flags, min_bfactor, v_names, vocab->atom_name_ids, v_el,
+                                         vocab->element_ids, v_res, vocab->residue_ids, v_counted, n, f, &h);
+            if (rc != TM_OK) return rc;
+            runs[f] = h.n_res;
+        }
         s_roff[f + 1] = s_roff[f] + runs[f] + 1;
         max_atoms = std::max(max_atoms, n);
         max_res = std::max(max_res, runs[f]);
@@ -919,8 +1058,20 @@ int tm_batch_create_from_pdb(int device, uint32_t n_files, const char *const *te
     b->has_residue_count = n_counted != 0;
     if (n_files) {
         hipLaunchKernelGGL(k_pdb_finalize, dim3(n_files), dim3(256), 0, stream, b->d_s_off.p, b->d_s_roff.p, P,
-                           b->d_rec.p, b->d_chain.p, b->d_orig.p, b->d_res_start.p, b->d_residue_count.p);
+                           b->d_rec.p, b->d_chain.p, b->d_orig.p, b->d_res_start.p, b->d_residue_count.p, d_needs_host.p);
         HIP_TRY(hipGetLastError());
+    }
+    for (const HostFlattened &h : host_files) {  // same stream: ordered after the kernels that wrote these ranges
+        const size_t a0 = s_off[h.file], n = h.rec.size();
+        if (n) {
+            HIP_TRY(hipMemcpyAsync(b->d_xyz.p + 3 * a0, h.xyz.data(), 3 * n * sizeof(double), hipMemcpyHostToDevice, stream));
+            HIP_TRY(hipMemcpyAsync(b->d_rec.p + a0, h.rec.data(), n * sizeof(float4), hipMemcpyHostToDevice, stream));
+            HIP_TRY(hipMemcpyAsync(b->d_chain.p + a0, h.chain.data(), n, hipMemcpyHostToDevice, stream));
+            HIP_TRY(hipMemcpyAsync(b->d_orig.p + a0, h.orig.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        }
+        HIP_TRY(hipMemcpyAsync(b->d_res_start.p + s_roff[h.file], h.res_start.data(), h.res_start.size() * sizeof(uint16_t),
+                               hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(b->d_residue_count.p + h.file, &h.residue_count, sizeof(uint32_t), hipMemcpyHostToDevice, stream));
     }
     HIP_TRY(hipStreamSynchronize(stream));
     guard.b = nullptr;
@@ -996,12 +1147,18 @@ static int build_index(const tm_library *lib, tm_batch *b, tm_result *r, hipStre
                            b->d_overflow.p, bucket_cap);
         HIP_TRY(hipGetLastError());
     }
-    // the outcome travels with the query: pool entries needed, and the overflow bit
+    b->index_for = lib->serial;
+    return TM_OK;
+}
+
+// The outcome of the index build the query searches -- pool entries needed, overflow bit -- travels with EVERY query
+// that uses that index, not only with the one that launched the build: a second query issued before the first one
+// was waited for reuses the index, and must report the same TM_E_OVERFLOW instead of returning with hits missing.
+static int carry_index_outcome(tm_batch *b, tm_result *r, hipStream_t stream) {
     HIP_TRY(hipMemcpyAsync(r->d_pool_used.p, b->d_cursor.p, sizeof(unsigned long long), hipMemcpyDeviceToDevice, stream));
     hipLaunchKernelGGL(k_flag_index_overflow, dim3(1), dim3(1), 0, stream, b->d_overflow.p, r->d_overflow.p);
     HIP_TRY(hipGetLastError());
-    r->pool_capacity = cap;
-    b->index_for = lib->serial;
+    r->pool_capacity = b->pool_capacity;
     return TM_OK;
 }
 
@@ -1099,6 +1256,10 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
     HIP_TRY(hipEventRecord(r->ev[0], stream));
     if (b->index_for != lib->serial || (p->flags & TM_FLAG_REBUILD_INDEX) || b->index_shared->stale.load()) {
         int rc = build_index(lib, b, r, stream);
+        if (rc != TM_OK) return rc;
+    }
+    {
+        int rc = carry_index_outcome(b, r, stream);
         if (rc != TM_OK) return rc;
     }
     HIP_TRY(hipEventRecord(r->ev[1], stream));

@@ -18,7 +18,7 @@ namespace tmx {
 
 constexpr int kScanBlock = 256;
 constexpr int kScanItems = 8;  // items per thread in the scan kernels
-constexpr int kMaxSortedRuns = 4096;
+constexpr int kMaxSortedRuns = 16384;  // residue runs per file checked on the device (128 KB of LDS); above: host path
 
 struct VocabView {
     uint32_t n_names, n_elements, n_res;
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void k_pdb_parse(const uint8_t *__restrict__ t
 // key (then the file is not residue-contiguous and the caller must take the host path)
 __global__ __launch_bounds__(256) void k_pdb_residues(const uint32_t *__restrict__ s_off, const uint64_t *__restrict__ key,
                                                        uint32_t *__restrict__ n_runs, uint32_t *__restrict__ needs_host) {
-    __shared__ uint64_t s_keys[kMaxSortedRuns];
+    extern __shared__ uint64_t s_keys[];  // [kMaxSortedRuns]
     __shared__ uint32_t s_count;
     const uint32_t s = blockIdx.x;
     const uint32_t a0 = s_off[s], n = s_off[s + 1] - a0;
@@ -354,7 +354,9 @@ __global__ __launch_bounds__(256) void k_pdb_residues(const uint32_t *__restrict
 __global__ __launch_bounds__(256) void k_pdb_finalize(const uint32_t *__restrict__ s_off, const uint32_t *__restrict__ s_roff,
                                                        ParsedAtoms P, float4 *__restrict__ rec, uint8_t *__restrict__ chain,
                                                        uint32_t *__restrict__ orig, uint16_t *__restrict__ res_start,
-                                                       uint32_t *__restrict__ residue_count) {
+                                                       uint32_t *__restrict__ residue_count,
+                                                       const uint32_t *__restrict__ needs_host) {
+    if (needs_host[blockIdx.x]) return;  // flattened on the host (tm_batch_create_from_pdb), its residue table differs
     __shared__ uint32_t s_wave[4];
     // distinct residue NUMBERS among atoms whose residue name is counted (enzymm's query_residue_count ignores
     // chains and insertion codes): one bit per value of the 4-column resSeq field, -999 .. 9999

@@ -67,9 +67,15 @@ def gather_tables(local: np.ndarray, structure_offset: int, group=None, device=N
     dist.gather(buf, out, dst=0, group=group)
     if rank != 0:
         return None
-    parts = [out[r][: counts[r] * width].cpu().numpy().view(_native.HIT_DTYPE) for r in range(world)]
-    table = np.concatenate(parts) if parts else local[:0]
-    order = np.lexsort((table["template_sel"], table["structure"]))
+    return merge_tables([out[r][: counts[r] * width].cpu().numpy().view(_native.HIT_DTYPE) for r in range(world)])
+
+
+def merge_tables(parts) -> np.ndarray:
+    """Per-rank hit tables (``structure`` already global) -> one table in (structure, template) order: what rank 0
+    holds after the gather.  Several hits of one pair (best_match off) keep their per-rank order."""
+    parts = [np.ascontiguousarray(p, dtype=_native.HIT_DTYPE) for p in parts]
+    table = np.concatenate(parts) if parts else np.zeros(0, dtype=_native.HIT_DTYPE)
+    order = np.lexsort((table["template_sel"], table["structure"]))  # stable
     return table[order]
 
 

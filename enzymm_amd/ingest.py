@@ -114,6 +114,10 @@ class PdbBatch:
         off = self.native.atom_offsets
         for i in indices:
             mol = self.molecules[i]
+            # a molecule with matches outlives the batch (Matcher.run_files keeps it as a dict key): give it its own
+            # copy of its file's text -- a view would pin the whole batch buffer (about 1000 files) per survivor
+            if isinstance(mol._text, memoryview):
+                mol._text = bytes(mol._text)
             mol._line_off = self._line_off[int(off[i]): int(off[i + 1])].copy()
             if self._res_counts is not None:
                 mol._residue_count = int(self._res_counts[i])

@@ -117,6 +117,13 @@ class Match:
         return [(t[0].residue_name, t[0].chain_id, str(t[0].residue_number)) for t in self.atom_triplets]
 
     @property
+    def truncated(self) -> bool:
+        """True when the search of this (template, molecule) pair stopped at ``max_candidates``: the hit is the best
+        of the assignments visited, and which ones are visited first is this engine's own order (not Jess's), so the
+        reported hit of such a pair may differ from PyJess's.  Not a column of the reference's TSV."""
+        return bool(getattr(self.hit, "truncated", False))
+
+    @property
     def multimeric(self) -> bool:
         atoms = self.hit.atoms()
         return any(a.chain_id != atoms[0].chain_id for a in atoms)
@@ -401,6 +408,13 @@ class Matcher:
                 groups.setdefault(bucket_of[position[id(h.template)]], []).append(h)
             for s, hs in groups.items():
                 by_size[s].append((mi, hs))
+
+        if self.warn:
+            cut_short = sum(1 for hits in per_molecule for h in hits if getattr(h, "truncated", False))
+            if cut_short:
+                warnings.warn(f"{cut_short} (template, molecule) searches stopped at max_candidates="
+                              f"{self.MAX_CANDIDATES}; their best hit is chosen among the assignments visited "
+                              "(Match.truncated), whose order differs from Jess's")
 
         processed: Dict[pyjess.Molecule, List[Match]] = collections.defaultdict(list)
         for s in sizes:  # replay the reference's per-size loop on the hit table

@@ -427,6 +427,16 @@ def check_template(template: Template, warn: bool = True) -> bool:
     if not template.cath:
         warnings.warn("Could not find CATH annotations")
         ok = False
+    if template.pdb_id:
+        # the template's UniProt accession against PDB-SIFTS, for every PDB chain the template takes residues from
+        # (template.py:1595-1615): a mismatch excludes the template from a Matcher built with warn=True
+        sifts = _annotation_tables()["sifts"]
+        for chain in {f"{template.pdb_id}{r.chain_id}" for r in template.residues}:
+            entry = sifts.get(chain)
+            if entry:
+                if template.uniprot_id != entry["uniprot_id"]:
+                    ok = False
+                    warnings.warn(f"Different UniProt Accessions {template.uniprot_id} and {entry['uniprot_id']} found")
     return ok
 
 

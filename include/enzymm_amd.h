@@ -185,7 +185,8 @@ struct tm_vocab;
 int tm_batch_create_from_columns(int device, const tm_columns_desc *desc, const struct tm_vocab *vocab, tm_batch **out);
 /* Device-side ingestion: raw PDB text is uploaded and parsed on the GPU (ATOM/HETATM records up to the first
  * ENDMDL, optional temperature-factor cutoff) -- replaces pyjess.Molecule.load + Molecule.conserved for batches,
- * enzymm/jess_run.py:538-545.  TM_E_UNSUPPORTED when a file is not residue-contiguous: use tm_batch_create. */
+ * enzymm/jess_run.py:538-545.  A file the device path cannot lay out (a residue whose records are not contiguous,
+ * or more than 16384 residue runs) is flattened on the host inside this call; the batch is still one tm_batch. */
 int tm_batch_create_from_pdb(int device, uint32_t n_files, const char *const *text, const uint64_t *length,
                              const tm_vocab *vocab, uint32_t flags, double min_bfactor, tm_batch **out);
 int tm_batch_atom_counts(tm_batch *batch, uint32_t *atom_offsets);            /* [n_structures + 1] */

@@ -161,3 +161,23 @@ def implant_templates(mol, templates, rng, max_templates=200, radius=14.0):
             new_atoms.append(b)
         out.append(pyjess.Template(new_atoms, id=f"implant_{ti}"))
     return out
+
+
+def check_completeness_vector(Matcher, jess_factory, amy, af):
+    """Matcher._check_completeness (/root/reference/enzymm/jess_run.py:738-783) on a real multi-member cluster: the
+    3-residue templates of M-CSA 285 form two clusters of two members each.  1AMY is hit by both members of
+    cluster 1 (complete), by neither of cluster 2; with member 2 of cluster 1 withheld, member 1's match is
+    incomplete.  AF-P0DUB6 needs the looser 1.2 A to be hit at all."""
+    from enzymm_amd import template
+    tpls = list(template.load_templates(GOLDEN / "templates" / "3_residues" / "results" / "csa3d_0285"))
+    assert sorted((t.cluster.id, t.cluster.member, t.cluster.size) for t in tpls) == \
+        [(1, 1, 2), (1, 2, 2), (2, 1, 2), (2, 2, 2)]
+    summary = lambda ms: sorted((m.hit.template.cluster.id, m.hit.template.cluster.member, m.complete) for m in ms)
+    out = Matcher(tpls, filter_matches=False, jess_factory=jess_factory).run([amy, af])
+    assert summary(out[amy]) == [(1, 1, True), (1, 2, True)] and af not in out
+    partial = [t for t in tpls if (t.cluster.id, t.cluster.member) != (1, 2)]
+    out = Matcher(partial, filter_matches=False, jess_factory=jess_factory).run([amy, af])
+    assert summary(out[amy]) == [(1, 1, False)]
+    loose = {s: {"rmsd": 2.0, "distance": 1.2, "max_dynamic_distance": 1.2} for s in range(3, 9)}
+    out = Matcher(tpls, jess_params=loose, filter_matches=False, jess_factory=jess_factory).run([amy, af])
+    assert summary(out[amy]) == summary(out[af]) == [(1, 1, True), (1, 2, True)]

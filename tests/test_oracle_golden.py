@@ -93,18 +93,36 @@ def test_g1_pdb_dumps_byte_exact(amy, fname, kw):
     assert buf.getvalue() == (helpers.GOLDEN / fname).read_text()
 
 
+UNREPRODUCIBLE_TSV_COLUMNS = {
+    # Jess's E-value model is in the absent pyjess/Jess C source: Hit.log_evalue is NaN (strict xfail below)
+    "log_evalue",
+    # AnnotatedTemplate columns: their data file is one of the reference's .MISSING_LARGE_BLOBS (template.py:1472)
+    "number_of_mutated_residues", "number_of_side_chain_residues_(template,reference)",
+    "number_of_metal_ligands_(template,reference)", "number_of_ptm_residues_(template, reference)",
+    "total_reference_residues",
+}
+
+
 def test_g1_tsv_row(amy):
-    """tests/test_data/results.tsv: every column except the AnnotatedTemplate tail
-    (needs a data blob the reference does not ship) and log_evalue (unpinned: reported as nan)."""
+    """tests/test_data/results.tsv (tests/test_jess_run.py:147-155): 24 of the 30 columns byte for byte; the six that
+    cannot be reproduced are named, and must be exactly the ones that differ."""
     _, _, hits = _golden_match("G1", amy)
     m = jess_run.Match(hit=hits[0], pairwise_distance=1.5, complete=True, index=0)
     got_h, got = [l.split("\t") for l in m.dumps(header=True).splitlines()]
     want_h, want = [l.split("\t") for l in (helpers.GOLDEN / "results.tsv").read_text().splitlines()]
-    assert got_h == want_h
-    skip = {"log_evalue"} | set(want_h[25:])
-    for name, a, b in zip(want_h, got, want):
-        if name not in skip:
-            assert a == b, name
+    assert got_h == want_h and len(want_h) == 30
+    differing = {name for name, a, b in zip(want_h, got, want) if a != b}
+    assert differing <= UNREPRODUCIBLE_TSV_COLUMNS, differing
+    assert "log_evalue" in differing and got[want_h.index("log_evalue")] == "nan"
+
+
+@pytest.mark.xfail(strict=True, reason="Hit.log_evalue is unpinned: Jess's E-value model is in absent third-party C "
+                                        "source and two known answers cannot determine it; reported as NaN, not invented")
+@pytest.mark.parametrize("key", ["G1", "G2"])
+def test_log_evalue_known_answers(amy, key):
+    """tests/test_jess_run.py:78 (-3.08424478) and :134 (1.8517964201)."""
+    g, _, hits = _golden_match(key, amy)
+    assert hits[0].log_evalue == pytest.approx(g["log_evalue"], abs=1e-7)
 
 
 def _matcher(templates, **kw):
