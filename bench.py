@@ -61,7 +61,7 @@ def reference_baseline(molecules, idx, cut, target_seconds):
         for i, c in zip(idx, cut):
             by_cut.setdefault(float(c), []).append(real.Template.loads(texts[i][1], id=str(i)))
         engines = [(c, real.Jess(tpls)) for c, tpls in by_cut.items()]
-        cores = len(os.sched_getaffinity(0))
+        cores = usable_cores()
 
         def one(mol):
             m = real.Molecule.loads(synthetic.to_pdb(mol))
@@ -82,6 +82,25 @@ def reference_baseline(molecules, idx, cut, target_seconds):
         return None
 
 
+def usable_cores() -> int:
+    """CPUs this process may actually use: the affinity mask, cut down to the cgroup's CPU quota (a GPU box can
+    show 256 CPUs in its mask and grant the container a handful)."""
+    cores = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            text = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = text[0], float(text[1])
+            else:
+                quota, period = text[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                cores = max(1, min(cores, int(float(quota) / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return cores
+
+
 def cpu_baseline(molecules, idx, cut, target_seconds, repeats=3):
     """Oracle (CPU restatement, NOT PyJess) timed on this host's cores as SURVEY.md 8(d) prescribes: one structure
     per task, one single-threaded oracle call per task, as many tasks in flight as the host has cores
@@ -92,7 +111,7 @@ def cpu_baseline(molecules, idx, cut, target_seconds, repeats=3):
     texts = parse.read_packed_library(ROOT / "enzymm_amd" / "data" / "jess_templates_20230210.txt.gz")
     otpl = [parse.parse_template(t) for _, t in texts]
     olib = oracle.OracleLibrary([otpl[i] for i in idx])
-    cores = len(os.sched_getaffinity(0))
+    cores = usable_cores()
 
     def as_oracle(mol):
         c = mol._cols
@@ -102,15 +121,19 @@ def cpu_baseline(molecules, idx, cut, target_seconds, repeats=3):
     def one(om):
         return oracle.query_library(om, olib, 2.0, cut, cut, max_candidates=10000, ignore_chain=True, threads=1)
 
-    # calibrate on one structure, then size the sample so that all repeats together take about target_seconds
+    # calibrate: one structure alone, then one structure per core in flight; the sample is sized from the loaded rate
+    # so that all repeats together take about target_seconds
     t0 = time.perf_counter()
     first = one(as_oracle(molecules[0]))
     per_structure = time.perf_counter() - t0
-    per_pass = max(1.0, target_seconds / repeats)
-    sample = int(min(len(molecules), max(cores, cores * (per_pass / max(per_structure, 1e-3)) // 2)))
-    oms = [as_oracle(m) for m in molecules[:sample]]
     rates, results = [], None
     with ThreadPoolExecutor(cores) as pool:
+        probe = [as_oracle(m) for m in molecules[:min(cores, len(molecules))]]
+        t0 = time.perf_counter()
+        list(pool.map(one, probe))
+        loaded_rate = len(probe) / (time.perf_counter() - t0)
+        sample = int(min(len(molecules), max(len(probe), loaded_rate * target_seconds / repeats)))
+        oms = [as_oracle(m) for m in molecules[:sample]]
         for _ in range(repeats):
             t0 = time.perf_counter()
             results = list(pool.map(one, oms))

@@ -229,6 +229,12 @@ struct StagedSelection {
     // then starts with the expensive templates and ends on the cheap ones); order[pos] is the caller's index.
     std::vector<uint32_t> order;
     DevBuf<uint32_t> d_order;
+    // pair tables the selection's templates read (see k_tab_* in tm_kernels.hip) and, per staged template, which ones
+    std::vector<TableDesc> tables;
+    DevBuf<TableDesc> d_tables;
+    DevBuf<uint16_t> d_pair_table, d_triple_table;
+    DevBuf<uint8_t> d_triple_key;
+    uint64_t serial = 0;  // identity for the batch-side table cache
     hipEvent_t ready = nullptr;  // recorded after k_stage_templates
     ~StagedSelection() {
         if (ready) (void)hipEventDestroy(ready);
@@ -254,6 +260,11 @@ struct tm_library {
     // per template: expected size of the cross product of its two top lead lists (residue types x atom names
     // admitted by each) -- the estimate of search cost the selection is ordered by
     std::vector<float> cost_weight;
+    // host copies in SEARCH order, for planning the pair tables of a selection: positions 0 .. n_groups - 1 of a
+    // template are its lead atoms
+    std::vector<double> h_xyz, h_w;
+    std::vector<uint16_t> h_lead_li;   // per atom: lead-kind index (lead positions only)
+    std::vector<uint8_t> h_n_groups;   // per template
     LibView view() const {
         LibView v;
         v.n_templates = n_templates; v.n_kinds = n_kinds; v.n_lead = n_lead;
@@ -270,6 +281,7 @@ struct tm_library {
 // What a query result may have to tell its batch after the fact (it can outlive the batch, hence shared).
 struct IndexShared {
     std::atomic<unsigned long long> pool_wanted{0};  // kind-list entries an overflowed build needed
+    std::atomic<unsigned long long> rows_wanted{0}, ents_wanted{0};  // pair-table row slots / entries, likewise
     std::atomic<bool> stale{false};                  // the index in the batch is incomplete: rebuild before use
 };
 
@@ -294,6 +306,15 @@ struct tm_batch {
     bool queried = false;
     uint64_t index_for = 0;  // serial of the library the candidate index was built for
     unsigned long long pool_capacity = 0;
+    // pair tables of one staged selection (rebuilt with the candidate index, or when the selection changes)
+    uint64_t tables_for = 0;  // serial of the selection
+    uint32_t n_tables = 0;
+    DevBuf<uint32_t> d_tab_dir, d_tab_rows, d_tab_ok, d_tab_overflow;
+    DevBuf<uint2> d_tab_seg, d_tab_ent;
+    DevBuf<unsigned long long> d_tab_cursors;  // [0] row slots, [1] entries handed out
+    DevBuf<TabWork> d_tab_work;
+    uint32_t tab_work_items = 0, tab_work_tables = 0xffffffffu;
+    unsigned long long row_capacity = 0, ent_capacity = 0;
     // The index build is not waited for: a query whose build overflowed the kind-list pool finds out in
     // tm_result_wait and leaves the size it needed here (shared with the results, which may outlive a batch);
     // the next build starts from it.
@@ -303,6 +324,8 @@ struct tm_batch {
         v.n_structs = n_structs; v.s_off = d_s_off.p; v.s_roff = d_s_roff.p; v.q_xyz = d_xyz.p;
         v.q_rec = d_rec.p; v.q_chain = d_chain.p; v.q_orig = d_orig.p; v.res_start = d_res_start.p;
         v.kl_off = d_kl_off.p; v.kl_pool = d_kl_pool.p;
+        v.n_tables = n_tables; v.tab_dir = d_tab_dir.p; v.tab_rows = d_tab_rows.p; v.tab_ent = d_tab_ent.p;
+        v.tab_seg = d_tab_seg.p; v.tab_ok = d_tab_ok.p;
         return v;
     }
 };
@@ -319,7 +342,8 @@ struct tm_result {
     std::shared_ptr<StagedSelection> selection;
     std::shared_ptr<IndexShared> index_shared;                      // the batch's (see tm_batch)
     DevBuf<unsigned long long> d_pool_used;                         // kind-list entries the index build needed
-    unsigned long long pool_capacity = 0;
+    DevBuf<unsigned long long> d_tab_used;                          // pair-table row slots, entries the build needed
+    unsigned long long pool_capacity = 0, row_capacity = 0, ent_capacity = 0;
     DevBuf<uint32_t> d_overflow, d_candidates;
     DevBuf<double> d_cand_rmsd, d_models;
     DevBuf<int32_t> d_model_set;
@@ -496,6 +520,17 @@ int tm_library_create(int device, const tm_library_desc *d, tm_library **out) {
     lib->t_off.assign(d->atom_offsets, d->atom_offsets + nt + 1);
     lib->cost_weight = std::move(cost_weight);
     lib->serial = ++g_serial;
+    lib->h_lead_li.assign(na, 0xffffu);
+    lib->h_n_groups.assign(nt, 0);
+    for (uint32_t t = 0; t < nt; ++t) {
+        const uint32_t o = d->atom_offsets[t], k = d->atom_offsets[t + 1] - o;
+        uint8_t g = 0;
+        for (uint32_t i = 0; i < k; ++i) g = std::max<uint8_t>(g, (uint8_t)(group[o + i] + 1));
+        lib->h_n_groups[t] = g;
+        for (uint32_t i = 0; i < g; ++i) lib->h_lead_li[o + i] = (uint16_t)k_lead[kind[o + i]];
+    }
+    lib->h_xyz = xyz;
+    lib->h_w = w;
     hipError_t e = hipSuccess;
     auto up = [&](hipError_t r) { if (e == hipSuccess) e = r; };
     up(lib->d_t_off.upload(lib->t_off)); up(lib->d_xyz.upload(xyz)); up(lib->d_w.upload(w));
@@ -1162,6 +1197,86 @@ static int carry_index_outcome(tm_batch *b, tm_result *r, hipStream_t stream) {
     return TM_OK;
 }
 
+// (Re)builds the batch's pair tables for selection `S` on `stream`, like the candidate index without waiting: the
+// pools are sized generously (or to what an earlier build reported); should one overflow, the structures that did
+// not fit are skipped by the search, bit 4 of the query's overflow word is set and tm_result_wait reports
+// TM_E_OVERFLOW so that the caller queries again with room.
+static int build_tables(const tm_library *lib, tm_batch *b, const StagedSelection *S, hipStream_t stream) {
+    const uint32_t nt = (uint32_t)S->tables.size(), ns = b->n_structs;
+    b->n_tables = nt;
+    const size_t dir_n = (size_t)ns * nt;
+    if (b->queried && (b->d_tab_dir.n != dir_n || b->d_tab_ok.n != ns)) HIP_TRY(hipStreamSynchronize(b->last_stream));
+    if (b->d_tab_dir.n != dir_n) { HIP_TRY(b->d_tab_dir.alloc(dir_n)); HIP_TRY(b->d_tab_seg.alloc(dir_n)); }
+    if (b->d_tab_ok.n != ns) HIP_TRY(b->d_tab_ok.alloc(ns));
+    if (!b->d_tab_cursors.p) { HIP_TRY(b->d_tab_cursors.alloc(2)); HIP_TRY(b->d_tab_overflow.alloc(1)); }
+    unsigned long long rows = b->row_capacity ? b->row_capacity
+                                              : std::max<unsigned long long>(4096, 16ull * b->n_atoms + (unsigned long long)ns * (nt + 8));
+    unsigned long long ents = b->ent_capacity ? b->ent_capacity : std::max<unsigned long long>(65536, 48ull * b->n_atoms);
+    if (!b->ent_capacity)
+        if (const char *env = std::getenv("ENZYMM_AMD_TABLE_POOL"))  // test hook: start from a pool that is too small
+            ents = std::max<unsigned long long>(64, std::strtoull(env, nullptr, 10));
+    const unsigned long long rows_wanted = b->index_shared->rows_wanted.load(), ents_wanted = b->index_shared->ents_wanted.load();
+    if (rows_wanted > rows) rows = rows_wanted + rows_wanted / 8 + 1024;
+    if (ents_wanted > ents) ents = ents_wanted + ents_wanted / 8 + 1024;
+    if (rows > 0xfffffff0ull || ents > 0xfffffff0ull)
+        return fail(TM_E_UNSUPPORTED, "pair tables need more than 2^32 entries: split the batch");
+    if (b->d_tab_rows.n != rows || b->d_tab_ent.n != ents) {
+        if (b->queried) HIP_TRY(hipStreamSynchronize(b->last_stream));  // an earlier query may still read the old pools
+        if (b->d_tab_rows.n != rows) HIP_TRY(b->d_tab_rows.alloc(rows));
+        if (b->d_tab_ent.n != ents) HIP_TRY(b->d_tab_ent.alloc(ents));
+    }
+    b->row_capacity = rows; b->ent_capacity = ents;
+    HIP_TRY(hipMemsetAsync(b->d_tab_cursors.p, 0, 2 * sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(b->d_tab_overflow.p, 0, sizeof(uint32_t), stream));
+    HIP_TRY(hipMemsetAsync(b->d_tab_ok.p, 0, std::max<uint32_t>(ns, 1) * sizeof(uint32_t), stream));
+    b->tables_for = S->serial;
+    if (!ns) return TM_OK;
+    if (!nt) {  // no template of the selection has two residues: nothing to build, every structure is searchable
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)b->d_tab_ok.p, 1, ns, stream));
+        return TM_OK;
+    }
+    // work items of the two build passes: a structure's tables are dealt to `parts` workgroups, parts growing with
+    // the square of its atom count (a 300-residue structure is one item)
+    if (b->tab_work_tables != nt) {
+        std::vector<TabWork> items;
+        for (uint32_t s = 0; s < ns; ++s) {
+            const double n = (double)(b->s_off[s + 1] - b->s_off[s]);
+            const uint32_t parts = (uint32_t)std::min<double>(std::min<double>(64.0, std::max(1u, nt / 4u)),
+                                                             std::max(1.0, std::floor(n * n / (3000.0 * 3000.0) + 0.5)));
+            for (uint32_t r = 0; r < parts; ++r) items.push_back(TabWork{s, (uint16_t)r, (uint16_t)parts});
+        }
+        // heaviest structures first
+        std::stable_sort(items.begin(), items.end(), [&](const TabWork &x, const TabWork &y) {
+            return b->s_off[x.s + 1] - b->s_off[x.s] > b->s_off[y.s + 1] - b->s_off[y.s];
+        });
+        HIP_TRY(hipStreamSynchronize(stream));  // a previous query may still read the old list
+        HIP_TRY(b->d_tab_work.upload(items));
+        b->tab_work_items = (uint32_t)items.size(); b->tab_work_tables = nt;
+    }
+    const BatchView B = b->view();
+    // LDS of a build workgroup: the atom record of every kind-list position of its structure (about 2.5 per atom)
+    const uint32_t lr_cap = (uint32_t)std::min<size_t>(9600, std::max<size_t>(1024, 3 * (size_t)b->max_atoms));
+    const size_t lds_bytes = (size_t)lr_cap * sizeof(float4) + ((size_t)lib->n_lead + 2 + nt) * sizeof(uint32_t);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tab_build), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_bytes));
+    hipLaunchKernelGGL(k_tab_layout, dim3(ns), dim3(256), 0, stream, lib->n_lead, B, S->d_tables.p, b->d_tab_dir.p,
+                       b->d_tab_cursors.p, rows, b->d_tab_overflow.p, b->d_tab_ok.p);
+    hipLaunchKernelGGL(k_tab_build, dim3(b->tab_work_items), dim3(kTabBlock), lds_bytes, stream, lib->n_lead, B,
+                       S->d_tables.p, b->d_tab_work.p, b->d_tab_ok.p, b->d_tab_rows.p, b->d_tab_ent.p, b->d_tab_seg.p,
+                       b->d_tab_cursors.p, ents, b->d_tab_overflow.p, lr_cap);
+    HIP_TRY(hipGetLastError());
+    return TM_OK;
+}
+
+// like carry_index_outcome, for the pair tables
+static int carry_table_outcome(tm_batch *b, tm_result *r, hipStream_t stream) {
+    HIP_TRY(hipMemcpyAsync(r->d_tab_used.p, b->d_tab_cursors.p, 2 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, stream));
+    hipLaunchKernelGGL(k_flag_table_overflow, dim3(1), dim3(1), 0, stream, b->d_tab_overflow.p, r->d_overflow.p);
+    HIP_TRY(hipGetLastError());
+    r->row_capacity = b->row_capacity; r->ent_capacity = b->ent_capacity;
+    return TM_OK;
+}
+
 int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_result **out) {
     if (!lib || !b || !p || !out) return fail(TM_E_INVALID, "tm_query: NULL argument");
     *out = nullptr;
@@ -1215,12 +1330,63 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
                 HIP_TRY(S->d_cut.upload(cu)); HIP_TRY(S->d_maxdyn.upload(md));
                 HIP_TRY(S->d_order.upload(S->order));
             }
+            {
+                // pair tables: one per (lead kind A, lead kind B, distance class) some template reads.  A template
+                // scans the (lead 0, lead 1) table and looks up rows of the (key, lead 2) table, the key being the
+                // lead (0 or 1) nearer to lead 2 in the template -- the thinner shell, the shorter rows.
+                std::map<std::tuple<uint16_t, uint16_t, int>, uint16_t> ids;
+                std::vector<uint16_t> tp(n_sel, 0xffffu), tt(n_sel, 0xffffu);
+                std::vector<uint8_t> key(n_sel, 0);
+                auto table_for = [&](uint16_t a, uint16_t b, double hi) -> int {
+                    int c = 0;
+                    while (c + 1 < kTableClasses && hi > kTableClassLimit[c]) ++c;
+                    auto it = ids.find(std::make_tuple(a, b, c));
+                    if (it == ids.end()) {
+                        if (S->tables.size() >= 0xffffu) return -1;
+                        const double lim = kTableClassLimit[c];
+                        const float d2 = c + 1 == kTableClasses ? 3.0e38f : (float)(lim * lim) * (1.0f + 4e-6f);
+                        it = ids.emplace(std::make_tuple(a, b, c), (uint16_t)S->tables.size()).first;
+                        S->tables.push_back(TableDesc{a, b, d2});
+                    }
+                    return it->second;
+                };
+                for (uint32_t i = 0; i < n_sel; ++i) {
+                    const uint32_t o = S->order[i], t = S->sel[o], off = lib->t_off[t];
+                    const int G = lib->h_n_groups[t];
+                    auto upper = [&](int x, int y) {  // upper edge of the fp32 window (x, y), as k_stage_templates builds it
+                        double d2 = 0;
+                        for (int a = 0; a < 3; ++a) {
+                            const double d = lib->h_xyz[3 * (size_t)(off + x) + a] - lib->h_xyz[3 * (size_t)(off + y) + a];
+                            d2 += d * d;
+                        }
+                        const double thr = std::min(S->cut[o] + lib->h_w[off + x] + lib->h_w[off + y], S->maxdyn[o]);
+                        return std::sqrt(d2) + thr + kPrefilterSlack;
+                    };
+                    int id = 0;
+                    if (G >= 2) {
+                        id = table_for(lib->h_lead_li[off], lib->h_lead_li[off + 1], upper(1, 0));
+                        if (id < 0) return fail(TM_E_UNSUPPORTED, "selection needs more than 65534 pair tables");
+                        tp[i] = (uint16_t)id;
+                    }
+                    if (G >= 3) {
+                        const double h20 = upper(2, 0), h21 = upper(2, 1);
+                        key[i] = h21 < h20 ? 1 : 0;
+                        id = table_for(lib->h_lead_li[off + key[i]], lib->h_lead_li[off + 2], std::min(h20, h21));
+                        if (id < 0) return fail(TM_E_UNSUPPORTED, "selection needs more than 65534 pair tables");
+                        tt[i] = (uint16_t)id;
+                    }
+                }
+                HIP_TRY(S->d_tables.upload(S->tables)); HIP_TRY(S->d_pair_table.upload(tp));
+                HIP_TRY(S->d_triple_table.upload(tt)); HIP_TRY(S->d_triple_key.upload(key));
+                S->serial = ++g_serial;
+            }
             HIP_TRY(S->d_bounds.alloc((size_t)n_sel * kMaxPairs));
             HIP_TRY(S->d_staged.alloc(n_sel));
             HIP_TRY(hipEventCreateWithFlags(&S->ready, hipEventDisableTiming));
             if (n_sel) {
                 hipLaunchKernelGGL(k_stage_templates, dim3(n_sel), dim3(64), 0, stream, lib->view(), n_sel, S->d_sel.p,
-                                   S->d_cut.p, S->d_maxdyn.p, S->d_staged.p, S->d_bounds.p);
+                                   S->d_cut.p, S->d_maxdyn.p, S->d_pair_table.p, S->d_triple_table.p, S->d_triple_key.p,
+                                   S->d_staged.p, S->d_bounds.p);
                 HIP_TRY(hipGetLastError());
             }
             HIP_TRY(hipEventRecord(S->ready, stream));
@@ -1242,6 +1408,7 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
     HIP_TRY(r->d_counters.alloc(3));
     HIP_TRY(r->d_overflow.alloc(1));
     HIP_TRY(r->d_pool_used.alloc(1));
+    HIP_TRY(r->d_tab_used.alloc(2));
     HIP_TRY(hipMemsetAsync(r->d_pool_used.p, 0, sizeof(unsigned long long), stream));
     r->index_shared = b->index_shared;
     HIP_TRY(hipMemsetAsync(r->d_counters.p, 0, 3 * sizeof(unsigned long long), stream));
@@ -1254,12 +1421,18 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
     if (b->queried && b->last_stream != stream) HIP_TRY(hipStreamSynchronize(b->last_stream));
     b->last_stream = stream; b->queried = true;
     HIP_TRY(hipEventRecord(r->ev[0], stream));
-    if (b->index_for != lib->serial || (p->flags & TM_FLAG_REBUILD_INDEX) || b->index_shared->stale.load()) {
+    const bool rebuild = b->index_for != lib->serial || (p->flags & TM_FLAG_REBUILD_INDEX) || b->index_shared->stale.load();
+    if (rebuild) {
         int rc = build_index(lib, b, r, stream);
+        if (rc != TM_OK) return rc;
+    }
+    if (rebuild || b->tables_for != S->serial) {
+        int rc = build_tables(lib, b, S.get(), stream);
         if (rc != TM_OK) return rc;
     }
     {
         int rc = carry_index_outcome(b, r, stream);
+        if (rc == TM_OK) rc = carry_table_outcome(b, r, stream);
         if (rc != TM_OK) return rc;
     }
     HIP_TRY(hipEventRecord(r->ev[1], stream));
@@ -1267,6 +1440,7 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
     QueryView Q;
     Q.n_sel = n_sel; Q.sel = S->d_sel.p; Q.rmsd_thr = S->d_rmsd.p; Q.cutoff = S->d_cut.p; Q.maxdyn = S->d_maxdyn.p;
     Q.staged = S->d_staged.p; Q.bounds = S->d_bounds.p; Q.order = S->d_order.p; Q.max_candidates = p->max_candidates; Q.flags = p->flags;
+    Q.n_tables = (uint32_t)S->tables.size(); Q.tables = S->d_tables.p;
     Q.model_set = nullptr; Q.model_offsets = nullptr; Q.model_votes = nullptr; Q.models = nullptr;
     if (p->model_set && p->n_model_sets && p->model_offsets && p->model_votes && p->models) {
         const uint32_t ns = p->n_model_sets, nm = p->model_offsets[ns];
@@ -1361,10 +1535,20 @@ int tm_result_wait(tm_result *r) {
         HIP_TRY(hipSetDevice(r->device));
         unsigned long long counters[3] = {0, 0, 0};
         HIP_TRY(hipMemcpyAsync(counters, r->d_counters.p, sizeof counters, hipMemcpyDeviceToHost, r->stream));
-        unsigned long long pool_used = 0;
+        unsigned long long pool_used = 0, tab_used[2] = {0, 0};
         HIP_TRY(hipMemcpyAsync(&r->overflow, r->d_overflow.p, sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
         HIP_TRY(hipMemcpyAsync(&pool_used, r->d_pool_used.p, sizeof pool_used, hipMemcpyDeviceToHost, r->stream));
+        HIP_TRY(hipMemcpyAsync(tab_used, r->d_tab_used.p, sizeof tab_used, hipMemcpyDeviceToHost, r->stream));
         HIP_TRY(hipStreamSynchronize(r->stream));
+        if ((r->overflow & 16u) && r->index_shared) {  // a pair-table pool ran out: remember what the build needed
+            auto raise = [](std::atomic<unsigned long long> &a, unsigned long long v) {
+                unsigned long long seen = a.load();
+                while (seen < v && !a.compare_exchange_weak(seen, v)) {}
+            };
+            raise(r->index_shared->rows_wanted, tab_used[0]);
+            raise(r->index_shared->ents_wanted, tab_used[1]);
+            r->index_shared->stale = true;
+        }
         r->n_hits = counters[0]; r->n_cands = counters[1]; r->n_pairs = counters[2];
         r->waited = true;
         if ((r->overflow & 8u) && r->index_shared) {  // the index build ran out of pool: remember what it needed
@@ -1373,6 +1557,10 @@ int tm_result_wait(tm_result *r) {
             r->index_shared->stale = true;
         }
     }
+    if (r->overflow & 16u)
+        return fail(TM_E_OVERFLOW, "pair-table pools too small (" + std::to_string(r->row_capacity) + " row slots, " +
+                                       std::to_string(r->ent_capacity) +
+                                       " entries): query again, the batch now reserves what this build needed");
     if (r->overflow & 8u)
         return fail(TM_E_OVERFLOW, "candidate index pool too small (" + std::to_string(r->pool_capacity) +
                                        " entries): query again, the batch now reserves what this build needed");

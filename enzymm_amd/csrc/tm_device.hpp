@@ -13,8 +13,18 @@ constexpr int kMaxPairs = kMaxK * (kMaxK - 1) / 2;  // 276 pair constraints
 constexpr int kWave = 64;
 constexpr int kSearchWaves = 16;  // waves per search workgroup (one structure copy in LDS serves all)
 constexpr int kSearchBlock = kWave * kSearchWaves;
-constexpr int kJointQueue = 128;  // pair-scan survivors buffered per wave (power of two)
-constexpr int kJointQueue3 = 64;  // triple-scan survivors buffered per wave before their subtrees are searched
+constexpr int kPairQueue = 128;   // pair-table survivors buffered per wave
+constexpr int kTripleQueue = 64;  // triple survivors of one pass, waiting for their subtrees
+
+// Pair tables (see k_tab_* in tm_kernels.hip): for an ordered pair of lead kinds (A, B) and a distance limit, every
+// pair (i, j) of list positions -- i in the structure's kind list A, j in list B -- whose atoms lie in different
+// residues and within the limit, stored row by row (CSR over i) as {i | j << 16, squared fp32 distance}.
+struct TableDesc {
+    uint16_t li_a, li_b;  // lead-kind indices
+    float dmax2;          // squared distance limit (already holds the prefilter slack); +inf: every pair
+};
+constexpr int kTableClasses = 5;
+constexpr double kTableClassLimit[kTableClasses] = {8.0, 12.0, 16.0, 24.0, 1e30};  // upper window edge (A) per class
 
 // fp32 prefilter slack (Angstrom) added to every pair threshold.  Centred fp32
 // coordinates of a <= 300 A structure carry < 4e-5 A of rounding; anything the
@@ -69,6 +79,14 @@ struct BatchView {
     // candidate index for one library: for each (structure, lead kind) the admissible atoms
     const uint32_t *kl_off;   // [n_structs*(n_lead+1)] offsets into kl_pool
     const uint16_t *kl_pool;  // local atom indices, ascending
+    // pair tables for one staged selection: row r of table t of structure s is entries
+    // [tab_rows[tab_dir[s * n_tables + t] + r], tab_rows[... + r + 1]) of tab_ent
+    uint32_t n_tables;
+    const uint32_t *tab_dir;   // [n_structs * n_tables] first row slot of the table
+    const uint2 *tab_seg;      // [n_structs * n_tables] (first entry, one past the last entry) of the table
+    const uint32_t *tab_ok;    // [n_structs] 1: the structure's tables are complete
+    const uint32_t *tab_rows;  // row offsets (absolute entry indices); a table with n rows owns n + 1 slots
+    const uint2 *tab_ent;      // {position in list A | position in list B << 16, squared distance (fp32 bits)}
 };
 
 // One selected template, flattened for the search kernel (written by k_stage_templates).
@@ -77,7 +95,11 @@ struct __align__(16) Staged {
     uint32_t resmask[kMaxK];
     uint16_t lead_li[kMaxK];  // lead levels: index among lead kinds; 0xffff otherwise
     uint8_t group[kMaxK], tchain[kMaxK], orig[kMaxK], any[kMaxK], ref[kMaxK];
-    uint8_t k, n_groups, pad[6];
+    uint8_t k, n_groups;
+    uint16_t pair_table;    // table (lead 0, lead 1); 0xffff: fewer than two residues
+    uint16_t triple_table;  // table (lead 0 or 1, lead 2); 0xffff: fewer than three residues
+    uint8_t triple_key;     // 0: rows of the triple table are positions of lead 0, 1: of lead 1
+    uint8_t pad;
 };
 
 struct QueryView {
@@ -90,6 +112,8 @@ struct QueryView {
     const float2 *bounds;       // [n_sel*kMaxPairs] (lo^2, hi^2) fp32 prefilter bounds, search order
     const uint32_t *order;      // [n_sel] every per-selection array above is sorted by descending estimated cost;
                                 // order[pos] = the caller's selection index (reported in tm_hit / candidate counts)
+    uint32_t n_tables;
+    const TableDesc *tables;    // [n_tables] pair tables this selection needs
     uint32_t max_candidates;
     uint32_t flags;
     // optional logistic filter

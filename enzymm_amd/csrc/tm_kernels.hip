@@ -69,6 +69,9 @@ __device__ __forceinline__ void pair_of(int p, int &i, int &j) {
 __global__ __launch_bounds__(64) void k_stage_templates(LibView L, uint32_t n_sel, const uint32_t *__restrict__ sel,
                                                          const double *__restrict__ cutoff,
                                                          const double *__restrict__ maxdyn,
+                                                         const uint16_t *__restrict__ pair_table,
+                                                         const uint16_t *__restrict__ triple_table,
+                                                         const uint8_t *__restrict__ triple_key,
                                                          Staged *__restrict__ staged, float2 *__restrict__ bounds) {
     const uint32_t ti = blockIdx.x;
     if (ti >= n_sel) return;
@@ -101,6 +104,10 @@ __global__ __launch_bounds__(64) void k_stage_templates(LibView L, uint32_t n_se
         for (int i = 0; i < k; ++i) g = max(g, (uint8_t)(L.a_group[off + i] + 1));
         S.k = (uint8_t)k;
         S.n_groups = g;
+        S.pair_table = pair_table[ti];
+        S.triple_table = triple_table[ti];
+        S.triple_key = triple_key[ti];
+        S.pad = 0;
     }
     for (int p = lane; p < npairs; p += 64) {
         int i, j;
@@ -248,6 +255,204 @@ __global__ void k_flag_index_overflow(const uint32_t *__restrict__ index_overflo
     if (*index_overflow) atomicOr(query_overflow, 8u);
 }
 
+// ------------------------------------------------------------------ pair tables
+//
+// The first two search levels of every template used to test the whole cross product of two kind lists against one
+// distance window (about 300 tests per template, of which 1.5 % pass), and the third level did the same for every
+// survivor.  Templates share lead kinds: the 6780 default templates need about a thousand distinct (kind A, kind B,
+// distance class) combinations.  So the distance work is done ONCE per structure and combination -- every pair of
+// list positions within the class's distance limit, stored row by row with its squared distance -- and a template's
+// first level becomes a scan of one short table segment (14 entries on average), its second a lookup of a few rows.
+//
+//   k_tab_layout   per structure: where each table's row slots live (bump allocation)
+//   k_tab_build    per (structure, share of its tables): row offsets, bump allocation of the entries, entries
+//
+// Inside a table the order is deterministic: rows by ascending position in list A, entries by ascending position in
+// list B, row offsets relative to the table's first entry.  WHERE a table sits in the entry pool is not (bump
+// allocation), and does not matter.
+
+struct TabWork {  // one workgroup of k_tab_count / k_tab_fill: tables part, part + parts, ... of structure s
+    uint32_t s;
+    uint16_t part, parts;
+};
+
+__global__ __launch_bounds__(256) void k_tab_layout(uint32_t n_lead, BatchView B, const TableDesc *__restrict__ tables,
+                                                     uint32_t *__restrict__ tab_dir,
+                                                     unsigned long long *__restrict__ cursors,
+                                                     unsigned long long row_capacity, uint32_t *__restrict__ overflow,
+                                                     uint32_t *__restrict__ tab_ok) {
+    __shared__ uint32_t s_part[256];
+    __shared__ unsigned long long s_base;
+    const uint32_t s = blockIdx.x, nt = B.n_tables;
+    const uint32_t *kl = B.kl_off + (size_t)s * (n_lead + 1);
+    const uint32_t per = (nt + blockDim.x - 1) / blockDim.x;
+    const uint32_t lo = min(threadIdx.x * per, nt), hi = min(lo + per, nt);
+    uint32_t sum = 0;
+    for (uint32_t t = lo; t < hi; ++t) sum += kl[tables[t].li_a + 1] - kl[tables[t].li_a] + 1u;
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (uint32_t i = 0; i < blockDim.x; ++i) { const uint32_t v = s_part[i]; s_part[i] = run; run += v; }
+        unsigned long long base = atomicAdd(&cursors[0], (unsigned long long)run);
+        if (base + run > row_capacity) {
+            atomicOr(overflow, 1u);
+            base = ~0ull;
+        }
+        s_base = base;
+        tab_ok[s] = base == ~0ull ? 0u : 1u;
+    }
+    __syncthreads();
+    const unsigned long long base = s_base;
+    uint32_t run = (uint32_t)base + s_part[threadIdx.x];
+    for (uint32_t t = lo; t < hi; ++t) {
+        tab_dir[(size_t)s * nt + t] = base == ~0ull ? 0u : run;
+        run += kl[tables[t].li_a + 1] - kl[tables[t].li_a] + 1u;
+    }
+}
+
+constexpr int kTabBlock = 1024;  // threads of a k_tab_build workgroup: 16 waves share one LDS copy of the lead records
+
+// One sweep over the tiles of one table.  A tile lays TI rows x TJ columns over the 64 lanes, row-major (TJ = the
+// power of two covering list B, at most 64); `lead(p)` returns the atom record at kind-list position p.  A lane's
+// pair passes when both positions exist, the atoms lie in different residues and within the distance limit.
+//   count sweep (kFill = false): only the number of passing pairs (one scalar popcount of the vote per tile)
+//   fill sweep  (kFill = true):  rows are visited in order, so the running count is the prefix sum: rows[i] = passing
+//                                pairs before row i, and every passing pair is written at running count + passing
+//                                pairs of the tile's earlier rows (when TI > 1 list B fits one tile, so the vote of
+//                                that tile holds them all) + its rank in its row.
+// Returns the number of passing pairs.
+template <bool kFill, class Lead>
+__device__ __forceinline__ uint32_t tab_sweep(Lead lead, uint32_t a_lo, uint32_t n_a, uint32_t b_lo, uint32_t n_b,
+                                              float dmax2, uint32_t *rows, uint2 *ent) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t shift = n_b <= 1u ? 0u : min(6u, 32u - (uint32_t)__clz((int)(n_b - 1u)));
+    const uint32_t TJ = 1u << shift, TI = 64u >> shift;
+    const uint32_t li = lane >> shift, lj = lane & (TJ - 1u);
+    const unsigned long long below = li == 0u ? 0ull : ((1ull << (li * TJ)) - 1ull);  // lanes of the tile's earlier rows
+    uint32_t running = 0;
+    if (n_b == 0u) {  // nothing to pair with: every row is empty
+        if (kFill)
+            for (uint32_t i = lane; i < n_a; i += 64u) rows[i] = 0u;
+        return 0u;
+    }
+    for (uint32_t i0 = 0; i0 < n_a; i0 += TI) {
+        const uint32_t i = i0 + li;
+        const bool vi = i < n_a;
+        const float4 ra = lead(a_lo + (vi ? i : 0u));
+        const uint32_t res_a = meta_res(__float_as_uint(ra.w));
+        uint32_t row_running = running;  // TI == 1: passing pairs before this tile of the row
+        for (uint32_t j0 = 0; j0 < n_b; j0 += TJ) {
+            const uint32_t j = j0 + lj;
+            const bool vj = j < n_b;
+            const float4 rb = lead(b_lo + (vj ? j : 0u));
+            const float dx = ra.x - rb.x, dy = ra.y - rb.y, dz = ra.z - rb.z;
+            const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            const bool ok = vi & vj & (d2 <= dmax2) & (res_a != meta_res(__float_as_uint(rb.w)));
+            const unsigned long long all = ballot64(ok);
+            if (kFill) {
+                // lanes of earlier rows of the tile come first in the vote: rank among ALL passing lanes
+                if (ok) ent[row_running + rank_in(all)] = make_uint2(i | (j << 16), __float_as_uint(d2));
+                if (j0 == 0u && vi && lj == 0u) rows[i] = running + (uint32_t)__popcll(all & below);
+            }
+            row_running += (uint32_t)__popcll(all);
+        }
+        running = row_running;
+    }
+    return running;
+}
+
+// All tables of one work item (structure, part).  Count phase: every table is swept once by one wave for its size.
+// Then the workgroup bump-allocates the entries of all its tables with ONE atomic (one per table would serialise a
+// million atomics on one address), and the fill phase sweeps every table again and writes row offsets (relative to
+// the table's first entry) and entries.  kLds: the atom records of every kind-list position were gathered into LDS first, so tiles
+// read their operands at consecutive LDS addresses.
+template <bool kLds>
+__device__ __forceinline__ void tab_build_tables(const BatchView &B, const TableDesc *__restrict__ tables,
+                                                 const TabWork w, const float4 *rec, const uint16_t *pool,
+                                                 const float4 *s_lr, const uint32_t *kl, uint32_t *s_size,
+                                                 uint32_t *__restrict__ tab_rows, uint2 *__restrict__ tab_ent,
+                                                 uint2 *__restrict__ tab_seg, unsigned long long *__restrict__ cursors,
+                                                 unsigned long long ent_capacity, uint32_t *__restrict__ overflow,
+                                                 uint32_t *__restrict__ tab_ok) {
+    __shared__ unsigned long long s_base;
+    const uint32_t nt = B.n_tables;
+    const uint32_t wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t n_mine = nt > w.part ? (nt - w.part + w.parts - 1) / w.parts : 0u;  // tables part, part + parts, ...
+    auto lead = [&](uint32_t p) -> float4 { return kLds ? s_lr[p] : rec[pool[p]]; };
+    for (uint32_t m = wave; m < n_mine; m += n_waves) {
+        const uint32_t t = w.part + w.parts * m;
+        const TableDesc T = tables[t];
+        const uint32_t a_lo = kl[T.li_a], n_a = kl[T.li_a + 1] - a_lo, b_lo = kl[T.li_b], n_b = kl[T.li_b + 1] - b_lo;
+        const uint32_t total = tab_sweep<false>(lead, a_lo, n_a, b_lo, n_b, T.dmax2, nullptr, nullptr);
+        if (lane == 0) s_size[m] = total;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // sizes -> offsets (about a thousand tables at most)
+        unsigned long long run = 0;
+        for (uint32_t m = 0; m < n_mine; ++m) { const uint32_t v = s_size[m]; s_size[m] = (uint32_t)run; run += v; }
+        s_size[n_mine] = (uint32_t)run;
+        unsigned long long base = atomicAdd(&cursors[1], run);
+        if (base + run > ent_capacity) {  // no room: the structure's tables are unusable, the query says so
+            atomicOr(overflow, 2u);
+            tab_ok[w.s] = 0u;
+            base = ~0ull;
+        }
+        s_base = base;
+    }
+    __syncthreads();
+    const unsigned long long base = s_base;
+    for (uint32_t m = wave; m < n_mine; m += n_waves) {
+        const uint32_t t = w.part + w.parts * m;
+        const TableDesc T = tables[t];
+        const uint32_t a_lo = kl[T.li_a], n_a = kl[T.li_a + 1] - a_lo, b_lo = kl[T.li_b], n_b = kl[T.li_b + 1] - b_lo;
+        uint32_t *rows = tab_rows + B.tab_dir[(size_t)w.s * nt + t];
+        const uint32_t first = (uint32_t)base + s_size[m], total = s_size[m + 1] - s_size[m];
+        if (lane == 0) {
+            tab_seg[(size_t)w.s * nt + t] = base == ~0ull ? make_uint2(0u, 0u) : make_uint2(first, first + total);
+            rows[n_a] = total;
+        }
+        if (base == ~0ull) continue;
+        tab_sweep<true>(lead, a_lo, n_a, b_lo, n_b, T.dmax2, rows, tab_ent + first);
+    }
+}
+
+// Dynamic LDS: [float4 x lr_cap] lead records (the record of the atom at every position of the structure's kind
+// lists), [u32 x (n_lead + 1)] kind-list offsets, [u32 x (ceil(n_tables / parts) + 1)] table sizes / offsets.  A structure whose kind
+// lists exceed lr_cap reads through L2.
+__global__ __launch_bounds__(kTabBlock) void k_tab_build(uint32_t n_lead, BatchView B, const TableDesc *__restrict__ tables,
+                                                          const TabWork *__restrict__ work, uint32_t *__restrict__ tab_ok,
+                                                          uint32_t *__restrict__ tab_rows, uint2 *__restrict__ tab_ent,
+                                                          uint2 *__restrict__ tab_seg,
+                                                          unsigned long long *__restrict__ cursors,
+                                                          unsigned long long ent_capacity, uint32_t *__restrict__ overflow,
+                                                          uint32_t lr_cap) {
+    extern __shared__ __align__(16) unsigned char tab_smem[];
+    const TabWork w = work[blockIdx.x];
+    if (tab_ok[w.s] == 0u) return;  // its row slots did not fit (k_tab_layout)
+    const uint32_t *kl = B.kl_off + (size_t)w.s * (n_lead + 1);
+    const float4 *rec = B.q_rec + B.s_off[w.s];
+    const uint32_t p0 = kl[0], plen = kl[n_lead] - p0;
+    float4 *s_lr = reinterpret_cast<float4 *>(tab_smem);
+    uint32_t *s_kl = reinterpret_cast<uint32_t *>(s_lr + lr_cap);
+    uint32_t *s_size = s_kl + n_lead + 1;
+    if (plen <= lr_cap) {
+        for (uint32_t i = threadIdx.x; i < plen; i += blockDim.x) s_lr[i] = rec[B.kl_pool[p0 + i]];
+        for (uint32_t i = threadIdx.x; i <= n_lead; i += blockDim.x) s_kl[i] = kl[i] - p0;
+        __syncthreads();
+        tab_build_tables<true>(B, tables, w, rec, B.kl_pool, s_lr, s_kl, s_size, tab_rows, tab_ent, tab_seg, cursors,
+                               ent_capacity, overflow, tab_ok);
+    } else {
+        tab_build_tables<false>(B, tables, w, rec, B.kl_pool, nullptr, kl, s_size, tab_rows, tab_ent, tab_seg, cursors,
+                                ent_capacity, overflow, tab_ok);
+    }
+}
+
+// one thread: the pair-table build's overflow word into the query's (bit 4)
+__global__ void k_flag_table_overflow(const uint32_t *__restrict__ table_overflow, uint32_t *__restrict__ query_overflow) {
+    if (*table_overflow) atomicOr(query_overflow, 16u);
+}
+
 // ------------------------------------------------------------------ k_search
 
 // Per-wave LDS: only what lanes exchange.  All search state lives in registers (see WaveRegs).
@@ -258,10 +463,9 @@ constexpr int kBoundsLds = kBoundRowsLds * (kBoundRowsLds + 1) / 2;  // 66 entri
 struct __align__(16) WaveScratch {
     float2 bnd[kBoundsLds];                    // the first rows of the template's pair bounds (all of them for k <= 12)
     uint16_t surv[kMaxG][64];                  // per template residue: one 64-entry chunk of its lead list
-    float4 rec0[64], rec1[64], rec2[64];       // atom records of the current 64-entry blocks of the top lead lists
-    uint16_t id0[64], id1[64], id2[64];        // and their atom indices
-    uint32_t queue[kJointQueue];               // pair-scan survivors (position in block 0 | position in block 1 << 8)
-    uint32_t queue3[kJointQueue3][2];          // survivors of one triple tile ((a | b << 16), c) waiting for their subtree
+    uint32_t queue[kPairQueue];                // pair-table survivors (position in list 0 | position in list 1 << 16)
+    uint32_t queue3[kTripleQueue][2];          // survivors of one triple pass ((a0 | a1 << 16), a2) waiting for their subtree
+    uint32_t x_first[64], x_excl[64];          // triple stage: first entry / exclusive item count of each queued pair's row
 };
 
 // Search state of one wave, held in VGPRs and indexed BY LANE: lane L holds the entry of search
@@ -301,6 +505,8 @@ struct SearchCtx {
     // two explicit loads instead of one through a generic pointer: ds_read is much cheaper than flat_load
     __device__ __forceinline__ uint32_t pool_at(uint32_t i) const { return pool_in_lds ? pool_lds[i] : pool_glb[i]; }
     const uint8_t *qchain;      // global, per atom of this structure
+    const uint32_t *tab_rows;   // pair tables: row offsets (global) ...
+    const uint2 *tab_ent;       // ... and entries
     const float2 *bnd;          // this template's pair bounds (global)
     WaveScratch *S;
     int lane, k, n_groups;
@@ -566,17 +772,6 @@ __device__ __forceinline__ bool dfs(const Ctx &C, WaveRegs &W, PairState &P, int
     }
 }
 
-// tile shape TI x TJ = 64 lanes (TJ = 1 << shift) that covers an n_i x n_j cross product with the fewest tiles
-// (a cheaper "narrowest TJ spanning n_j" rule costs 20 % more pair tiles than the comparisons here)
-__device__ __forceinline__ uint32_t best_tile_shift(uint32_t n_i, uint32_t n_j) {
-    uint32_t shift = 3, best = 0xffffffffu;
-    for (uint32_t sh = 3; sh <= 6; ++sh) {
-        const uint32_t tiles = ((n_i + (64u >> sh) - 1) >> (6 - sh)) * ((n_j + (1u << sh) - 1) >> sh);
-        if (tiles < best) { best = tiles; shift = sh; }
-    }
-    return shift;
-}
-
 // fp32 prefilter of one pair constraint; the bounds carry kPrefilterSlack, which also covers the
 // fused multiply-adds (the exact test is repeated in fp64 before a candidate is emitted)
 __device__ __forceinline__ bool in_window(const float4 &p, const float4 &q, const float2 &b) {
@@ -585,215 +780,161 @@ __device__ __forceinline__ bool in_window(const float4 &p, const float4 &q, cons
     return (d2 >= b.x) & (d2 <= b.y);
 }
 
-// Padding records for unused slots of a staged block: far away from every atom and from each
-// other, so that any pair involving a padding slot fails its distance window by itself.
-constexpr float kPadFar = 3.0e18f;
-// Upper bound (squared distance) of the pass-everything window used with wildcard lists: above any
-// real squared distance (PDB coordinates stay below 1e4 A), below kPadFar squared.
-constexpr float kWildWindow = 1.0e30f;
+// The pair tables a (structure, template) search reads: segment of the (lead 0, lead 1) table, first row slot of
+// the (lead 0 or 1, lead 2) table.  Uniform values, fetched when the template is claimed.
+struct TableRefs {
+    uint32_t pair_begin, pair_end;  // entries of the pair table
+    uint32_t triple_rows;           // first row slot of the triple table (row offsets are relative to ...
+    uint32_t triple_begin;          // ... the table's first entry)
+    uint32_t key_is_1;              // rows of the triple table are positions of lead 1 (else lead 0)
+};
 
-// The lead atoms of the first three template residues are matched by tiled scans: the wave lays
-// the cross product list0 x list1 over its 64 lanes and tests the pair constraint (1, 0);
-// surviving pairs are queued in LDS and the cross product queue x list2 is tiled the same way
-// against the constraints (2, 0) and (2, 1).  Only what survives that is searched depth-first
-// (levels >= 3).  A template with fewer than three residues gets one-entry "wildcard" lists for
-// the missing ones, which pass every test, so that all templates run the same code.
+// The lead atoms of the first three template residues come from the structure's pair tables (k_tab_*):
 //
-// The lists are walked in blocks of 64 entries whose atom records are copied into a compact
-// per-wave LDS array once (one scattered gather per list entry); every tile then reads its
-// operands at consecutive or broadcast addresses, free of bank conflicts, and lists of any
-// length are handled.
+//   pair stage    the (lead 0, lead 1) table's segment is scanned 64 entries at a time; an entry survives when its
+//                 stored squared distance lies in the template's window (1, 0).  Survivors are queued in LDS.
+//   triple stage  every queued pair names a row of the (key lead, lead 2) table -- the atoms of list 2 near the key
+//                 atom.  The rows of up to 64 queued pairs are laid end to end over the lanes (prefix sum of the row
+//                 lengths, binary search for the owning pair), each item is tested against the windows (2, key)
+//                 (stored distance) and (2, other) (computed), and what survives is searched depth-first.
 //
-// Plain nested loops; each stage -- pair tile, triple tile, depth-first search -- exists exactly
-// once in the instruction stream (the kernel must fit the instruction cache).  The pair queue is
-// consumed whenever it may not take another tile; the triple queue holds one tile of survivors
-// and is searched as soon as it is not empty.
+// Different residues are guaranteed by the tables for (0, 1) and (key, 2); (other, 2) is tested here.  Templates with
+// two residues search below the pairs, templates with one residue below every atom of their lead list.
 template <class Ctx>
-__device__ __forceinline__ bool joint_top_scan(const Ctx &C, WaveRegs &W, PairState &P, uint32_t flags) {
+__device__ __forceinline__ bool table_scan(const Ctx &C, WaveRegs &W, PairState &P, const TableRefs &TR,
+                                           const uint2 first_ent) {
     WaveScratch &S = *C.S;
     const int lane = C.lane;
-    const bool real1 = C.n_groups >= 2, real2 = C.n_groups >= 3;
-    const int floor = real2 ? 3 : C.n_groups;  // levels the queue3 entries assign
-    const uint32_t n0 = RL(W.cnt, 0), n1 = real1 ? RL(W.cnt, 1) : 1u, n2 = real2 ? RL(W.cnt, 2) : 1u;
+    const int G = C.n_groups;
     const uint32_t lo0 = RL(W.lo, 0), lo1 = RL(W.lo, 1), lo2 = RL(W.lo, 2);
-    const float2 pass_all = make_float2(-1.f, kWildWindow);
-    const float2 b10 = real1 ? S.bnd[0] : pass_all;                       // pair (1, 0)
-    const float2 b20 = real2 ? S.bnd[tri(2)] : pass_all;                  // pairs (2, 0), (2, 1)
-    const float2 b21 = real2 ? S.bnd[tri(2) + 1] : pass_all;
+    if (G == 1) {
+        const uint32_t n0 = RL(W.cnt, 0);
+        for (uint32_t i = 0; i < n0; ++i) {
+            assign_level(C, W, 0, uni((uint32_t)C.pool_at(lo0 + i)));
+            if (!dfs(C, W, P, 1)) return false;
+        }
+        return true;
+    }
+    const float2 b10 = S.bnd[0];                  // window (1, 0)
+    const float2 b20 = S.bnd[tri(2)], b21 = S.bnd[tri(2) + 1];
+    const bool key1 = TR.key_is_1 != 0u;
+    const float2 b_key = key1 ? b21 : b20, b_other = key1 ? b20 : b21;
     const bool tc10 = RL(W.tchain, 0) == RL(W.tchain, 1);
     const bool tc20 = RL(W.tchain, 0) == RL(W.tchain, 2), tc21 = RL(W.tchain, 1) == RL(W.tchain, 2);
 
-    // A block of a lead list is copied into LDS in two steps -- fetch (ids from the kind-list pool, records from
-    // the structure) and store -- so that the fetches of several blocks overlap.  Slots past the end get a
-    // padding record, so tiles may read any of the 64 slots unmasked.  A wildcard list is one record at the
-    // origin with a residue number no atom has.
-    struct Block { float4 r; uint32_t a; };
-    auto fetch_block = [&](bool real, uint32_t lo, uint32_t base, uint32_t cnt, float pad_x, float pad_y,
-                           uint32_t wild_res) {
-        Block b;
-        b.r = make_float4(0.f, 0.f, 0.f, __uint_as_float(wild_res));
-        b.a = 0;
-        if (real) {
-            b.a = C.pool_at(lo + base + min((uint32_t)lane, cnt - 1u));
-            b.r = C.rec[b.a];
-        }
-        if ((uint32_t)lane >= cnt) { b.r.x = pad_x; b.r.y = pad_y; }
-        return b;
-    };
-    auto store_block = [&](float4 *rec, uint16_t *id, const Block &b) {
-        id[lane] = (uint16_t)b.a;
-        rec[lane] = b.r;
-    };
-
-    // the first block of each list (usually the only one) is staged in one go
-    uint32_t jb_st = 0, cb_st = 0xffffffffu;  // blocks of list1 / list2 present in LDS
-    wave_sync();
-    {
-        // straight-line on purpose: three independent kind-list reads, then three independent record gathers, then
-        // the selects and stores -- two memory round trips for all three blocks instead of two per block.  A list
-        // that is a wildcard reads entry lo0 instead; the value is dropped.
-        const uint32_t c0 = min(64u, n0), c1 = min(64u, n1), c2 = min(64u, n2);
-        const uint32_t i0 = lo0 + min((uint32_t)lane, c0 - 1u);
-        const uint32_t i1 = real1 ? lo1 + min((uint32_t)lane, c1 - 1u) : i0;
-        const uint32_t i2 = real2 ? lo2 + min((uint32_t)lane, c2 - 1u) : i0;
-        const uint32_t a0 = C.pool_at(i0), a1 = C.pool_at(i1), a2 = C.pool_at(i2);
-        float4 r0 = C.rec[a0], r1 = C.rec[a1], r2 = C.rec[a2];
-        Block f0, f1, f2;
-        f0.a = a0;
-        f1.a = real1 ? a1 : 0u;
-        f2.a = real2 ? a2 : 0u;
-        if (!real1) r1 = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xfffeu));
-        if (!real2) r2 = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xfffdu));
-        if ((uint32_t)lane >= c0) { r0.x = kPadFar; r0.y = 0.f; }
-        if ((uint32_t)lane >= c1) { r1.x = -kPadFar; r1.y = 0.f; }
-        if ((uint32_t)lane >= c2) { r2.x = 0.f; r2.y = kPadFar; }
-        f0.r = r0; f1.r = r1; f2.r = r2;
-        store_block(S.rec2, S.id2, f2);  // block 0 of list2 whatever its length
-        cb_st = 0;
-        store_block(S.rec0, S.id0, f0);
-        store_block(S.rec1, S.id1, f1);
-    }
-    for (uint32_t ib = 0; ib < n0; ib += 64u) {
-        const uint32_t cn0 = min(64u, n0 - ib);
-        if (ib != 0u) {
-            wave_sync();
-            store_block(S.rec0, S.id0, fetch_block(true, lo0, ib, cn0, kPadFar, 0.f, 0u));
-        }
-        for (uint32_t jb = 0; jb < n1; jb += 64u) {
-            const uint32_t cn1 = min(64u, n1 - jb);
-            if (jb_st != jb) {
-                wave_sync();
-                store_block(S.rec1, S.id1, fetch_block(real1, lo1, jb, cn1, -kPadFar, 0.f, 0xfffeu));
-                jb_st = jb;
+    uint32_t e = TR.pair_begin;
+    const uint32_t e_end = TR.pair_end;
+    bool have_first = true;  // `first_ent` holds entry e + lane of the first round (fetched when the template was set up)
+    while (e < e_end) {
+        // ---- pair stage: scan until the queue may not take another 64 entries (or the segment ends)
+        uint32_t nq = 0;
+        wave_sync();  // the queue of the previous round has been consumed
+        do {
+            const uint32_t idx = e + (uint32_t)lane;
+            bool ok = idx < e_end;
+            uint2 ent = first_ent;
+            if (!have_first) {
+                ent = make_uint2(0u, 0u);
+                if (ok) ent = C.tab_ent[idx];
             }
+            have_first = false;
+            const float d2 = __uint_as_float(ent.y);
+            ok = ok & (d2 >= b10.x) & (d2 <= b10.y);
+            if (!C.ignore_chain) {
+                if (ok) ok = (C.qchain[C.pool_at(lo0 + (ent.x & 0xffffu))] == C.qchain[C.pool_at(lo1 + (ent.x >> 16))]) == tc10;
+            }
+            const unsigned long long m = ballot64(ok);
+            TM_STAT(52, 1);
+            if (m) {
+                if (ok) S.queue[nq + rank_in(m)] = ent.x;
+                nq += (uint32_t)__popcll(m);
+            }
+            e += 64u;
+        } while (e < e_end && nq + 64u <= (uint32_t)kPairQueue);
+        TM_STAT(53, nq);
+        if (nq == 0u) continue;
+        wave_sync();
+        if (G == 2) {
+            for (uint32_t q = 0; q < nq; ++q) {
+                const uint32_t pos = uni(S.queue[q]);
+                const uint32_t a0 = C.pool_at(lo0 + (pos & 0xffffu)), a1 = C.pool_at(lo1 + (pos >> 16));
+                const float4 r0 = C.rec[a0], r1 = C.rec[a1];
+                assign_record(C, W, 0, a0, r0);
+                assign_record(C, W, 1, a1, r1);
+                if (!dfs(C, W, P, 2)) return false;
+            }
+            continue;
+        }
+        // ---- triple stage, up to 64 queued pairs at a time
+        for (uint32_t p0 = 0; p0 < nq; p0 += 64u) {
+            const uint32_t np = min(64u, nq - p0);
+            uint32_t first = 0, len = 0;
+            if ((uint32_t)lane < np) {
+                const uint32_t pos = S.queue[p0 + (uint32_t)lane];
+                const uint32_t row = TR.triple_rows + (key1 ? pos >> 16 : pos & 0xffffu);
+                const uint32_t r0 = C.tab_rows[row];
+                first = TR.triple_begin + r0;
+                len = C.tab_rows[row + 1] - r0;
+            }
+            uint32_t incl = len;  // inclusive prefix sum of the row lengths over the lanes
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+                if (lane >= d) incl += up;
+            }
+            const uint32_t total = RL(incl, 63);
+            if (total == 0u) continue;
+            wave_sync();  // x_first / x_excl of the previous chunk have been read
+            S.x_first[lane] = first;
+            S.x_excl[lane] = incl - len;
             wave_sync();
-            const uint32_t tj_shift = best_tile_shift(cn0, cn1);
-            const uint32_t TJ = 1u << tj_shift, TI = 64u >> tj_shift;
-            const uint32_t li = (uint32_t)lane >> tj_shift, lj = (uint32_t)lane & (TJ - 1);
-            const float4 *pa = S.rec0 + li, *pb = S.rec1 + lj;
-            const uint32_t lpos = li | (lj << 8);
-            uint32_t i0 = 0, j0 = 0;
-            while (i0 < cn0) {
-                // ---- pair tiles until the queue may not take another one (or the block pair is done)
-                uint32_t nq = 0;
-                do {
-                    // one row of tiles: TI entries of block 0 (fixed) against block 1, TJ entries at a time
-                    const float4 ra = pa[i0];  // slots < 64: tiles never leave the block
-                    const uint32_t res_a = meta_res(__float_as_uint(ra.w));
-                    for (;;) {
-                        const float4 rb = pb[j0];
-                        bool ok = in_window(ra, rb, b10) & (res_a != meta_res(__float_as_uint(rb.w)));  // padding fails
-                        if (!C.ignore_chain && real1)
-                            ok = ok && ((C.qchain[S.id0[i0 + li]] == C.qchain[S.id1[j0 + lj]]) == tc10);
-                        const unsigned long long m = ballot64(ok);
-                        TM_STAT(52, 1);
-                        TM_STAT(53, __popcll(m));
-                        if (m) {  // most tiles have no survivor: nothing to append, nothing to count
-                            if (ok) S.queue[nq + rank_in(m)] = lpos + (i0 | (j0 << 8));
-                            nq += (uint32_t)__popcll(m);
-                            if (nq + 64u > (uint32_t)kJointQueue) {  // the queue may not take another tile
-                                j0 += TJ;
-                                break;
-                            }
-                        }
-                        j0 += TJ;
-                        if (j0 >= cn1) break;
-                    }
-                    if (j0 >= cn1) {
-                        j0 = 0;
-                        i0 += TI;
-                    }
-                } while (i0 < cn0 && nq + 64u <= (uint32_t)kJointQueue);
-#if defined(TM_STATS) || defined(TM_ABLATE)
-                if (flags & 0x100u) nq = 0;
-#endif
-                if (nq == 0) continue;
-                wave_sync();
-                // ---- the queued pairs against list2, block by block
-                for (uint32_t cb = 0; cb < n2; cb += 64u) {
-                    const uint32_t cn2 = min(64u, n2 - cb);
-                    if (cb_st != cb) {
-                        wave_sync();
-                        store_block(S.rec2, S.id2, fetch_block(real2, lo2, cb, cn2, 0.f, kPadFar, 0xfffdu));
-                        cb_st = cb;
-                        wave_sync();
-                    }
-                    const uint32_t sh2 = best_tile_shift(nq, cn2);
-                    const uint32_t TJ2 = 1u << sh2, TI2 = 64u >> sh2, lj2 = (uint32_t)lane & (TJ2 - 1);
-                    const float4 *pc = S.rec2 + lj2;
-                    for (uint32_t e0 = 0; e0 < nq; e0 += TI2) {
-                        uint32_t c0 = 0;
-                        while (c0 < cn2) {
-                            // one row of tiles: TI2 queued pairs (fixed) against the block of list2, TJ2 entries at a time
-                            const uint32_t e = e0 + ((uint32_t)lane >> sh2);
-                            const uint32_t pos = S.queue[e & (uint32_t)(kJointQueue - 1)];  // masked by `e < nq` below
-                            const uint32_t ip = pos & 63u, jp = (pos >> 8) & 63u;
-                            const float4 ra = S.rec0[ip], rb = S.rec1[jp];
-                            const uint32_t res_a = meta_res(__float_as_uint(ra.w)), res_b = meta_res(__float_as_uint(rb.w));
-                            const bool ve = e < nq;
-                            uint32_t nq3 = 0;
-                            do {
-                                const float4 rc = pc[c0];  // slot < 64: padding records fail the windows
-                                const uint32_t res_c = meta_res(__float_as_uint(rc.w));
-                                // every test is evaluated unconditionally: no divergent short-circuit branches
-                                bool ok = ve & in_window(rc, ra, b20) & in_window(rc, rb, b21) & (res_c != res_a) & (res_c != res_b);
-                                if (!C.ignore_chain && real2) {
-                                    const uint8_t qc = C.qchain[S.id2[c0 + lj2]];
-                                    ok = ok && ((qc == C.qchain[S.id0[ip]]) == tc20) && ((qc == C.qchain[S.id1[jp]]) == tc21);
-                                }
-                                const unsigned long long m = ballot64(ok);
-                                TM_STAT(2, 1);
-                                TM_STAT(24 + 2, __popcll(m));
-                                if (ok) {
-                                    const uint32_t slot = rank_in(m);
-                                    S.queue3[slot][0] = (uint32_t)S.id0[ip] | ((uint32_t)S.id1[jp] << 16);
-                                    S.queue3[slot][1] = S.id2[c0 + lj2];
-                                }
-                                nq3 = (uint32_t)__popcll(m);
-                                c0 += TJ2;
-                            } while (c0 < cn2 && nq3 == 0);
-                            if (nq3 == 0) break;
-                            // ---- depth-first search below every surviving triple (the only dfs call site)
-                            wave_sync();
-#if defined(TM_STATS) || defined(TM_ABLATE)
-                            if (flags & 0x400u) nq3 = 0;
-#endif
-                            for (uint32_t q = 0; q < nq3; ++q) {
-                                // all three records are fetched at once; for templates with fewer than three
-                                // residues the wildcard entries name atom 0, and the levels they are written to
-                                // are re-assigned by the search before anything reads them
-                                const uint32_t ab = uni(S.queue3[q][0]), c = uni(S.queue3[q][1]);
-                                const uint32_t a0 = ab & 0xffffu, a1 = ab >> 16;
-                                const float4 r0 = C.rec[a0], r1 = C.rec[a1], r2 = C.rec[c];
-                                assign_record(C, W, 0, a0, r0);
-                                assign_record(C, W, 1, a1, r1);
-                                assign_record(C, W, 2, c, r2);
-                                if (!dfs(C, W, P, floor)) return false;
-                            }
-                            wave_sync();
-                        }
+            for (uint32_t w0 = 0; w0 < total; w0 += 64u) {
+                // lanes past the last item repeat it (every address below stays valid) and are masked out of the vote
+                const uint32_t w = min(w0 + (uint32_t)lane, total - 1u);
+                // owning pair: the last lane whose exclusive count is <= w (rows of length 0 share their count with
+                // the next row and are skipped by "last")
+                uint32_t p = 0;
+#pragma unroll
+                for (uint32_t step = 32u; step != 0u; step >>= 1) {
+                    const uint32_t c = p + step;  // at most 63
+                    if (S.x_excl[c] <= w) p = c;
+                }
+                bool ok = w0 + (uint32_t)lane < total;
+                const uint2 ent = C.tab_ent[S.x_first[p] + (w - S.x_excl[p])];
+                const float dk2 = __uint_as_float(ent.y);
+                ok = ok & (dk2 >= b_key.x) & (dk2 <= b_key.y);
+                const uint32_t pos = S.queue[p0 + p];
+                const uint32_t a0 = C.pool_at(lo0 + (pos & 0xffffu)), a1 = C.pool_at(lo1 + (pos >> 16));
+                const uint32_t c2 = C.pool_at(lo2 + (ent.x >> 16));
+                const float4 rc = C.rec[c2], ro = C.rec[key1 ? a0 : a1];
+                ok = ok & in_window(rc, ro, b_other) & (meta_res(__float_as_uint(rc.w)) != meta_res(__float_as_uint(ro.w)));
+                if (!C.ignore_chain) {
+                    if (ok) {
+                        const uint8_t qc = C.qchain[c2];
+                        ok = ((qc == C.qchain[a0]) == tc20) & ((qc == C.qchain[a1]) == tc21);
                     }
                 }
+                const unsigned long long m = ballot64(ok);
+                TM_STAT(2, 1);
+                TM_STAT(24 + 2, __popcll(m));
+                if (m == 0ull) continue;
+                if (ok) {
+                    const uint32_t slot = rank_in(m);
+                    S.queue3[slot][0] = a0 | (a1 << 16);
+                    S.queue3[slot][1] = c2;
+                }
+                const uint32_t nq3 = (uint32_t)__popcll(m);
+                wave_sync();
+                for (uint32_t q = 0; q < nq3; ++q) {
+                    const uint32_t ab = uni(S.queue3[q][0]), c = uni(S.queue3[q][1]);
+                    const uint32_t x0 = ab & 0xffffu, x1 = ab >> 16;
+                    const float4 r0 = C.rec[x0], r1 = C.rec[x1], r2 = C.rec[c];
+                    assign_record(C, W, 0, x0, r0);
+                    assign_record(C, W, 1, x1, r1);
+                    assign_record(C, W, 2, c, r2);
+                    if (!dfs(C, W, P, 3)) return false;
+                }
+                wave_sync();
             }
         }
     }
@@ -812,6 +953,7 @@ struct TemplateRegs {
     uint32_t group, ref, tchain, orig, any, resmask, nm_lo, nm_hi, li;
     float2 bound0, bound1;  // bounds[lane], bounds[64 + (lane & 1)]
     uint32_t k, n_groups;
+    uint32_t pair_table, triple_table, triple_key;
 };
 
 __device__ __forceinline__ void load_template(const QueryView &Q, uint32_t ti, int lane, TemplateRegs &R) {
@@ -831,6 +973,25 @@ __device__ __forceinline__ void load_template(const QueryView &Q, uint32_t ti, i
     R.bound1 = Q.bounds[(size_t)ti * kMaxPairs + 64 + (lane & 1)];
     R.k = T.k;
     R.n_groups = T.n_groups;
+    R.pair_table = T.pair_table;
+    R.triple_table = T.triple_table;
+    R.triple_key = T.triple_key;
+}
+
+// Where the claimed template's tables are for structure s: the pair table's segment and the triple table's first
+// row slot (one uint2 and one u32 load at uniform addresses).
+struct TableDir {
+    uint2 seg;
+    uint32_t rows, begin;
+};
+__device__ __forceinline__ TableDir load_table_dir(const BatchView &B, uint32_t s, const TemplateRegs &R) {
+    TableDir D;
+    const size_t base = (size_t)s * B.n_tables;
+    const uint32_t tp = uni(R.pair_table), tt = uni(R.triple_table);
+    D.seg = tp != 0xffffu ? B.tab_seg[base + tp] : make_uint2(0u, 0u);
+    D.rows = tt != 0xffffu ? B.tab_dir[base + tt] : 0u;
+    D.begin = tt != 0xffffu ? B.tab_seg[base + tt].x : 0u;
+    return D;
 }
 
 template <bool kLds, bool kIgnoreChain>
@@ -869,6 +1030,7 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
     const uint32_t n_chunks = (uint32_t)item.rounds << cx;
     if (chunk >= Q.n_sel) return;
 
+    if (B.tab_ok[s] != 1u) return;  // pair tables incomplete (pool overflow, reported with the result): nothing to search
     const uint32_t a0 = B.s_off[s], n = B.s_off[s + 1] - a0;
     const uint32_t r0 = B.s_roff[s], nres1 = B.s_roff[s + 1] - r0;  // n_res + 1 entries
     const uint32_t *kl_off = B.kl_off + (size_t)s * (L.n_lead + 1);
@@ -899,6 +1061,8 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
     C.pool_glb = B.kl_pool;
     C.pool_in_lds = pool_in_lds;
     C.qchain = B.q_chain + a0;
+    C.tab_rows = B.tab_rows;
+    C.tab_ent = B.tab_ent;
     C.S = scratch + (threadIdx.x >> 6);
     C.lane = lane_id();
     const bool count_candidates = A.O.candidates != nullptr;
@@ -911,6 +1075,7 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
     ti = uni(ti);
     TemplateRegs R;
     load_template(Q, min(ti, Q.n_sel - 1u), lane, R);
+    TableDir D = load_table_dir(B, s, R);
 
     while (ti < t_end) {
         const int k = (int)uni(R.k);
@@ -943,6 +1108,16 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
         }
         const bool feasible = ballot64(empty) == 0ull;  // an empty lead list: no assignment exists
         bool feasible_override = true;
+        // this template's tables (located while the previous template was searched); the first 64 entries of the pair
+        // table are fetched now and used by table_scan after the set-up below
+        TableRefs TR;
+        TR.pair_begin = uni(D.seg.x);
+        TR.pair_end = uni(D.seg.y);
+        TR.triple_rows = uni(D.rows);
+        TR.triple_begin = uni(D.begin);
+        TR.key_is_1 = uni(R.triple_key);
+        uint2 first_ent = make_uint2(0u, 0u);
+        if (TR.pair_begin + (uint32_t)lane < TR.pair_end) first_ent = B.tab_ent[TR.pair_begin + (uint32_t)lane];
         S.bnd[lane] = R.bound0;
         if (lane < kBoundsLds - 64) S.bnd[64 + lane] = R.bound1;
         wave_sync();
@@ -961,8 +1136,9 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
         if (Q.flags & 0x200u) feasible_override = false;
 #endif
         if (feasible && feasible_override) {
-            joint_top_scan(C, W, P, Q.flags);
+            table_scan(C, W, P, TR, first_ent);
         }
+        D = load_table_dir(B, s, R);  // R holds the next template by now
 
         // ---- the pair's outcome
         const uint32_t packed = P.ncand | (P.truncated ? 0x80000000u : 0u);

@@ -358,6 +358,17 @@ int oracle_residue_ids(int n, const char *qchain, const int *qresseq, const char
  * One template against one molecule.  Returns the number of hits written
  * (best_match: 0 or 1), or a negative error code.
  */
+/* scratch != NULL: room for ORACLE_MAXK * max(n, 1) ints, owned by the caller (oracle_query_library keeps one per
+ * thread: 15 allocations of n ints per template, freed again, make glibc trim and re-fault its heaps, which
+ * serialises many threads on the kernel's address-space lock) */
+static int query_one(
+    int n, const double *qxyz, const char *qname, const char *qres, const char *qchain, const int *qresid,
+    int k, const double *txyz, const int *tmode, const char *tname, const char *tresnames, const int *tnres,
+    int maxresn, const char *tchain, const int *tresseq, const double *tweight,
+    double rmsd_thr, double dist_cutoff, double max_dyn, int max_candidates, int best_match, int ignore_chain,
+    int max_hits, int *out_atoms, double *out_rmsd, double *out_rot, double *out_trans, int *out_candidates,
+    int *out_truncated, int *scratch);
+
 int oracle_query(
     /* molecule */
     int n, const double *qxyz, const char *qname, const char *qres, const char *qchain, const int *qresid,
@@ -369,6 +380,19 @@ int oracle_query(
     /* results */
     int max_hits, int *out_atoms, double *out_rmsd, double *out_rot, double *out_trans, int *out_candidates,
     int *out_truncated)
+{
+    return query_one(n, qxyz, qname, qres, qchain, qresid, k, txyz, tmode, tname, tresnames, tnres, maxresn, tchain,
+                     tresseq, tweight, rmsd_thr, dist_cutoff, max_dyn, max_candidates, best_match, ignore_chain,
+                     max_hits, out_atoms, out_rmsd, out_rot, out_trans, out_candidates, out_truncated, NULL);
+}
+
+static int query_one(
+    int n, const double *qxyz, const char *qname, const char *qres, const char *qchain, const int *qresid,
+    int k, const double *txyz, const int *tmode, const char *tname, const char *tresnames, const int *tnres,
+    int maxresn, const char *tchain, const int *tresseq, const double *tweight,
+    double rmsd_thr, double dist_cutoff, double max_dyn, int max_candidates, int best_match, int ignore_chain,
+    int max_hits, int *out_atoms, double *out_rmsd, double *out_rot, double *out_trans, int *out_candidates,
+    int *out_truncated, int *scratch)
 {
     search_t s;
     int i, j, a, ngroups = 0, rc = 0;
@@ -397,7 +421,7 @@ int oracle_query(
         }
     /* admissible target atoms per template atom */
     for (i = 0; i < k; ++i) {
-        s.cand[i] = malloc(sizeof(int) * (n > 0 ? n : 1));
+        s.cand[i] = scratch ? scratch + (size_t)i * (n > 0 ? n : 1) : malloc(sizeof(int) * (n > 0 ? n : 1));
         if (!s.cand[i]) { rc = ORACLE_EINVAL; goto done; }
         for (a = 0; a < n; ++a) {
             int ok;
@@ -412,7 +436,8 @@ int oracle_query(
     if (out_candidates) *out_candidates = s.candidates;
     if (out_truncated) *out_truncated = s.truncated;
 done:
-    for (i = 0; i < k; ++i) free(s.cand[i]);
+    if (!scratch)
+        for (i = 0; i < k; ++i) free(s.cand[i]);
     return rc;
 }
 
@@ -432,22 +457,34 @@ int oracle_query_library(
     int *out_candidates, int *out_truncated)
 {
     int t, err = 0;
-#pragma omp parallel for schedule(dynamic, 8)
-    for (t = 0; t < nt; ++t) {
-        int o = toff[t], k = toff[t + 1] - o, rc;
-        int atoms[ORACLE_MAXK];
-        rc = oracle_query(n, qxyz, qname, qres, qchain, qresid, k, txyz + 3 * o, tmode + o, tname + 4 * o,
-                          tresnames + 3 * maxresn * o, tnres + o, maxresn, tchain + 2 * o, tresseq + o, tweight + o,
-                          rmsd_thr[t], dist_cutoff[t], max_dyn[t], max_candidates, 1, ignore_chain, 1, atoms,
-                          out_rmsd + t, out_rot + 9 * t, out_trans + 3 * t, out_candidates + t, out_truncated + t);
-        if (rc < 0) {
+#pragma omp parallel
+    {
+        int *scratch = malloc(sizeof(int) * (size_t)ORACLE_MAXK * (n > 0 ? n : 1));  /* one per thread */
+#pragma omp for schedule(dynamic, 8)
+        for (t = 0; t < nt; ++t) {
+            int o = toff[t], k = toff[t + 1] - o, rc;
+            int atoms[ORACLE_MAXK];
+            if (!scratch) {
 #pragma omp critical
-            err = rc;
-            out_hit[t] = 0;
-            continue;
+                err = ORACLE_EINVAL;
+                out_hit[t] = 0;
+                continue;
+            }
+            rc = query_one(n, qxyz, qname, qres, qchain, qresid, k, txyz + 3 * o, tmode + o, tname + 4 * o,
+                           tresnames + 3 * maxresn * o, tnres + o, maxresn, tchain + 2 * o, tresseq + o, tweight + o,
+                           rmsd_thr[t], dist_cutoff[t], max_dyn[t], max_candidates, 1, ignore_chain, 1, atoms,
+                           out_rmsd + t, out_rot + 9 * t, out_trans + 3 * t, out_candidates + t, out_truncated + t,
+                           scratch);
+            if (rc < 0) {
+#pragma omp critical
+                err = rc;
+                out_hit[t] = 0;
+                continue;
+            }
+            out_hit[t] = rc;
+            if (rc > 0) memcpy(out_atoms + (size_t)maxk * t, atoms, sizeof(int) * k);
         }
-        out_hit[t] = rc;
-        if (rc > 0) memcpy(out_atoms + (size_t)maxk * t, atoms, sizeof(int) * k);
+        free(scratch);
     }
     return err;
 }
