@@ -311,6 +311,7 @@ struct tm_batch {
     uint32_t n_tables = 0;
     DevBuf<uint32_t> d_tab_dir, d_tab_rows, d_tab_ok, d_tab_overflow;
     DevBuf<uint2> d_tab_seg, d_tab_ent;
+    DevBuf<uint4> d_tab_ref;
     DevBuf<unsigned long long> d_tab_cursors;  // [0] row slots, [1] entries handed out
     DevBuf<TabWork> d_tab_work;
     uint32_t tab_work_items = 0, tab_work_tables = 0xffffffffu;
@@ -325,7 +326,7 @@ struct tm_batch {
         v.q_rec = d_rec.p; v.q_chain = d_chain.p; v.q_orig = d_orig.p; v.res_start = d_res_start.p;
         v.kl_off = d_kl_off.p; v.kl_pool = d_kl_pool.p;
         v.n_tables = n_tables; v.tab_dir = d_tab_dir.p; v.tab_rows = d_tab_rows.p; v.tab_ent = d_tab_ent.p;
-        v.tab_seg = d_tab_seg.p; v.tab_ok = d_tab_ok.p;
+        v.tab_seg = d_tab_seg.p; v.tab_ok = d_tab_ok.p; v.tab_ref = d_tab_ref.p;
         return v;
     }
 };
@@ -1220,10 +1221,13 @@ static int build_tables(const tm_library *lib, tm_batch *b, const StagedSelectio
     if (ents_wanted > ents) ents = ents_wanted + ents_wanted / 8 + 1024;
     if (rows > 0xfffffff0ull || ents > 0xfffffff0ull)
         return fail(TM_E_UNSUPPORTED, "pair tables need more than 2^32 entries: split the batch");
-    if (b->d_tab_rows.n != rows || b->d_tab_ent.n != ents) {
+    // 64 slots of slack: a search prefetches 64 row slots / entries from a table's start, whatever its size
+    const size_t ref_n = (size_t)ns * S->sel.size();
+    if (b->d_tab_rows.n != rows + 64 || b->d_tab_ent.n != ents + 64 || b->d_tab_ref.n != ref_n) {
         if (b->queried) HIP_TRY(hipStreamSynchronize(b->last_stream));  // an earlier query may still read the old pools
-        if (b->d_tab_rows.n != rows) HIP_TRY(b->d_tab_rows.alloc(rows));
-        if (b->d_tab_ent.n != ents) HIP_TRY(b->d_tab_ent.alloc(ents));
+        if (b->d_tab_rows.n != rows + 64) HIP_TRY(b->d_tab_rows.alloc(rows + 64));
+        if (b->d_tab_ent.n != ents + 64) HIP_TRY(b->d_tab_ent.alloc(ents + 64));
+        if (b->d_tab_ref.n != ref_n) HIP_TRY(b->d_tab_ref.alloc(ref_n));
     }
     b->row_capacity = rows; b->ent_capacity = ents;
     HIP_TRY(hipMemsetAsync(b->d_tab_cursors.p, 0, 2 * sizeof(unsigned long long), stream));
@@ -1233,6 +1237,7 @@ static int build_tables(const tm_library *lib, tm_batch *b, const StagedSelectio
     if (!ns) return TM_OK;
     if (!nt) {  // no template of the selection has two residues: nothing to build, every structure is searchable
         HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)b->d_tab_ok.p, 1, ns, stream));
+        HIP_TRY(hipMemsetAsync(b->d_tab_ref.p, 0, std::max<size_t>(ref_n, 1) * sizeof(uint4), stream));
         return TM_OK;
     }
     // work items of the two build passes: a structure's tables are dealt to `parts` workgroups, parts growing with
@@ -1264,6 +1269,10 @@ static int build_tables(const tm_library *lib, tm_batch *b, const StagedSelectio
     hipLaunchKernelGGL(k_tab_build, dim3(b->tab_work_items), dim3(kTabBlock), lds_bytes, stream, lib->n_lead, B,
                        S->d_tables.p, b->d_tab_work.p, b->d_tab_ok.p, b->d_tab_rows.p, b->d_tab_ent.p, b->d_tab_seg.p,
                        b->d_tab_cursors.p, ents, b->d_tab_overflow.p, lr_cap);
+    {
+        const uint32_t n_sel = (uint32_t)S->sel.size();
+        hipLaunchKernelGGL(k_tab_refs, dim3(ns, (n_sel + 255) / 256), dim3(256), 0, stream, B, n_sel, S->d_staged.p, b->d_tab_ref.p);
+    }
     HIP_TRY(hipGetLastError());
     return TM_OK;
 }

@@ -85,6 +85,7 @@ struct BatchView {
     const uint32_t *tab_dir;   // [n_structs * n_tables] first row slot of the table
     const uint2 *tab_seg;      // [n_structs * n_tables] (first entry, one past the last entry) of the table
     const uint32_t *tab_ok;    // [n_structs] 1: the structure's tables are complete
+    const uint4 *tab_ref;      // [n_structs * n_sel] per (structure, selected template): see k_tab_refs
     const uint32_t *tab_rows;  // row offsets (absolute entry indices); a table with n rows owns n + 1 slots
     const uint2 *tab_ent;      // {position in list A | position in list B << 16, squared distance (fp32 bits)}
 };

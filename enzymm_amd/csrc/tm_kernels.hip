@@ -48,6 +48,34 @@ __device__ __forceinline__ unsigned long long uni64(unsigned long long v) {
     return ((unsigned long long)hi << 32) | lo;
 }
 
+// Inclusive scans over the 64 lanes in six DPP steps (no LDS round trips): row_shr 1, 2, 4, 8 scan each row of 16
+// lanes -- a lane whose source falls outside its row keeps the identity --, row_bcast:15 adds a row's total to the
+// next row (rows 1 and 3), row_bcast:31 adds the total of the first 32 lanes to rows 2 and 3.
+#define TM_DPP(x, ctrl, rows) (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), ctrl, rows, 0xf, false)
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t x) {
+    x += TM_DPP(x, 0x111, 0xf);
+    x += TM_DPP(x, 0x112, 0xf);
+    x += TM_DPP(x, 0x114, 0xf);
+    x += TM_DPP(x, 0x118, 0xf);
+    x += TM_DPP(x, 0x142, 0xa);
+    x += TM_DPP(x, 0x143, 0xc);
+    return x;
+}
+__device__ __forceinline__ uint32_t wave_scan_max(uint32_t x) {  // identity 0
+    x = max(x, TM_DPP(x, 0x111, 0xf));
+    x = max(x, TM_DPP(x, 0x112, 0xf));
+    x = max(x, TM_DPP(x, 0x114, 0xf));
+    x = max(x, TM_DPP(x, 0x118, 0xf));
+    x = max(x, TM_DPP(x, 0x142, 0xa));
+    x = max(x, TM_DPP(x, 0x143, 0xc));
+    return x;
+}
+#undef TM_DPP
+// value of `v` in lane `src` (any lane may ask for any lane; every lane of the wave must execute this)
+__device__ __forceinline__ uint32_t lane_get(uint32_t v, uint32_t src) {
+    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)v);
+}
+
 // Orders this wave's LDS traffic: lanes exchange data through LDS without a workgroup barrier.
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -448,6 +476,31 @@ __global__ __launch_bounds__(kTabBlock) void k_tab_build(uint32_t n_lead, BatchV
     }
 }
 
+// Where every (structure, selected template) search finds its tables: {first entry of its pair table, number of
+// entries, first row slot of its triple table, first entry of its triple table}.  One 16-byte load at an address
+// known the moment a template is claimed, instead of three loads that depend on the template's record.
+__global__ __launch_bounds__(256) void k_tab_refs(BatchView B, uint32_t n_sel, const Staged *__restrict__ staged,
+                                                   uint4 *__restrict__ tab_ref) {
+    const uint32_t s = blockIdx.x;
+    const uint32_t ti = blockIdx.y * blockDim.x + threadIdx.x;
+    if (ti >= n_sel) return;
+    const size_t base = (size_t)s * B.n_tables;
+    const uint32_t tp = staged[ti].pair_table, tt = staged[ti].triple_table;
+    uint4 r = make_uint4(0u, 0u, 0u, 0u);
+    if (B.tab_ok[s] == 1u) {
+        if (tp != 0xffffu) {
+            const uint2 seg = B.tab_seg[base + tp];
+            r.x = seg.x;
+            r.y = seg.y - seg.x;
+        }
+        if (tt != 0xffffu) {
+            r.z = B.tab_dir[base + tt];
+            r.w = B.tab_seg[base + tt].x;
+        }
+    }
+    tab_ref[(size_t)s * n_sel + ti] = r;
+}
+
 // one thread: the pair-table build's overflow word into the query's (bit 4)
 __global__ void k_flag_table_overflow(const uint32_t *__restrict__ table_overflow, uint32_t *__restrict__ query_overflow) {
     if (*table_overflow) atomicOr(query_overflow, 16u);
@@ -465,7 +518,7 @@ struct __align__(16) WaveScratch {
     uint16_t surv[kMaxG][64];                  // per template residue: one 64-entry chunk of its lead list
     uint32_t queue[kPairQueue];                // pair-table survivors (position in list 0 | position in list 1 << 16)
     uint32_t queue3[kTripleQueue][2];          // survivors of one triple pass ((a0 | a1 << 16), a2) waiting for their subtree
-    uint32_t x_first[64], x_excl[64];          // triple stage: first entry / exclusive item count of each queued pair's row
+    uint32_t owner[64];                        // triple stage: queued pair owning the item at which its row starts
 };
 
 // Search state of one wave, held in VGPRs and indexed BY LANE: lane L holds the entry of search
@@ -787,6 +840,16 @@ struct TableRefs {
     uint32_t triple_rows;           // first row slot of the triple table (row offsets are relative to ...
     uint32_t triple_begin;          // ... the table's first entry)
     uint32_t key_is_1;              // rows of the triple table are positions of lead 1 (else lead 0)
+    uint32_t flags;                 // diagnostic builds: the query flags (phase ablation)
+};
+
+// What a search fetches from the tables while the template is being set up, one value per lane: the first 64
+// entries of the pair table, the first 64 row slots and the first 64 entries of the triple table.  Most tables are
+// smaller than that, and the triple stage then runs without a dependent global load.
+struct TablePrefetch {
+    uint2 pair_ent;
+    uint32_t triple_row;
+    uint2 triple_ent;
 };
 
 // The lead atoms of the first three template residues come from the structure's pair tables (k_tab_*):
@@ -802,7 +865,7 @@ struct TableRefs {
 // two residues search below the pairs, templates with one residue below every atom of their lead list.
 template <class Ctx>
 __device__ __forceinline__ bool table_scan(const Ctx &C, WaveRegs &W, PairState &P, const TableRefs &TR,
-                                           const uint2 first_ent) {
+                                           const TablePrefetch &F) {
     WaveScratch &S = *C.S;
     const int lane = C.lane;
     const int G = C.n_groups;
@@ -824,7 +887,7 @@ __device__ __forceinline__ bool table_scan(const Ctx &C, WaveRegs &W, PairState 
 
     uint32_t e = TR.pair_begin;
     const uint32_t e_end = TR.pair_end;
-    bool have_first = true;  // `first_ent` holds entry e + lane of the first round (fetched when the template was set up)
+    bool have_first = true;  // F.pair_ent holds entry e + lane of the first round (fetched when the template was set up)
     while (e < e_end) {
         // ---- pair stage: scan until the queue may not take another 64 entries (or the segment ends)
         uint32_t nq = 0;
@@ -832,7 +895,7 @@ __device__ __forceinline__ bool table_scan(const Ctx &C, WaveRegs &W, PairState 
         do {
             const uint32_t idx = e + (uint32_t)lane;
             bool ok = idx < e_end;
-            uint2 ent = first_ent;
+            uint2 ent = F.pair_ent;
             if (!have_first) {
                 ent = make_uint2(0u, 0u);
                 if (ok) ent = C.tab_ent[idx];
@@ -852,6 +915,9 @@ __device__ __forceinline__ bool table_scan(const Ctx &C, WaveRegs &W, PairState 
             e += 64u;
         } while (e < e_end && nq + 64u <= (uint32_t)kPairQueue);
         TM_STAT(53, nq);
+#if defined(TM_STATS) || defined(TM_ABLATE)
+        if (TR.flags & 0x100u) nq = 0;
+#endif
         if (nq == 0u) continue;
         wave_sync();
         if (G == 2) {
@@ -868,42 +934,39 @@ __device__ __forceinline__ bool table_scan(const Ctx &C, WaveRegs &W, PairState 
         // ---- triple stage, up to 64 queued pairs at a time
         for (uint32_t p0 = 0; p0 < nq; p0 += 64u) {
             const uint32_t np = min(64u, nq - p0);
-            uint32_t first = 0, len = 0;
-            if ((uint32_t)lane < np) {
-                const uint32_t pos = S.queue[p0 + (uint32_t)lane];
-                const uint32_t row = TR.triple_rows + (key1 ? pos >> 16 : pos & 0xffffu);
-                const uint32_t r0 = C.tab_rows[row];
-                first = TR.triple_begin + r0;
-                len = C.tab_rows[row + 1] - r0;
+            const bool vp = (uint32_t)lane < np;
+            const uint32_t pos_p = vp ? S.queue[p0 + (uint32_t)lane] : 0u;
+            const uint32_t key = key1 ? pos_p >> 16 : pos_p & 0xffffu;
+            // the row of the key atom: offsets from the prefetched slots (lanes key, key + 1), or from memory
+            uint32_t r0 = lane_get(F.triple_row, key), r1 = lane_get(F.triple_row, key + 1u);
+            if (vp && key >= 63u) {
+                r0 = C.tab_rows[TR.triple_rows + key];
+                r1 = C.tab_rows[TR.triple_rows + key + 1u];
             }
-            uint32_t incl = len;  // inclusive prefix sum of the row lengths over the lanes
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
-                if (lane >= d) incl += up;
-            }
+            const uint32_t len = vp ? r1 - r0 : 0u;
+            const uint32_t incl = wave_scan_add(len);  // inclusive prefix sum of the row lengths over the lanes
+            const uint32_t excl = incl - len;
             const uint32_t total = RL(incl, 63);
-            if (total == 0u) continue;
-            wave_sync();  // x_first / x_excl of the previous chunk have been read
-            S.x_first[lane] = first;
-            S.x_excl[lane] = incl - len;
-            wave_sync();
             for (uint32_t w0 = 0; w0 < total; w0 += 64u) {
+                // Owner of every item of this pass: each queued pair writes its lane number where its row starts
+                // (or at item w0, when the row started in an earlier pass); a running maximum spreads it.
+                S.owner[lane] = 0u;
+                {
+                    const uint32_t start = max(excl, w0);
+                    if (len != 0u && start < w0 + 64u && incl > w0) S.owner[start - w0] = (uint32_t)lane;
+                }
+                wave_sync();
+                const uint32_t p = wave_scan_max(S.owner[lane]);
+                wave_sync();
                 // lanes past the last item repeat it (every address below stays valid) and are masked out of the vote
                 const uint32_t w = min(w0 + (uint32_t)lane, total - 1u);
-                // owning pair: the last lane whose exclusive count is <= w (rows of length 0 share their count with
-                // the next row and are skipped by "last")
-                uint32_t p = 0;
-#pragma unroll
-                for (uint32_t step = 32u; step != 0u; step >>= 1) {
-                    const uint32_t c = p + step;  // at most 63
-                    if (S.x_excl[c] <= w) p = c;
-                }
                 bool ok = w0 + (uint32_t)lane < total;
-                const uint2 ent = C.tab_ent[S.x_first[p] + (w - S.x_excl[p])];
+                const uint32_t e_rel = lane_get(r0, p) + (w - lane_get(excl, p));  // entry, relative to the table's first
+                uint2 ent = make_uint2(lane_get(F.triple_ent.x, e_rel & 63u), lane_get(F.triple_ent.y, e_rel & 63u));
+                if (e_rel >= 64u) ent = C.tab_ent[TR.triple_begin + e_rel];
                 const float dk2 = __uint_as_float(ent.y);
                 ok = ok & (dk2 >= b_key.x) & (dk2 <= b_key.y);
-                const uint32_t pos = S.queue[p0 + p];
+                const uint32_t pos = lane_get(pos_p, p);
                 const uint32_t a0 = C.pool_at(lo0 + (pos & 0xffffu)), a1 = C.pool_at(lo1 + (pos >> 16));
                 const uint32_t c2 = C.pool_at(lo2 + (ent.x >> 16));
                 const float4 rc = C.rec[c2], ro = C.rec[key1 ? a0 : a1];
@@ -914,9 +977,12 @@ __device__ __forceinline__ bool table_scan(const Ctx &C, WaveRegs &W, PairState 
                         ok = ((qc == C.qchain[a0]) == tc20) & ((qc == C.qchain[a1]) == tc21);
                     }
                 }
-                const unsigned long long m = ballot64(ok);
+                unsigned long long m = ballot64(ok);
                 TM_STAT(2, 1);
                 TM_STAT(24 + 2, __popcll(m));
+#if defined(TM_STATS) || defined(TM_ABLATE)
+                if (TR.flags & 0x400u) m = 0ull;
+#endif
                 if (m == 0ull) continue;
                 if (ok) {
                     const uint32_t slot = rank_in(m);
@@ -928,10 +994,10 @@ __device__ __forceinline__ bool table_scan(const Ctx &C, WaveRegs &W, PairState 
                 for (uint32_t q = 0; q < nq3; ++q) {
                     const uint32_t ab = uni(S.queue3[q][0]), c = uni(S.queue3[q][1]);
                     const uint32_t x0 = ab & 0xffffu, x1 = ab >> 16;
-                    const float4 r0 = C.rec[x0], r1 = C.rec[x1], r2 = C.rec[c];
-                    assign_record(C, W, 0, x0, r0);
-                    assign_record(C, W, 1, x1, r1);
-                    assign_record(C, W, 2, c, r2);
+                    const float4 q0 = C.rec[x0], q1 = C.rec[x1], q2 = C.rec[c];
+                    assign_record(C, W, 0, x0, q0);
+                    assign_record(C, W, 1, x1, q1);
+                    assign_record(C, W, 2, c, q2);
                     if (!dfs(C, W, P, 3)) return false;
                 }
                 wave_sync();
@@ -976,22 +1042,6 @@ __device__ __forceinline__ void load_template(const QueryView &Q, uint32_t ti, i
     R.pair_table = T.pair_table;
     R.triple_table = T.triple_table;
     R.triple_key = T.triple_key;
-}
-
-// Where the claimed template's tables are for structure s: the pair table's segment and the triple table's first
-// row slot (one uint2 and one u32 load at uniform addresses).
-struct TableDir {
-    uint2 seg;
-    uint32_t rows, begin;
-};
-__device__ __forceinline__ TableDir load_table_dir(const BatchView &B, uint32_t s, const TemplateRegs &R) {
-    TableDir D;
-    const size_t base = (size_t)s * B.n_tables;
-    const uint32_t tp = uni(R.pair_table), tt = uni(R.triple_table);
-    D.seg = tp != 0xffffu ? B.tab_seg[base + tp] : make_uint2(0u, 0u);
-    D.rows = tt != 0xffffu ? B.tab_dir[base + tt] : 0u;
-    D.begin = tt != 0xffffu ? B.tab_seg[base + tt].x : 0u;
-    return D;
 }
 
 template <bool kLds, bool kIgnoreChain>
@@ -1075,7 +1125,8 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
     ti = uni(ti);
     TemplateRegs R;
     load_template(Q, min(ti, Q.n_sel - 1u), lane, R);
-    TableDir D = load_table_dir(B, s, R);
+    const uint4 *tab_ref = B.tab_ref + (size_t)s * Q.n_sel;
+    uint4 ref = tab_ref[min(ti, Q.n_sel - 1u)];
 
     while (ti < t_end) {
         const int k = (int)uni(R.k);
@@ -1108,16 +1159,19 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
         }
         const bool feasible = ballot64(empty) == 0ull;  // an empty lead list: no assignment exists
         bool feasible_override = true;
-        // this template's tables (located while the previous template was searched); the first 64 entries of the pair
-        // table are fetched now and used by table_scan after the set-up below
+        // this template's tables (their whereabouts arrived with the template's constants); what the search reads
+        // of them first is fetched now, one value per lane, and is there when table_scan starts after the set-up
         TableRefs TR;
-        TR.pair_begin = uni(D.seg.x);
-        TR.pair_end = uni(D.seg.y);
-        TR.triple_rows = uni(D.rows);
-        TR.triple_begin = uni(D.begin);
+        TR.pair_begin = uni(ref.x);
+        TR.pair_end = TR.pair_begin + uni(ref.y);
+        TR.triple_rows = uni(ref.z);
+        TR.triple_begin = uni(ref.w);
         TR.key_is_1 = uni(R.triple_key);
-        uint2 first_ent = make_uint2(0u, 0u);
-        if (TR.pair_begin + (uint32_t)lane < TR.pair_end) first_ent = B.tab_ent[TR.pair_begin + (uint32_t)lane];
+        TR.flags = Q.flags;
+        TablePrefetch F;
+        F.pair_ent = B.tab_ent[TR.pair_begin + (uint32_t)lane];  // past the table's end: other tables, never used
+        F.triple_row = B.tab_rows[TR.triple_rows + (uint32_t)lane];
+        F.triple_ent = B.tab_ent[TR.triple_begin + (uint32_t)lane];
         S.bnd[lane] = R.bound0;
         if (lane < kBoundsLds - 64) S.bnd[64 + lane] = R.bound1;
         wave_sync();
@@ -1127,6 +1181,7 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
         if (lane == 0) ti = atomicAdd(&s_next, n_chunks);
         ti = uni(ti);
         load_template(Q, min(ti, Q.n_sel - 1u), lane, R);
+        ref = tab_ref[min(ti, Q.n_sel - 1u)];
 
         PairState P;
         P.s = s; P.ti = ti_cur;
@@ -1136,9 +1191,8 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
         if (Q.flags & 0x200u) feasible_override = false;
 #endif
         if (feasible && feasible_override) {
-            table_scan(C, W, P, TR, first_ent);
+            table_scan(C, W, P, TR, F);
         }
-        D = load_table_dir(B, s, R);  // R holds the next template by now
 
         // ---- the pair's outcome
         const uint32_t packed = P.ncand | (P.truncated ? 0x80000000u : 0u);

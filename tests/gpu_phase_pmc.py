@@ -1,20 +1,20 @@
-"""Per-phase instruction counters: summarise a rocprofv3 --pmc run of tests/gpu_ablate.py. Not a test.
+"""Per-phase instruction counters: summarise a rocprofv3 --pmc --output-format csv run of tests/gpu_ablate.py. Not a test.
 
-usage: gpu_phase_pmc.py <dir with the rocpd .db> [searches per launch]
+usage: gpu_phase_pmc.py <dir with *counter_collection.csv> [searches per launch]
 gpu_ablate.py launches k_search 4x per mode in the order full / no dfs / no subtrees / staging only."""
 import collections
+import csv
 import glob
-import sqlite3
 import sys
 
 d = sys.argv[1]
 searches = float(sys.argv[2]) if len(sys.argv) > 2 else 6.78e6
 rows = collections.defaultdict(dict)
-for f in glob.glob(f"{d}/**/*.db", recursive=True):
-    cur = sqlite3.connect(f).cursor()
-    for did, name, cn, cv in cur.execute("select dispatch_id, name, counter_name, counter_value from pmc_events"):
-        if "k_search" in name:
-            rows[did][cn] = rows[did].get(cn, 0.0) + cv
+for f in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "k_search" in r["Kernel_Name"]:
+            did = int(r["Dispatch_Id"])
+            rows[did][r["Counter_Name"]] = rows[did].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
 ids = sorted(rows)
 labels = ["full", "no dfs", "no subtrees", "staging only"]
 per = len(ids) // 4
