@@ -1262,13 +1262,17 @@ static int build_tables(const tm_library *lib, tm_batch *b, const StagedSelectio
     // LDS of a build workgroup: the atom record of every kind-list position of its structure (about 2.5 per atom)
     const uint32_t lr_cap = (uint32_t)std::min<size_t>(9600, std::max<size_t>(1024, 3 * (size_t)b->max_atoms));
     const size_t lds_bytes = (size_t)lr_cap * sizeof(float4) + ((size_t)lib->n_lead + 2 + nt) * sizeof(uint32_t);
+    uint32_t lr_arg = lr_cap;
+#ifdef TM_ABLATE
+    if (const char *env = std::getenv("ENZYMM_AMD_TAB_DEBUG")) lr_arg |= (uint32_t)std::atoi(env) << 30;
+#endif
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tab_build), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_bytes));
     hipLaunchKernelGGL(k_tab_layout, dim3(ns), dim3(256), 0, stream, lib->n_lead, B, S->d_tables.p, b->d_tab_dir.p,
                        b->d_tab_cursors.p, rows, b->d_tab_overflow.p, b->d_tab_ok.p);
     hipLaunchKernelGGL(k_tab_build, dim3(b->tab_work_items), dim3(kTabBlock), lds_bytes, stream, lib->n_lead, B,
                        S->d_tables.p, b->d_tab_work.p, b->d_tab_ok.p, b->d_tab_rows.p, b->d_tab_ent.p, b->d_tab_seg.p,
-                       b->d_tab_cursors.p, ents, b->d_tab_overflow.p, lr_cap);
+                       b->d_tab_cursors.p, ents, b->d_tab_overflow.p, lr_arg);
     {
         const uint32_t n_sel = (uint32_t)S->sel.size();
         hipLaunchKernelGGL(k_tab_refs, dim3(ns, (n_sel + 255) / 256), dim3(256), 0, stream, B, n_sel, S->d_staged.p, b->d_tab_ref.p);

@@ -95,7 +95,8 @@ struct __align__(16) Staged {
     unsigned long long namemask[kMaxK];
     uint32_t resmask[kMaxK];
     uint16_t lead_li[kMaxK];  // lead levels: index among lead kinds; 0xffff otherwise
-    uint8_t group[kMaxK], tchain[kMaxK], orig[kMaxK], any[kMaxK], ref[kMaxK];
+    uint32_t packed[kMaxK];   // group | ref << 8 | any << 13 | orig << 14 | tchain << 24 (see lvl_* in tm_kernels.hip)
+    uint8_t orig[kMaxK];      // search position -> template (file) order, also part of `packed`
     uint8_t k, n_groups;
     uint16_t pair_table;    // table (lead 0, lead 1); 0xffff: fewer than two residues
     uint16_t triple_table;  // table (lead 0 or 1, lead 2); 0xffff: fewer than three residues

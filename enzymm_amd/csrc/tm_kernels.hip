@@ -92,6 +92,17 @@ __device__ __forceinline__ void pair_of(int p, int &i, int &j) {
     j = p - tri(i);
 }
 
+// Per-level template constants in one word: template residue (search-order numbering, 0xff = unused level), search
+// position of the residue's lead, "any residue type", position in template (file) order, template chain ordinal.
+__host__ __device__ __forceinline__ uint32_t lvl_pack(uint32_t group, uint32_t ref, uint32_t any, uint32_t orig, uint32_t tchain) {
+    return (group & 0xffu) | ((ref & 31u) << 8) | ((any & 1u) << 13) | ((orig & 31u) << 14) | ((tchain & 0xffu) << 24);
+}
+__host__ __device__ __forceinline__ uint32_t lvl_group(uint32_t p) { return p & 0xffu; }
+__host__ __device__ __forceinline__ uint32_t lvl_ref(uint32_t p) { return (p >> 8) & 31u; }
+__host__ __device__ __forceinline__ uint32_t lvl_any(uint32_t p) { return (p >> 13) & 1u; }
+__host__ __device__ __forceinline__ uint32_t lvl_orig(uint32_t p) { return (p >> 14) & 31u; }
+__host__ __device__ __forceinline__ uint32_t lvl_tchain(uint32_t p) { return p >> 24; }
+
 // ------------------------------------------------------------------ k_stage_templates
 
 __global__ __launch_bounds__(64) void k_stage_templates(LibView L, uint32_t n_sel, const uint32_t *__restrict__ sel,
@@ -117,14 +128,12 @@ __global__ __launch_bounds__(64) void k_stage_templates(LibView L, uint32_t n_se
             S.namemask[lane] = L.k_namemask[kind];
             S.resmask[lane] = L.k_resmask[kind];
             S.lead_li[lane] = ref == lane ? (uint16_t)L.k_lead[kind] : (uint16_t)0xffffu;
-            S.group[lane] = L.a_group[off + lane];
-            S.tchain[lane] = L.a_chain[off + lane];
             S.orig[lane] = L.a_orig[off + lane];
-            S.any[lane] = L.k_any[kind];
-            S.ref[lane] = ref;
+            S.packed[lane] = lvl_pack(L.a_group[off + lane], ref, L.k_any[kind], L.a_orig[off + lane], L.a_chain[off + lane]);
         } else {
             S.namemask[lane] = 0; S.resmask[lane] = 0; S.lead_li[lane] = 0xffffu;
-            S.group[lane] = 0xff; S.tchain[lane] = 0; S.orig[lane] = 0; S.any[lane] = 0; S.ref[lane] = 0;
+            S.orig[lane] = 0;
+            S.packed[lane] = lvl_pack(0xff, 0, 0, 0, 0);
         }
     }
     if (lane == 0) {
@@ -346,46 +355,73 @@ constexpr int kTabBlock = 1024;  // threads of a k_tab_build workgroup: 16 waves
 // pair passes when both positions exist, the atoms lie in different residues and within the distance limit.
 //   count sweep (kFill = false): only the number of passing pairs (one scalar popcount of the vote per tile)
 //   fill sweep  (kFill = true):  rows are visited in order, so the running count is the prefix sum: rows[i] = passing
-//                                pairs before row i, and every passing pair is written at running count + passing
-//                                pairs of the tile's earlier rows (when TI > 1 list B fits one tile, so the vote of
-//                                that tile holds them all) + its rank in its row.
+//                                pairs before row i, and every passing pair is written at running count + its rank
+//                                among the passing lanes of the tile (lanes of earlier rows come first in the vote).
+// Two tiles are in flight per iteration (two independent chains of LDS read -> distance -> vote): the loop is bound
+// by those latencies, not by issue.  When list B fits one tile its operand is loaded once per table.
 // Returns the number of passing pairs.
 template <bool kFill, class Lead>
 __device__ __forceinline__ uint32_t tab_sweep(Lead lead, uint32_t a_lo, uint32_t n_a, uint32_t b_lo, uint32_t n_b,
                                               float dmax2, uint32_t *rows, uint2 *ent) {
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t shift = n_b <= 1u ? 0u : min(6u, 32u - (uint32_t)__clz((int)(n_b - 1u)));
-    const uint32_t TJ = 1u << shift, TI = 64u >> shift;
-    const uint32_t li = lane >> shift, lj = lane & (TJ - 1u);
-    const unsigned long long below = li == 0u ? 0ull : ((1ull << (li * TJ)) - 1ull);  // lanes of the tile's earlier rows
     uint32_t running = 0;
-    if (n_b == 0u) {  // nothing to pair with: every row is empty
+    if (n_b == 0u || n_a == 0u) {  // nothing to pair with: every row is empty
         if (kFill)
             for (uint32_t i = lane; i < n_a; i += 64u) rows[i] = 0u;
         return 0u;
     }
-    for (uint32_t i0 = 0; i0 < n_a; i0 += TI) {
-        const uint32_t i = i0 + li;
-        const bool vi = i < n_a;
-        const float4 ra = lead(a_lo + (vi ? i : 0u));
-        const uint32_t res_a = meta_res(__float_as_uint(ra.w));
-        uint32_t row_running = running;  // TI == 1: passing pairs before this tile of the row
-        for (uint32_t j0 = 0; j0 < n_b; j0 += TJ) {
-            const uint32_t j = j0 + lj;
-            const bool vj = j < n_b;
-            const float4 rb = lead(b_lo + (vj ? j : 0u));
-            const float dx = ra.x - rb.x, dy = ra.y - rb.y, dz = ra.z - rb.z;
-            const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-            const bool ok = vi & vj & (d2 <= dmax2) & (res_a != meta_res(__float_as_uint(rb.w)));
-            const unsigned long long all = ballot64(ok);
+    const uint32_t shift = n_b <= 1u ? 0u : min(6u, 32u - (uint32_t)__clz((int)(n_b - 1u)));
+    const uint32_t TJ = 1u << shift, TI = 64u >> shift;
+    const uint32_t li = lane >> shift, lj = lane & (TJ - 1u);
+    const unsigned long long below = li == 0u ? 0ull : ((1ull << (li * TJ)) - 1ull);  // lanes of the tile's earlier rows
+    auto test = [&](const float4 &ra, const float4 &rb, bool valid, float &d2) {
+        const float dx = ra.x - rb.x, dy = ra.y - rb.y, dz = ra.z - rb.z;
+        d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+        return valid & (d2 <= dmax2) & (meta_res(__float_as_uint(ra.w)) != meta_res(__float_as_uint(rb.w)));
+    };
+    if (n_b <= TJ) {
+        // ---- list B is one tile wide: the column operand never changes, rows go by 2 x TI
+        const bool vj = lj < n_b;
+        const float4 rb = lead(b_lo + (vj ? lj : 0u));
+        for (uint32_t i0 = 0; i0 < n_a; i0 += 2u * TI) {
+            const uint32_t iA = i0 + li, iB = iA + TI;
+            const bool vA = iA < n_a, vB = iB < n_a;
+            const float4 raA = lead(a_lo + (vA ? iA : 0u)), raB = lead(a_lo + (vB ? iB : 0u));
+            float dA, dB;
+            const bool okA = test(raA, rb, vA & vj, dA), okB = test(raB, rb, vB & vj, dB);
+            const unsigned long long allA = ballot64(okA), allB = ballot64(okB);
+            const uint32_t nA = (uint32_t)__popcll(allA);
             if (kFill) {
-                // lanes of earlier rows of the tile come first in the vote: rank among ALL passing lanes
-                if (ok) ent[row_running + rank_in(all)] = make_uint2(i | (j << 16), __float_as_uint(d2));
-                if (j0 == 0u && vi && lj == 0u) rows[i] = running + (uint32_t)__popcll(all & below);
+                if (okA) ent[running + rank_in(allA)] = make_uint2(iA | (lj << 16), __float_as_uint(dA));
+                if (okB) ent[running + nA + rank_in(allB)] = make_uint2(iB | (lj << 16), __float_as_uint(dB));
+                if (lj == 0u) {
+                    if (vA) rows[iA] = running + (uint32_t)__popcll(allA & below);
+                    if (vB) rows[iB] = running + nA + (uint32_t)__popcll(allB & below);
+                }
             }
-            row_running += (uint32_t)__popcll(all);
+            running += nA + (uint32_t)__popcll(allB);
         }
-        running = row_running;
+        return running;
+    }
+    // ---- list B is longer than 64: one row per tile (TI = 1), columns go by 2 x 64
+    for (uint32_t i = 0; i < n_a; ++i) {
+        const float4 ra = lead(a_lo + i);
+        if (kFill)
+            if (lane == 0u) rows[i] = running;
+        for (uint32_t j0 = 0; j0 < n_b; j0 += 128u) {
+            const uint32_t jA = j0 + lane, jB = jA + 64u;
+            const bool vA = jA < n_b, vB = jB < n_b;
+            const float4 rbA = lead(b_lo + (vA ? jA : 0u)), rbB = lead(b_lo + (vB ? jB : 0u));
+            float dA, dB;
+            const bool okA = test(ra, rbA, vA, dA), okB = test(ra, rbB, vB, dB);
+            const unsigned long long allA = ballot64(okA), allB = ballot64(okB);
+            const uint32_t nA = (uint32_t)__popcll(allA);
+            if (kFill) {
+                if (okA) ent[running + rank_in(allA)] = make_uint2(i | (jA << 16), __float_as_uint(dA));
+                if (okB) ent[running + nA + rank_in(allB)] = make_uint2(i | (jB << 16), __float_as_uint(dB));
+            }
+            running += nA + (uint32_t)__popcll(allB);
+        }
     }
     return running;
 }
@@ -402,24 +438,35 @@ __device__ __forceinline__ void tab_build_tables(const BatchView &B, const Table
                                                  uint32_t *__restrict__ tab_rows, uint2 *__restrict__ tab_ent,
                                                  uint2 *__restrict__ tab_seg, unsigned long long *__restrict__ cursors,
                                                  unsigned long long ent_capacity, uint32_t *__restrict__ overflow,
-                                                 uint32_t *__restrict__ tab_ok) {
+                                                 uint32_t *__restrict__ tab_ok, uint32_t dbg_mode) {
     __shared__ unsigned long long s_base;
     const uint32_t nt = B.n_tables;
-    const uint32_t wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t wave = uni(threadIdx.x >> 6), n_waves = blockDim.x >> 6, lane = threadIdx.x & 63;
     const uint32_t n_mine = nt > w.part ? (nt - w.part + w.parts - 1) / w.parts : 0u;  // tables part, part + parts, ...
     auto lead = [&](uint32_t p) -> float4 { return kLds ? s_lr[p] : rec[pool[p]]; };
     for (uint32_t m = wave; m < n_mine; m += n_waves) {
         const uint32_t t = w.part + w.parts * m;
         const TableDesc T = tables[t];
-        const uint32_t a_lo = kl[T.li_a], n_a = kl[T.li_a + 1] - a_lo, b_lo = kl[T.li_b], n_b = kl[T.li_b + 1] - b_lo;
-        const uint32_t total = tab_sweep<false>(lead, a_lo, n_a, b_lo, n_b, T.dmax2, nullptr, nullptr);
+        // wave-uniform values, said so: loop counters and branches of the sweep stay scalar
+        const uint32_t a_lo = uni(kl[T.li_a]), n_a = uni(kl[T.li_a + 1]) - a_lo, b_lo = uni(kl[T.li_b]),
+                       n_b = uni(kl[T.li_b + 1]) - b_lo;
+        const uint32_t total = dbg_mode == 2u ? 0u : tab_sweep<false>(lead, a_lo, n_a, b_lo, n_b, T.dmax2, nullptr, nullptr);
         if (lane == 0) s_size[m] = total;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {  // sizes -> offsets (about a thousand tables at most)
-        unsigned long long run = 0;
-        for (uint32_t m = 0; m < n_mine; ++m) { const uint32_t v = s_size[m]; s_size[m] = (uint32_t)run; run += v; }
-        s_size[n_mine] = (uint32_t)run;
+    if (wave == 0u) {  // sizes -> offsets, 64 tables per step
+        uint32_t carry = 0;
+        for (uint32_t m0 = 0; m0 < n_mine; m0 += 64u) {
+            const uint32_t m = m0 + lane;
+            const uint32_t v = m < n_mine ? s_size[m] : 0u;
+            const uint32_t incl = wave_scan_add(v);
+            if (m < n_mine) s_size[m] = carry + incl - v;
+            carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+        if (lane == 0) s_size[n_mine] = carry;
+    }
+    if (threadIdx.x == 0) {
+        const unsigned long long run = s_size[n_mine];
         unsigned long long base = atomicAdd(&cursors[1], run);
         if (base + run > ent_capacity) {  // no room: the structure's tables are unusable, the query says so
             atomicOr(overflow, 2u);
@@ -433,14 +480,15 @@ __device__ __forceinline__ void tab_build_tables(const BatchView &B, const Table
     for (uint32_t m = wave; m < n_mine; m += n_waves) {
         const uint32_t t = w.part + w.parts * m;
         const TableDesc T = tables[t];
-        const uint32_t a_lo = kl[T.li_a], n_a = kl[T.li_a + 1] - a_lo, b_lo = kl[T.li_b], n_b = kl[T.li_b + 1] - b_lo;
+        const uint32_t a_lo = uni(kl[T.li_a]), n_a = uni(kl[T.li_a + 1]) - a_lo, b_lo = uni(kl[T.li_b]),
+                       n_b = uni(kl[T.li_b + 1]) - b_lo;
         uint32_t *rows = tab_rows + B.tab_dir[(size_t)w.s * nt + t];
         const uint32_t first = (uint32_t)base + s_size[m], total = s_size[m + 1] - s_size[m];
         if (lane == 0) {
             tab_seg[(size_t)w.s * nt + t] = base == ~0ull ? make_uint2(0u, 0u) : make_uint2(first, first + total);
             rows[n_a] = total;
         }
-        if (base == ~0ull) continue;
+        if (base == ~0ull || dbg_mode != 0u) continue;
         tab_sweep<true>(lead, a_lo, n_a, b_lo, n_b, T.dmax2, rows, tab_ent + first);
     }
 }
@@ -458,6 +506,12 @@ __global__ __launch_bounds__(kTabBlock) void k_tab_build(uint32_t n_lead, BatchV
     extern __shared__ __align__(16) unsigned char tab_smem[];
     const TabWork w = work[blockIdx.x];
     if (tab_ok[w.s] == 0u) return;  // its row slots did not fit (k_tab_layout)
+#ifdef TM_ABLATE
+    const uint32_t dbg_mode = lr_cap >> 30;  // timing experiments: 1 no fill sweep, 2 no sweeps at all
+    lr_cap &= 0x3fffffffu;
+#else
+    const uint32_t dbg_mode = 0;
+#endif
     const uint32_t *kl = B.kl_off + (size_t)w.s * (n_lead + 1);
     const float4 *rec = B.q_rec + B.s_off[w.s];
     const uint32_t p0 = kl[0], plen = kl[n_lead] - p0;
@@ -469,10 +523,10 @@ __global__ __launch_bounds__(kTabBlock) void k_tab_build(uint32_t n_lead, BatchV
         for (uint32_t i = threadIdx.x; i <= n_lead; i += blockDim.x) s_kl[i] = kl[i] - p0;
         __syncthreads();
         tab_build_tables<true>(B, tables, w, rec, B.kl_pool, s_lr, s_kl, s_size, tab_rows, tab_ent, tab_seg, cursors,
-                               ent_capacity, overflow, tab_ok);
+                               ent_capacity, overflow, tab_ok, dbg_mode);
     } else {
         tab_build_tables<false>(B, tables, w, rec, B.kl_pool, nullptr, kl, s_size, tab_rows, tab_ent, tab_seg, cursors,
-                                ent_capacity, overflow, tab_ok);
+                                ent_capacity, overflow, tab_ok, dbg_mode);
     }
 }
 
@@ -510,11 +564,11 @@ __global__ void k_flag_table_overflow(const uint32_t *__restrict__ table_overflo
 
 // Per-wave LDS: only what lanes exchange.  All search state lives in registers (see WaveRegs).
 // Pair-bound rows 1..kBoundRowsLds (row L = bounds of level L against levels 0..L-1, at tri(L)) are kept in LDS.
-constexpr int kBoundRowsLds = 11;
-constexpr int kBoundsLds = kBoundRowsLds * (kBoundRowsLds + 1) / 2;  // 66 entries
+constexpr int kBoundRowsLds = 10;
+constexpr int kBoundsLds = kBoundRowsLds * (kBoundRowsLds + 1) / 2;  // 55 entries: one per lane
 
 struct __align__(16) WaveScratch {
-    float2 bnd[kBoundsLds];                    // the first rows of the template's pair bounds (all of them for k <= 12)
+    float2 bnd[64];                            // the first kBoundsLds pair bounds of the template (all of them for k <= 11)
     uint16_t surv[kMaxG][64];                  // per template residue: one 64-entry chunk of its lead list
     uint32_t queue[kPairQueue];                // pair-table survivors (position in list 0 | position in list 1 << 16)
     uint32_t queue3[kTripleQueue][2];          // survivors of one triple pass ((a0 | a1 << 16), a2) waiting for their subtree
@@ -526,7 +580,7 @@ struct __align__(16) WaveScratch {
 // machine touches no memory at all.
 struct WaveRegs {
     // template constants per level (loaded once per template by lane < k)
-    uint32_t group, ref, tchain, orig, any, lead, resmask, nm_lo, nm_hi;
+    uint32_t pk, lead, resmask, nm_lo, nm_hi;  // pk: lvl_pack word
     // per level: candidate source and cursor
     uint32_t lo, cnt;      // lead: pool offset/length of the kind list; else first atom/size of the residue
     uint32_t cur, base;    // next chunk to evaluate; chunk the pending mask refers to
@@ -581,7 +635,7 @@ __device__ __forceinline__ unsigned long long eval_chunk(const Ctx &C, WaveRegs 
     const int lane = C.lane;
     const uint32_t cnt = RL(W.cnt, level), lo = RL(W.lo, level);
     const bool lead = RL(W.lead, level) != 0;
-    const uint32_t mygroup = RL(W.group, level);
+    const uint32_t mygroup = lvl_group(RL(W.pk, level));
     // this level's row of pair bounds, one entry per lane j < level, loaded before the candidate gather
     float2 brow = make_float2(0.f, 0.f);
     if (level <= kBoundRowsLds) {  // two explicit loads: a pointer select would turn both into flat loads
@@ -607,7 +661,7 @@ __device__ __forceinline__ unsigned long long eval_chunk(const Ctx &C, WaveRegs 
     uint32_t cchain = 0, mychain = 0;
     if (!C.ignore_chain) {
         cchain = C.qchain[cand];
-        mychain = RL(W.tchain, level);
+        mychain = lvl_tchain(RL(W.pk, level));
     }
     TM_STAT(level, 1);
     unsigned long long alive;
@@ -618,11 +672,11 @@ __device__ __forceinline__ unsigned long long eval_chunk(const Ctx &C, WaveRegs 
             const float dx = r.x - RLf(W.ax, j), dy = r.y - RLf(W.ay, j), dz = r.z - RLf(W.az, j);
             const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
             const float blo = RLf(brow.x, j), bhi = RLf(brow.y, j);
-            const bool same_t = RL(W.group, j) == mygroup;
+            const bool same_t = lvl_group(RL(W.pk, j)) == mygroup;
             const bool same_q = meta_res(RL(W.ameta, j)) == cres;
             ok = ok & (d2 >= blo) & (d2 <= bhi) & (same_t == same_q) & (cand != RL(W.aidx, j));
             if (!C.ignore_chain) {
-                const bool tc = RL(W.tchain, j) == mychain;
+                const bool tc = lvl_tchain(RL(W.pk, j)) == mychain;
                 const bool qc = RL(W.achain, j) == cchain;
                 ok = ok & (tc == qc);
             }
@@ -632,12 +686,12 @@ __device__ __forceinline__ unsigned long long eval_chunk(const Ctx &C, WaveRegs 
     } else {
         const unsigned long long nm = ((unsigned long long)RL(W.nm_hi, level) << 32) | RL(W.nm_lo, level);
         const uint32_t rm = RL(W.resmask, level);
-        const bool any = RL(W.any, level) != 0;
+        const bool any = lvl_any(RL(W.pk, level)) != 0;
         ok = ok & (((nm >> meta_name(m)) & 1ull) != 0ull) & (any | (((rm >> meta_rtype(m)) & 1u) != 0u));
         alive = 0ull;
         const bool active = lane < level;
-        const bool same_t = W.group == mygroup;
-        const bool tc = W.tchain == mychain;
+        const bool same_t = lvl_group(W.pk) == mygroup;
+        const bool tc = lvl_tchain(W.pk) == mychain;
         for (unsigned long long todo = ballot64(ok); todo; todo &= todo - 1ull) {
             const int b = __ffsll((long long)todo) - 1;
             const float dx = RLf(r.x, b) - W.ax, dy = RLf(r.y, b) - W.ay, dz = RLf(r.z, b) - W.az;
@@ -661,7 +715,7 @@ __device__ __forceinline__ void init_level(const Ctx &C, WaveRegs &W, int level)
     WL(W.pend_hi, level, 0u);
     if (RL(W.lead, level) == 0) {
         // same template residue as an already placed lead atom: scan the atoms of that target residue
-        const uint32_t res = meta_res(RL(W.ameta, (int)RL(W.ref, level)));
+        const uint32_t res = meta_res(RL(W.ameta, (int)lvl_ref(RL(W.pk, level))));
         const uint32_t s0 = C.res_start[res], s1 = C.res_start[res + 1];  // uniform address: same value in every lane
         WL(W.lo, level, s0);
         WL(W.cnt, level, s1 - s0);
@@ -773,7 +827,7 @@ __device__ __forceinline__ bool on_complete(const Ctx &C, WaveRegs &W, PairState
         c->pad = 0;
     }
     if (lane < kMaxK) {
-        if (lane < k) c->atoms[W.orig] = (uint16_t)W.aidx;
+        if (lane < k) c->atoms[lvl_orig(W.pk)] = (uint16_t)W.aidx;
         else c->atoms[lane] = 0xffffu;
     }
     P.prev = (uint32_t)slot;
@@ -813,7 +867,7 @@ __device__ __forceinline__ bool dfs(const Ctx &C, WaveRegs &W, PairState &P, int
         WL(W.pend_lo, level, (uint32_t)pend);
         WL(W.pend_hi, level, (uint32_t)(pend >> 32));
         uint32_t cand;
-        if (RL(W.lead, level)) cand = uni((uint32_t)C.S->surv[RL(W.group, level)][b]);
+        if (RL(W.lead, level)) cand = uni((uint32_t)C.S->surv[lvl_group(RL(W.pk, level))][b]);
         else cand = RL(W.lo, level) + RL(W.base, level) + (uint32_t)b;
         assign_level(C, W, level, cand);
         if (level < k - 1) {
@@ -831,6 +885,50 @@ __device__ __forceinline__ bool in_window(const float4 &p, const float4 &q, cons
     const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
     const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
     return (d2 >= b.x) & (d2 <= b.y);
+}
+
+// Quick look at level 3 for a triple that survived the tables, before the general search machinery is set up for
+// it: is there ANY candidate for the template's fourth search position that fits the three assigned atoms?  Four in
+// five triples end here.  The three atoms are wave-uniform values, so a candidate costs three plain window tests.
+// The test is the one eval_chunk makes for level 3, minus the chain rule (a superset is all a filter needs; the
+// search proper repeats every test).
+template <class Ctx>
+__device__ __forceinline__ bool level3_has_candidate(const Ctx &C, const WaveRegs &W, uint32_t x0, uint32_t x1,
+                                                     uint32_t x2, const float4 &q0, const float4 &q1, const float4 &q2) {
+    const WaveScratch &S = *C.S;
+    const uint32_t lane = (uint32_t)C.lane;
+    const float2 w0 = S.bnd[tri(3)], w1 = S.bnd[tri(3) + 1], w2 = S.bnd[tri(3) + 2];
+    const uint32_t res0 = meta_res(__float_as_uint(q0.w)), res1 = meta_res(__float_as_uint(q1.w)),
+                   res2 = meta_res(__float_as_uint(q2.w));
+    if (RL(W.lead, 3) != 0u) {  // the lead atom of a fourth residue: its kind list, 64 entries at a time
+        const uint32_t lo = RL(W.lo, 3), cnt = RL(W.cnt, 3);
+        for (uint32_t base = 0; base < cnt; base += 64u) {
+            const uint32_t idx = base + lane;
+            const float4 r = C.rec[C.pool_at(lo + min(idx, cnt - 1u))];
+            const uint32_t cres = meta_res(__float_as_uint(r.w));
+            const bool ok = (idx < cnt) & in_window(r, q0, w0) & in_window(r, q1, w1) & in_window(r, q2, w2) &
+                            (cres != res0) & (cres != res1) & (cres != res2);
+            if (ballot64(ok) != 0ull) return true;
+        }
+        return false;
+    }
+    // another atom of an assigned residue: the atoms of that target residue (at most a few dozen)
+    const uint32_t ref = lvl_ref(RL(W.pk, 3));
+    const uint32_t res = ref == 0u ? res0 : ref == 1u ? res1 : res2, own = ref == 0u ? x0 : ref == 1u ? x1 : x2;
+    const uint32_t s0 = C.res_start[res], s1 = C.res_start[res + 1];
+    const unsigned long long nm = ((unsigned long long)RL(W.nm_hi, 3) << 32) | RL(W.nm_lo, 3);
+    const uint32_t rm = RL(W.resmask, 3);
+    const bool any = lvl_any(RL(W.pk, 3)) != 0u;
+    for (uint32_t base = s0; base < s1; base += 64u) {
+        const uint32_t idx = base + lane;
+        const float4 r = C.rec[min(idx, s1 - 1u)];
+        const uint32_t m = __float_as_uint(r.w);
+        const bool ok = (idx < s1) & (idx != own) & (((nm >> meta_name(m)) & 1ull) != 0ull) &
+                        (any | (((rm >> meta_rtype(m)) & 1u) != 0u)) & in_window(r, q0, w0) & in_window(r, q1, w1) &
+                        in_window(r, q2, w2);
+        if (ballot64(ok) != 0ull) return true;
+    }
+    return false;
 }
 
 // The pair tables a (structure, template) search reads: segment of the (lead 0, lead 1) table, first row slot of
@@ -882,8 +980,8 @@ __device__ __forceinline__ bool table_scan(const Ctx &C, WaveRegs &W, PairState 
     const float2 b20 = S.bnd[tri(2)], b21 = S.bnd[tri(2) + 1];
     const bool key1 = TR.key_is_1 != 0u;
     const float2 b_key = key1 ? b21 : b20, b_other = key1 ? b20 : b21;
-    const bool tc10 = RL(W.tchain, 0) == RL(W.tchain, 1);
-    const bool tc20 = RL(W.tchain, 0) == RL(W.tchain, 2), tc21 = RL(W.tchain, 1) == RL(W.tchain, 2);
+    const bool tc10 = lvl_tchain(RL(W.pk, 0)) == lvl_tchain(RL(W.pk, 1));
+    const bool tc20 = lvl_tchain(RL(W.pk, 0)) == lvl_tchain(RL(W.pk, 2)), tc21 = lvl_tchain(RL(W.pk, 1)) == lvl_tchain(RL(W.pk, 2));
 
     uint32_t e = TR.pair_begin;
     const uint32_t e_end = TR.pair_end;
@@ -995,6 +1093,7 @@ __device__ __forceinline__ bool table_scan(const Ctx &C, WaveRegs &W, PairState 
                     const uint32_t ab = uni(S.queue3[q][0]), c = uni(S.queue3[q][1]);
                     const uint32_t x0 = ab & 0xffffu, x1 = ab >> 16;
                     const float4 q0 = C.rec[x0], q1 = C.rec[x1], q2 = C.rec[c];
+                    if (!level3_has_candidate(C, W, x0, x1, c, q0, q1, q2)) continue;
                     assign_record(C, W, 0, x0, q0);
                     assign_record(C, W, 1, x1, q1);
                     assign_record(C, W, 2, c, q2);
@@ -1016,32 +1115,22 @@ __host__ __device__ inline size_t search_kl_words(uint32_t n_lead) { return ((si
 // Held in registers one template ahead of the search, so that the global-memory latency of the
 // next template overlaps the current search.
 struct TemplateRegs {
-    uint32_t group, ref, tchain, orig, any, resmask, nm_lo, nm_hi, li;
-    float2 bound0, bound1;  // bounds[lane], bounds[64 + (lane & 1)]
-    uint32_t k, n_groups;
-    uint32_t pair_table, triple_table, triple_key;
+    uint32_t pk, resmask, nm_lo, nm_hi, li;
+    float2 bound;  // bounds[lane]
+    uint32_t hdr;  // k | n_groups << 8 | triple_key << 16
 };
 
 __device__ __forceinline__ void load_template(const QueryView &Q, uint32_t ti, int lane, TemplateRegs &R) {
     const Staged &T = Q.staged[ti];
     const int l = lane < kMaxK ? lane : kMaxK - 1;  // every lane loads: no dependence on k
     const unsigned long long nm = T.namemask[l];
-    R.group = T.group[l];
-    R.ref = T.ref[l];
-    R.tchain = T.tchain[l];
-    R.orig = T.orig[l];
-    R.any = T.any[l];
+    R.pk = T.packed[l];
     R.resmask = T.resmask[l];
     R.nm_lo = (uint32_t)nm;
     R.nm_hi = (uint32_t)(nm >> 32);
     R.li = T.lead_li[l];
-    R.bound0 = Q.bounds[(size_t)ti * kMaxPairs + lane];
-    R.bound1 = Q.bounds[(size_t)ti * kMaxPairs + 64 + (lane & 1)];
-    R.k = T.k;
-    R.n_groups = T.n_groups;
-    R.pair_table = T.pair_table;
-    R.triple_table = T.triple_table;
-    R.triple_key = T.triple_key;
+    R.bound = Q.bounds[(size_t)ti * kMaxPairs + lane];
+    R.hdr = (uint32_t)T.k | ((uint32_t)T.n_groups << 8) | ((uint32_t)T.triple_key << 16);
 }
 
 template <bool kLds, bool kIgnoreChain>
@@ -1129,8 +1218,9 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
     uint4 ref = tab_ref[min(ti, Q.n_sel - 1u)];
 
     while (ti < t_end) {
-        const int k = (int)uni(R.k);
-        const int G = (int)uni(R.n_groups);
+        const uint32_t hdr = uni(R.hdr);
+        const int k = (int)(hdr & 0xffu);
+        const int G = (int)((hdr >> 8) & 0xffu);
         C.k = k;
         C.n_groups = G;
         C.bnd = Q.bounds + (size_t)ti * kMaxPairs;
@@ -1141,11 +1231,7 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
         W.surv_base = 0xffffffffu;
         bool empty = false;
         if (lane < k) {
-            W.group = R.group;
-            W.ref = R.ref;
-            W.tchain = R.tchain;
-            W.orig = R.orig;
-            W.any = R.any;
+            W.pk = R.pk;
             W.resmask = R.resmask;
             W.nm_lo = R.nm_lo;
             W.nm_hi = R.nm_hi;
@@ -1166,14 +1252,13 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
         TR.pair_end = TR.pair_begin + uni(ref.y);
         TR.triple_rows = uni(ref.z);
         TR.triple_begin = uni(ref.w);
-        TR.key_is_1 = uni(R.triple_key);
+        TR.key_is_1 = hdr >> 16;
         TR.flags = Q.flags;
         TablePrefetch F;
         F.pair_ent = B.tab_ent[TR.pair_begin + (uint32_t)lane];  // past the table's end: other tables, never used
         F.triple_row = B.tab_rows[TR.triple_rows + (uint32_t)lane];
         F.triple_ent = B.tab_ent[TR.triple_begin + (uint32_t)lane];
-        S.bnd[lane] = R.bound0;
-        if (lane < kBoundsLds - 64) S.bnd[64 + lane] = R.bound1;
+        S.bnd[lane] = R.bound;
         wave_sync();
 
         // ---- claim the next template and start loading it
