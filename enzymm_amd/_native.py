@@ -92,7 +92,8 @@ EXPORTS = (
     "tm_batch_destroy", "tm_query", "tm_result_wait", "tm_result_needed", "tm_result_hit_count",
     "tm_result_copy_hits", "tm_result_copy_candidates", "tm_result_timing", "tm_result_device_hits",
     "tm_result_destroy", "tm_pdb_count_host", "tm_pdb_parse_host", "tm_pdb_count_host_many",
-    "tm_pdb_parse_host_many", "tm_files_sizes", "tm_files_read",
+    "tm_pdb_parse_host_many", "tm_files_sizes", "tm_files_read", "tm_batch_create_from_files", "tm_batch_file_text",
+    "tm_stream_create", "tm_stream_destroy", "tm_batch_text_layout",
 )
 
 _lock = threading.Lock()
@@ -277,6 +278,23 @@ def parse_pdb_host_many(datas, ignore_endmdl: bool = False):
     return result
 
 
+class Stream:
+    """A HIP stream owned by the library (``tm_stream_create``); ``handle`` goes into ``query(stream=...)``."""
+
+    def __init__(self, device: int):
+        self.device = device
+        h = C.c_void_p()
+        _check(load().tm_stream_create(C.c_int(device), C.byref(h)))
+        self.handle = h.value
+
+    def close(self):
+        if getattr(self, "handle", None):
+            load().tm_stream_destroy(C.c_int(self.device), C.c_void_p(self.handle))
+            self.handle = None
+
+    __del__ = close
+
+
 def device_count() -> int:
     n = C.c_int(0)
     _check(load().tm_device_count(C.byref(n)))
@@ -382,6 +400,53 @@ class Batch:
         self.atom_offsets = np.zeros(len(texts) + 1, dtype=np.uint32)
         _check(lib.tm_batch_atom_counts(self._h, _ptr(self.atom_offsets)))
         return self
+
+    @classmethod
+    def from_files(cls, device, paths, vocab_tables, min_bfactor: float = 0.0, ignore_endmdl: bool = False,
+                   counted_residues=()) -> "Batch":
+        """Read the files natively (host threads, one page-locked buffer, one upload) and parse them on the GPU
+        (``tm_batch_create_from_files``).  ``file_text(i)`` returns a file's bytes while the batch is open."""
+        lib = load()
+        self = cls.__new__(cls)
+        self._h = C.c_void_p()
+        self.n_structures = len(paths)
+        names, name_ids, els, el_ids, res, res_ids, _ = vocab_tables
+        keep = [_arr(names, "S4"), _arr(name_ids, np.uint8), _arr(els, "S2"), _arr(el_ids, np.uint8),
+                _arr(res, "S3"), _arr(res_ids, np.uint8)]
+        keep.append(_arr(np.array([str(r).rjust(3)[:3].encode() for r in counted_residues], dtype="S3"), "S3"))
+        vocab = _Vocab(len(keep[0]), _ptr(keep[0]), _ptr(keep[1]), len(keep[2]), _ptr(keep[2]), _ptr(keep[3]),
+                       len(keep[4]), _ptr(keep[4]), _ptr(keep[5]), len(keep[6]), _ptr(keep[6]) if len(keep[6]) else None)
+        self.has_residue_counts = len(keep[6]) > 0
+        encoded = [os.fsencode(p) for p in paths]
+        arr = (C.c_char_p * max(1, len(encoded)))(*encoded)
+        bad = C.c_int64(-1)
+        rc = lib.tm_batch_create_from_files(C.c_int(device), C.c_uint32(len(encoded)), arr, C.byref(vocab),
+                                            C.c_uint32(TM_PDB_IGNORE_ENDMDL if ignore_endmdl else 0),
+                                            C.c_double(min_bfactor), C.byref(self._h), C.byref(bad))
+        if rc != TM_OK and bad.value >= 0:
+            open(paths[bad.value], "rb").close()  # raises the ordinary OSError of that file, if it still fails
+        _check(rc)
+        self.device = device
+        self.atom_offsets = np.zeros(len(paths) + 1, dtype=np.uint32)
+        _check(lib.tm_batch_atom_counts(self._h, _ptr(self.atom_offsets)))
+        return self
+
+    def file_text(self, index: int) -> bytes:
+        """A private copy of file ``index``'s bytes (batches made by ``from_files``, while open)."""
+        text, length = C.c_char_p(), C.c_uint64()
+        ptr = C.c_void_p()
+        _check(load().tm_batch_file_text(self._h, C.c_uint32(index), C.byref(ptr), C.byref(length)))
+        return C.string_at(ptr, length.value)
+
+    def text_view(self):
+        """(uint8 view of the native text buffer, file offsets [n + 1]) of a batch made by ``from_files``; the view is
+        valid until the batch is closed."""
+        base = C.c_void_p()
+        offsets = np.zeros(self.n_structures + 1, dtype=np.uint64)
+        _check(load().tm_batch_text_layout(self._h, C.byref(base), _ptr(offsets)))
+        total = int(offsets[-1])
+        view = np.ctypeslib.as_array((C.c_ubyte * max(total, 1)).from_address(base.value)) if total else np.zeros(0, np.uint8)
+        return view, offsets
 
     def line_offsets(self) -> np.ndarray:
         """Byte offset of every kept ATOM/HETATM record inside its file (device-parsed batches)."""

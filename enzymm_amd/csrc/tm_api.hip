@@ -3,7 +3,9 @@
 // C ABI declared in include/enzymm_amd.h.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -55,8 +57,12 @@ class DevicePool {
         size_t c = 256;
         while (c < bytes && c < (size_t(1) << 20)) c <<= 1;
         if (c >= bytes) return c;
-        const size_t mib = size_t(1) << 20;
-        return (bytes + mib - 1) / mib * mib;
+        // above 1 MiB: eight classes per octave (at most 12.5 % over), so that batches of about the same size --
+        // whose pools differ by a few per cent -- recycle each other's blocks instead of going to hipMalloc
+        size_t top = size_t(1) << 20;
+        while ((top << 1) <= bytes) top <<= 1;
+        const size_t step = top >> 3;
+        return (bytes + step - 1) / step * step;
     }
     hipError_t acquire(size_t bytes, void **p, size_t *granted) {
         int device = 0;
@@ -297,6 +303,8 @@ struct tm_batch {
     DevBuf<unsigned long long> d_cursor;
     DevBuf<uint32_t> d_overflow;
     DevBuf<uint32_t> d_line_off;  // device-parsed batches: byte offset of every atom record in its file
+    PinnedBuf<char> h_text;       // tm_batch_create_from_files: the files' text, kept for tm_batch_file_text
+    std::vector<uint64_t> h_text_off;
     DevBuf<uint32_t> d_residue_count;  // device-parsed batches with counted residue names: distinct residue numbers
     bool has_residue_count = false;
     // search work items (structure, round), cached for the (cx, n_sel) they were planned for
@@ -434,6 +442,23 @@ extern "C" {
 int tm_abi_version(void) { return TM_ABI_VERSION; }
 
 const char *tm_last_error(void) { return g_err.c_str(); }
+
+int tm_stream_create(int device, void **stream) {
+    if (!stream) return fail(TM_E_INVALID, "stream is NULL");
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t st = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    *stream = st;
+    return TM_OK;
+}
+
+int tm_stream_destroy(int device, void *stream) {
+    if (!stream) return TM_OK;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+    return TM_OK;
+}
 
 int tm_device_count(int *count) {
     if (!count) return fail(TM_E_INVALID, "count is NULL");
@@ -960,10 +985,19 @@ int tm_batch_create_from_pdb(int device, uint32_t n_files, const char *const *te
     DevBuf<uint8_t> d_kind;
     HIP_TRY(d_text.alloc(n_bytes + 16));
     HIP_TRY(hipMemsetAsync(d_text.p + file_off[n_files], ' ', n_bytes + 16 - file_off[n_files], stream));
-    for (uint32_t f = 0; f < n_files; ++f) {
-        if (length[f]) HIP_TRY(hipMemcpyAsync(d_text.p + file_off[f], text[f], length[f], hipMemcpyHostToDevice, stream));
-        if (file_off[f + 1] - file_off[f] != length[f])
-            HIP_TRY(hipMemsetAsync(d_text.p + file_off[f + 1] - 1, '\n', 1, stream));
+    // files that already sit back to back in host memory, each ending in a newline (tm_batch_create_from_files
+    // lays them out so), are the device layout: one copy.  Otherwise one copy per file.
+    bool contiguous = n_files > 0;
+    for (uint32_t f = 0; f < n_files && contiguous; ++f)
+        contiguous = file_off[f + 1] - file_off[f] == length[f] && (f + 1 == n_files || text[f] + length[f] == text[f + 1]);
+    if (contiguous) {
+        if (file_off[n_files]) HIP_TRY(hipMemcpyAsync(d_text.p, text[0], file_off[n_files], hipMemcpyHostToDevice, stream));
+    } else {
+        for (uint32_t f = 0; f < n_files; ++f) {
+            if (length[f]) HIP_TRY(hipMemcpyAsync(d_text.p + file_off[f], text[f], length[f], hipMemcpyHostToDevice, stream));
+            if (file_off[f + 1] - file_off[f] != length[f])
+                HIP_TRY(hipMemsetAsync(d_text.p + file_off[f + 1] - 1, '\n', 1, stream));
+        }
     }
     HIP_TRY(d_file_off.upload(file_off, stream));
     const uint64_t n_gran = n_bytes / 16;
@@ -1254,7 +1288,7 @@ static int build_tables(const tm_library *lib, tm_batch *b, const StagedSelectio
         std::stable_sort(items.begin(), items.end(), [&](const TabWork &x, const TabWork &y) {
             return b->s_off[x.s + 1] - b->s_off[x.s] > b->s_off[y.s + 1] - b->s_off[y.s];
         });
-        HIP_TRY(hipStreamSynchronize(stream));  // a previous query may still read the old list
+        if (b->d_tab_work.p) HIP_TRY(hipStreamSynchronize(stream));  // a previous query may still read the old list
         HIP_TRY(b->d_tab_work.upload(items));
         b->tab_work_items = (uint32_t)items.size(); b->tab_work_tables = nt;
     }
@@ -1290,8 +1324,28 @@ static int carry_table_outcome(tm_batch *b, tm_result *r, hipStream_t stream) {
     return TM_OK;
 }
 
+namespace {
+// ENZYMM_AMD_TRACE=1: host-side phase times of tm_query on stderr (diagnostics)
+struct PhaseTrace {
+    bool on = std::getenv("ENZYMM_AMD_TRACE") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0;
+    std::string line;
+    void mark(const char *what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        line += std::string(what) + " " + std::to_string(std::chrono::duration<double, std::milli>(now - last).count()).substr(0, 6) + " | ";
+        last = now;
+    }
+    ~PhaseTrace() {
+        if (on) std::fprintf(stderr, "tm_query host ms: %s total %.3f\n", line.c_str(),
+                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+};
+}  // namespace
+
 int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_result **out) {
     if (!lib || !b || !p || !out) return fail(TM_E_INVALID, "tm_query: NULL argument");
+    PhaseTrace trace;
     *out = nullptr;
     if (lib->device != b->device) return fail(TM_E_INVALID, "library and batch live on different devices");
     if (p->n_selected && (!p->template_index || !p->rmsd_threshold || !p->distance_cutoff || !p->max_dynamic_distance))
@@ -1408,6 +1462,7 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
         }
     }
     if (!stage_now) HIP_TRY(hipStreamWaitEvent(stream, S->ready, 0));  // staged on another stream, possibly
+    trace.mark("selection");
     r->selection = S;
     unsigned long long hcap = p->hit_capacity, ccap = p->candidate_capacity;
     if (!hcap) hcap = std::max<unsigned long long>(4096, 64ull * b->n_structs);
@@ -1434,6 +1489,7 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
     if (b->queried && b->last_stream != stream) HIP_TRY(hipStreamSynchronize(b->last_stream));
     b->last_stream = stream; b->queried = true;
     HIP_TRY(hipEventRecord(r->ev[0], stream));
+    trace.mark("alloc");
     const bool rebuild = b->index_for != lib->serial || (p->flags & TM_FLAG_REBUILD_INDEX) || b->index_shared->stale.load();
     if (rebuild) {
         int rc = build_index(lib, b, r, stream);
@@ -1449,6 +1505,7 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
         if (rc != TM_OK) return rc;
     }
     HIP_TRY(hipEventRecord(r->ev[1], stream));
+    trace.mark("index+tables");
 
     QueryView Q;
     Q.n_sel = n_sel; Q.sel = S->d_sel.p; Q.rmsd_thr = S->d_rmsd.p; Q.cutoff = S->d_cut.p; Q.maxdyn = S->d_maxdyn.p;
@@ -1505,7 +1562,7 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
                 const uint32_t rounds = (uint32_t)std::min<double>(max_rounds, std::max<double>(1.0, std::floor(share + 0.5)));
                 for (uint32_t r = 0; r < rounds; ++r) items.push_back(WorkItem{s, (uint16_t)r, (uint16_t)rounds});
             }
-            HIP_TRY(hipStreamSynchronize(stream));  // a previous query may still read the old list
+            if (b->d_work.p) HIP_TRY(hipStreamSynchronize(stream));  // a previous query may still read the old list
             HIP_TRY(b->d_work.upload(items));
             b->work_items = (uint32_t)items.size(); b->work_cx = cx; b->work_n_sel = n_sel;
         }
@@ -1529,6 +1586,7 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(r->ev[2], stream));
+    trace.mark("search launch");
     if (n_sel && b->n_structs) {
         // candidate and pair counts live on the device: fixed grids with grid-stride loops, no host sync
         hipLaunchKernelGGL(k_superpose, dim3(512), dim3(256), 0, stream, lib->view(), b->view(), Q, O);
@@ -1537,6 +1595,7 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(r->ev[3], stream));
+    trace.mark("finish launch");
     guard.r = nullptr;
     *out = r;
     return TM_OK;
@@ -1606,7 +1665,9 @@ int tm_result_copy_hits(tm_result *r, tm_hit *out, uint64_t capacity) {
     if (r->n_hits > capacity) return fail(TM_E_INVALID, "output buffer too small");
     if (r->n_hits == 0) return TM_OK;
     if (!out) return fail(TM_E_INVALID, "out is NULL");
-    HIP_TRY(hipMemcpy(out, r->d_hits.p, r->n_hits * sizeof(tm_hit), hipMemcpyDeviceToHost));
+    // on the query's own stream: a copy through the null stream would also wait for queries other streams run
+    HIP_TRY(hipMemcpyAsync(out, r->d_hits.p, r->n_hits * sizeof(tm_hit), hipMemcpyDeviceToHost, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
     // (structure, template) order; several hits of one pair (best_match off) by ascending atom tuple,
     // which is the enumeration order of the reference semantics
     std::sort(out, out + r->n_hits, [](const tm_hit &a, const tm_hit &b) {
@@ -1925,6 +1986,75 @@ int tm_pdb_parse_host_many(uint32_t n_files, const char *const *text, const uint
             return fail(status[f], "malformed PDB record");
         }
     if (bad_file) *bad_file = -1;
+    return TM_OK;
+}
+
+}  // extern "C"
+
+extern "C" {
+
+int tm_batch_create_from_files(int device, uint32_t n_files, const char *const *paths, const tm_vocab *vocab,
+                               uint32_t flags, double min_bfactor, tm_batch **out, int64_t *bad_file) {
+    if (!out || !vocab || (n_files && !paths)) return fail(TM_E_INVALID, "tm_batch_create_from_files: NULL argument");
+    *out = nullptr;
+    if (bad_file) *bad_file = -1;
+    HIP_TRY(hipSetDevice(device));
+    // sizes, then every file into its slot of ONE page-locked buffer, a newline after each (an empty extra line
+    // when the file already ends in one): the buffer is the device layout and goes up in a single DMA
+    std::vector<uint64_t> sizes(n_files, 0), off(n_files + 1, 0);
+    int rc = tm_files_sizes(n_files, paths, sizes.data(), bad_file);
+    if (rc != TM_OK) return rc;
+    for (uint32_t f = 0; f < n_files; ++f) off[f + 1] = off[f] + sizes[f] + 1;
+    PinnedBuf<char> text;
+    HIP_TRY(text.alloc(off[n_files] + 16));
+    {
+        std::vector<uint64_t> read_off(n_files + 1, 0);  // tm_files_read wants [off[f], off[f] + size) ranges
+        std::vector<uint8_t> failed(n_files, 0);
+        parallel_for(n_files, 16, [&](uint32_t f) {
+            const uint64_t want = sizes[f];
+            const int fd = ::open(paths[f], O_RDONLY | O_CLOEXEC);
+            if (fd < 0) { failed[f] = 1; return; }
+            uint64_t got = 0;
+            while (got < want) {
+                const ssize_t r = ::read(fd, text.p + off[f] + got, want - got);
+                if (r <= 0) break;
+                got += (uint64_t)r;
+            }
+            ::close(fd);
+            if (got != want) failed[f] = 1;
+            text.p[off[f] + want] = '\n';
+        });
+        for (uint32_t f = 0; f < n_files; ++f)
+            if (failed[f]) {
+                if (bad_file) *bad_file = f;
+                return fail(TM_E_INVALID, std::string("cannot read ") + paths[f]);
+            }
+    }
+    std::vector<const char *> ptr(n_files);
+    std::vector<uint64_t> len(n_files);
+    for (uint32_t f = 0; f < n_files; ++f) { ptr[f] = text.p + off[f]; len[f] = sizes[f] + 1; }
+    rc = tm_batch_create_from_pdb(device, n_files, ptr.data(), len.data(), vocab, flags, min_bfactor, out);
+    if (rc != TM_OK) return rc;
+    tm_batch *b = *out;
+    std::swap(b->h_text.p, text.p); std::swap(b->h_text.n, text.n); std::swap(b->h_text.bytes, text.bytes);
+    b->h_text_off = std::move(off);
+    return TM_OK;
+}
+
+int tm_batch_text_layout(tm_batch *b, const char **base, uint64_t *offsets) {
+    if (!b || !base || !offsets) return fail(TM_E_INVALID, "NULL argument");
+    if (b->h_text_off.size() != (size_t)b->n_structs + 1) return fail(TM_E_INVALID, "batch was not created from files");
+    *base = b->h_text.p;
+    std::memcpy(offsets, b->h_text_off.data(), b->h_text_off.size() * sizeof(uint64_t));
+    return TM_OK;
+}
+
+int tm_batch_file_text(tm_batch *b, uint32_t file, const char **text, uint64_t *length) {
+    if (!b || !text || !length) return fail(TM_E_INVALID, "NULL argument");
+    if (b->h_text_off.size() != (size_t)b->n_structs + 1) return fail(TM_E_INVALID, "batch was not created from files");
+    if (file >= b->n_structs) return fail(TM_E_INVALID, "file index out of range");
+    *text = b->h_text.p + b->h_text_off[file];
+    *length = b->h_text_off[file + 1] - b->h_text_off[file] - 1;  // without the newline added after the file
     return TM_OK;
 }
 

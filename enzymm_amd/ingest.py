@@ -23,8 +23,12 @@ from ._vocab import VOCAB
 class LazyMolecule(pyjess.Molecule):
     """A ``Molecule`` backed by PDB text; columns appear on first use."""
 
-    def __init__(self, text: bytes, id: Optional[str], n_atoms: int, min_bfactor: float, ignore_endmdl: bool):
-        self._text = text
+    def __init__(self, text: Optional[bytes], id: Optional[str], n_atoms: int, min_bfactor: float, ignore_endmdl: bool,
+                 path: Optional[str] = None):
+        #: the file's bytes; None for a molecule of a batch read natively (PdbBatch.from_paths) until something
+        #: needs them -- PdbBatch.annotate hands them to molecules with matches, anything else re-reads ``path``
+        self._text_bytes = text
+        self._path = path
         self.id = id
         self._n = int(n_atoms)
         self._min_bfactor = float(min_bfactor)
@@ -40,17 +44,40 @@ class LazyMolecule(pyjess.Molecule):
         self._line_off = None
         self._residue_count = None
         self._picked: dict = {}
+        #: PdbBatch.annotate_hits: the records of the matched atoms, copied out of the batch's text buffer -- sorted
+        #: kept-record indices and, row for row, 96 bytes from the start of each record's line
+        self._picked_idx = None
+        self._picked_lines = None
+
+    @property
+    def _text(self):
+        if self._text_bytes is None:
+            if self._path is None:
+                raise RuntimeError(f"the text of molecule {self.id!r} is gone with its batch")
+            with open(self._path, "rb") as handle:
+                self._text_bytes = handle.read()
+        return self._text_bytes
+
+    @_text.setter
+    def _text(self, value):
+        self._text_bytes = value
 
     def _atoms_at(self, indices) -> List[pyjess.Atom]:
         """The atoms with these (kept-record) indices; only their lines are parsed."""
-        if self._loaded is not None or self._line_off is None:
+        if self._loaded is not None or (self._line_off is None and self._picked_idx is None):
             return [self._materialise()._atom(int(i)) for i in indices]
         missing = [int(i) for i in indices if int(i) not in self._picked]
         if missing:
             lines = []
             for i in missing:
-                lo = int(self._line_off[i])
-                piece = bytes(self._text[lo: lo + 96])  # a record is at most 80 columns + its line end
+                if self._picked_idx is not None:
+                    row = int(np.searchsorted(self._picked_idx, i))
+                    if row >= len(self._picked_idx) or int(self._picked_idx[row]) != i:  # not a matched atom
+                        return [self._materialise()._atom(int(j)) for j in indices]
+                    piece = self._picked_lines[row].tobytes()
+                else:
+                    lo = int(self._line_off[i])
+                    piece = bytes(self._text[lo: lo + 96])  # a record is at most 80 columns + its line end
                 hi = piece.find(b"\n")
                 lines.append(piece if hi < 0 else piece[:hi])
             cols, xyz, _ = pyjess._parse_pdb_bytes(b"\n".join(lines) + b"\n", True)
@@ -84,20 +111,28 @@ class LazyMolecule(pyjess.Molecule):
 class PdbBatch:
     """PDB files resident in HBM, ready for ``Jess.query_batch(..., batch=pdb_batch)``."""
 
-    def __init__(self, texts: Sequence[bytes], ids: Sequence[Optional[str]], device: Optional[int] = None,
-                 conservation_cutoff: float = 0.0, ignore_endmdl: bool = False):
+    def __init__(self, texts: Optional[Sequence[bytes]], ids: Sequence[Optional[str]], device: Optional[int] = None,
+                 conservation_cutoff: float = 0.0, ignore_endmdl: bool = False, paths: Optional[Sequence[str]] = None):
         self.device = pyjess.default_device() if device is None else int(device)
         tables = VOCAB.native_tables()
         self.vocab_version = tables[-1]
         from .jess_run import _COUNTED_RESIDUES
-        if not isinstance(texts, _native.TextBlock):
-            texts = list(texts)
-        self.native = _native.Batch.from_pdb(self.device, texts, tables, min_bfactor=conservation_cutoff,
-                                             ignore_endmdl=ignore_endmdl, counted_residues=sorted(_COUNTED_RESIDUES))
+        if texts is None:  # read natively: one page-locked buffer, one upload; the text stays on the native side
+            self.native = _native.Batch.from_files(self.device, paths, tables, min_bfactor=conservation_cutoff,
+                                                   ignore_endmdl=ignore_endmdl, counted_residues=sorted(_COUNTED_RESIDUES))
+            texts = [None] * len(paths)
+        else:
+            if not isinstance(texts, _native.TextBlock):
+                texts = list(texts)
+            self.native = _native.Batch.from_pdb(self.device, texts, tables, min_bfactor=conservation_cutoff,
+                                                 ignore_endmdl=ignore_endmdl, counted_residues=sorted(_COUNTED_RESIDUES))
+        self._from_files = paths is not None and texts[:1] == [None]
         self.native.vocab_version = self.vocab_version
-        counts = np.diff(self.native.atom_offsets)
+        counts = np.diff(self.native.atom_offsets).tolist()
+        paths = list(paths) if paths is not None else [None] * len(counts)
         self.molecules: List[LazyMolecule] = [
-            LazyMolecule(texts[k], i, n, conservation_cutoff, ignore_endmdl) for k, (i, n) in enumerate(zip(ids, counts))]
+            LazyMolecule(texts[k], ids[k], counts[k], conservation_cutoff, ignore_endmdl, paths[k])
+            for k in range(len(counts))]
         self._annotated = False
 
     def annotate(self, indices) -> None:
@@ -116,11 +151,47 @@ class PdbBatch:
             mol = self.molecules[i]
             # a molecule with matches outlives the batch (Matcher.run_files keeps it as a dict key): give it its own
             # copy of its file's text -- a view would pin the whole batch buffer (about 1000 files) per survivor
-            if isinstance(mol._text, memoryview):
-                mol._text = bytes(mol._text)
+            if mol._text_bytes is None and self._from_files:
+                mol._text_bytes = self.native.file_text(i)
+            elif isinstance(mol._text_bytes, memoryview):
+                mol._text_bytes = bytes(mol._text_bytes)
             mol._line_off = self._line_off[int(off[i]): int(off[i + 1])].copy()
             if self._res_counts is not None:
                 mol._residue_count = int(self._res_counts[i])
+
+    def annotate_hits(self, table: np.ndarray) -> None:
+        """The bulk form of ``annotate`` for batches read natively: from the raw hit table, copy the records of every
+        matched atom out of the batch's text buffer (one gather for the whole batch) and hand each molecule with
+        hits its rows and its counted-residue total.  A matched molecule then never needs its file again unless
+        somebody asks for atoms that were not matched (it is re-read from its path in that case)."""
+        if len(table) == 0:
+            return
+        if not self._from_files:
+            return self.annotate(np.unique(table["structure"]).tolist())
+        if not self._annotated:
+            self._line_off = self.native.line_offsets()
+            self._res_counts = self.native.residue_counts() if self.native.has_residue_counts else None
+            self._text_view = self.native.text_view()
+            self._annotated = True
+        buffer, text_off = self._text_view
+        n = len(table)
+        valid = np.arange(table["atoms"].shape[1])[None, :] < table["n_atoms"][:, None]
+        structure = np.broadcast_to(table["structure"].astype(np.int64)[:, None], valid.shape)[valid]
+        key = np.unique(structure * 65536 + table["atoms"][valid].astype(np.int64))  # (structure, atom), sorted
+        structure, atom = key >> 16, key & 0xFFFF
+        record = self.native.atom_offsets.astype(np.int64)[structure] + atom
+        start = text_off.astype(np.int64)[structure] + self._line_off[record].astype(np.int64)
+        index = np.minimum(start[:, None] + np.arange(96, dtype=np.int64)[None, :], len(buffer) - 1)
+        lines = buffer[index]  # [matched atoms, 96] bytes, a private copy
+        bounds = np.searchsorted(structure, np.arange(len(self.molecules) + 1))
+        counts = self._res_counts
+        for mi in np.unique(structure).tolist():
+            mol = self.molecules[mi]
+            lo, hi = bounds[mi], bounds[mi + 1]
+            mol._picked_idx = atom[lo:hi]
+            mol._picked_lines = lines[lo:hi]
+            if counts is not None:
+                mol._residue_count = int(counts[mi])
 
     @classmethod
     def from_paths(cls, paths: Sequence, **kw) -> "PdbBatch":
@@ -135,8 +206,7 @@ class PdbBatch:
             stem = os.path.splitext(os.path.basename(p))[0]
             seen[stem] += 1
             ids.append(stem if seen[stem] == 1 else f"{stem}_{seen[stem]}")
-        texts = _native.read_files(paths)  # one buffer for all files, read on native host threads
-        return cls(texts, ids, **kw)
+        return cls(None, ids, paths=paths, **kw)  # read, uploaded and parsed without passing through Python
 
     def __len__(self):
         return len(self.molecules)

@@ -289,6 +289,91 @@ def load_molecules(molecule_paths: List[Path], conservation_cutoff: float = 0, w
     return molecules
 
 
+class _BatchHits:
+    """The hit table of one searched batch plus what the per-size replay derived from it (completeness, pairwise
+    distance); builds ``Match`` objects for a range of kept rows on demand."""
+
+    def __init__(self, templates, molecules, table, rows, complete, pairwise):
+        self._templates, self._molecules, self._table = templates, molecules, table
+        self._rows, self._complete, self._pairwise = rows, complete, pairwise
+        self._cols = None
+
+    def matches(self, lo: int, hi: int) -> List["Match"]:
+        c = self._cols
+        if c is None:  # columns of the KEPT rows as Python lists, once per batch
+            t = self._table[self._rows]
+            n = len(t)
+            c = self._cols = dict(
+                structure=t["structure"].tolist(), template=t["template_sel"].tolist(), n_atoms=t["n_atoms"].tolist(),
+                rmsd=t["rmsd"].tolist(), flags=t["flags"].tolist(), orientation=t["orientation"].tolist(),
+                n_candidates=t["n_candidates"].tolist(), atoms=t["atoms"].tolist(),
+                rot=np.ascontiguousarray(t["rot"]).reshape(n, 3, 3), trans=np.ascontiguousarray(t["trans"]),
+                complete=self._complete[self._rows].tolist(), pairwise=self._pairwise[self._rows].tolist())
+            self._table = None
+        from . import _native
+        TRUNC, PRED, CORRECT = _native.TM_HIT_TRUNCATED, _native.TM_HIT_PREDICTED, _native.TM_HIT_CORRECT
+        new, Hit = pyjess.Hit.__new__, pyjess.Hit
+        out = []
+        for i in range(lo, hi):
+            h = new(Hit)
+            f = c["flags"][i]
+            h.template = self._templates[c["template"][i]]
+            h._molecule = self._molecules[c["structure"][i]]
+            h.rmsd = c["rmsd"][i]
+            h._rot = c["rot"][i]
+            h._trans = c["trans"][i]
+            h._atom_index = tuple(c["atoms"][i][:c["n_atoms"][i]])
+            h.n_candidates = c["n_candidates"][i]
+            h.truncated = bool(f & TRUNC)
+            h.orientation = c["orientation"][i]
+            h.predicted = bool(f & CORRECT) if f & PRED else None
+            out.append(Match(h, c["complete"][i], c["pairwise"][i]))
+        return out
+
+
+class _LazyMatchList(list):
+    """The matches of one molecule.  A plain list to its users; its ``Match`` objects are built from the batch's hit
+    table the first time anything but ``len()`` looks at them (at tens of thousands of structures per second,
+    building every object eagerly is what the host would spend its time on)."""
+
+    def __init__(self, source: _BatchHits, lo: int, hi: int):
+        super().__init__()
+        self._source, self._lo, self._hi = source, lo, hi
+
+    def _fill(self):
+        src = self._source
+        if src is not None:
+            self._source = None
+            list.extend(self, src.matches(self._lo, self._hi))
+
+    def __len__(self):
+        return self._hi - self._lo if self._source is not None else list.__len__(self)
+
+    def __bool__(self):
+        return len(self) > 0
+
+    def __reduce__(self):
+        self._fill()
+        return (list, (list(self),))
+
+
+def _filling(name):
+    method = getattr(list, name)
+
+    def wrapper(self, *args, **kw):
+        self._fill()
+        return method(self, *args, **kw)
+    wrapper.__name__ = name
+    return wrapper
+
+
+for _name in ("__iter__", "__getitem__", "__setitem__", "__delitem__", "__contains__", "__eq__", "__ne__", "__repr__",
+              "__reversed__", "__add__", "__iadd__", "__mul__", "__lt__", "__le__", "__gt__", "__ge__", "append",
+              "extend", "insert", "pop", "remove", "index", "count", "sort", "reverse", "copy", "clear"):
+    setattr(_LazyMatchList, _name, _filling(_name))
+del _name
+
+
 def _default_cpus() -> int:
     return len(os.sched_getaffinity(0)) if sys.platform == "linux" else (os.cpu_count() or 1)
 
@@ -383,62 +468,181 @@ class Matcher:
 
         ``molecules`` may also be an ``enzymm_amd.ingest.PdbBatch`` (PDB files parsed on the GPU); the
         result is then keyed by its lazy ``Molecule`` objects."""
+        return self._collect(self._submit(molecules))
+
+    def _submit(self, molecules, stream: int = 0):
+        """Launch the search of one batch (every molecule x every searched template, ONE launch) and return at
+        once; ``_collect`` waits for it and builds the matches."""
         device_batch = None
         if hasattr(molecules, "native") and hasattr(molecules, "molecules"):  # an ingest.PdbBatch
             device_batch, molecules = molecules, molecules.molecules
-        sizes, searched, rmsd, dist, dyn, bucket_of, position, models, jess = self._plan()
-
-        # ONE launch for every (molecule, template) pair of every bucket; the orientation angle and the
-        # logistic filter are evaluated in the hit epilogue on the GPU (Hit.orientation, Hit.predicted)
-        per_molecule: List[List[pyjess.Hit]] = [[] for _ in molecules]
+        plan = self._plan()
+        sizes, searched, rmsd, dist, dyn, size_of, pairwise, models, jess = plan
+        pending = None
         if searched and molecules:
-            per_molecule = jess.query_batch(molecules, rmsd, dist, dyn, max_candidates=self.MAX_CANDIDATES,
-                                            best_match=True, ignore_chain=True, models=models, batch=device_batch)
+            # the orientation angle and the logistic filter are evaluated in the hit epilogue on the GPU
+            # (Hit.orientation, Hit.predicted)
+            kw = dict(max_candidates=self.MAX_CANDIDATES, best_match=True, ignore_chain=True, models=models,
+                      batch=device_batch)
+            if getattr(jess, "query_batch_accepts_async", False):
+                pending = jess.query_batch(molecules, rmsd, dist, dyn, _async=True, stream=stream, return_raw=True, **kw)
+            else:  # a stand-in engine (tests): synchronous
+                pending = pyjess._Ready(jess.query_batch(molecules, rmsd, dist, dyn, **kw))
+        return plan, device_batch, molecules, pending
 
-        if device_batch is not None and hasattr(device_batch, "annotate"):
+    def _collect(self, submitted) -> Dict[pyjess.Molecule, List[Match]]:
+        plan, device_batch, molecules, pending = submitted
+        sizes, searched, rmsd, dist, dyn, size_of, pairwise, models, jess = plan
+        result = pending.result() if pending is not None else [[] for _ in molecules]
+        table = result if isinstance(result, np.ndarray) else None
+        if table is not None:
+            if device_batch is not None and hasattr(device_batch, "annotate_hits"):
+                device_batch.annotate_hits(table)
+            processed = self._collect_table(plan, molecules, table)
+            if processed is not None:
+                return processed
+            result = jess._hits_from_table(table, np.arange(len(searched)), molecules)  # the object-by-object replay
+        per_molecule: List[List[pyjess.Hit]] = result
+        if table is None and device_batch is not None and hasattr(device_batch, "annotate"):
             device_batch.annotate(mi for mi, hits in enumerate(per_molecule) if hits)
 
-        # hits bucketed by size once; only molecules that have hits are visited below
-        by_size: Dict[int, List[Tuple[int, List[pyjess.Hit]]]] = {s: [] for s in sizes}
-        for mi, hits in enumerate(per_molecule):
-            if not hits:
-                continue
-            groups: Dict[int, List[pyjess.Hit]] = {}
-            for h in hits:
-                groups.setdefault(bucket_of[position[id(h.template)]], []).append(h)
-            for s, hs in groups.items():
-                by_size[s].append((mi, hs))
-
+        # Replay of the reference's per-size loop (jess_run.py:930-988) on the hit table.  Only molecules with hits
+        # are visited; for each, its hits are bucketed by size once.  The result's insertion order is the
+        # reference's: sizes descending, molecules in input order within a size.
         if self.warn:
-            cut_short = sum(1 for hits in per_molecule for h in hits if getattr(h, "truncated", False))
+            cut_short = sum(1 for hits in per_molecule for h in hits if h.truncated)
             if cut_short:
                 warnings.warn(f"{cut_short} (template, molecule) searches stopped at max_candidates="
                               f"{self.MAX_CANDIDATES}; their best hit is chosen among the assignments visited "
                               "(Match.truncated), whose order differs from Jess's")
+        filtering, skipping = self.filter_matches, self.skip_smaller_hits
+        check = self._check_completeness
+        buckets: Dict[int, List[Tuple[int, List[Match]]]] = {s: [] for s in sizes}
+        for mi, hits in enumerate(per_molecule):
+            if not hits:
+                continue
+            if len(hits) == 1:
+                s = size_of[id(hits[0].template)]
+                buckets[s].append((mi, [Match(hits[0], False, pairwise[s])]))
+                continue
+            groups: Dict[int, List[Match]] = {}
+            for h in hits:
+                s = size_of[id(h.template)]
+                groups.setdefault(s, []).append(Match(h, False, pairwise[s]))
+            for s, ms in groups.items():
+                buckets[s].append((mi, ms))
 
         processed: Dict[pyjess.Molecule, List[Match]] = collections.defaultdict(list)
-        for s in sizes:  # replay the reference's per-size loop on the hit table
-            _, distance, _ = self._get_jess_parameters(s)
+        for s in sizes:
             self.verbose_print(f"Now matching query structure(s) to template of size {s}")
             total = 0
-            for mi, hits in by_size[s]:
+            for mi, matches in buckets[s]:
                 mol = molecules[mi]
-                if self.skip_smaller_hits and mol in processed:
+                if skipping and mol in processed:
                     continue
-                matches = self._check_completeness([Match(hit=h, pairwise_distance=distance) for h in hits])
-                if self.filter_matches:
-                    for m in matches:
-                        # the epilogue's verdict when it had a model set for this bucket; otherwise the
-                        # reference's Python rule (which also raises KeyError for a distance without models)
-                        verdict = m.hit.predicted if getattr(m.hit, "predicted", None) is not None \
-                            else m.predicted_correct
-                        if verdict:
-                            processed[mol].append(m)
-                            total += 1
+                check(matches)
+                if filtering:
+                    # the epilogue's verdict when it had a model set for this bucket; otherwise the reference's
+                    # Python rule (which also raises KeyError for a distance without models)
+                    kept = [m for m in matches
+                            if (m.hit.predicted if m.hit.predicted is not None else m.predicted_correct)]
+                    if not kept:
+                        continue
+                    matches = kept
+                have = processed.get(mol)
+                if have is None:
+                    processed[mol] = matches
                 else:
-                    processed[mol].extend(matches)
-                    total += len(matches)
+                    have.extend(matches)
+                total += len(matches)
             self.verbose_print(f"{total} matches found!")
+        return processed
+
+    def _template_arrays(self, plan):
+        """Per searched template, as arrays: size bucket, pairwise distance of the bucket, completeness group
+        (templates sharing bucket, M-CSA id, cluster id and dimension; -1 when a template has no cluster), cluster
+        member and size, and whether its bucket has logistic models.  Cached with the plan."""
+        cached = getattr(self, "_arrays_cache", None)
+        if cached is not None and cached[0] is plan:
+            return cached[1]
+        sizes, searched, rmsd, dist, dyn, size_of, pairwise, models, jess = plan
+        n = len(searched)
+        size = np.array([size_of[id(t)] for t in searched], dtype=np.int64)
+        groups: Dict[tuple, int] = {}
+        group = np.full(n, -1, dtype=np.int64)
+        member = np.zeros(n, dtype=np.int64)
+        csize = np.zeros(n, dtype=np.int64)
+        for i, t in enumerate(searched):
+            if t.mcsa_id is not None and t.cluster is not None:
+                group[i] = groups.setdefault((int(size[i]), t.mcsa_id, t.cluster.id, t.dimension), len(groups))
+                member[i], csize[i] = t.cluster.member, t.cluster.size
+        arrays = dict(size=size, pairwise=np.array([pairwise[int(b)] for b in size], dtype=np.float64), group=group,
+                      member=member, csize=csize, n_groups=max(1, len(groups)),
+                      has_models=(models[0] >= 0) if models is not None else np.zeros(n, dtype=bool))
+        self._arrays_cache = (plan, arrays)
+        return arrays
+
+    def _collect_table(self, plan, molecules, table) -> Optional[Dict[pyjess.Molecule, List[Match]]]:
+        """The per-size replay of the reference (jess_run.py:930-988) done on whole columns of the hit table:
+        completeness, filter verdicts, skip_smaller_hits and the insertion order of the result, without touching a
+        Python object per hit.  Returns None when a verdict needs the reference's Python rule (no fused models for
+        a bucket that has them): the caller then replays object by object."""
+        sizes, searched, rmsd, dist, dyn, size_of, pairwise, models, jess = plan
+        from . import _native
+        A = self._template_arrays(plan)
+        flags = table["flags"]
+        ts = table["template_sel"].astype(np.int64)
+        st = table["structure"].astype(np.int64)
+        predicted = (flags & _native.TM_HIT_PREDICTED) != 0
+        if self.filter_matches and bool((A["has_models"][ts] & ~predicted).any() if models is not None
+                                        else np.isin(A["size"][ts], [int(k) for k in Match._logistic_regression_models]).any()):
+            return None
+        if self.warn:
+            cut_short = int(((flags & _native.TM_HIT_TRUNCATED) != 0).sum())
+            if cut_short:
+                warnings.warn(f"{cut_short} (template, molecule) searches stopped at max_candidates="
+                              f"{self.MAX_CANDIDATES}; their best hit is chosen among the assignments visited "
+                              "(Match.truncated), whose order differs from Jess's")
+        size = A["size"][ts]
+        # completeness: every member 1..size of a template's cluster hit the molecule (within one size bucket)
+        group = A["group"][ts]
+        complete = group < 0
+        idx = np.nonzero(~complete)[0]
+        if len(idx):
+            key = st[idx] * A["n_groups"] + group[idx]
+            uniq, first, inv = np.unique(key, return_index=True, return_inverse=True)
+            member, want = A["member"][ts[idx]], A["csize"][ts[idx]][first]
+            count = np.bincount(inv, minlength=len(uniq))
+            distinct = np.bincount(np.unique(inv * (int(member.max()) + 2) + member) // (int(member.max()) + 2),
+                                   minlength=len(uniq))
+            lowest = np.full(len(uniq), np.iinfo(np.int64).max)
+            highest = np.zeros(len(uniq), dtype=np.int64)
+            np.minimum.at(lowest, inv, member)
+            np.maximum.at(highest, inv, member)
+            ok = (count == want) & (distinct == want) & (lowest == 1) & (highest == want)
+            complete[idx] = ok[inv]
+        keep = np.ones(len(table), dtype=bool)
+        if self.filter_matches:
+            keep = np.where(predicted, (flags & _native.TM_HIT_CORRECT) != 0, True)
+        if self.skip_smaller_hits and keep.any():
+            top = np.zeros(len(molecules), dtype=np.int64)
+            np.maximum.at(top, st[keep], size[keep])
+            keep &= size == top[st]
+        rows = np.nonzero(keep)[0]  # (structure, template) order = per molecule: sizes descending, template order
+        processed: Dict[pyjess.Molecule, List[Match]] = collections.defaultdict(list)
+        if len(rows) == 0:
+            return processed
+        mol_of_row = st[rows]
+        mols, lo = np.unique(mol_of_row, return_index=True)
+        hi = np.append(lo[1:], len(rows))
+        first_size = size[rows[lo]]  # the bucket in which the molecule got its first kept match
+        source = _BatchHits(searched, molecules, table, rows, complete, A["pairwise"][ts])
+        for j in np.lexsort((mols, -first_size)).tolist():
+            processed[molecules[int(mols[j])]] = _LazyMatchList(source, int(lo[j]), int(hi[j]))
+        if self.verbose:
+            for s_ in sizes:
+                self.verbose_print(f"Now matching query structure(s) to template of size {s_}")
+                self.verbose_print(f"{int((size[rows] == s_).sum())} matches found!")
         return processed
 
     def _plan(self):
@@ -458,9 +662,10 @@ class Matcher:
             for t in self.templates_by_effective_size[s]:
                 searched.append(t)
                 rmsd.append(r); dist.append(d); dyn.append(m); bucket_of.append(s)
-        position = {id(t): i for i, t in enumerate(searched)}
-        plan = (sizes, searched, np.array(rmsd, float), np.array(dist, float), np.array(dyn, float), bucket_of,
-                position, self._model_tables(searched, dist), self._jess_factory(searched) if searched else None)
+        size_of = {id(t): b for t, b in zip(searched, bucket_of)}           # template -> its size bucket
+        pairwise = {s: self._get_jess_parameters(s)[1] for s in sizes}      # bucket -> Match.pairwise_distance
+        plan = (sizes, searched, np.array(rmsd, float), np.array(dist, float), np.array(dyn, float), size_of,
+                pairwise, self._model_tables(searched, dist), self._jess_factory(searched) if searched else None)
         self._plan_cache = (key, plan)
         return plan
 
@@ -497,17 +702,43 @@ class Matcher:
                 np.array(params, np.float64).reshape(-1, 4))
 
     def run_files(self, paths, batch_size: int = 1000, **ingest_options) -> Dict[pyjess.Molecule, List[Match]]:
-        """``run`` over PDB files without host-side parsing: the files are read, uploaded and parsed on the GPU in
-        batches of ``batch_size`` on a worker thread while the previous batch is searched
-        (``enzymm_amd.ingest.iter_batches``).  ``ingest_options``: ``conservation_cutoff`` (default 0: like
-        ``load_molecules``, which computes the filtered molecule and drops it), ``ignore_endmdl``."""
-        from . import ingest
+        """``run`` over PDB files without host-side parsing, as a three-stage pipeline: a worker thread reads,
+        uploads and parses batch i + 1 on the GPU (``enzymm_amd.ingest.iter_batches``) while batch i is searched
+        on a stream of its own and the matches of batch i - 1 are built here.  ``ingest_options``:
+        ``conservation_cutoff`` (default 0: like ``load_molecules``, which computes the filtered molecule and
+        drops it), ``ignore_endmdl``."""
+        from . import _native, ingest
         out: Dict[pyjess.Molecule, List[Match]] = {}
-        for batch in ingest.iter_batches(paths, batch_size=batch_size, **ingest_options):
-            try:
-                out.update(self.run(batch))
-            finally:
-                batch.close()
+        streams = [_native.Stream(pyjess.default_device()) for _ in range(2)]
+        in_flight = None  # (batch, submitted) of the previous batch
+        try:
+            for n, batch in enumerate(ingest.iter_batches(paths, batch_size=batch_size, **ingest_options)):
+                try:
+                    submitted = self._submit(batch, stream=streams[n % 2].handle)
+                except BaseException:
+                    batch.close()
+                    raise
+                previous, in_flight = in_flight, (batch, submitted)
+                if previous is not None:
+                    try:
+                        out.update(self._collect(previous[1]))
+                    finally:
+                        previous[0].close()
+            if in_flight is not None:
+                previous, in_flight = in_flight, None
+                try:
+                    out.update(self._collect(previous[1]))
+                finally:
+                    previous[0].close()
+        finally:
+            if in_flight is not None:  # an exception above: wait for the launched search, then release
+                try:
+                    in_flight[1][3].result()
+                except Exception:
+                    pass
+                in_flight[0].close()
+            for st in streams:
+                st.close()
         return out
 
     def run_single(self, molecule: pyjess.Molecule) -> List[Match]:

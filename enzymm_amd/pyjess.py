@@ -547,7 +547,14 @@ class Template:
     @property
     def dimension(self) -> int:
         """Number of template residues (distinct chain + residue number)."""
-        return len({(a.chain_id, a.residue_number) for a in self._atoms})
+        d = self.__dict__.get("_dimension") if hasattr(self, "__dict__") else None
+        if d is None:
+            d = len({(a.chain_id, a.residue_number) for a in self._atoms})
+            try:
+                self._dimension = d  # the atoms of a template never change
+            except AttributeError:
+                pass
+        return d
 
 
 # ---------------------------------------------------------------------------------- packing
@@ -753,6 +760,50 @@ class Hit:
         return f"Hit(template={getattr(self.template, 'id', None)!r}, rmsd={self.rmsd:.4f})"
 
 
+class _Ready:
+    """Result of a query that needed no launch."""
+
+    def __init__(self, value):
+        self._value = value
+
+    def result(self):
+        return self._value
+
+
+class _PendingQuery:
+    """A query in flight on the GPU (``Jess.query_batch(..., _async=True)``): the launch has been issued, ``result()``
+    waits for it and builds what ``query_batch`` returns.  If a result table overflowed, the query is repeated with the
+    sizes the first run reported."""
+
+    def __init__(self, jess, molecules, sel, args, models, owned_batch, count_candidates, return_raw, stream=0):
+        self._jess, self._molecules, self._sel, self._args, self._models = jess, molecules, sel, args, models
+        self._owned_batch, self._count, self._raw, self._stream = owned_batch, count_candidates, return_raw, stream
+        self._res = _native.query(*args, models=models, retry=False, stream=stream)
+
+    def result(self):
+        try:
+            try:
+                table = self._res.hits()
+            except _native.NativeError as exc:
+                if exc.code != _native.TM_E_OVERFLOW:
+                    raise
+                cands, pairs = self._res.needed()
+                self._res.close()
+                self._res = _native.query(*self._args, models=self._models, retry=True, stream=self._stream,
+                                          candidate_capacity=max(int(1.25 * cands) + 1024, 65536),
+                                          hit_capacity=max(int(1.25 * pairs) + 1024, 4096))
+                table = self._res.hits()
+            cands = self._res.candidates() if self._count else None
+        finally:
+            self._res.close()
+            if self._owned_batch is not None:
+                self._owned_batch.close()
+        self.table = table  # the raw rows, for callers that post-process in bulk (ingest.PdbBatch.annotate_hits)
+        if self._raw:
+            return (table, cands) if self._count else table
+        return self._jess._hits_from_table(table, self._sel, self._molecules)
+
+
 class Query(collections.abc.Iterator):
     """Iterator over the hits of one ``Jess.query`` call, in template order."""
 
@@ -789,6 +840,8 @@ def register_vocabulary(templates) -> None:
 
 
 class Jess:
+    query_batch_accepts_async = True  # Matcher pipelines batches through query_batch(_async=True)
+
     """A set of templates to search structures with (device-resident once constructed)."""
 
     def __init__(self, templates: Iterable[Template] = (), device: Optional[int] = None):
@@ -817,7 +870,7 @@ class Jess:
     def query_batch(self, molecules: Sequence[Molecule], rmsd_threshold, distance_cutoff, max_dynamic_distance, *,
                     max_candidates: Optional[int] = None, ignore_chain: bool = False, best_match: bool = True,
                     template_index=None, batch=None, count_candidates: bool = False, return_raw: bool = False,
-                    models=None):
+                    models=None, _async: bool = False, stream: int = 0):
         """Search every molecule with every (selected) template in one launch.
 
         The three thresholds are scalars or arrays with one entry per selected template, so all of
@@ -831,7 +884,10 @@ class Jess:
         sel = np.arange(len(self._templates), dtype=np.uint32) if template_index is None \
             else np.ascontiguousarray(template_index, dtype=np.uint32)
         if not len(self._templates) or not len(sel) or not molecules:
-            return np.zeros(0, dtype=_native.HIT_DTYPE) if return_raw else [[] for _ in molecules]
+            empty = np.zeros(0, dtype=_native.HIT_DTYPE) if return_raw else [[] for _ in molecules]
+            if return_raw and count_candidates:
+                empty = (empty, np.zeros((len(molecules), len(sel)), dtype=np.uint32))
+            return _Ready(empty) if _async else empty
         # the device copy is looked up by the identity of the templates; remembered on this object, so that a
         # long-lived Jess does not rebuild the 6780-entry key for every batch
         packed = getattr(self, "_packed_ref", None)
@@ -853,25 +909,47 @@ class Jess:
         if count_candidates:
             flags |= _native.TM_FLAG_COUNT_CANDIDATES
         cap = _UNLIMITED if max_candidates is None else max(0, min(int(max_candidates), _UNLIMITED))
-        res = _native.query(packed.native, batch, sel, rmsd_threshold, distance_cutoff, max_dynamic_distance, cap,
-                            flags, models=models)
-        try:
-            table = res.hits()
-            cands = res.candidates() if count_candidates else None
-        finally:
-            res.close()
-            if own_batch:
-                batch.close()
-        if return_raw:
-            return (table, cands) if count_candidates else table
+        args = (packed.native, batch, sel, rmsd_threshold, distance_cutoff, max_dynamic_distance, cap, flags)
+        pending = _PendingQuery(self, molecules, sel, args, models, batch if own_batch else None, count_candidates,
+                                return_raw, stream)
+        return pending if _async else pending.result()
+
+    def _hits_from_table(self, table: np.ndarray, sel: np.ndarray, molecules: Sequence[Molecule]) -> List[List[Hit]]:
+        """``[[Hit, ...] per molecule]`` from a hit table (sorted by structure, template).  Columns are pulled out
+        of the table once; a Hit costs about a microsecond (tens of thousands of structures per second come with
+        thousands of hits per batch)."""
         out: List[List[Hit]] = [[] for _ in molecules]
-        for h in table:
-            tpl = self._templates[int(sel[h["template_sel"]])]
-            k = int(h["n_atoms"])
-            out[int(h["structure"])].append(
-                Hit(tpl, molecules[int(h["structure"])], h["rmsd"], h["rot"], h["trans"], h["atoms"][:k],
-                    h["n_candidates"], bool(h["flags"] & _native.TM_HIT_TRUNCATED), h["orientation"],
-                    bool(h["flags"] & _native.TM_HIT_CORRECT) if h["flags"] & _native.TM_HIT_PREDICTED else None))
+        n = len(table)
+        if n == 0:
+            return out
+        structure = table["structure"].tolist()
+        tpl_index = sel[table["template_sel"]].tolist()
+        n_atoms = table["n_atoms"].tolist()
+        rmsd = table["rmsd"].tolist()
+        flags = table["flags"].tolist()
+        orientation = table["orientation"].tolist()
+        n_candidates = table["n_candidates"].tolist()
+        atoms = table["atoms"].tolist()
+        rot = np.ascontiguousarray(table["rot"]).reshape(n, 3, 3)
+        trans = np.ascontiguousarray(table["trans"])
+        templates = self._templates
+        TRUNC, PRED, CORRECT = _native.TM_HIT_TRUNCATED, _native.TM_HIT_PREDICTED, _native.TM_HIT_CORRECT
+        new = Hit.__new__
+        for i in range(n):
+            h = new(Hit)
+            s = structure[i]
+            f = flags[i]
+            h.template = templates[tpl_index[i]]
+            h._molecule = molecules[s]
+            h.rmsd = rmsd[i]
+            h._rot = rot[i]
+            h._trans = trans[i]
+            h._atom_index = tuple(atoms[i][:n_atoms[i]])
+            h.n_candidates = n_candidates[i]
+            h.truncated = bool(f & TRUNC)
+            h.orientation = orientation[i]
+            h.predicted = bool(f & CORRECT) if f & PRED else None
+            out[s].append(h)
         return out
 
     # -- the pyjess call enzymm makes ----------------------------------------

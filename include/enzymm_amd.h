@@ -176,6 +176,10 @@ typedef struct tm_hit {
 int tm_abi_version(void);
 const char *tm_last_error(void);
 int tm_device_count(int *count);
+/* A stream of its own for tm_query_params.stream (non-blocking with respect to the null stream): queries on
+ * different streams overlap, e.g. the next batch's search with fetching the previous batch's hits. */
+int tm_stream_create(int device, void **stream);
+int tm_stream_destroy(int device, void *stream);
 
 int tm_library_create(int device, const tm_library_desc *desc, tm_library **out);
 void tm_library_destroy(tm_library *lib);
@@ -189,6 +193,15 @@ int tm_batch_create_from_columns(int device, const tm_columns_desc *desc, const 
  * or more than 16384 residue runs) is flattened on the host inside this call; the batch is still one tm_batch. */
 int tm_batch_create_from_pdb(int device, uint32_t n_files, const char *const *text, const uint64_t *length,
                              const tm_vocab *vocab, uint32_t flags, double min_bfactor, tm_batch **out);
+/* The same from file paths: the files are read on a team of host threads straight into one page-locked buffer and
+ * uploaded in a single copy -- the loop of load_molecules (enzymm/jess_run.py:523-556) without a Python-side read.
+ * *bad_file = first file that could not be read (-1: none).  The text stays available (for reporting the matched
+ * atoms) through tm_batch_file_text until the batch is destroyed. */
+int tm_batch_create_from_files(int device, uint32_t n_files, const char *const *paths, const tm_vocab *vocab,
+                               uint32_t flags, double min_bfactor, tm_batch **out, int64_t *bad_file);
+int tm_batch_file_text(tm_batch *batch, uint32_t file, const char **text, uint64_t *length);
+/* the whole text buffer: file f occupies [offsets[f], offsets[f + 1] - 1) of it; offsets has n_structures + 1 entries */
+int tm_batch_text_layout(tm_batch *batch, const char **base, uint64_t *offsets);
 int tm_batch_atom_counts(tm_batch *batch, uint32_t *atom_offsets);            /* [n_structures + 1] */
 int tm_batch_line_offsets(tm_batch *batch, uint32_t *out, uint64_t n);        /* byte offset of each kept record in its file */
 int tm_batch_residue_counts(tm_batch *batch, uint32_t *out);                  /* [n_structures]; TM_E_UNSUPPORTED without tm_vocab.counted_residue_names */

@@ -323,3 +323,27 @@ def test_truncated_matches_are_flagged(amy):
     assert flagged and any("max_candidates" in str(w.message) for w in seen)
     assert all(m.hit.truncated for m in flagged) and not all(m.truncated for m in out[amy])
     del lib
+
+
+@pytest.mark.parametrize("options", [dict(), dict(filter_matches=False), dict(skip_smaller_hits=True),
+                                     dict(filter_matches=False, skip_smaller_hits=True, match_small_templates=True)])
+def test_column_replay_equals_object_replay(amy, af, options):
+    """Matcher replays the reference's per-size loop (jess_run.py:930-988) on whole columns of the hit table and
+    builds Match objects lazily; the object-by-object replay it replaced must give the same molecules in the same
+    order with the same matches, completeness flags, distances and verdicts."""
+    lib = template.load_packed_library()
+    mols = [amy] + synthetic.structures(30) + [af, pyjess.Molecule()] + synthetic.structures(10, start=500)
+    fast = jess_run.Matcher(lib, **options)
+    slow = jess_run.Matcher(lib, **options)
+    slow._collect_table = lambda *a, **k: None  # forces the object-by-object path
+    a, b = fast.run(mols), slow.run(mols)
+    assert type(next(iter(a.values()))).__name__ == "_LazyMatchList" and type(next(iter(b.values()))) is list
+    assert [len(v) for v in a.values()] == [len(v) for v in b.values()]  # len() without materialising
+    row = lambda m: (m.hit.template.id, m.complete, m.pairwise_distance, m.hit.rmsd, m.hit._atom_index,
+                     m.hit.predicted, m.hit.truncated, m.hit.n_candidates)
+    assert [mol.id for mol in a] == [mol.id for mol in b] and len(a) > 5
+    for (ma, la), (mb, lb) in zip(a.items(), b.items()):
+        assert ma is mb and [row(m) for m in la] == [row(m) for m in lb]
+    assert sum(len(v) for v in a.values()) > 10
+    if not options.get("filter_matches", True):
+        assert any(not m.complete for v in a.values() for m in v) and any(m.complete for v in a.values() for m in v)
