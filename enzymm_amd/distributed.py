@@ -79,6 +79,104 @@ def merge_tables(parts) -> np.ndarray:
     return table[order]
 
 
+class _DeviceBytes:
+    """Device memory owned by someone else, presented to torch through ``__cuda_array_interface__``."""
+
+    def __init__(self, pointer: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (pointer, False), "version": 2}
+
+
+def gather_result(result: "_native.Result", n_hits: int, structure_offset: int, group=None,
+                  device=None) -> Optional[np.ndarray]:
+    """Gather a query's hit table to rank 0 straight from HBM: the rows leave the device table the search wrote
+    (``tm_result_device_hits``) over RCCL, with no device-to-host-to-device round trip on the sending ranks.  The
+    device table is unsorted and carries batch-local structure indices; rank 0 adds every rank's
+    ``structure_offset`` and sorts.  Returns the merged table on rank 0, None elsewhere.  Needs a backend that moves
+    device tensors ("nccl" = RCCL); with one rank it is ``result.hits()`` plus the offset."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        local = result.hits()
+        local["structure"] += np.uint32(structure_offset)
+        return local
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    width = _native.HIT_DTYPE.itemsize
+    meta = torch.tensor([n_hits, structure_offset], dtype=torch.int64, device=dev)
+    metas = [torch.zeros_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta, group=group)
+    counts = [int(m[0].item()) for m in metas]
+    offsets = [int(m[1].item()) for m in metas]
+    pad = max(counts + [1]) * width
+    send = torch.zeros(pad, dtype=torch.uint8, device=dev)
+    if n_hits:
+        rows = torch.as_tensor(_DeviceBytes(result.device_hits_ptr(), n_hits * width), device=dev)
+        send[: n_hits * width] = rows  # device-to-device
+    out = [torch.zeros_like(send) for _ in range(world)] if rank == 0 else None
+    dist.gather(send, out, dst=0, group=group)
+    if rank != 0:
+        return None
+    parts = []
+    for r in range(world):
+        part = out[r][: counts[r] * width].cpu().numpy().view(_native.HIT_DTYPE).copy()
+        part["structure"] += np.uint32(offsets[r])
+        parts.append(part)
+    table = np.concatenate(parts) if parts else np.zeros(0, dtype=_native.HIT_DTYPE)
+    # (structure, template) order; several hits of one pair (best_match off) by ascending atom tuple, like
+    # tm_result_copy_hits
+    keys = [table["atoms"][:, c] for c in range(table["atoms"].shape[1] - 1, -1, -1)]
+    return table[np.lexsort(keys + [table["template_sel"], table["structure"]])]
+
+
+def run_files_sharded(matcher, paths, group=None, device_ingest: bool = True, batch_size: int = 1000, **ingest_options):
+    """One process per GPU over a list of structure files -- the single-node counterpart of the reference's Nextflow
+    sharding (/root/reference/nextflow/template_matcher.nf:43-62: ``splitText(by: batch_size)`` -> one CLI run per
+    shard): rank r takes the contiguous range ``shard_range(len(paths), r, world)`` and runs the matcher on it.
+    Returns ``(matches of this rank's shard, lo, hi)``; merge reports with ``gather_report``.  ``device_ingest``
+    False loads the shard through ``load_molecules`` (host parser) instead of ``Matcher.run_files``."""
+    import torch.distributed as dist
+
+    paths = list(paths)
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    lo, hi = shard_range(len(paths), rank, world)
+    if device_ingest:
+        local = matcher.run_files(paths[lo:hi], batch_size=batch_size, **ingest_options)
+    else:
+        from . import jess_run
+        local = matcher.run(jess_run.load_molecules(paths[lo:hi]))
+    return local, lo, hi
+
+
+def gather_report(processed, group=None, predict_correctness: bool = True) -> Optional[str]:
+    """The TSV of a sharded run on rank 0 (None elsewhere): every rank renders its rows exactly as ``report.write_tsv``
+    would, rank 0 concatenates them in rank order under one header -- what the reference's ``collectFile`` merge does
+    with its per-batch TSVs (nextflow/template_matcher.nf:65-78).  As there, the rows are those of a single run over
+    all files; the ORDER of the molecules is per shard (inside a shard: first the molecules matched by the largest
+    templates, jess_run.py:930), so it can differ from the single run's.  Python objects travel, so the group needs an
+    object collective (gloo, or RCCL's via torch)."""
+    import io
+
+    import torch.distributed as dist
+
+    from . import report
+
+    buf = io.StringIO()
+    report.write_tsv(processed, buf, predict_correctness=predict_correctness)
+    lines = buf.getvalue().splitlines(keepends=True)
+    version, header, rows = lines[0], (lines[1] if len(lines) > 1 else None), lines[2:]
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return buf.getvalue()
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object((header, rows), gathered, dst=0, group=group)
+    if rank != 0:
+        return None
+    header = next((h for h, _ in gathered if h is not None), None)
+    return version + (header or "") + "".join("".join(r) for _, r in gathered)
+
+
 def gather_hit_table(result: "_native.Result", n_hits: int, structure_offset: int, world: int, rank: int,
                      device: str):
     """bench.py's per-step exchange: this rank's (sorted) hit table, gathered to rank 0 when world > 1

@@ -87,3 +87,65 @@ def test_gather_without_process_group_is_identity():
     local["structure"] = [0, 1, 1]
     out = distributed.gather_tables(local, 10)
     assert out["structure"].tolist() == [10, 11, 11]
+
+
+def _shard_files(tmp_path):
+    """The reference's two test structures + three synthetic ones as files, and the A2 template set."""
+    import shutil
+    from enzymm_amd import synthetic, template
+    paths = []
+    for name in ("1AMY.pdb", "AF-P0DUB6-F1-model_v4.pdb"):
+        shutil.copy(helpers.GOLDEN / name, tmp_path / name)
+        paths.append(tmp_path / name)
+    for i, m in enumerate(synthetic.structures(3)):
+        p = tmp_path / f"synthetic_{i}.pdb"
+        p.write_text(synthetic.to_pdb(m))
+        paths.append(p)
+    tdir = helpers.GOLDEN / "templates"
+    tpls = list(template.load_templates(tdir / "5_residues")) + list(template.load_templates(tdir / "4_residues")) + \
+        list(template.load_templates(tdir / "3_residues" / "results" / "csa3d_0285"))
+    tpls.sort(key=lambda t: (t.effective_size, t.template_id_string, str(t.cluster)))
+    return paths, tpls
+
+
+def _file_worker(rank, world, port, tmp, out_path):
+    import torch.distributed as dist
+    from pathlib import Path
+    from enzymm_amd import jess_run
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        paths, tpls = _shard_files(Path(tmp))
+        matcher = jess_run.Matcher(tpls, filter_matches=False, jess_factory=helpers.OracleJess)
+        local, lo, hi = distributed.run_files_sharded(matcher, paths, device_ingest=False)
+        assert (lo, hi) == distributed.shard_range(len(paths), rank, world)
+        text = distributed.gather_report(local)
+        if rank == 0:
+            Path(out_path).write_text(text)
+        else:
+            assert text is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_file_run_world_size_2(tmp_path):
+    """The multi-GPU file path (one process per shard of the path list, reports merged on rank 0 -- the analogue of
+    /root/reference/nextflow/template_matcher.nf:43-78) with world size 2 over gloo: the merged TSV equals the TSV
+    of one process over all files, byte for byte."""
+    import io
+    import torch.multiprocessing as mp
+    from enzymm_amd import jess_run, report
+    (tmp_path / "a").mkdir(); (tmp_path / "b").mkdir()
+    out = tmp_path / "merged.tsv"
+    mp.spawn(_file_worker, args=(2, _free_port(), str(tmp_path / "a"), str(out)), nprocs=2, join=True)
+    paths, tpls = _shard_files(tmp_path / "a")  # same files (already written by the workers)
+    whole = jess_run.Matcher(tpls, filter_matches=False, jess_factory=helpers.OracleJess).run(jess_run.load_molecules(paths))
+    buf = io.StringIO()
+    rows = report.write_tsv(whole, buf)
+    got, want = out.read_text().splitlines(), buf.getvalue().splitlines()
+    assert rows >= 4 and got[:2] == want[:2] and sorted(got[2:]) == sorted(want[2:])  # same rows under one header
+    # molecule order is per shard (as with the reference's per-batch TSVs); inside a molecule the rows keep their order
+    by_mol = lambda lines: {q: [l for l in lines if l.split("\t")[0] == q] for q in {l.split("\t")[0] for l in lines}}
+    assert by_mol(got[2:]) == by_mol(want[2:])
+    # one rank: the same text without a process group
+    assert distributed.gather_report(whole) == buf.getvalue()
