@@ -1,6 +1,6 @@
 #!/bin/bash
 # Profile session of the headline bench on the GPU box: run from the repo root as
-#     bash profiles/collect.sh <tag>            (e.g. r02_v11)
+#     bash profiles/collect.sh <tag>            (e.g. r02_v14)
 # Writes gpurun_out/<tag>/: the bench line, rocprofv3 --kernel-trace --stats of the same command, and separate --pmc
 # passes (SQ counters in groups of <= 8, FETCH_SIZE and WRITE_SIZE each alone -- MI355X_MICROARCH.md, PMC slots)
 # condensed by summarize_pmc.py.  Copy <tag>_* into profiles/ and point profiles/LATEST at them.
@@ -9,22 +9,28 @@ tag=${1:?tag}
 out=gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp ENZYMM_AMD_SYNTH_CACHE=/tmp/synth
-BENCH="python3 bench.py --steps 10 --warmup 2"
-$BENCH > "$out/${tag}_bench1000.json" 2> "$out/bench.err"
-rocprofv3 --kernel-trace --stats -d "$out/trace" -o run -- $BENCH --no-cpu-baseline > "$out/trace.log" 2>&1
-cp "$(ls "$out"/trace/*kernel_stats.csv | head -1)" "$out/${tag}_bench1000_kernel_stats.csv"
-pass() { rocprofv3 --pmc "$@" --kernel-trace -d "$out/pmc_$1" -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > "$out/pmc_$1.log" 2>&1; }
+timeout 300 python3 bench.py --steps 10 --warmup 2 > "$out/${tag}_bench1000.json" 2> "$out/bench.err"
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o run -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --streamed-passes 0 > "$out/trace.log" 2>&1
+stats=$(find "$out/trace" -name "*kernel_stats.csv" | head -1)
+[ -n "$stats" ] && cp "$stats" "$out/${tag}_bench1000_kernel_stats.csv"
+pass() { timeout 200 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$out/pmc_$1" -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --streamed-passes 0 > "$out/pmc_$1.log" 2>&1; }
 pass SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES
 pass SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT
 pass SQ_INSTS_BRANCH SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU
 pass FETCH_SIZE
 pass WRITE_SIZE
-kms=$(python3 - "$out/${tag}_bench1000_kernel_stats.csv" <<'PY'
+for kernel in k_search k_tab_build; do
+    kms=0
+    if [ -f "$out/${tag}_bench1000_kernel_stats.csv" ]; then
+        kms=$(python3 - "$out/${tag}_bench1000_kernel_stats.csv" "$kernel" <<'PY'
 import csv, sys
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if "k_search" in r["Name"]]
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if sys.argv[2] in r["Name"]]
 print(float(rows[0]["AverageNs"]) / 1e6 if rows else 0.0)
 PY
 )
-python3 profiles/summarize_pmc.py k_search "$out/${tag}_k_search_pmc.json" --searches 6780000 --kernel-ms "$kms" \
-    "$out"/pmc_SQ_INSTS_VALU "$out"/pmc_SQ_ACTIVE_INST_ANY "$out"/pmc_SQ_INSTS_BRANCH "$out"/pmc_FETCH_SIZE "$out"/pmc_WRITE_SIZE > "$out/summary.log" 2>&1
+    fi
+    python3 profiles/summarize_pmc.py "$kernel" "$out/${tag}_${kernel}_pmc.json" --searches 6780000 --kernel-ms "$kms" \
+        "$out"/pmc_SQ_INSTS_VALU "$out"/pmc_SQ_ACTIVE_INST_ANY "$out"/pmc_SQ_INSTS_BRANCH "$out"/pmc_FETCH_SIZE "$out"/pmc_WRITE_SIZE >> "$out/summary.log" 2>&1
+done
 cat "$out/${tag}_bench1000.json" "$out/summary.log"
+[ -f "$out/${tag}_bench1000_kernel_stats.csv" ] && head -8 "$out/${tag}_bench1000_kernel_stats.csv"

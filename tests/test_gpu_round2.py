@@ -347,3 +347,29 @@ def test_column_replay_equals_object_replay(amy, af, options):
     assert sum(len(v) for v in a.values()) > 10
     if not options.get("filter_matches", True):
         assert any(not m.complete for v in a.values() for m in v) and any(m.complete for v in a.values() for m in v)
+
+
+def test_device_hit_table_reaches_torch_without_a_host_copy(amy, af):
+    """The RCCL leg of the multi-GPU gather (distributed.gather_result) sends rows straight from the device hit table
+    (tm_result_device_hits).  What can be checked on one GPU: the table is visible to torch through
+    __cuda_array_interface__, holds exactly the rows tm_result_copy_hits returns, and the single-rank path of
+    gather_result gives the globally indexed table."""
+    import torch
+    idx, cut = helpers.default_selection()
+    jess = pyjess.Jess(helpers.product_library_templates())
+    packed = pyjess._packed(jess._templates, jess._device)
+    batch = pyjess.make_batch([amy, af] + synthetic.structures(5), jess._device)
+    flags = _native.TM_FLAG_BEST_MATCH | _native.TM_FLAG_IGNORE_CHAIN
+    res = _native.query(packed.native, batch, idx, 2.0, cut, cut, 10000, flags)
+    n = res.hit_count()
+    width = _native.HIT_DTYPE.itemsize
+    rows = torch.as_tensor(distributed._DeviceBytes(res.device_hits_ptr(), n * width), device=f"cuda:{jess._device}")
+    assert rows.is_cuda and rows.numel() == n * width
+    raw = rows.cpu().numpy().view(_native.HIT_DTYPE)
+    want = res.hits()
+    order = np.lexsort((raw["template_sel"], raw["structure"]))
+    assert n > 20 and raw[order].tobytes() == want.tobytes()
+    shifted = distributed.gather_result(res, n, 1000)
+    assert (shifted["structure"] == want["structure"] + 1000).all() and len(shifted) == n
+    res.close()
+    batch.close()
