@@ -530,8 +530,10 @@ __global__ __launch_bounds__(kTabBlock) void k_tab_build(uint32_t n_lead, BatchV
     }
 }
 
+constexpr uint32_t kRefLenMask = (1u << 25) - 1u;
 // Where every (structure, selected template) search finds its tables: {first entry of its pair table, number of
-// entries, first row slot of its triple table, first entry of its triple table}.  One 16-byte load at an address
+// entries (25 bits) | entries of the triple table to prefetch (7 bits), first row slot of its triple table, first
+// entry of its triple table}.  One 16-byte load at an address
 // known the moment a template is claimed, instead of three loads that depend on the template's record.
 __global__ __launch_bounds__(256) void k_tab_refs(BatchView B, uint32_t n_sel, const Staged *__restrict__ staged,
                                                    uint4 *__restrict__ tab_ref) {
@@ -545,11 +547,13 @@ __global__ __launch_bounds__(256) void k_tab_refs(BatchView B, uint32_t n_sel, c
         if (tp != 0xffffu) {
             const uint2 seg = B.tab_seg[base + tp];
             r.x = seg.x;
-            r.y = seg.y - seg.x;
+            r.y = min(seg.y - seg.x, kRefLenMask);  // kRefLenMask itself: "longer, see tab_seg" (never seen so far)
         }
         if (tt != 0xffffu) {
+            const uint2 seg = B.tab_seg[base + tt];
             r.z = B.tab_dir[base + tt];
-            r.w = B.tab_seg[base + tt].x;
+            r.w = seg.x;
+            r.y |= min(seg.y - seg.x, 64u) << 25;  // how many of the triple table's entries a search prefetches
         }
     }
     tab_ref[(size_t)s * n_sel + ti] = r;
@@ -1249,15 +1253,23 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
         // of them first is fetched now, one value per lane, and is there when table_scan starts after the set-up
         TableRefs TR;
         TR.pair_begin = uni(ref.x);
-        TR.pair_end = TR.pair_begin + uni(ref.y);
+        uint32_t pair_len = uni(ref.y) & kRefLenMask;
+        const uint32_t triple_prefetch = uni(ref.y) >> 25;
+        if (pair_len == kRefLenMask) {  // a pair table of 2^25 entries or more: its true end is in the segment table
+            const uint2 seg = B.tab_seg[(size_t)s * B.n_tables + Q.staged[ti].pair_table];
+            pair_len = uni(seg.y - seg.x);
+        }
+        TR.pair_end = TR.pair_begin + pair_len;
         TR.triple_rows = uni(ref.z);
         TR.triple_begin = uni(ref.w);
         TR.key_is_1 = hdr >> 16;
         TR.flags = Q.flags;
+        // only what exists is fetched: lanes past a table's end (or past the key list's rows) repeat its last
+        // element -- the same cache line, no extra traffic, and no divergent branch around the loads
         TablePrefetch F;
-        F.pair_ent = B.tab_ent[TR.pair_begin + (uint32_t)lane];  // past the table's end: other tables, never used
-        F.triple_row = B.tab_rows[TR.triple_rows + (uint32_t)lane];
-        F.triple_ent = B.tab_ent[TR.triple_begin + (uint32_t)lane];
+        F.pair_ent = B.tab_ent[TR.pair_begin + min((uint32_t)lane, max(pair_len, 1u) - 1u)];
+        F.triple_row = B.tab_rows[TR.triple_rows + min((uint32_t)lane, G >= 3 ? RL(W.cnt, (int)TR.key_is_1) : 0u)];
+        F.triple_ent = B.tab_ent[TR.triple_begin + min((uint32_t)lane, max(triple_prefetch, 1u) - 1u)];
         S.bnd[lane] = R.bound;
         wave_sync();
 
