@@ -1212,7 +1212,7 @@ static int build_index(const tm_library *lib, tm_batch *b, tm_result *r, hipStre
         // LDS for the per-name atom buckets: structures above the cap scan all atoms for every lead kind
         const uint32_t bucket_cap = 12288;
         const size_t lds = ((size_t)lib->n_lead + 1 + std::min<uint32_t>(b->max_atoms, bucket_cap)) * sizeof(uint32_t);
-        hipLaunchKernelGGL(k_kind_lists, dim3(b->n_structs), dim3(256), lds, stream,
+        hipLaunchKernelGGL(k_kind_lists, dim3(b->n_structs), dim3(512), lds, stream,
                            lib->view(), b->view(), b->d_kl_off.p, b->d_kl_pool.p, b->d_cursor.p, cap,
                            b->d_overflow.p, bucket_cap);
         HIP_TRY(hipGetLastError());
@@ -1278,10 +1278,13 @@ static int build_tables(const tm_library *lib, tm_batch *b, const StagedSelectio
     // the square of its atom count (a 300-residue structure is one item)
     if (b->tab_work_tables != nt) {
         std::vector<TabWork> items;
+        // a batch too small to fill the GPU with one workgroup per structure (a single query structure, say) has
+        // every structure's tables dealt to more workgroups
+        const double spread = ns < 256 ? std::ceil(256.0 / ns) : 1.0;
         for (uint32_t s = 0; s < ns; ++s) {
             const double n = (double)(b->s_off[s + 1] - b->s_off[s]);
             const uint32_t parts = (uint32_t)std::min<double>(std::min<double>(64.0, std::max(1u, nt / 4u)),
-                                                             std::max(1.0, std::floor(n * n / (3000.0 * 3000.0) + 0.5)));
+                                                             std::max(spread, std::floor(n * n / (3000.0 * 3000.0) + 0.5)));
             for (uint32_t r = 0; r < parts; ++r) items.push_back(TabWork{s, (uint16_t)r, (uint16_t)parts});
         }
         // heaviest structures first
@@ -1294,7 +1297,10 @@ static int build_tables(const tm_library *lib, tm_batch *b, const StagedSelectio
     }
     const BatchView B = b->view();
     // LDS of a build workgroup: the atom record of every kind-list position of its structure (about 2.5 per atom)
-    const uint32_t lr_cap = (uint32_t)std::min<size_t>(9600, std::max<size_t>(1024, 3 * (size_t)b->max_atoms));
+    // (a batch of mostly large structures would not use the copy: without it two workgroups fit a CU and hide the
+    // latency of reading the records through L2 twice as well)
+    const bool mostly_large = (size_t)b->n_atoms > (size_t)3800 * ns;
+    const uint32_t lr_cap = mostly_large ? 0u : (uint32_t)std::min<size_t>(9600, std::max<size_t>(1024, 3 * (size_t)b->max_atoms));
     const size_t lds_bytes = (size_t)lr_cap * sizeof(float4) + ((size_t)lib->n_lead + 2 + nt) * sizeof(uint32_t);
     uint32_t lr_arg = lr_cap;
 #ifdef TM_ABLATE

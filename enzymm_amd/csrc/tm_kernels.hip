@@ -171,7 +171,7 @@ __global__ __launch_bounds__(64) void k_stage_templates(LibView L, uint32_t n_se
 //
 // Dynamic LDS: [n_lead + 1] counts/offsets, then (when n <= bucket_cap) one u32 per atom:
 // atom index | residue-type id << 16, grouped by name id.
-__global__ __launch_bounds__(256) void k_kind_lists(LibView L, BatchView B, uint32_t *__restrict__ kl_off,
+__global__ __launch_bounds__(512) void k_kind_lists(LibView L, BatchView B, uint32_t *__restrict__ kl_off,
                                                      uint16_t *__restrict__ kl_pool,
                                                      unsigned long long *__restrict__ cursor,
                                                      unsigned long long capacity, uint32_t *__restrict__ overflow,
