@@ -151,7 +151,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--structures", type=int, default=1000, help="synthetic structures per GPU")
     ap.add_argument("--batch", type=int, default=1000, help="structures per resident batch (one search launch each)")
     ap.add_argument("--streamed-passes", type=int, default=2,

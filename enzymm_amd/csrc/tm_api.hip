@@ -241,6 +241,13 @@ struct StagedSelection {
     DevBuf<uint16_t> d_pair_table, d_triple_table;
     DevBuf<uint8_t> d_triple_key;
     uint64_t serial = 0;  // identity for the batch-side table cache
+    // Order of the selection on the device: first by an a-priori estimate; the first query with the selection also
+    // clocks every template's searches (Q.cost), and when that result has been waited for the selection is staged
+    // again in descending MEASURED cost -- a workgroup's queue then ends on its cheapest searches, which is what
+    // keeps the other fifteen waves from idling behind one long search (results do not depend on the order).
+    DevBuf<unsigned long long> d_cost;
+    std::vector<float> measured;           // per caller index, valid in state 2
+    std::atomic<int> calibration{0};       // 0 not measured, 1 measuring query in flight, 2 measured, 3 staged by measured cost
     hipEvent_t ready = nullptr;  // recorded after k_stage_templates
     ~StagedSelection() {
         if (ready) (void)hipEventDestroy(ready);
@@ -349,6 +356,7 @@ struct tm_result {
     DevBuf<PairEntry> d_pairs;
     DevBuf<unsigned long long> d_counters;  // [0] hits, [1] candidates, [2] pairs
     std::shared_ptr<StagedSelection> selection;
+    bool calibrates = false;                                        // this query clocks the selection's templates
     std::shared_ptr<IndexShared> index_shared;                      // the batch's (see tm_batch)
     DevBuf<unsigned long long> d_pool_used;                         // kind-list entries the index build needed
     DevBuf<unsigned long long> d_tab_used;                          // pair-table row slots, entries the build needed
@@ -1375,11 +1383,13 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
     {
         std::lock_guard<std::mutex> lock(lib->sel_mu);
         const auto &last = lib->last_selection;
-        if (last && last->sel.size() == n_sel &&
+        const bool same = last && last->sel.size() == n_sel &&
             std::equal(last->sel.begin(), last->sel.end(), p->template_index) &&
             std::equal(last->rmsd.begin(), last->rmsd.end(), p->rmsd_threshold) &&
             std::equal(last->cut.begin(), last->cut.end(), p->distance_cutoff) &&
-            std::equal(last->maxdyn.begin(), last->maxdyn.end(), p->max_dynamic_distance)) {
+            std::equal(last->maxdyn.begin(), last->maxdyn.end(), p->max_dynamic_distance);
+        const bool restage = same && last->calibration.load() == 2;  // measured: stage once more, in measured order
+        if (same && !restage) {
             S = last;
         } else {
             S = std::make_shared<StagedSelection>();
@@ -1389,9 +1399,15 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
             S->maxdyn.assign(p->max_dynamic_distance, p->max_dynamic_distance + n_sel);
             S->order.resize(n_sel);
             std::iota(S->order.begin(), S->order.end(), 0u);
-            std::stable_sort(S->order.begin(), S->order.end(), [&](uint32_t x, uint32_t y) {
-                return lib->cost_weight[S->sel[x]] > lib->cost_weight[S->sel[y]];
-            });
+            if (restage) {
+                const std::vector<float> &cost = last->measured;
+                std::stable_sort(S->order.begin(), S->order.end(), [&](uint32_t x, uint32_t y) { return cost[x] > cost[y]; });
+                S->calibration = 3;
+            } else {
+                std::stable_sort(S->order.begin(), S->order.end(), [&](uint32_t x, uint32_t y) {
+                    return lib->cost_weight[S->sel[x]] > lib->cost_weight[S->sel[y]];
+                });
+            }
             {
                 std::vector<uint32_t> sel(n_sel);
                 std::vector<double> rm(n_sel), cu(n_sel), md(n_sel);
@@ -1517,6 +1533,16 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
     Q.n_sel = n_sel; Q.sel = S->d_sel.p; Q.rmsd_thr = S->d_rmsd.p; Q.cutoff = S->d_cut.p; Q.maxdyn = S->d_maxdyn.p;
     Q.staged = S->d_staged.p; Q.bounds = S->d_bounds.p; Q.order = S->d_order.p; Q.max_candidates = p->max_candidates; Q.flags = p->flags;
     Q.n_tables = (uint32_t)S->tables.size(); Q.tables = S->d_tables.p;
+    Q.cost = nullptr;
+    {
+        int expected = 0;
+        if (n_sel && b->n_structs >= 64 && S->calibration.compare_exchange_strong(expected, 1)) {  // enough searches to average
+            HIP_TRY(S->d_cost.alloc(n_sel));
+            HIP_TRY(hipMemsetAsync(S->d_cost.p, 0, n_sel * sizeof(unsigned long long), stream));
+            Q.cost = S->d_cost.p;
+            r->calibrates = true;
+        }
+    }
     Q.model_set = nullptr; Q.model_offsets = nullptr; Q.model_votes = nullptr; Q.models = nullptr;
     if (p->model_set && p->n_model_sets && p->model_offsets && p->model_votes && p->models) {
         const uint32_t ns = p->n_model_sets, nm = p->model_offsets[ns];
@@ -1543,8 +1569,12 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
         const uint32_t min_chunk = 2 * kSearchWaves;
         // template chunks: 2^cx of them spread over the XCDs (each XCD then touches 1/2^cx of the staged
         // templates), times `rounds` more when the batch alone cannot fill the GPU
-        uint32_t cx = 2;
-        if (b->n_structs * 4u < 2048u) cx = 3;
+        // fewer, longer workgroups: every workgroup ends with waves idling behind its last searches, so for a batch
+        // that fills the GPU anyway two chunks per structure beat four (5.6 vs 6.0 ms) and eight lose 30 %
+        uint32_t cx = 1;
+        if (b->n_structs * 2u < 1024u) cx = 2;
+        if (b->n_structs * 4u < 1024u) cx = 3;
+        if (const char *env = std::getenv("ENZYMM_AMD_CX")) cx = (uint32_t)std::atoi(env) & 3u;  // experiments
         while (cx > 0 && (n_sel >> cx) < min_chunk) --cx;
         // work items: every structure gets rounds ~ its share of the estimated cost (pair tests grow with the
         // square of the atom count), at least one; heaviest structures first
@@ -1629,6 +1659,17 @@ int tm_result_wait(tm_result *r) {
         }
         r->n_hits = counters[0]; r->n_cands = counters[1]; r->n_pairs = counters[2];
         r->waited = true;
+        if (r->calibrates && r->selection) {  // the measured cost of every template, back in the caller's numbering
+            StagedSelection &S = *r->selection;
+            std::vector<unsigned long long> ticks(S.sel.size());
+            if (!ticks.empty()) {
+                HIP_TRY(hipMemcpyAsync(ticks.data(), S.d_cost.p, ticks.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, r->stream));
+                HIP_TRY(hipStreamSynchronize(r->stream));
+            }
+            S.measured.assign(S.sel.size(), 0.f);
+            for (size_t i = 0; i < ticks.size(); ++i) S.measured[S.order[i]] = (float)ticks[i];
+            S.calibration = 2;
+        }
         if ((r->overflow & 8u) && r->index_shared) {  // the index build ran out of pool: remember what it needed
             unsigned long long seen = r->index_shared->pool_wanted.load();
             while (seen < pool_used && !r->index_shared->pool_wanted.compare_exchange_weak(seen, pool_used)) {}

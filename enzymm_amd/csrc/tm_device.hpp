@@ -116,6 +116,7 @@ struct QueryView {
                                 // order[pos] = the caller's selection index (reported in tm_hit / candidate counts)
     uint32_t n_tables;
     const TableDesc *tables;    // [n_tables] pair tables this selection needs
+    unsigned long long *cost;   // [n_sel] or NULL: shader-clock ticks spent per staged template (calibration query)
     uint32_t max_candidates;
     uint32_t flags;
     // optional logistic filter

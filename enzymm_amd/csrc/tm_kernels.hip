@@ -1098,6 +1098,9 @@ __device__ __forceinline__ bool table_scan(const Ctx &C, WaveRegs &W, PairState 
                     const uint32_t x0 = ab & 0xffffu, x1 = ab >> 16;
                     const float4 q0 = C.rec[x0], q1 = C.rec[x1], q2 = C.rec[c];
                     if (!level3_has_candidate(C, W, x0, x1, c, q0, q1, q2)) continue;
+#if defined(TM_STATS) || defined(TM_ABLATE)
+                    if (TR.flags & 0x800u) continue;  // phase timing: the look at level 3, but no search below it
+#endif
                     assign_record(C, W, 0, x0, q0);
                     assign_record(C, W, 1, x1, q1);
                     assign_record(C, W, 2, c, q2);
@@ -1280,6 +1283,8 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
         load_template(Q, min(ti, Q.n_sel - 1u), lane, R);
         ref = tab_ref[min(ti, Q.n_sel - 1u)];
 
+        // calibration query: how long does this template's search take?  (orders the next staging of the selection)
+        const unsigned long long t_start = Q.cost ? __builtin_amdgcn_s_memtime() : 0ull;
         PairState P;
         P.s = s; P.ti = ti_cur;
         P.ncand = 0; P.prev = 0xffffffffu; P.truncated = false;
@@ -1291,6 +1296,7 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
             table_scan(C, W, P, TR, F);
         }
 
+        if (Q.cost && lane == 0) atomicAdd(&Q.cost[ti_cur], __builtin_amdgcn_s_memtime() - t_start);
         // ---- the pair's outcome
         const uint32_t packed = P.ncand | (P.truncated ? 0x80000000u : 0u);
         if (count_candidates && lane == 0) {

@@ -16,7 +16,8 @@ mols = synthetic.structures(n)
 packed = pyjess._packed(jess._templates, jess._device)
 batch = pyjess.make_batch(mols, jess._device)
 base = _native.TM_FLAG_BEST_MATCH | _native.TM_FLAG_IGNORE_CHAIN
-for label, extra in (("full", 0), ("no dfs below the tiled scans", 0x400), ("no subtrees", 0x100), ("staging only", 0x200)):
+for label, extra in (("full", 0), ("level-3 look but no search below it", 0x800), ("no level-3 look, no search", 0x400),
+                     ("pair stage only", 0x100), ("set-up only", 0x200)):
     times = []
     for _ in range(4):
         res = _native.query(packed.native, batch, idx, 2.0, cut, cut, 10000, base | extra)

@@ -1,7 +1,7 @@
 """Per-phase instruction counters: summarise a rocprofv3 --pmc --output-format csv run of tests/gpu_ablate.py. Not a test.
 
 usage: gpu_phase_pmc.py <dir with *counter_collection.csv> [searches per launch]
-gpu_ablate.py launches k_search 4x per mode in the order full / no dfs / no subtrees / staging only."""
+gpu_ablate.py launches k_search 4x per mode in the order full / no dfs / no level-3 look / pair stage only / set-up only."""
 import collections
 import csv
 import glob
@@ -16,8 +16,8 @@ for f in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
             did = int(r["Dispatch_Id"])
             rows[did][r["Counter_Name"]] = rows[did].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
 ids = sorted(rows)
-labels = ["full", "no dfs", "no subtrees", "staging only"]
-per = len(ids) // 4
+labels = ["full", "no dfs", "no level-3 look", "pair stage only", "set-up only"]
+per = len(ids) // len(labels)
 prev = None
 for m, label in reversed(list(enumerate(labels))):
     sel = ids[m * per:(m + 1) * per]
