@@ -585,6 +585,7 @@ struct __align__(16) WaveScratch {
 struct WaveRegs {
     // template constants per level (loaded once per template by lane < k)
     uint32_t pk, lead, resmask, nm_lo, nm_hi;  // pk: lvl_pack word
+    float bnd_lo, bnd_hi;  // NOT by level: lane p holds the window of pair p (pair (i, j < i) = tri(i) + j), p < 64
     // per level: candidate source and cursor
     uint32_t lo, cnt;      // lead: pool offset/length of the kind list; else first atom/size of the residue
     uint32_t cur, base;    // next chunk to evaluate; chunk the pending mask refers to
@@ -899,9 +900,10 @@ __device__ __forceinline__ bool in_window(const float4 &p, const float4 &q, cons
 template <class Ctx>
 __device__ __forceinline__ bool level3_has_candidate(const Ctx &C, const WaveRegs &W, uint32_t x0, uint32_t x1,
                                                      uint32_t x2, const float4 &q0, const float4 &q1, const float4 &q2) {
-    const WaveScratch &S = *C.S;
     const uint32_t lane = (uint32_t)C.lane;
-    const float2 w0 = S.bnd[tri(3)], w1 = S.bnd[tri(3) + 1], w2 = S.bnd[tri(3) + 2];
+    // windows (3, 0), (3, 1), (3, 2): lanes 3, 4, 5 of the per-pair registers (no LDS round trip)
+    const float2 w0 = make_float2(RLf(W.bnd_lo, 3), RLf(W.bnd_hi, 3)), w1 = make_float2(RLf(W.bnd_lo, 4), RLf(W.bnd_hi, 4)),
+                 w2 = make_float2(RLf(W.bnd_lo, 5), RLf(W.bnd_hi, 5));
     const uint32_t res0 = meta_res(__float_as_uint(q0.w)), res1 = meta_res(__float_as_uint(q1.w)),
                    res2 = meta_res(__float_as_uint(q2.w));
     if (RL(W.lead, 3) != 0u) {  // the lead atom of a fourth residue: its kind list, 64 entries at a time
@@ -980,8 +982,8 @@ __device__ __forceinline__ bool table_scan(const Ctx &C, WaveRegs &W, PairState 
         }
         return true;
     }
-    const float2 b10 = S.bnd[0];                  // window (1, 0)
-    const float2 b20 = S.bnd[tri(2)], b21 = S.bnd[tri(2) + 1];
+    const float2 b10 = make_float2(RLf(W.bnd_lo, 0), RLf(W.bnd_hi, 0));  // window (1, 0): pair 0
+    const float2 b20 = make_float2(RLf(W.bnd_lo, 1), RLf(W.bnd_hi, 1)), b21 = make_float2(RLf(W.bnd_lo, 2), RLf(W.bnd_hi, 2));
     const bool key1 = TR.key_is_1 != 0u;
     const float2 b_key = key1 ? b21 : b20, b_other = key1 ? b20 : b21;
     const bool tc10 = lvl_tchain(RL(W.pk, 0)) == lvl_tchain(RL(W.pk, 1));
@@ -1225,6 +1227,9 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
     uint4 ref = tab_ref[min(ti, Q.n_sel - 1u)];
 
     while (ti < t_end) {
+        // claim the next template first: the LDS atomic's round trip runs under the set-up of the current one
+        uint32_t claimed = 0;
+        if (lane == 0) claimed = atomicAdd(&s_next, n_chunks);
         const uint32_t hdr = uni(R.hdr);
         const int k = (int)(hdr & 0xffu);
         const int G = (int)((hdr >> 8) & 0xffu);
@@ -1273,13 +1278,14 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
         F.pair_ent = B.tab_ent[TR.pair_begin + min((uint32_t)lane, max(pair_len, 1u) - 1u)];
         F.triple_row = B.tab_rows[TR.triple_rows + min((uint32_t)lane, G >= 3 ? RL(W.cnt, (int)TR.key_is_1) : 0u)];
         F.triple_ent = B.tab_ent[TR.triple_begin + min((uint32_t)lane, max(triple_prefetch, 1u) - 1u)];
-        S.bnd[lane] = R.bound;
+        S.bnd[lane] = R.bound;  // rows of bounds for eval_chunk (LDS); the first windows are read from the registers
+        W.bnd_lo = R.bound.x;
+        W.bnd_hi = R.bound.y;
         wave_sync();
 
-        // ---- claim the next template and start loading it
+        // ---- the next template (claimed at the top of this iteration) starts loading
         const uint32_t ti_cur = ti;
-        if (lane == 0) ti = atomicAdd(&s_next, n_chunks);
-        ti = uni(ti);
+        ti = uni(claimed);
         load_template(Q, min(ti, Q.n_sel - 1u), lane, R);
         ref = tab_ref[min(ti, Q.n_sel - 1u)];
 
