@@ -1254,7 +1254,12 @@ static int build_tables(const tm_library *lib, tm_batch *b, const StagedSelectio
     if (!b->d_tab_cursors.p) { HIP_TRY(b->d_tab_cursors.alloc(2)); HIP_TRY(b->d_tab_overflow.alloc(1)); }
     unsigned long long rows = b->row_capacity ? b->row_capacity
                                               : std::max<unsigned long long>(4096, 16ull * b->n_atoms + (unsigned long long)ns * (nt + 8));
-    unsigned long long ents = b->ent_capacity ? b->ent_capacity : std::max<unsigned long long>(65536, 48ull * b->n_atoms);
+    // entries: about 20 per atom, plus what the build's per-wave chunks leave unused (16 waves per workgroup)
+    unsigned long long ents = b->ent_capacity;
+    if (!ents) {
+        ents = 65536 + 48ull * b->n_atoms;
+        for (uint32_t s = 0; s < ns; ++s) ents += 20ull * tab_chunk(b->s_off[s + 1] - b->s_off[s]);
+    }
     if (!b->ent_capacity)
         if (const char *env = std::getenv("ENZYMM_AMD_TABLE_POOL"))  // test hook: start from a pool that is too small
             ents = std::max<unsigned long long>(64, std::strtoull(env, nullptr, 10));

@@ -426,76 +426,82 @@ __device__ __forceinline__ uint32_t tab_sweep(Lead lead, uint32_t a_lo, uint32_t
     return running;
 }
 
-// All tables of one work item (structure, part).  Count phase: every table is swept once by one wave for its size.
-// Then the workgroup bump-allocates the entries of all its tables with ONE atomic (one per table would serialise a
-// million atomics on one address), and the fill phase sweeps every table again and writes row offsets (relative to
-// the table's first entry) and entries.  kLds: the atom records of every kind-list position were gathered into LDS first, so tiles
-// read their operands at consecutive LDS addresses.
+// All tables of one work item (structure, part), one wave per table.  Entries are bump-allocated per WAVE in chunks of
+// tab_chunk() entries (one atomic per chunk; one per table would serialise a million atomics on one address): a table whose
+// cross product fits the rest of the wave's chunk is swept ONCE -- rows and entries written as they are found, the
+// chunk advanced by what was written; a larger table is counted first, allocated exactly, then filled.  kLds: the
+// atom records of every kind-list position were gathered into LDS first, so tiles read their operands at
+// consecutive LDS addresses.
+// entries a wave reserves at a time for a structure of n atoms: about 3.5 per atom, between 1 Ki and 8 Ki
+__host__ __device__ inline uint32_t tab_chunk(uint32_t n_atoms) {
+    uint32_t c = 1024;
+    while (c < 8192 && c < 2 * n_atoms) c <<= 1;
+    return c;
+}
 template <bool kLds>
 __device__ __forceinline__ void tab_build_tables(const BatchView &B, const TableDesc *__restrict__ tables,
                                                  const TabWork w, const float4 *rec, const uint16_t *pool,
-                                                 const float4 *s_lr, const uint32_t *kl, uint32_t *s_size,
+                                                 const float4 *s_lr, const uint32_t *kl,
                                                  uint32_t *__restrict__ tab_rows, uint2 *__restrict__ tab_ent,
                                                  uint2 *__restrict__ tab_seg, unsigned long long *__restrict__ cursors,
                                                  unsigned long long ent_capacity, uint32_t *__restrict__ overflow,
                                                  uint32_t *__restrict__ tab_ok, uint32_t dbg_mode) {
-    __shared__ unsigned long long s_base;
     const uint32_t nt = B.n_tables;
     const uint32_t wave = uni(threadIdx.x >> 6), n_waves = blockDim.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t n_mine = nt > w.part ? (nt - w.part + w.parts - 1) / w.parts : 0u;  // tables part, part + parts, ...
     auto lead = [&](uint32_t p) -> float4 { return kLds ? s_lr[p] : rec[pool[p]]; };
-    for (uint32_t m = wave; m < n_mine; m += n_waves) {
-        const uint32_t t = w.part + w.parts * m;
+    // entries [first, first + n) of the pool, or ~0 when the pool is exhausted (the query then reports the overflow)
+    auto allocate = [&](unsigned long long n) -> unsigned long long {
+        unsigned long long first = 0;
+        if (lane == 0) {
+            first = atomicAdd(&cursors[1], n);
+            if (first + n > ent_capacity) {
+                atomicOr(overflow, 2u);
+                tab_ok[w.s] = 0u;
+                first = ~0ull;
+            }
+        }
+        return uni64(first);
+    };
+    const uint32_t kTabChunk = tab_chunk(B.s_off[w.s + 1] - B.s_off[w.s]);
+    unsigned long long chunk = ~0ull;  // the wave's current chunk and how much of it is used
+    uint32_t used = kTabChunk;
+    for (uint32_t t = w.part + w.parts * wave; t < nt; t += w.parts * n_waves) {
         const TableDesc T = tables[t];
         // wave-uniform values, said so: loop counters and branches of the sweep stay scalar
         const uint32_t a_lo = uni(kl[T.li_a]), n_a = uni(kl[T.li_a + 1]) - a_lo, b_lo = uni(kl[T.li_b]),
                        n_b = uni(kl[T.li_b + 1]) - b_lo;
-        const uint32_t total = dbg_mode == 2u ? 0u : tab_sweep<false>(lead, a_lo, n_a, b_lo, n_b, T.dmax2, nullptr, nullptr);
-        if (lane == 0) s_size[m] = total;
-    }
-    __syncthreads();
-    if (wave == 0u) {  // sizes -> offsets, 64 tables per step
-        uint32_t carry = 0;
-        for (uint32_t m0 = 0; m0 < n_mine; m0 += 64u) {
-            const uint32_t m = m0 + lane;
-            const uint32_t v = m < n_mine ? s_size[m] : 0u;
-            const uint32_t incl = wave_scan_add(v);
-            if (m < n_mine) s_size[m] = carry + incl - v;
-            carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        }
-        if (lane == 0) s_size[n_mine] = carry;
-    }
-    if (threadIdx.x == 0) {
-        const unsigned long long run = s_size[n_mine];
-        unsigned long long base = atomicAdd(&cursors[1], run);
-        if (base + run > ent_capacity) {  // no room: the structure's tables are unusable, the query says so
-            atomicOr(overflow, 2u);
-            tab_ok[w.s] = 0u;
-            base = ~0ull;
-        }
-        s_base = base;
-    }
-    __syncthreads();
-    const unsigned long long base = s_base;
-    for (uint32_t m = wave; m < n_mine; m += n_waves) {
-        const uint32_t t = w.part + w.parts * m;
-        const TableDesc T = tables[t];
-        const uint32_t a_lo = uni(kl[T.li_a]), n_a = uni(kl[T.li_a + 1]) - a_lo, b_lo = uni(kl[T.li_b]),
-                       n_b = uni(kl[T.li_b + 1]) - b_lo;
         uint32_t *rows = tab_rows + B.tab_dir[(size_t)w.s * nt + t];
-        const uint32_t first = (uint32_t)base + s_size[m], total = s_size[m + 1] - s_size[m];
+        const unsigned long long bound = (unsigned long long)n_a * n_b;
+        unsigned long long first = 0;
+        uint32_t total = 0;
+        if (dbg_mode == 2u) {
+            // timing experiment: no sweeps
+        } else if (bound <= kTabChunk) {
+            if (used + (uint32_t)bound > kTabChunk) {
+                chunk = allocate(kTabChunk);
+                used = 0;
+            }
+            if (chunk != ~0ull) {
+                first = chunk + used;
+                total = tab_sweep<true>(lead, a_lo, n_a, b_lo, n_b, T.dmax2, rows, tab_ent + first);
+                used += total;
+            } else {
+                first = ~0ull;
+            }
+        } else {
+            total = tab_sweep<false>(lead, a_lo, n_a, b_lo, n_b, T.dmax2, nullptr, nullptr);
+            first = allocate(total);
+            if (first != ~0ull && dbg_mode == 0u) tab_sweep<true>(lead, a_lo, n_a, b_lo, n_b, T.dmax2, rows, tab_ent + first);
+        }
         if (lane == 0) {
-            tab_seg[(size_t)w.s * nt + t] = base == ~0ull ? make_uint2(0u, 0u) : make_uint2(first, first + total);
+            tab_seg[(size_t)w.s * nt + t] = first == ~0ull ? make_uint2(0u, 0u) : make_uint2((uint32_t)first, (uint32_t)first + total);
             rows[n_a] = total;
         }
-        if (base == ~0ull || dbg_mode != 0u) continue;
-        tab_sweep<true>(lead, a_lo, n_a, b_lo, n_b, T.dmax2, rows, tab_ent + first);
     }
 }
 
 // Dynamic LDS: [float4 x lr_cap] lead records (the record of the atom at every position of the structure's kind
-// lists), [u32 x (n_lead + 1)] kind-list offsets, [u32 x (ceil(n_tables / parts) + 1)] table sizes / offsets.  A structure whose kind
-// lists exceed lr_cap reads through L2.
+// lists), [u32 x (n_lead + 1)] kind-list offsets.  A structure whose kind lists exceed lr_cap reads through L2.
 __global__ __launch_bounds__(kTabBlock) void k_tab_build(uint32_t n_lead, BatchView B, const TableDesc *__restrict__ tables,
                                                           const TabWork *__restrict__ work, uint32_t *__restrict__ tab_ok,
                                                           uint32_t *__restrict__ tab_rows, uint2 *__restrict__ tab_ent,
@@ -517,15 +523,14 @@ __global__ __launch_bounds__(kTabBlock) void k_tab_build(uint32_t n_lead, BatchV
     const uint32_t p0 = kl[0], plen = kl[n_lead] - p0;
     float4 *s_lr = reinterpret_cast<float4 *>(tab_smem);
     uint32_t *s_kl = reinterpret_cast<uint32_t *>(s_lr + lr_cap);
-    uint32_t *s_size = s_kl + n_lead + 1;
     if (plen <= lr_cap) {
         for (uint32_t i = threadIdx.x; i < plen; i += blockDim.x) s_lr[i] = rec[B.kl_pool[p0 + i]];
         for (uint32_t i = threadIdx.x; i <= n_lead; i += blockDim.x) s_kl[i] = kl[i] - p0;
         __syncthreads();
-        tab_build_tables<true>(B, tables, w, rec, B.kl_pool, s_lr, s_kl, s_size, tab_rows, tab_ent, tab_seg, cursors,
+        tab_build_tables<true>(B, tables, w, rec, B.kl_pool, s_lr, s_kl, tab_rows, tab_ent, tab_seg, cursors,
                                ent_capacity, overflow, tab_ok, dbg_mode);
     } else {
-        tab_build_tables<false>(B, tables, w, rec, B.kl_pool, nullptr, kl, s_size, tab_rows, tab_ent, tab_seg, cursors,
+        tab_build_tables<false>(B, tables, w, rec, B.kl_pool, nullptr, kl, tab_rows, tab_ent, tab_seg, cursors,
                                 ent_capacity, overflow, tab_ok, dbg_mode);
     }
 }
