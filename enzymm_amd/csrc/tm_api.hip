@@ -17,6 +17,7 @@
 #include <thread>
 
 #include <fcntl.h>
+#include <sched.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <tuple>
@@ -30,6 +31,51 @@ using namespace tmx;
 namespace {
 
 thread_local std::string g_err;
+
+// ENZYMM_AMD_TRACE=1: one stderr line per call with the host-side milliseconds between marks.
+struct PhaseTrace {
+    const char *label;
+    bool on = std::getenv("ENZYMM_AMD_TRACE") != nullptr;
+    explicit PhaseTrace(const char *l = "tm_query") : label(l) {}
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0;
+    std::string line;
+    void mark(const char *what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        line += std::string(what) + " " + std::to_string(std::chrono::duration<double, std::milli>(now - last).count()).substr(0, 6) + " | ";
+        last = now;
+    }
+    ~PhaseTrace() {
+        if (on) std::fprintf(stderr, "%s host ms: %s total %.3f\n", label, line.c_str(),
+                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+};
+
+// Host threads one native call may use: ENZYMM_AMD_HOST_THREADS, else the smallest of the hardware threads, the
+// affinity mask, the container's CPU quota (cgroup v2 cpu.max; a box that shows 256 CPUs may grant 16) and 16.
+// More threads than the quota grants are throttled in bursts, which shows as run-to-run variance.
+uint32_t host_team() {
+    static const uint32_t team = [] {
+        if (const char *e = std::getenv("ENZYMM_AMD_HOST_THREADS")) {
+            const long v = std::strtol(e, nullptr, 10);
+            if (v >= 1) return (uint32_t)std::min<long>(v, 256);
+        }
+        uint32_t n = std::max(1u, std::thread::hardware_concurrency());
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min<uint32_t>(n, std::max(1, CPU_COUNT(&set)));
+        if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char quota[32] = {0};
+            long period = 0;
+            if (std::fscanf(f, "%31s %ld", quota, &period) == 2 && period > 0 && std::strcmp(quota, "max") != 0) {
+                const long q = std::strtol(quota, nullptr, 10);
+                if (q > 0) n = std::min<uint32_t>(n, (uint32_t)std::max<long>(1, q / period));
+            }
+            std::fclose(f);
+        }
+        return std::min(n, 16u);
+    }();
+    return team;
+}
 
 int fail(int code, const std::string &msg) {
     g_err = msg;
@@ -668,8 +714,7 @@ int tm_batch_create(int device, const tm_batch_desc *d, tm_batch **out) {
         }
     };
     {
-        const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
-        const uint32_t team = std::min<uint32_t>({hw, 16u, std::max(1u, na / 65536u)});  // ~64 k atoms per thread at least
+        const uint32_t team = std::min<uint32_t>(host_team(), std::max(1u, na / 65536u));  // ~64 k atoms per thread at least
         if (team <= 1) {
             flatten(0, ns);
         } else {
@@ -781,8 +826,7 @@ int tm_batch_create_from_columns(int device, const tm_columns_desc *d, const tm_
         }
     };
     {
-        const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
-        const uint32_t team = std::min<uint32_t>({hw, 16u, std::max(1u, na / 65536u)});
+        const uint32_t team = std::min<uint32_t>(host_team(), std::max(1u, na / 65536u));
         if (team <= 1) {
             encode(0, ns);
         } else {
@@ -977,6 +1021,7 @@ int tm_batch_create_from_pdb(int device, uint32_t n_files, const char *const *te
     HIP_TRY(hipSetDevice(device));
     hipStream_t stream = nullptr;
     HIP_TRY(ingest_stream(device, &stream));
+    PhaseTrace trace("tm_batch_create_from_pdb");
 
     // ---- one contiguous text buffer, every file newline-terminated, padded to 16-byte granules
     std::vector<uint64_t> file_off(n_files + 1, 0);
@@ -992,6 +1037,7 @@ int tm_batch_create_from_pdb(int device, uint32_t n_files, const char *const *te
     DevBuf<uint32_t> d_counts, d_rank, d_sums, d_total, d_line_file, d_first_end, d_keep, d_atom_rank, d_bad;
     DevBuf<uint8_t> d_kind;
     HIP_TRY(d_text.alloc(n_bytes + 16));
+    trace.mark("text alloc");
     HIP_TRY(hipMemsetAsync(d_text.p + file_off[n_files], ' ', n_bytes + 16 - file_off[n_files], stream));
     // files that already sit back to back in host memory, each ending in a newline (tm_batch_create_from_files
     // lays them out so), are the device layout: one copy.  Otherwise one copy per file.
@@ -1019,6 +1065,7 @@ int tm_batch_create_from_pdb(int device, uint32_t n_files, const char *const *te
         if (rc != TM_OK) return rc;
         HIP_TRY(hipMemcpyAsync(&n_lines, d_total.p, sizeof n_lines, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
+        trace.mark("sync0");
     }
     HIP_TRY(d_nl.alloc(n_lines)); HIP_TRY(d_line_file.alloc(n_lines)); HIP_TRY(d_kind.alloc(n_lines));
     HIP_TRY(d_keep.alloc(n_lines)); HIP_TRY(d_atom_rank.alloc(n_lines));
@@ -1040,6 +1087,7 @@ int tm_batch_create_from_pdb(int device, uint32_t n_files, const char *const *te
         if (rc != TM_OK) return rc;
         HIP_TRY(hipMemcpyAsync(&n_atoms, d_total.p + 1, sizeof n_atoms, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
+        trace.mark("sync1");
     }
 
     tm_batch *b = new (std::nothrow) tm_batch;
@@ -1102,6 +1150,7 @@ int tm_batch_create_from_pdb(int device, uint32_t n_files, const char *const *te
     }
     HIP_TRY(hipMemcpyAsync(&bad, d_bad.p, sizeof bad, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    trace.mark("sync2");
     if (bad) return fail(TM_E_INVALID, "malformed ATOM/HETATM record in the PDB text");
     std::vector<uint32_t> s_roff(n_files + 1, 0);
     uint32_t max_atoms = 0, max_res = 0;
@@ -1152,6 +1201,7 @@ int tm_batch_create_from_pdb(int device, uint32_t n_files, const char *const *te
         HIP_TRY(hipMemcpyAsync(b->d_residue_count.p + h.file, &h.residue_count, sizeof(uint32_t), hipMemcpyHostToDevice, stream));
     }
     HIP_TRY(hipStreamSynchronize(stream));
+    trace.mark("sync3");
     guard.b = nullptr;
     *out = b;
     return TM_OK;
@@ -1342,25 +1392,6 @@ static int carry_table_outcome(tm_batch *b, tm_result *r, hipStream_t stream) {
     r->row_capacity = b->row_capacity; r->ent_capacity = b->ent_capacity;
     return TM_OK;
 }
-
-namespace {
-// ENZYMM_AMD_TRACE=1: host-side phase times of tm_query on stderr (diagnostics)
-struct PhaseTrace {
-    bool on = std::getenv("ENZYMM_AMD_TRACE") != nullptr;
-    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0;
-    std::string line;
-    void mark(const char *what) {
-        if (!on) return;
-        const auto now = std::chrono::steady_clock::now();
-        line += std::string(what) + " " + std::to_string(std::chrono::duration<double, std::milli>(now - last).count()).substr(0, 6) + " | ";
-        last = now;
-    }
-    ~PhaseTrace() {
-        if (on) std::fprintf(stderr, "tm_query host ms: %s total %.3f\n", line.c_str(),
-                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-    }
-};
-}  // namespace
 
 int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_result **out) {
     if (!lib || !b || !p || !out) return fail(TM_E_INVALID, "tm_query: NULL argument");
@@ -1937,8 +1968,7 @@ namespace {
 // Runs f(i) for i in [0, n) on a team of host threads (contiguous slices, at least `grain` items each).
 template <class F>
 void parallel_for(uint32_t n, uint32_t grain, F &&f) {
-    const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
-    const uint32_t team = std::min<uint32_t>({hw, 16u, std::max(1u, n / std::max(1u, grain))});
+    const uint32_t team = std::min<uint32_t>(host_team(), std::max(1u, n / std::max(1u, grain)));
     if (team <= 1) {
         for (uint32_t i = 0; i < n; ++i) f(i);
         return;
@@ -2051,14 +2081,17 @@ int tm_batch_create_from_files(int device, uint32_t n_files, const char *const *
     *out = nullptr;
     if (bad_file) *bad_file = -1;
     HIP_TRY(hipSetDevice(device));
+    PhaseTrace trace("tm_batch_create_from_files");
     // sizes, then every file into its slot of ONE page-locked buffer, a newline after each (an empty extra line
     // when the file already ends in one): the buffer is the device layout and goes up in a single DMA
     std::vector<uint64_t> sizes(n_files, 0), off(n_files + 1, 0);
     int rc = tm_files_sizes(n_files, paths, sizes.data(), bad_file);
     if (rc != TM_OK) return rc;
     for (uint32_t f = 0; f < n_files; ++f) off[f + 1] = off[f] + sizes[f] + 1;
+    trace.mark("stat");
     PinnedBuf<char> text;
     HIP_TRY(text.alloc(off[n_files] + 16));
+    trace.mark("pinned");
     {
         std::vector<uint64_t> read_off(n_files + 1, 0);  // tm_files_read wants [off[f], off[f] + size) ranges
         std::vector<uint8_t> failed(n_files, 0);
@@ -2082,10 +2115,12 @@ int tm_batch_create_from_files(int device, uint32_t n_files, const char *const *
                 return fail(TM_E_INVALID, std::string("cannot read ") + paths[f]);
             }
     }
+    trace.mark("read");
     std::vector<const char *> ptr(n_files);
     std::vector<uint64_t> len(n_files);
     for (uint32_t f = 0; f < n_files; ++f) { ptr[f] = text.p + off[f]; len[f] = sizes[f] + 1; }
     rc = tm_batch_create_from_pdb(device, n_files, ptr.data(), len.data(), vocab, flags, min_bfactor, out);
+    trace.mark("from_pdb");
     if (rc != TM_OK) return rc;
     tm_batch *b = *out;
     std::swap(b->h_text.p, text.p); std::swap(b->h_text.n, text.n); std::swap(b->h_text.bytes, text.bytes);

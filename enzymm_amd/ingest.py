@@ -11,6 +11,7 @@ row) actually needs it.
 from __future__ import annotations
 
 import io
+import threading
 from pathlib import Path
 from typing import List, Optional, Sequence
 
@@ -22,6 +23,8 @@ from ._vocab import VOCAB
 
 class LazyMolecule(pyjess.Molecule):
     """A ``Molecule`` backed by PDB text; columns appear on first use."""
+
+    _lock = threading.Lock()  # shared: the lazy ones are rarely flattened on the host (Molecule._encoded)
 
     def __init__(self, text: Optional[bytes], id: Optional[str], n_atoms: int, min_bfactor: float, ignore_endmdl: bool,
                  path: Optional[str] = None):
@@ -36,14 +39,12 @@ class LazyMolecule(pyjess.Molecule):
         self._loaded = None
         self._atoms = None
         self._enc = None
-        import threading
-        self._lock = threading.Lock()
         #: filled by PdbBatch.annotate(): byte offset of every kept record in the text, and the number of
         #: distinct residue numbers among the counted residue names (what a TSV row needs) -- with those a
         #: match is reported without parsing the whole file on the host
         self._line_off = None
         self._residue_count = None
-        self._picked: dict = {}
+        self._picked = None  # {kept-record index: Atom}, made on first use
         #: PdbBatch.annotate_hits: the records of the matched atoms, copied out of the batch's text buffer -- sorted
         #: kept-record indices and, row for row, 96 bytes from the start of each record's line
         self._picked_idx = None
@@ -66,6 +67,8 @@ class LazyMolecule(pyjess.Molecule):
         """The atoms with these (kept-record) indices; only their lines are parsed."""
         if self._loaded is not None or (self._line_off is None and self._picked_idx is None):
             return [self._materialise()._atom(int(i)) for i in indices]
+        if self._picked is None:
+            self._picked = {}
         missing = [int(i) for i in indices if int(i) not in self._picked]
         if missing:
             lines = []
@@ -215,45 +218,39 @@ class PdbBatch:
         self.native.close()
 
 
-def iter_batches(paths: Sequence, batch_size: int = 1000, prefetch: int = 1, **kw):
-    """Yield ``PdbBatch`` objects over ``paths`` in slices of ``batch_size`` files, built on a worker thread
-    ``prefetch`` batches ahead: reading, uploading and parsing batch i+1 overlaps the search of batch i
-    (ingestion runs on its own HIP stream, and the native calls release the GIL).  The consumer closes each
-    batch when it is done with it."""
-    import queue
-    import threading
+def iter_batches(paths: Sequence, batch_size: int = 1000, prefetch: int = 2, workers: int = 2, **kw):
+    """Yield ``PdbBatch`` objects over ``paths`` in slices of ``batch_size`` files, in order, built on ``workers``
+    ingest threads up to ``prefetch`` batches ahead: reading, uploading and parsing batch i+1 (and i+2) overlaps
+    the search of batch i, and with two workers the file reads of one batch overlap the upload and the device parse
+    of the other (every host thread ingests on a HIP stream of its own, and the native calls release the GIL).
+    The consumer closes each batch when it is done with it."""
+    from collections import deque
+    from concurrent.futures import ThreadPoolExecutor
 
     paths = list(paths)
-    slices = [paths[i:i + batch_size] for i in range(0, len(paths), batch_size)]
-    q: "queue.Queue" = queue.Queue(maxsize=max(1, int(prefetch)))
-    stop = threading.Event()
+    slices = iter([paths[i:i + batch_size] for i in range(0, len(paths), batch_size)])
+    prefetch = max(1, int(prefetch))
+    pool = ThreadPoolExecutor(max_workers=max(1, min(int(workers), prefetch)), thread_name_prefix="enzymm_amd-ingest")
+    pending: "deque" = deque()
 
-    def worker():
-        try:
-            for chunk in slices:
-                if stop.is_set():
-                    return
-                q.put(("ok", PdbBatch.from_paths(chunk, **kw)))
-            q.put(("done", None))
-        except BaseException as exc:  # handed to the consumer
-            q.put(("error", exc))
+    def launch():
+        chunk = next(slices, None)
+        if chunk is not None:
+            pending.append(pool.submit(PdbBatch.from_paths, chunk, **kw))
 
-    t = threading.Thread(target=worker, name="enzymm_amd-ingest", daemon=True)
-    t.start()
     try:
-        while True:
-            kind, payload = q.get()
-            if kind == "done":
-                return
-            if kind == "error":
-                raise payload
-            yield payload
+        for _ in range(prefetch):
+            launch()
+        while pending:
+            batch = pending.popleft().result()  # an ingestion error is raised here, in the consumer
+            launch()
+            yield batch
     finally:
-        stop.set()
-        while t.is_alive():  # let a blocked put() through, closing what the consumer will not take
-            try:
-                kind, payload = q.get(timeout=0.05)
-                if kind == "ok":
-                    payload.close()
-            except queue.Empty:
-                pass
+        # the consumer stopped early or an error came through: close what it will not take, leave no thread behind
+        for fut in pending:
+            if not fut.cancel():
+                try:
+                    fut.result().close()
+                except BaseException:
+                    pass
+        pool.shutdown(wait=True)

@@ -706,11 +706,17 @@ class Matcher:
         uploads and parses batch i + 1 on the GPU (``enzymm_amd.ingest.iter_batches``) while batch i is searched
         on a stream of its own and the matches of batch i - 1 are built here.  ``ingest_options``:
         ``conservation_cutoff`` (default 0: like ``load_molecules``, which computes the filtered molecule and
-        drops it), ``ignore_endmdl``."""
+        drops it), ``ignore_endmdl``, and ``workers`` / ``prefetch`` of ``iter_batches`` (2 / 2)."""
+        import gc
         from . import _native, ingest
         out: Dict[pyjess.Molecule, List[Match]] = {}
         streams = [_native.Stream(pyjess.default_device()) for _ in range(2)]
         in_flight = None  # (batch, submitted) of the previous batch
+        # The pipeline builds no reference cycles, but its allocations do trigger full collections, and one of those
+        # walks the quarter of a million objects of the template library with the GIL held: 90-300 ms in which none
+        # of the three stages moves (thirty batches' worth of search).  The cyclic collector rests until we return.
+        collecting = gc.isenabled()
+        gc.disable()
         try:
             for n, batch in enumerate(ingest.iter_batches(paths, batch_size=batch_size, **ingest_options)):
                 try:
@@ -739,6 +745,8 @@ class Matcher:
                 in_flight[0].close()
             for st in streams:
                 st.close()
+            if collecting:
+                gc.enable()
         return out
 
     def run_single(self, molecule: pyjess.Molecule) -> List[Match]:
