@@ -184,8 +184,13 @@ class PdbBatch:
         structure, atom = key >> 16, key & 0xFFFF
         record = self.native.atom_offsets.astype(np.int64)[structure] + atom
         start = text_off.astype(np.int64)[structure] + self._line_off[record].astype(np.int64)
-        index = np.minimum(start[:, None] + np.arange(96, dtype=np.int64)[None, :], len(buffer) - 1)
-        lines = buffer[index]  # [matched atoms, 96] bytes, a private copy
+        if len(start) and int(start.max()) + 96 <= len(buffer):
+            # rows of a sliding 96-byte window over the buffer: one 96-byte copy per matched atom
+            lines = np.lib.stride_tricks.sliding_window_view(buffer, 96)[start]
+        else:  # a record within 96 bytes of the end of the buffer: byte by byte, clamped
+            index = np.minimum(start[:, None] + np.arange(96, dtype=np.int64)[None, :], len(buffer) - 1)
+            lines = buffer[index]
+        # lines: [matched atoms, 96] bytes, a private copy
         bounds = np.searchsorted(structure, np.arange(len(self.molecules) + 1))
         counts = self._res_counts
         for mi in np.unique(structure).tolist():
