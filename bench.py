@@ -157,6 +157,8 @@ def main():
     ap.add_argument("--streamed-passes", type=int, default=2,
                     help="extra passes with the batches uploaded from host memory under the timer (reported in "
                          "config.streamed_structures_per_s, never in value); 0 = skip")
+    ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2],
+                    help="searches in flight per rank (2: launch j + 1 before fetching j's hit table; 1: one after the other)")
     ap.add_argument("--generator", default="v2", choices=["v2", "v1", "real"],
                     help="v2: natively packed synthetic globules (default); v1: the round-1 generator (under-dense, "
                          "kept for side-by-side rates); real: rigid-transform copies of 1AMY / AF-P0DUB6 (density reference)")
@@ -213,7 +215,16 @@ def main():
     chunks = [molecules[i:i + args.batch] for i in range(0, len(molecules), args.batch)]
     starts = [lo + i for i in range(0, len(molecules), args.batch)]
     batches = [pyjess.make_batch(chunk, local_rank) for chunk in chunks]
-    stream = torch.cuda.current_stream().cuda_stream
+    # Steps are software-pipelined two deep, the way Matcher.run_files drives the library: search j + 1 is launched
+    # (on the other of two streams) before the hit table of search j is fetched, so the host side of a launch and the
+    # copy back run under the kernels of the neighbouring search.  Every search still does all of its work inside the
+    # timed region (candidate index + pair tables + search + superposition + selection + hit table to the host).
+    # Two searches in flight must not share a batch (TM_FLAG_REBUILD_INDEX rebuilds its index and tables in place):
+    # a rank with a single resident batch keeps a second copy of it and alternates.
+    resident_sets = [list(zip(starts, batches))]
+    if len(batches) == 1 and args.pipeline > 1:
+        resident_sets.append([(starts[0], pyjess.make_batch(chunks[0], local_rank))])
+    streams = [_native.Stream(local_rank) for _ in range(max(1, args.pipeline))]
     flags = _native.TM_FLAG_BEST_MATCH | _native.TM_FLAG_IGNORE_CHAIN | _native.TM_FLAG_REBUILD_INDEX
     capacity = max(4096, 64 * args.batch)
     cand_capacity = max(65536, 256 * args.batch)
@@ -221,42 +232,63 @@ def main():
     search_ms, index_ms, finish_ms, hit_total = [], [], [], 0
     last_hits = None
 
-    def search(batch):
+    def search(batch, stream=None):
         return _native.query(packed.native, batch, idx, 2.0, cut, cut, 10000, flags, hit_capacity=capacity,
-                             stream=stream, candidate_capacity=cand_capacity, retry=False)
+                             stream=streams[0].handle if stream is None else stream,
+                             candidate_capacity=cand_capacity, retry=False)
 
-    def step(record, resident=batches):
-        """One pass over this rank's structures: every batch searched (candidate index + pair tables + search +
-        superposition + selection), the rank's hit table gathered to rank 0."""
-        nonlocal hit_total, last_hits
-        tables, times, n_local = [], [], 0
-        for start, batch in zip(starts, resident):
-            res = search(batch)
+    def run_steps(n_steps, record):
+        """n_steps passes over this rank's structures: every batch searched (candidate index + pair tables + search
+        + superposition + selection), the rank's hit table gathered to rank 0 -- at most --pipeline searches in
+        flight, results taken in launch order (so every rank enters the gathers in the same order)."""
+        import collections
+        in_flight = collections.deque()
+        state = {}  # step -> [tables, times, hits of this rank, searches still out]
+
+        def collect():
+            nonlocal hit_total, last_hits
+            step_no, start, res = in_flight.popleft()
+            st = state[step_no]
             if world > 1 and not one_gpu:
                 # the RCCL leg: rows go from the device hit table to rank 0 without touching the host on the way
-                n = res.hit_count()  # waits for the kernels on `stream`
+                n = res.hit_count()  # waits for the kernels on the search's stream
                 t = distributed.gather_result(res, n, start, device=gather_device)
-                n_local += n
+                st[2] += n
             else:
-                t = res.hits()  # waits for the kernels on `stream`
-                n_local += len(t)
+                t = res.hits()  # waits for the kernels on the search's stream
+                st[2] += len(t)
                 t["structure"] += np.uint32(start - lo)
             if t is not None:
-                tables.append(t)
+                st[0].append(t)
             if record:
-                times.append(res.timing())
+                st[1].append(res.timing())
             res.close()
-        if world > 1 and not one_gpu:
-            table = distributed.merge_tables(tables) if rank == 0 else None
-        else:
-            local = np.concatenate(tables) if len(tables) > 1 else tables[0]
-            table = local if world == 1 else distributed.gather_tables(local, lo, device=gather_device)
-        if record:
-            index_ms.extend(t[0] for t in times)
-            search_ms.extend(t[1] for t in times)
-            finish_ms.extend(t[2] for t in times)
-            hit_total = n_local
-            last_hits = table
+            st[3] -= 1
+            if st[3] == 0:  # the step is complete: its table goes to rank 0
+                tables, times, n_local, _ = state.pop(step_no)
+                if world > 1 and not one_gpu:
+                    table = distributed.merge_tables(tables) if rank == 0 else None
+                else:
+                    local = np.concatenate(tables) if len(tables) > 1 else tables[0]
+                    table = local if world == 1 else distributed.gather_tables(local, lo, device=gather_device)
+                if record:
+                    index_ms.extend(t[0] for t in times)
+                    search_ms.extend(t[1] for t in times)
+                    finish_ms.extend(t[2] for t in times)
+                    hit_total = n_local
+                    last_hits = table
+
+        launched = 0
+        for step_no in range(n_steps):
+            resident = resident_sets[step_no % len(resident_sets)]
+            state[step_no] = [[], [], 0, len(resident)]
+            for start, batch in resident:
+                in_flight.append((step_no, start, search(batch, streams[launched % len(streams)].handle)))
+                launched += 1
+                if len(in_flight) >= len(streams):
+                    collect()
+        while in_flight:
+            collect()
 
     def fence():
         torch.cuda.synchronize()
@@ -264,18 +296,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step(False)
+    run_steps(args.warmup, False)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
+    run_steps(args.steps, True)
     fence()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_gpu else "cuda")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+
+    # ---- not part of `value`: the kernels' durations with ONE search in flight (nothing else on the GPU), for
+    # roofline.exclusive -- with two in flight the HIP events of a search also span what the other search's kernels ran
+    exclusive_ms = None
+    if len(streams) > 1:
+        timed = (list(index_ms), list(search_ms), list(finish_ms), hit_total, last_hits)
+        saved, streams = streams, streams[:1]
+        index_ms, search_ms, finish_ms = [], [], []
+        run_steps(3, True)
+        fence()
+        exclusive_ms = {"index": float(np.mean(index_ms)), "search": float(np.mean(search_ms)), "finish": float(np.mean(finish_ms))}
+        streams = saved
+        index_ms, search_ms, finish_ms, hit_total, last_hits = timed
 
     # ---- not part of `value`: the same pass with the structures coming from HOST memory (encoded atom tables), batch
     # i + 1 flattened and uploaded on a worker thread while batch i is searched -- the PCIe-inclusive rate
@@ -360,11 +403,22 @@ def main():
                 "parallelism": f"structures sharded over {world} GPU(s), hit-table gather to rank 0",
                 "hits_rank0": int(hit_total), "index_ms": float(np.mean(index_ms)), "search_ms": k_ms,
                 "finish_ms": float(np.mean(finish_ms)),
+                # searches in flight per rank; with 2, index_ms/search_ms/finish_ms (HIP events on each search's own
+                # stream) include whatever the neighbouring search's kernels took from the GPU meanwhile
+                "pipeline": len(streams),
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_search",
                          "algorithmic_bytes_per_launch": algo_bytes,
+                         # average k_search launch over the timed region (HIP events on the search's own stream)
+                         "kernel_ms": k_ms,
+                         # the same kernel with one search in flight, measured after the timed region, and the
+                         # fraction of peak that duration gives
+                         "exclusive": None if exclusive_ms is None else {
+                             "kernel_ms": exclusive_ms["search"], "index_ms": exclusive_ms["index"],
+                             "finish_ms": exclusive_ms["finish"],
+                             "frac": algo_bytes / (exclusive_ms["search"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
                          # what actually bounds the kernel (instruction issue of a divergent search), from the same
                          # committed PMC passes: instructions per (structure, template) search, VALU issue share
                          "secondary": secondary},

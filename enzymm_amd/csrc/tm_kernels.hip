@@ -1024,6 +1024,9 @@ __device__ __forceinline__ bool table_scan(const Ctx &C, WaveRegs &W, PairState 
             e += 64u;
         } while (e < e_end && nq + 64u <= (uint32_t)kPairQueue);
         TM_STAT(53, nq);
+        TM_STAT(54, nq != 0u ? 1 : 0);                      // pair-stage rounds with a survivor ...
+        TM_STAT(58, e_end - TR.pair_begin <= 64u ? 1 : 0);  // ... and rounds of segments that fit one tile
+        TM_STAT(59, (e_end - TR.pair_begin <= 64u && nq == 0u) ? 1 : 0);
 #if defined(TM_STATS) || defined(TM_ABLATE)
         if (TR.flags & 0x100u) nq = 0;
 #endif

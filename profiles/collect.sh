@@ -13,7 +13,12 @@ timeout 300 python3 bench.py --steps 10 --warmup 2 > "$out/${tag}_bench1000.json
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o run -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --streamed-passes 0 > "$out/trace.log" 2>&1
 stats=$(find "$out/trace" -name "*kernel_stats.csv" | head -1)
 [ -n "$stats" ] && cp "$stats" "$out/${tag}_bench1000_kernel_stats.csv"
-pass() { timeout 200 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$out/pmc_$1" -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --streamed-passes 0 > "$out/pmc_$1.log" 2>&1; }
+# the same with ONE search in flight: kernel durations with nothing else on the GPU (roofline.exclusive, and the
+# duration the per-search instruction figures of summarize_pmc.py are set against)
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace1" -o run -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --streamed-passes 0 --pipeline 1 > "$out/trace1.log" 2>&1
+stats=$(find "$out/trace1" -name "*kernel_stats.csv" | head -1)
+[ -n "$stats" ] && cp "$stats" "$out/${tag}_bench1000_pipeline1_kernel_stats.csv"
+pass() { timeout 200 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$out/pmc_$1" -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --streamed-passes 0 --pipeline 1 > "$out/pmc_$1.log" 2>&1; }
 pass SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES
 pass SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT
 pass SQ_INSTS_BRANCH SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU
@@ -21,8 +26,8 @@ pass FETCH_SIZE
 pass WRITE_SIZE
 for kernel in k_search k_tab_build; do
     kms=0
-    if [ -f "$out/${tag}_bench1000_kernel_stats.csv" ]; then
-        kms=$(python3 - "$out/${tag}_bench1000_kernel_stats.csv" "$kernel" <<'PY'
+    if [ -f "$out/${tag}_bench1000_pipeline1_kernel_stats.csv" ]; then
+        kms=$(python3 - "$out/${tag}_bench1000_pipeline1_kernel_stats.csv" "$kernel" <<'PY'
 import csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if sys.argv[2] in r["Name"]]
 print(float(rows[0]["AverageNs"]) / 1e6 if rows else 0.0)

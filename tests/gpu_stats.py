@@ -33,6 +33,8 @@ print("evals per level  ", np.round(s[:24] / searches, 2))
 print("surv per level   ", np.round(s[24:48] / searches, 2))
 print("joint tiles/search", s[52] / searches, "joint survivors/search", s[53] / searches,
       "searches with survivor", s[54] / searches)
+print("pair rounds with a survivor / search", s[54] / searches, "one-tile segments / search", s[58] / searches,
+      "one-tile segments without survivor / search", s[59] / searches)
 print("workgroups", int(s[55]), "with kind lists in LDS", int(s[56]), "mean kind-list pool entries", s[57] / max(s[55], 1))
 
 # ablation: k_search time with (a) everything, (b) no subtrees below the joint scan, (c) staging only
