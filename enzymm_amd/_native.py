@@ -87,7 +87,7 @@ class _QueryParams(C.Structure):
 
 EXPORTS = (
     "tm_abi_version", "tm_last_error", "tm_device_count", "tm_library_create", "tm_library_destroy",
-    "tm_batch_create", "tm_batch_create_from_columns", "tm_batch_create_from_pdb", "tm_batch_atom_counts", "tm_batch_line_offsets",
+    "tm_batch_create", "tm_batch_create_from_columns", "tm_batch_create_from_structures", "tm_batch_create_from_pdb", "tm_batch_atom_counts", "tm_batch_line_offsets",
     "tm_batch_residue_counts",
     "tm_batch_destroy", "tm_query", "tm_result_wait", "tm_result_needed", "tm_result_hit_count",
     "tm_result_copy_hits", "tm_result_copy_candidates", "tm_result_timing", "tm_result_device_hits",
@@ -368,6 +368,30 @@ class Batch:
         _check(lib.tm_batch_create_from_columns(C.c_int(device), C.byref(desc), C.byref(vocab), C.byref(self._h)))
         self.device = device
         self.atom_offsets = keep[0]
+        self.has_residue_counts = False
+        return self
+
+    @classmethod
+    def from_structures(cls, device, rows: np.ndarray, vocab_tables) -> "Batch":
+        """Raw atom-table columns of many molecules, each wherever it lies: ``rows`` is a ``[n, 7]`` uint64 table of
+        ``tm_structure_columns`` records (atom count, then the addresses of xyz float64[n,3], name S4, residue_name S3,
+        chain_id S2, residue_number int32, insertion_code S1 -- ``Molecule._pointer_row``).  The caller keeps the
+        arrays alive for the duration of the call (``tm_batch_create_from_structures``)."""
+        lib = load()
+        self = cls.__new__(cls)
+        self._h = C.c_void_p()
+        rows = _arr(rows, np.uint64).reshape(-1, 7)
+        self.n_structures = len(rows)
+        names, name_ids, els, el_ids, res, res_ids, _ = vocab_tables
+        vk = [_arr(names, "S4"), _arr(name_ids, np.uint8), _arr(els, "S2"), _arr(el_ids, np.uint8),
+              _arr(res, "S3"), _arr(res_ids, np.uint8)]
+        vocab = _Vocab(len(vk[0]), _ptr(vk[0]), _ptr(vk[1]), len(vk[2]), _ptr(vk[2]), _ptr(vk[3]),
+                       len(vk[4]), _ptr(vk[4]), _ptr(vk[5]), 0, None)
+        _check(lib.tm_batch_create_from_structures(C.c_int(device), C.c_uint32(len(rows)), _ptr(rows), C.byref(vocab),
+                                                   C.byref(self._h)))
+        self.device = device
+        self.atom_offsets = np.zeros(len(rows) + 1, dtype=np.uint32)
+        np.cumsum(rows[:, 0], out=self.atom_offsets[1:], dtype=np.uint32)
         self.has_residue_counts = False
         return self
 

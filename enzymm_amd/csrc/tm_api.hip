@@ -643,12 +643,19 @@ void tm_library_destroy(tm_library *lib) {
 
 static hipError_t ingest_stream(int device, hipStream_t *out);
 
-int tm_batch_create(int device, const tm_batch_desc *d, tm_batch **out) {
+}  // extern "C" (reopened below: the next function is shared by the three batch constructors)
+
+namespace {
+// Encoded structures -> residue-sorted records, uploaded.  The coordinates of structure s start at xyz_of[s]
+// (the structures need not sit back to back in host memory); the encoded columns are contiguous.
+int batch_from_encoded(int device, const tm_batch_desc *d, const double *const *xyz_of, const uint32_t *nres_known,
+                       tm_batch **out) {
     if (!d || !out || !d->atom_offsets ||
-        (d->n_structures && d->atom_offsets[d->n_structures] && (!d->xyz || !d->res_type || !d->name_id || !d->residue)))
+        (d->n_structures && d->atom_offsets[d->n_structures] && (!xyz_of || !d->res_type || !d->name_id || !d->residue)))
         return fail(TM_E_INVALID, "tm_batch_create: NULL argument");
     *out = nullptr;
     HIP_TRY(hipSetDevice(device));
+    PhaseTrace trace("tm_batch_create");
     const uint32_t ns = d->n_structures;
     const uint32_t na = d->atom_offsets[ns];
     PinnedBuf<double> xyz;
@@ -666,8 +673,9 @@ int tm_batch_create(int device, const tm_batch_desc *d, tm_batch **out) {
         if (n > TM_MAX_STRUCTURE_ATOMS)
             return fail(TM_E_UNSUPPORTED, "structure " + std::to_string(s) + " has " + std::to_string(n) +
                                               " atoms; limit " + std::to_string(TM_MAX_STRUCTURE_ATOMS));
-        uint32_t nres = 0;
-        for (uint32_t i = 0; i < n; ++i) nres = std::max(nres, d->residue[o + i] + 1);
+        uint32_t nres = nres_known ? nres_known[s] : 0u;
+        if (!nres_known)
+            for (uint32_t i = 0; i < n; ++i) nres = std::max(nres, d->residue[o + i] + 1);
         if (nres > TM_MAX_STRUCTURE_RESIDUES)
             return fail(TM_E_UNSUPPORTED, "structure " + std::to_string(s) + " has more than " +
                                               std::to_string(TM_MAX_STRUCTURE_RESIDUES) + " residues");
@@ -677,6 +685,7 @@ int tm_batch_create(int device, const tm_batch_desc *d, tm_batch **out) {
         max_res = std::max(max_res, nres);
     }
     HIP_TRY(res_start.alloc(s_roff[ns]));
+    trace.mark("limits");
 
     // pass 2: the structures are independent; a small team of threads flattens them
     auto flatten = [&](uint32_t s_begin, uint32_t s_end) {
@@ -691,18 +700,20 @@ int tm_batch_create(int device, const tm_batch_desc *d, tm_batch **out) {
             perm.assign(n, 0);
             fill.assign(count.begin(), count.end() - 1);
             for (uint32_t i = 0; i < n; ++i) perm[fill[d->residue[o + i]]++] = i;
+            const double *sx = xyz_of[s];
             double c[3] = {0, 0, 0};
             for (uint32_t i = 0; i < n; ++i)
-                for (int a = 0; a < 3; ++a) c[a] += d->xyz[3 * (size_t)(o + i) + a];
+                for (int a = 0; a < 3; ++a) c[a] += sx[3 * (size_t)i + a];
             if (n)
                 for (int a = 0; a < 3; ++a) c[a] /= (double)n;
             for (uint32_t j = 0; j < n; ++j) {
                 const uint32_t src = o + perm[j], dst = o + j;
-                for (int a = 0; a < 3; ++a) xyz[3 * (size_t)dst + a] = d->xyz[3 * (size_t)src + a];
+                const double *px = sx + 3 * (size_t)perm[j];
+                for (int a = 0; a < 3; ++a) xyz[3 * (size_t)dst + a] = px[a];
                 float4 r;
-                r.x = (float)(d->xyz[3 * (size_t)src] - c[0]);
-                r.y = (float)(d->xyz[3 * (size_t)src + 1] - c[1]);
-                r.z = (float)(d->xyz[3 * (size_t)src + 2] - c[2]);
+                r.x = (float)(px[0] - c[0]);
+                r.y = (float)(px[1] - c[1]);
+                r.z = (float)(px[2] - c[2]);
                 const uint32_t nm = std::min<uint32_t>(d->name_id[src], TM_NAME_OTHER);
                 const uint32_t rt = std::min<uint32_t>(d->res_type[src], TM_RES_OTHER);
                 const uint32_t m = meta_pack(d->residue[src], nm, rt);
@@ -732,6 +743,7 @@ int tm_batch_create(int device, const tm_batch_desc *d, tm_batch **out) {
         }
     }
 
+    trace.mark("flatten");
     tm_batch *b = new (std::nothrow) tm_batch;
     if (!b) return fail(TM_E_NOMEM, "out of host memory");
     b->device = device;
@@ -747,6 +759,7 @@ int tm_batch_create(int device, const tm_batch_desc *d, tm_batch **out) {
     up(b->d_s_off.upload(b->s_off, stream)); up(b->d_s_roff.upload(s_roff, stream));  // these also wait for the stream
     up(b->d_cursor.alloc(1)); up(b->d_overflow.alloc(1));
     if (e == hipSuccess && stream) up(hipStreamSynchronize(stream));
+    trace.mark("upload");
     if (e != hipSuccess) {
         delete b;
         return fail(TM_E_DEVICE, std::string("tm_batch_create upload: ") + hipGetErrorString(e));
@@ -754,75 +767,126 @@ int tm_batch_create(int device, const tm_batch_desc *d, tm_batch **out) {
     *out = b;
     return TM_OK;
 }
+}  // namespace
 
-// Raw atom-table columns -> vocabulary ids and residue / chain ordinals (per structure, on host threads), then
-// tm_batch_create.  Ordinals are numbered by first appearance; only their equality matters.
-int tm_batch_create_from_columns(int device, const tm_columns_desc *d, const tm_vocab *vocab, tm_batch **out) {
-    if (!d || !vocab || !out || !d->atom_offsets)
-        return fail(TM_E_INVALID, "tm_batch_create_from_columns: NULL argument");
-    const uint32_t ns = d->n_structures;
-    const uint32_t na = d->atom_offsets[ns];
-    if (na && (!d->xyz || !d->name || !d->residue_name || !d->chain_id || !d->residue_number || !d->insertion_code))
-        return fail(TM_E_INVALID, "tm_batch_create_from_columns: NULL column");
-    std::vector<uint32_t> v_names(vocab->n_atom_names), v_res(vocab->n_residues, 0u);
-    std::vector<uint16_t> v_el(vocab->n_elements);
-    for (uint32_t i = 0; i < vocab->n_atom_names; ++i) std::memcpy(&v_names[i], vocab->atom_names + 4 * i, 4);
-    for (uint32_t i = 0; i < vocab->n_elements; ++i) std::memcpy(&v_el[i], vocab->elements + 2 * i, 2);
-    for (uint32_t i = 0; i < vocab->n_residues; ++i) std::memcpy(&v_res[i], vocab->residue_names + 3 * i, 3);
+extern "C" {
+
+int tm_batch_create(int device, const tm_batch_desc *d, tm_batch **out) {
+    if (!d || !out || !d->atom_offsets) return fail(TM_E_INVALID, "tm_batch_create: NULL argument");
+    std::vector<const double *> xyz_of(d->n_structures, nullptr);
+    if (d->xyz)
+        for (uint32_t s = 0; s < d->n_structures; ++s) xyz_of[s] = d->xyz + 3 * (size_t)d->atom_offsets[s];
+    return batch_from_encoded(device, d, d->xyz ? xyz_of.data() : nullptr, nullptr, out);
+}
+
+}  // extern "C"
+
+namespace {
+
+// Raw atom-table columns, one tm_structure_columns per structure -> vocabulary ids and residue / chain ordinals (per
+// structure, on host threads), then batch_from_encoded.  Ordinals are numbered by first appearance; only their
+// equality matters.
+int batch_from_structures(int device, uint32_t ns, const tm_structure_columns *src, const tm_vocab *vocab, tm_batch **out) {
+    PhaseTrace trace("tm_batch_create_from_structures");
+    std::vector<uint32_t> atom_offsets(ns + 1, 0);
+    for (uint32_t s = 0; s < ns; ++s) {
+        const uint64_t n = src[s].n_atoms;
+        if (n > TM_MAX_STRUCTURE_ATOMS)
+            return fail(TM_E_UNSUPPORTED, "structure " + std::to_string(s) + " has " + std::to_string(n) +
+                                              " atoms; limit " + std::to_string(TM_MAX_STRUCTURE_ATOMS));
+        if (n && (!src[s].xyz || !src[s].name || !src[s].residue_name || !src[s].chain_id || !src[s].residue_number ||
+                  !src[s].insertion_code))
+            return fail(TM_E_INVALID, "structure " + std::to_string(s) + ": NULL column");
+        if ((uint64_t)atom_offsets[s] + n > 0xffffffffull) return fail(TM_E_UNSUPPORTED, "more than 2^32 atoms in one batch");
+        atom_offsets[s + 1] = atom_offsets[s] + (uint32_t)n;
+    }
+    const uint32_t na = atom_offsets[ns];
+    // the vocabulary as open-addressed tables keyed by the raw field (a linear scan per atom name was the cost of
+    // this function: names change with every atom)
+    struct Lookup {
+        std::vector<uint32_t> key;
+        std::vector<uint16_t> val;  // 0xffff: empty
+        uint32_t mask = 0;
+        void build(uint32_t n, const char *fields, uint32_t width, const uint8_t *ids) {
+            uint32_t cap = 16;
+            while (cap < 4 * n) cap <<= 1;
+            key.assign(cap, 0); val.assign(cap, 0xffffu); mask = cap - 1;
+            for (uint32_t i = 0; i < n; ++i) {
+                uint32_t k = 0;
+                std::memcpy(&k, fields + (size_t)width * i, width);
+                uint32_t h = (k * 2654435761u) >> 7 & mask;
+                while (val[h] != 0xffffu && key[h] != k) h = (h + 1) & mask;
+                if (val[h] == 0xffffu) { key[h] = k; val[h] = ids[i]; }  // the first listing of a field wins, as in a scan
+            }
+        }
+        bool find(uint32_t k, uint32_t *id) const {
+            uint32_t h = (k * 2654435761u) >> 7 & mask;
+            while (val[h] != 0xffffu) {
+                if (key[h] == k) { *id = val[h]; return true; }
+                h = (h + 1) & mask;
+            }
+            return false;
+        }
+    } names, elements, residues;
+    names.build(vocab->n_atom_names, vocab->atom_names, 4, vocab->atom_name_ids);
+    elements.build(vocab->n_elements, vocab->elements, 2, vocab->element_ids);
+    residues.build(vocab->n_residues, vocab->residue_names, 3, vocab->residue_ids);
+
     std::vector<uint8_t> res_type(na), name_id(na), chain(na);
-    std::vector<uint32_t> residue(na);
+    std::vector<uint32_t> residue(na), nres_of(ns, 0);
     auto encode = [&](uint32_t s_begin, uint32_t s_end) {
         std::vector<uint16_t> seen_chain;
+        std::vector<std::pair<uint64_t, uint32_t>> table;  // residue key -> ordinal, open addressing, per structure
         for (uint32_t s = s_begin; s < s_end; ++s) {
-            const uint32_t o = d->atom_offsets[s], n = d->atom_offsets[s + 1] - o;
+            const tm_structure_columns &c = src[s];
+            const uint32_t o = atom_offsets[s], n = atom_offsets[s + 1] - o;
             seen_chain.clear();
-            std::map<uint64_t, uint32_t> by_key;
+            uint32_t cap = 64;
+            while (cap < 2 * n) cap <<= 1;  // at most one residue per atom
+            table.assign(cap, {~0ull, 0u});
+            uint32_t n_keys = 0;
             uint64_t last_key = ~0ull;
             uint32_t last_ord = 0;
-            uint32_t last_name = 0, last_name_id = TM_NAME_OTHER;
-            bool have_name = false;
             uint32_t last_res = 0, last_res_id = TM_RES_OTHER;
             bool have_res = false;
+            uint16_t last_chain = 0;
+            uint8_t last_chain_ord = 0;
+            bool have_chain = false;
             for (uint32_t i = 0; i < n; ++i) {
                 const size_t a = (size_t)o + i;
                 uint32_t nm = 0;
-                std::memcpy(&nm, d->name + 4 * a, 4);
-                if (!have_name || nm != last_name) {
-                    uint32_t id = TM_NAME_OTHER;
-                    for (uint32_t q = 0; q < vocab->n_atom_names; ++q)
-                        if (v_names[q] == nm) { id = vocab->atom_name_ids[q]; break; }
-                    if (id == TM_NAME_OTHER) {
-                        const uint16_t el = (uint16_t)(nm & 0xffffu);
-                        for (uint32_t q = 0; q < vocab->n_elements; ++q)
-                            if (v_el[q] == el) { id = vocab->element_ids[q]; break; }
-                    }
-                    last_name = nm; last_name_id = id; have_name = true;
-                }
-                name_id[a] = (uint8_t)last_name_id;
+                std::memcpy(&nm, c.name + 4 * (size_t)i, 4);
+                uint32_t id = TM_NAME_OTHER;
+                if (!names.find(nm, &id) || id == TM_NAME_OTHER) (void)elements.find(nm & 0xffffu, &id);  // by element (cols 13-14)
+                name_id[a] = (uint8_t)id;
                 uint32_t rn = 0;
-                std::memcpy(&rn, d->residue_name + 3 * a, 3);
+                std::memcpy(&rn, c.residue_name + 3 * (size_t)i, 3);
                 if (!have_res || rn != last_res) {
-                    uint32_t id = TM_RES_OTHER;
-                    for (uint32_t q = 0; q < vocab->n_residues; ++q)
-                        if (v_res[q] == rn) { id = vocab->residue_ids[q]; break; }
-                    last_res = rn; last_res_id = id; have_res = true;
+                    uint32_t rid = TM_RES_OTHER;
+                    (void)residues.find(rn, &rid);
+                    last_res = rn; last_res_id = rid; have_res = true;
                 }
                 res_type[a] = (uint8_t)last_res_id;
-                const uint16_t ch = (uint16_t)((uint8_t)d->chain_id[2 * a] << 8 | (uint8_t)d->chain_id[2 * a + 1]);
-                const uint64_t key = ((uint64_t)ch << 40) | ((uint64_t)(uint32_t)(d->residue_number[a] + (1 << 24)) << 8) |
-                                     (uint8_t)d->insertion_code[a];
+                const uint16_t ch = (uint16_t)((uint8_t)c.chain_id[2 * (size_t)i] << 8 | (uint8_t)c.chain_id[2 * (size_t)i + 1]);
+                const uint64_t key = ((uint64_t)ch << 40) | ((uint64_t)(uint32_t)(c.residue_number[i] + (1 << 24)) << 8) |
+                                     (uint8_t)c.insertion_code[i];
                 if (key != last_key) {
-                    auto it = by_key.find(key);
-                    if (it == by_key.end()) it = by_key.emplace(key, (uint32_t)by_key.size()).first;
+                    uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & (cap - 1);
+                    while (table[h].first != ~0ull && table[h].first != key) h = (h + 1) & (cap - 1);
+                    if (table[h].first == ~0ull) table[h] = {key, n_keys++};
                     last_key = key;
-                    last_ord = it->second;
+                    last_ord = table[h].second;
                 }
                 residue[a] = last_ord;
-                uint32_t c = 0;
-                while (c < seen_chain.size() && seen_chain[c] != ch) ++c;
-                if (c == seen_chain.size()) seen_chain.push_back(ch);
-                chain[a] = (uint8_t)(c & 0xffu);
+                if (!have_chain || ch != last_chain) {
+                    uint32_t k = 0;
+                    while (k < seen_chain.size() && seen_chain[k] != ch) ++k;
+                    if (k == seen_chain.size()) seen_chain.push_back(ch);
+                    last_chain = ch; last_chain_ord = (uint8_t)(k & 0xffu); have_chain = true;
+                }
+                chain[a] = last_chain_ord;
             }
+            nres_of[s] = n_keys;
         }
     };
     {
@@ -835,22 +899,59 @@ int tm_batch_create_from_columns(int device, const tm_columns_desc *d, const tm_
             for (uint32_t t = 0; t < team; ++t) {
                 const uint64_t target = (uint64_t)na * (t + 1) / team;
                 uint32_t s1 = s0;
-                while (s1 < ns && (t + 1 == team || d->atom_offsets[s1 + 1] <= target)) ++s1;
+                while (s1 < ns && (t + 1 == team || atom_offsets[s1 + 1] <= target)) ++s1;
                 if (s1 > s0) workers.emplace_back(encode, s0, s1);
                 s0 = s1;
             }
             for (auto &w : workers) w.join();
         }
     }
+    trace.mark("encode");
+    std::vector<const double *> xyz_of(ns);
+    for (uint32_t s = 0; s < ns; ++s) xyz_of[s] = src[s].xyz;
     tm_batch_desc enc;
     enc.n_structures = ns;
-    enc.atom_offsets = d->atom_offsets;
-    enc.xyz = d->xyz;
+    enc.atom_offsets = atom_offsets.data();
+    enc.xyz = nullptr;
     enc.res_type = res_type.data();
     enc.name_id = name_id.data();
     enc.residue = residue.data();
     enc.chain = chain.data();
-    return tm_batch_create(device, &enc, out);
+    return batch_from_encoded(device, &enc, xyz_of.data(), nres_of.data(), out);
+}
+
+}  // namespace
+
+extern "C" {
+
+int tm_batch_create_from_structures(int device, uint32_t n_structures, const tm_structure_columns *structures,
+                                    const tm_vocab *vocab, tm_batch **out) {
+    if (!vocab || !out || (n_structures && !structures))
+        return fail(TM_E_INVALID, "tm_batch_create_from_structures: NULL argument");
+    return batch_from_structures(device, n_structures, structures, vocab, out);
+}
+
+// The same from columns that hold all structures back to back.
+int tm_batch_create_from_columns(int device, const tm_columns_desc *d, const tm_vocab *vocab, tm_batch **out) {
+    if (!d || !vocab || !out || !d->atom_offsets)
+        return fail(TM_E_INVALID, "tm_batch_create_from_columns: NULL argument");
+    const uint32_t ns = d->n_structures;
+    const uint32_t na = d->atom_offsets[ns];
+    if (na && (!d->xyz || !d->name || !d->residue_name || !d->chain_id || !d->residue_number || !d->insertion_code))
+        return fail(TM_E_INVALID, "tm_batch_create_from_columns: NULL column");
+    std::vector<tm_structure_columns> src(ns);
+    for (uint32_t s = 0; s < ns; ++s) {
+        const size_t o = d->atom_offsets[s];
+        if (d->atom_offsets[s + 1] < o) return fail(TM_E_INVALID, "tm_batch_create_from_columns: offsets must not decrease");
+        src[s].n_atoms = d->atom_offsets[s + 1] - o;
+        src[s].xyz = d->xyz + 3 * o;
+        src[s].name = d->name + 4 * o;
+        src[s].residue_name = d->residue_name + 3 * o;
+        src[s].chain_id = d->chain_id + 2 * o;
+        src[s].residue_number = d->residue_number + o;
+        src[s].insertion_code = d->insertion_code + o;
+    }
+    return batch_from_structures(device, ns, src.data(), vocab, out);
 }
 
 // exclusive prefix sum of n u32 values on the device; *total (device) receives the sum

@@ -277,7 +277,23 @@ class Molecule:
         self.id = id
         self._atoms = None
         self._enc = None  # (vocabulary version, encoded arrays)
+        self._row = None  # (tm_structure_columns record, the arrays it points into)
         self._lock = threading.Lock()
+
+    _ROW_COLUMNS = (("name", "S4"), ("residue_name", "S3"), ("chain_id", "S2"), ("residue_number", np.int32),
+                    ("insertion_code", "S1"))
+
+    def _pointer_row(self) -> np.ndarray:
+        """This molecule as a ``tm_structure_columns`` record (7 x uint64: atom count and the addresses of its xyz /
+        name / residue_name / chain_id / residue_number / insertion_code arrays), cached together with the arrays:
+        ``make_batch`` hands a list of molecules to the library without copying their columns together first."""
+        row = getattr(self, "_row", None)
+        if row is None:
+            keep = [np.ascontiguousarray(self._xyz, dtype=np.float64)]
+            keep += [np.ascontiguousarray(self._cols[k], dtype=dt) for k, dt in self._ROW_COLUMNS]
+            rec = np.array([len(self)] + [a.__array_interface__["data"][0] for a in keep], dtype=np.uint64)
+            row = self._row = (rec, keep)
+        return row[0]
 
     @classmethod
     def from_columns(cls, id: Optional[str] = None, *, xyz, name, residue_name, chain_id, residue_number, **other):
@@ -654,42 +670,14 @@ def _packed(templates: Sequence[Template], device: int) -> _PackedLibrary:
         return packed
 
 
-def _joined(parts: List[np.ndarray], dtype) -> np.ndarray:
-    """The arrays one after the other; without copying when they already are consecutive views of one array
-    (molecules that came out of ``Molecule.load_many`` together)."""
-    if not parts:
-        return np.zeros(0, dtype=dtype)
-    base = parts[0].base
-    if base is not None and isinstance(base, np.ndarray) and base.ndim == parts[0].ndim and base.flags.c_contiguous \
-            and len(base) and base.strides[0]:
-        step = base.strides[0]
-        start = (parts[0].__array_interface__["data"][0] - base.__array_interface__["data"][0])
-        addr, ok = parts[0].__array_interface__["data"][0], start % step == 0
-        for a in parts:
-            if not ok:
-                break
-            ok = a.base is base and a.dtype == base.dtype and a.flags.c_contiguous and \
-                a.__array_interface__["data"][0] == addr
-            addr += a.shape[0] * step
-        if ok:
-            first = start // step
-            return base[first: first + sum(len(a) for a in parts)]
-    return np.concatenate(parts).astype(dtype, copy=False)
-
-
 def make_batch(molecules: Sequence[Molecule], device: int) -> "_native.Batch":
-    """Flatten molecules into one device-resident batch.  The raw columns go to the library, which encodes them
-    with the vocabulary and packs them on host threads (``tm_batch_create_from_columns``)."""
+    """Flatten molecules into one device-resident batch.  The library reads every molecule's raw columns where they
+    lie, encodes them with the vocabulary and packs them on host threads (``tm_batch_create_from_structures``)."""
     tables = VOCAB.native_tables()
-    offsets = np.zeros(len(molecules) + 1, dtype=np.uint32)
+    rows = np.empty((len(molecules), 7), dtype=np.uint64)
     for i, m in enumerate(molecules):
-        offsets[i + 1] = offsets[i] + len(m)
-    cols = [m._cols for m in molecules]
-    cat = lambda k, dt: _joined([c[k] for c in cols], dt)  # noqa: E731
-    xyz = _joined([m._xyz for m in molecules], np.float64).reshape(-1, 3)
-    batch = _native.Batch.from_columns(device, offsets, xyz, cat("name", "S4"), cat("residue_name", "S3"),
-                                       cat("chain_id", "S2"), cat("residue_number", np.int32),
-                                       cat("insertion_code", "S1"), tables)
+        rows[i] = m._pointer_row()
+    batch = _native.Batch.from_structures(device, rows, tables)
     batch.vocab_version = tables[-1]  # ids are only meaningful against this state of the vocabulary
     return batch
 

@@ -117,6 +117,19 @@ typedef struct tm_columns_desc {
     const char *insertion_code;     /* [n_atoms] */
 } tm_columns_desc;
 
+/* One target structure as the raw columns of its atom table, wherever they lie in host memory: the hand-over of
+ * Molecule objects to Jess.query (enzymm/jess_run.py:800-811, molecules from load_molecules :523-556) for a whole
+ * list of molecules at once, without first copying their columns together (tm_batch_create_from_structures). */
+typedef struct tm_structure_columns {
+    uint64_t n_atoms;
+    const double *xyz;              /* [n_atoms * 3] */
+    const char *name;               /* [n_atoms * 4] raw atom-name fields */
+    const char *residue_name;       /* [n_atoms * 3] */
+    const char *chain_id;           /* [n_atoms * 2] */
+    const int32_t *residue_number;  /* [n_atoms] */
+    const char *insertion_code;     /* [n_atoms] */
+} tm_structure_columns;
+
 /* How raw PDB fields map to the ids of the host's vocabulary (tm_batch_create_from_pdb). */
 typedef struct tm_vocab {
     uint32_t n_atom_names;
@@ -187,6 +200,9 @@ void tm_library_destroy(tm_library *lib);
 int tm_batch_create(int device, const tm_batch_desc *desc, tm_batch **out);
 struct tm_vocab;
 int tm_batch_create_from_columns(int device, const tm_columns_desc *desc, const struct tm_vocab *vocab, tm_batch **out);
+struct tm_structure_columns;
+int tm_batch_create_from_structures(int device, uint32_t n_structures, const struct tm_structure_columns *structures,
+                                    const struct tm_vocab *vocab, tm_batch **out);
 /* Device-side ingestion: raw PDB text is uploaded and parsed on the GPU (ATOM/HETATM records up to the first
  * ENDMDL, optional temperature-factor cutoff) -- replaces pyjess.Molecule.load + Molecule.conserved for batches,
  * enzymm/jess_run.py:538-545.  A file the device path cannot lay out (a residue whose records are not contiguous,
