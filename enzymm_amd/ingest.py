@@ -223,25 +223,36 @@ class PdbBatch:
         self.native.close()
 
 
-def iter_batches(paths: Sequence, batch_size: int = 1000, prefetch: int = 2, workers: int = 2, **kw):
-    """Yield ``PdbBatch`` objects over ``paths`` in slices of ``batch_size`` files, in order, built on ``workers``
-    ingest threads up to ``prefetch`` batches ahead: reading, uploading and parsing batch i+1 (and i+2) overlaps
-    the search of batch i, and with two workers the file reads of one batch overlap the upload and the device parse
-    of the other (every host thread ingests on a HIP stream of its own, and the native calls release the GIL).
-    The consumer closes each batch when it is done with it."""
+class MoleculeBatch:
+    """Host-parsed molecules flattened into one device-resident batch (``pyjess.make_batch``): what
+    ``Matcher._run_pipelined`` needs of a batch -- ``native``, ``molecules``, ``close()``."""
+
+    def __init__(self, molecules: Sequence[pyjess.Molecule], device: Optional[int] = None):
+        self.molecules = list(molecules)
+        self.native = pyjess.make_batch(self.molecules, pyjess.default_device() if device is None else int(device))
+
+    def __len__(self):
+        return len(self.molecules)
+
+    def close(self):
+        self.native.close()
+
+
+def _prefetched(items, build, prefetch: int, workers: int):
+    """``build(item)`` for every item, in order, on ``workers`` threads up to ``prefetch`` results ahead of the
+    consumer.  A build error is raised in the consumer; results it never takes are closed."""
     from collections import deque
     from concurrent.futures import ThreadPoolExecutor
 
-    paths = list(paths)
-    slices = iter([paths[i:i + batch_size] for i in range(0, len(paths), batch_size)])
+    items = iter(items)
     prefetch = max(1, int(prefetch))
     pool = ThreadPoolExecutor(max_workers=max(1, min(int(workers), prefetch)), thread_name_prefix="enzymm_amd-ingest")
     pending: "deque" = deque()
 
     def launch():
-        chunk = next(slices, None)
-        if chunk is not None:
-            pending.append(pool.submit(PdbBatch.from_paths, chunk, **kw))
+        item = next(items, None)
+        if item is not None:
+            pending.append(pool.submit(build, item))
 
     try:
         for _ in range(prefetch):
@@ -259,3 +270,31 @@ def iter_batches(paths: Sequence, batch_size: int = 1000, prefetch: int = 2, wor
                 except BaseException:
                     pass
         pool.shutdown(wait=True)
+
+
+def iter_molecule_batches(molecules: Sequence[pyjess.Molecule], batch_size: int = 2000, max_atoms: int = 8_000_000,
+                          prefetch: int = 2, workers: int = 1, device: Optional[int] = None):
+    """Yield ``MoleculeBatch`` objects over consecutive slices of ``molecules`` (at most ``batch_size`` molecules
+    or ``max_atoms`` atoms each, at least one molecule), flattened and uploaded on a worker thread ahead of the
+    consumer (the native call releases the GIL).  The consumer closes each batch."""
+    chunks, chunk, atoms = [], [], 0
+    for m in molecules:
+        if chunk and (len(chunk) >= batch_size or atoms + len(m) > max_atoms):
+            chunks.append(chunk)
+            chunk, atoms = [], 0
+        chunk.append(m)
+        atoms += len(m)
+    if chunk:
+        chunks.append(chunk)
+    return _prefetched(chunks, lambda c: MoleculeBatch(c, device), prefetch, workers)
+
+
+def iter_batches(paths: Sequence, batch_size: int = 1000, prefetch: int = 2, workers: int = 2, **kw):
+    """Yield ``PdbBatch`` objects over ``paths`` in slices of ``batch_size`` files, in order, built on ``workers``
+    ingest threads up to ``prefetch`` batches ahead: reading, uploading and parsing batch i+1 (and i+2) overlaps
+    the search of batch i, and with two workers the file reads of one batch overlap the upload and the device parse
+    of the other (every host thread ingests on a HIP stream of its own, and the native calls release the GIL).
+    The consumer closes each batch when it is done with it."""
+    paths = list(paths)
+    slices = [paths[i:i + batch_size] for i in range(0, len(paths), batch_size)]
+    return _prefetched(slices, lambda chunk: PdbBatch.from_paths(chunk, **kw), prefetch, workers)

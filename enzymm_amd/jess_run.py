@@ -336,9 +336,11 @@ class _LazyMatchList(list):
     table the first time anything but ``len()`` looks at them (at tens of thousands of structures per second,
     building every object eagerly is what the host would spend its time on)."""
 
-    def __init__(self, source: _BatchHits, lo: int, hi: int):
+    def __init__(self, source: _BatchHits, lo: int, hi: int, first_size: int = 0):
         super().__init__()
         self._source, self._lo, self._hi = source, lo, hi
+        #: size bucket of the first match (where the molecule entered the result): Matcher._merged orders by it
+        self.first_size = first_size
 
     def _fill(self):
         src = self._source
@@ -463,12 +465,27 @@ class Matcher:
             ignore_chain=True)
         return [Match(hit=h, pairwise_distance=distance_cutoff) for h in query]
 
-    def run(self, molecules: List[pyjess.Molecule]) -> Dict[pyjess.Molecule, List[Match]]:
+    #: ``run`` searches a longer list in batches of this many molecules (or RUN_BATCH_ATOMS atoms), the next batch
+    #: flattened and uploaded on a worker thread while the previous one is searched
+    RUN_BATCH = 2000
+    RUN_BATCH_ATOMS = 8_000_000
+
+    def run(self, molecules: List[pyjess.Molecule], batch_size: Optional[int] = None
+            ) -> Dict[pyjess.Molecule, List[Match]]:
         """Search all molecules; larger templates first, sizes < 3 skipped unless match_small_templates.
 
         ``molecules`` may also be an ``enzymm_amd.ingest.PdbBatch`` (PDB files parsed on the GPU); the
-        result is then keyed by its lazy ``Molecule`` objects."""
-        return self._collect(self._submit(molecules))
+        result is then keyed by its lazy ``Molecule`` objects.  A list longer than ``batch_size`` (default
+        ``RUN_BATCH``) goes through the GPU in batches, pipelined like ``run_files``; the result -- its insertion
+        order included -- is that of one pass over the whole list."""
+        if hasattr(molecules, "native") and hasattr(molecules, "molecules"):
+            return self._collect(self._submit(molecules))
+        molecules = list(molecules)
+        limit = int(batch_size) if batch_size else self.RUN_BATCH
+        if len(molecules) <= limit and sum(len(m) for m in molecules) <= self.RUN_BATCH_ATOMS:
+            return self._collect(self._submit(molecules))
+        from . import ingest
+        return self._run_pipelined(ingest.iter_molecule_batches(molecules, limit, self.RUN_BATCH_ATOMS))
 
     def _submit(self, molecules, stream: int = 0):
         """Launch the search of one batch (every molecule x every searched template, ONE launch) and return at
@@ -638,7 +655,7 @@ class Matcher:
         first_size = size[rows[lo]]  # the bucket in which the molecule got its first kept match
         source = _BatchHits(searched, molecules, table, rows, complete, A["pairwise"][ts])
         for j in np.lexsort((mols, -first_size)).tolist():
-            processed[molecules[int(mols[j])]] = _LazyMatchList(source, int(lo[j]), int(hi[j]))
+            processed[molecules[int(mols[j])]] = _LazyMatchList(source, int(lo[j]), int(hi[j]), int(first_size[j]))
         if self.verbose:
             for s_ in sizes:
                 self.verbose_print(f"Now matching query structure(s) to template of size {s_}")
@@ -702,14 +719,22 @@ class Matcher:
                 np.array(params, np.float64).reshape(-1, 4))
 
     def run_files(self, paths, batch_size: int = 1000, **ingest_options) -> Dict[pyjess.Molecule, List[Match]]:
-        """``run`` over PDB files without host-side parsing, as a three-stage pipeline: a worker thread reads,
-        uploads and parses batch i + 1 on the GPU (``enzymm_amd.ingest.iter_batches``) while batch i is searched
-        on a stream of its own and the matches of batch i - 1 are built here.  ``ingest_options``:
+        """``run`` over PDB files without host-side parsing, as a three-stage pipeline: worker threads read,
+        upload and parse batches i + 1, i + 2 on the GPU (``enzymm_amd.ingest.iter_batches``) while batch i is
+        searched on a stream of its own and the matches of batch i - 1 are built here.  ``ingest_options``:
         ``conservation_cutoff`` (default 0: like ``load_molecules``, which computes the filtered molecule and
-        drops it), ``ignore_endmdl``, and ``workers`` / ``prefetch`` of ``iter_batches`` (2 / 2)."""
+        drops it), ``ignore_endmdl``, and ``workers`` / ``prefetch`` of ``iter_batches`` (2 / 2).  The result is
+        that of ``run(load_molecules(paths))``, insertion order included, keyed by lazy molecules."""
+        from . import ingest
+        return self._run_pipelined(ingest.iter_batches(paths, batch_size=batch_size, **ingest_options))
+
+    def _run_pipelined(self, batches) -> Dict[pyjess.Molecule, List[Match]]:
+        """Search device-resident batches (objects with ``native``, ``molecules`` and ``close()``) as they come out
+        of ``batches``: batch i is searched on one of two streams while the matches of batch i - 1 are built here
+        and whoever feeds the iterator prepares the next ones."""
         import gc
-        from . import _native, ingest
-        out: Dict[pyjess.Molecule, List[Match]] = {}
+        from . import _native
+        parts: List[Dict[pyjess.Molecule, List[Match]]] = []
         streams = [_native.Stream(pyjess.default_device()) for _ in range(2)]
         in_flight = None  # (batch, submitted) of the previous batch
         # The pipeline builds no reference cycles, but its allocations do trigger full collections, and one of those
@@ -718,7 +743,7 @@ class Matcher:
         collecting = gc.isenabled()
         gc.disable()
         try:
-            for n, batch in enumerate(ingest.iter_batches(paths, batch_size=batch_size, **ingest_options)):
+            for n, batch in enumerate(batches):
                 try:
                     submitted = self._submit(batch, stream=streams[n % 2].handle)
                 except BaseException:
@@ -727,13 +752,13 @@ class Matcher:
                 previous, in_flight = in_flight, (batch, submitted)
                 if previous is not None:
                     try:
-                        out.update(self._collect(previous[1]))
+                        parts.append(self._collect(previous[1]))
                     finally:
                         previous[0].close()
             if in_flight is not None:
                 previous, in_flight = in_flight, None
                 try:
-                    out.update(self._collect(previous[1]))
+                    parts.append(self._collect(previous[1]))
                 finally:
                     previous[0].close()
         finally:
@@ -747,6 +772,26 @@ class Matcher:
                 st.close()
             if collecting:
                 gc.enable()
+        return self._merged(parts)
+
+    def _merged(self, parts: List[Dict[pyjess.Molecule, List[Match]]]) -> Dict[pyjess.Molecule, List[Match]]:
+        """One result from the results of consecutive batches, in the order one pass over all molecules gives
+        (jess_run.py:930-988: a molecule enters the result in the first -- largest -- size bucket that keeps a match
+        of it; within a bucket, molecules in input order)."""
+        if len(parts) == 1:
+            return parts[0]
+        size_of = self._plan()[5]
+        entries = []
+        for part in parts:
+            for mol, matches in part.items():
+                first = getattr(matches, "first_size", None)
+                if first is None:
+                    first = size_of[id(matches[0].hit.template)] if len(matches) else 0
+                entries.append((-first, mol, matches))
+        entries.sort(key=lambda e: e[0])  # stable: batches, and molecules within a batch, stay in input order
+        out: Dict[pyjess.Molecule, List[Match]] = collections.defaultdict(list)
+        for _, mol, matches in entries:
+            out[mol] = matches
         return out
 
     def run_single(self, molecule: pyjess.Molecule) -> List[Match]:

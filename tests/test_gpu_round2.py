@@ -373,3 +373,38 @@ def test_device_hit_table_reaches_torch_without_a_host_copy(amy, af):
     assert (shifted["structure"] == want["structure"] + 1000).all() and len(shifted) == n
     res.close()
     batch.close()
+
+
+@pytest.mark.parametrize("options", [dict(), dict(filter_matches=False, skip_smaller_hits=True)])
+def test_run_in_batches_equals_one_pass(amy, af, tmp_path, options):
+    """A long molecule list goes through the GPU in pipelined batches (Matcher.run, batch_size) and so do files
+    (Matcher.run_files); both must give the result of ONE pass over everything -- the same molecules in the
+    reference's insertion order (jess_run.py:930-988: first the molecules that enter in the largest size bucket, input
+    order within a bucket), with the same matches."""
+    lib = template.load_packed_library()
+    matcher = jess_run.Matcher(lib, **options)
+    mols = synthetic.structures(12) + [amy, pyjess.Molecule()] + synthetic.structures(14, start=700) + [af] + \
+        synthetic.structures(9, start=300)
+    row = lambda m: (m.hit.template.id, m.complete, m.pairwise_distance, m.hit.rmsd, m.hit._atom_index,
+                     m.hit.predicted, m.hit.truncated)
+    whole = matcher.run(mols)
+    first = [ms[0].hit.template.effective_size for ms in whole.values()]
+    assert len(set(min(8, s) for s in first)) >= 2  # molecules enter in different buckets: the order is not input order
+    for size in (1, 7, 16):
+        parts = matcher.run(mols, batch_size=size)
+        assert [m.id for m in parts] == [m.id for m in whole], size
+        for (ma, la), (mb, lb) in zip(parts.items(), whole.items()):
+            assert ma is mb and [row(m) for m in la] == [row(m) for m in lb]
+    # the same through files
+    paths = []
+    for i, m in enumerate(mols):
+        if len(m):
+            p = tmp_path / f"m{i:03d}.pdb"
+            p.write_text(synthetic.to_pdb(m))
+            paths.append(p)
+    host = matcher.run(jess_run.load_molecules(paths))
+    dev = matcher.run_files(paths, batch_size=5)
+    assert [m.id for m in dev] == [m.id for m in host] and len(host) > 10
+    key = lambda m: (m.hit.template.id, m.complete, round(m.hit.rmsd, 9), m.hit._atom_index)
+    for la, lb in zip(dev.values(), host.values()):
+        assert [key(m) for m in la] == [key(m) for m in lb]
