@@ -467,7 +467,7 @@ class Matcher:
 
     #: ``run`` searches a longer list in batches of this many molecules (or RUN_BATCH_ATOMS atoms), the next batch
     #: flattened and uploaded on a worker thread while the previous one is searched
-    RUN_BATCH = 2000
+    RUN_BATCH = 1000
     RUN_BATCH_ATOMS = 8_000_000
 
     def run(self, molecules: List[pyjess.Molecule], batch_size: Optional[int] = None
