@@ -1405,11 +1405,21 @@ static int build_tables(const tm_library *lib, tm_batch *b, const StagedSelectio
     if (!b->d_tab_cursors.p) { HIP_TRY(b->d_tab_cursors.alloc(2)); HIP_TRY(b->d_tab_overflow.alloc(1)); }
     unsigned long long rows = b->row_capacity ? b->row_capacity
                                               : std::max<unsigned long long>(4096, 16ull * b->n_atoms + (unsigned long long)ns * (nt + 8));
-    // entries: about 20 per atom, plus what the build's per-wave chunks leave unused (16 waves per workgroup)
+    // a structure's tables are dealt to `parts` workgroups, parts growing with the square of its atom count (a
+    // 300-residue structure is one item); a batch too small to fill the GPU with one workgroup per structure (a single
+    // query structure, say) has every structure's tables dealt to more workgroups
+    const double spread = ns < 256 ? std::ceil(256.0 / std::max(1u, ns)) : 1.0;
+    auto parts_of = [&](uint32_t s) {
+        const double n = (double)(b->s_off[s + 1] - b->s_off[s]);
+        return (uint32_t)std::min<double>(std::min<double>(64.0, std::max(1u, nt / 4u)),
+                                          std::max(spread, std::floor(n * n / (3000.0 * 3000.0) + 0.5)));
+    };
+    // entries: about 35 per atom, plus what the build's per-wave chunks leave unused -- every one of the 16 waves of
+    // every workgroup that builds a share of the structure's tables ends on a partly used chunk
     unsigned long long ents = b->ent_capacity;
     if (!ents) {
         ents = 65536 + 48ull * b->n_atoms;
-        for (uint32_t s = 0; s < ns; ++s) ents += 20ull * tab_chunk(b->s_off[s + 1] - b->s_off[s]);
+        for (uint32_t s = 0; s < ns; ++s) ents += (20ull * parts_of(s)) * tab_chunk(b->s_off[s + 1] - b->s_off[s]);
     }
     if (!b->ent_capacity)
         if (const char *env = std::getenv("ENZYMM_AMD_TABLE_POOL"))  // test hook: start from a pool that is too small
@@ -1438,17 +1448,11 @@ static int build_tables(const tm_library *lib, tm_batch *b, const StagedSelectio
         HIP_TRY(hipMemsetAsync(b->d_tab_ref.p, 0, std::max<size_t>(ref_n, 1) * sizeof(uint4), stream));
         return TM_OK;
     }
-    // work items of the two build passes: a structure's tables are dealt to `parts` workgroups, parts growing with
-    // the square of its atom count (a 300-residue structure is one item)
+    // work items of the build: one per (structure, part)
     if (b->tab_work_tables != nt) {
         std::vector<TabWork> items;
-        // a batch too small to fill the GPU with one workgroup per structure (a single query structure, say) has
-        // every structure's tables dealt to more workgroups
-        const double spread = ns < 256 ? std::ceil(256.0 / ns) : 1.0;
         for (uint32_t s = 0; s < ns; ++s) {
-            const double n = (double)(b->s_off[s + 1] - b->s_off[s]);
-            const uint32_t parts = (uint32_t)std::min<double>(std::min<double>(64.0, std::max(1u, nt / 4u)),
-                                                             std::max(spread, std::floor(n * n / (3000.0 * 3000.0) + 0.5)));
+            const uint32_t parts = parts_of(s);
             for (uint32_t r = 0; r < parts; ++r) items.push_back(TabWork{s, (uint16_t)r, (uint16_t)parts});
         }
         // heaviest structures first

@@ -87,16 +87,17 @@ class _DeviceBytes:
 
 
 def gather_result(result: "_native.Result", n_hits: int, structure_offset: int, group=None,
-                  device=None) -> Optional[np.ndarray]:
+                  device=None, force_collective: bool = False) -> Optional[np.ndarray]:
     """Gather a query's hit table to rank 0 straight from HBM: the rows leave the device table the search wrote
     (``tm_result_device_hits``) over RCCL, with no device-to-host-to-device round trip on the sending ranks.  The
     device table is unsorted and carries batch-local structure indices; rank 0 adds every rank's
     ``structure_offset`` and sorts.  Returns the merged table on rank 0, None elsewhere.  Needs a backend that moves
-    device tensors ("nccl" = RCCL); with one rank it is ``result.hits()`` plus the offset."""
+    device tensors ("nccl" = RCCL); with one rank it is ``result.hits()`` plus the offset (``force_collective``:
+    go through the collectives all the same -- how a one-GPU box tests the RCCL leg)."""
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force_collective):
         local = result.hits()
         local["structure"] += np.uint32(structure_offset)
         return local

@@ -2,6 +2,7 @@
 sharding, configs[4] large complexes), the reference CLI's remaining vectors (tests/test_cli.py), the TSV through
 the HIP path, and the regressions behind the round-1 code review.  Every test calls through the C ABI."""
 import io
+import os
 import warnings
 
 import numpy as np
@@ -408,3 +409,36 @@ def test_run_in_batches_equals_one_pass(amy, af, tmp_path, options):
     key = lambda m: (m.hit.template.id, m.complete, round(m.hit.rmsd, 9), m.hit._atom_index)
     for la, lb in zip(dev.values(), host.values()):
         assert [key(m) for m in la] == [key(m) for m in lb]
+
+
+def test_first_query_of_a_small_batch_does_not_overflow():
+    """The pair-table pools are sized before the build runs.  A batch too small to fill the GPU has every structure's
+    tables dealt to several workgroups, each of whose waves ends on a partly used chunk of entries: the reserve must
+    follow (a 64-structure batch used to overflow on its first query and silently run twice through the retry)."""
+    idx, cut = helpers.default_selection()
+    jess = pyjess.Jess(helpers.product_library_templates())
+    packed = pyjess._packed(jess._templates, jess._device)
+    flags = _native.TM_FLAG_BEST_MATCH | _native.TM_FLAG_IGNORE_CHAIN
+    cases = [synthetic.structures(n, start=40 * n) for n in (1, 7, 64, 300)]
+    cases.append([synthetic.complex_structure(2, 6000)])
+    cases.append([synthetic.complex_structure(3, 6000)] + synthetic.structures(5))
+    for mols in cases:
+        batch = pyjess.make_batch(mols, jess._device)
+        res = _native.query(packed.native, batch, idx, 2.0, cut, cut, 10000, flags, retry=False)
+        res.wait()  # raises NativeError(-5) when a pool was too small
+        assert res.hit_count() >= 0
+        res.close()
+        batch.close()
+
+
+@pytest.mark.timeout(240)
+def test_rccl_gather_world_size_1():
+    """The RCCL leg of the multi-GPU gather (distributed.gather_result: counts by all_gather, rows by a padded gather,
+    both from device memory) on the one GPU there is: a world-size-1 "nccl" group with the collectives forced.  Run in
+    a child process -- a process group must not outlive the test in the pytest process."""
+    import subprocess
+    import sys
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    out = subprocess.run([sys.executable, str(helpers.ROOT / "tests" / "gpu_rccl_world1.py")], env=env, timeout=200,
+                         capture_output=True, text=True)
+    assert out.returncode == 0 and "RCCL world-size-1 gather ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
