@@ -63,7 +63,7 @@ uint32_t host_team() {
         uint32_t n = std::max(1u, std::thread::hardware_concurrency());
         cpu_set_t set;
         if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min<uint32_t>(n, std::max(1, CPU_COUNT(&set)));
-        if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota|max> <period>"
             char quota[32] = {0};
             long period = 0;
             if (std::fscanf(f, "%31s %ld", quota, &period) == 2 && period > 0 && std::strcmp(quota, "max") != 0) {
@@ -71,6 +71,17 @@ uint32_t host_team() {
                 if (q > 0) n = std::min<uint32_t>(n, (uint32_t)std::max<long>(1, q / period));
             }
             std::fclose(f);
+        } else {  // cgroup v1
+            long q = -1, period = 0;
+            if (FILE *fq = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+                if (std::fscanf(fq, "%ld", &q) != 1) q = -1;
+                std::fclose(fq);
+            }
+            if (FILE *fp = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+                if (std::fscanf(fp, "%ld", &period) != 1) period = 0;
+                std::fclose(fp);
+            }
+            if (q > 0 && period > 0) n = std::min<uint32_t>(n, (uint32_t)std::max<long>(1, q / period));
         }
         return std::min(n, 16u);
     }();
@@ -1605,6 +1616,20 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
                         if (id < 0) return fail(TM_E_UNSUPPORTED, "selection needs more than 65534 pair tables");
                         tt[i] = (uint16_t)id;
                     }
+                }
+                if (std::getenv("ENZYMM_AMD_TRACE")) {  // census of the table plan
+                    std::map<std::pair<uint16_t, uint16_t>, int> ordered, unordered;
+                    int per_class[kTableClasses] = {0};
+                    for (const auto &kv : ids) {
+                        const uint16_t a = std::get<0>(kv.first), bb = std::get<1>(kv.first);
+                        ordered[{a, bb}]++;
+                        unordered[{std::min(a, bb), std::max(a, bb)}]++;
+                        per_class[std::get<2>(kv.first)]++;
+                    }
+                    std::fprintf(stderr, "table plan: %zu tables over %u lead kinds; %zu ordered kind pairs, %zu unordered; per class",
+                                 S->tables.size(), lib->n_lead, ordered.size(), unordered.size());
+                    for (int c = 0; c < kTableClasses; ++c) std::fprintf(stderr, " %d", per_class[c]);
+                    std::fprintf(stderr, "\n");
                 }
                 HIP_TRY(S->d_tables.upload(S->tables)); HIP_TRY(S->d_pair_table.upload(tp));
                 HIP_TRY(S->d_triple_table.upload(tt)); HIP_TRY(S->d_triple_key.upload(key));
