@@ -612,15 +612,20 @@ __device__ __forceinline__ void WLf(float &v, int lane, float x) { v = lane_id()
 
 // kIgnoreChain is a compile-time property of the launch: the default (ignore_chain=True in enzymm) drops
 // every chain test from the instruction stream.
-template <bool kIgnoreChain>
+template <bool kIgnoreChain, bool kPoolLds>
 struct SearchCtx {
     const float4 *rec;          // structure atom records (LDS or global)
     const uint16_t *res_start;  // residue -> first atom (LDS or global)
-    const uint16_t *pool_lds;   // kind lists of this structure in LDS (when they fit) ...
-    const uint16_t *pool_glb;   // ... or the batch-wide pool in global memory; offsets are rebased accordingly
-    bool pool_in_lds;
-    // two explicit loads instead of one through a generic pointer: ds_read is much cheaper than flat_load
-    __device__ __forceinline__ uint32_t pool_at(uint32_t i) const { return pool_in_lds ? pool_lds[i] : pool_glb[i]; }
+    // kind lists of this structure in LDS (when they fit: kPoolLds) or the batch-wide pool in global memory (offsets
+    // are rebased accordingly).  Which of the two is a compile-time property of the search body a workgroup runs: a
+    // run-time choice per load either becomes ONE flat_load through a selected generic pointer (64-bit address
+    // arithmetic per lane, both wait counters) or a branch per load, and both measured slower.
+    const __attribute__((address_space(3))) uint16_t *pool_lds;
+    const uint16_t *pool_glb;
+    __device__ __forceinline__ uint32_t pool_at(uint32_t i) const {
+        if constexpr (kPoolLds) return pool_lds[i];
+        else return pool_glb[i];
+    }
     const uint8_t *qchain;      // global, per atom of this structure
     const uint32_t *tab_rows;   // pair tables: row offsets (global) ...
     const uint2 *tab_ent;       // ... and entries
@@ -648,8 +653,13 @@ __device__ __forceinline__ unsigned long long eval_chunk(const Ctx &C, WaveRegs 
     const uint32_t mygroup = lvl_group(RL(W.pk, level));
     // this level's row of pair bounds, one entry per lane j < level, loaded before the candidate gather
     float2 brow = make_float2(0.f, 0.f);
-    if (level <= kBoundRowsLds) {  // two explicit loads: a pointer select would turn both into flat loads
-        if (lane < level) brow = S.bnd[tri(level) + lane];
+    if (level <= kBoundRowsLds) {
+        // read through a pointer that carries the LDS address space: from two generic pointers the compiler makes
+        // one flat_load through a selected address
+        if (lane < level) {
+            const unsigned long long raw = ((const __attribute__((address_space(3))) unsigned long long *)S.bnd)[tri(level) + lane];
+            brow = make_float2(__uint_as_float((uint32_t)raw), __uint_as_float((uint32_t)(raw >> 32)));
+        }
     } else {
         if (lane < level) brow = C.bnd[tri(level) + lane];
     }
@@ -1153,72 +1163,24 @@ __device__ __forceinline__ void load_template(const QueryView &Q, uint32_t ti, i
     R.hdr = (uint32_t)T.k | ((uint32_t)T.n_groups << 8) | ((uint32_t)T.triple_key << 16);
 }
 
-template <bool kLds, bool kIgnoreChain>
-__global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
+// The template loop of one workgroup: its waves claim the templates of the workgroup's chunk one by one and search
+// the structure staged in LDS.  kPoolLds: the structure's kind lists are in LDS too (the rule), else in global memory.
+template <bool kLds, bool kIgnoreChain, bool kPoolLds>
+__device__ __forceinline__ void search_templates(const SearchArgs &A, WaveScratch *scratch, const float4 *s_rec,
+                                                 const uint16_t *s_res, const uint32_t *s_kl, const uint16_t *s_pool,
+                                                 const uint32_t *kl_off, uint32_t *s_next_p, uint32_t s, uint32_t a0,
+                                                 uint32_t r0, uint32_t n_chunks) {
     const LibView &L = A.L;
     const BatchView &B = A.B;
     const QueryView &Q = A.Q;
-    const uint32_t max_atoms = A.max_atoms, max_res = A.max_res,
-                   pool_cap = A.pool_cap;
-    extern __shared__ __align__(16) unsigned char smem[];
-    // [WaveScratch x kSearchWaves][rec float4 x max_atoms][res_start u16 x (max_res+1)]
-    // [kind-list offsets u32 x (n_lead+1)][kind-list pool u16 x pool_cap]
-    WaveScratch *scratch = reinterpret_cast<WaveScratch *>(smem);
-    float4 *s_rec = reinterpret_cast<float4 *>(smem + sizeof(WaveScratch) * kSearchWaves);
-    uint16_t *s_res = reinterpret_cast<uint16_t *>(s_rec + (kLds ? max_atoms : 0));
-    uint32_t *s_kl = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(s_res) +
-                                                  (kLds ? search_res_bytes(max_res) : 0));
-    uint16_t *s_pool = reinterpret_cast<uint16_t *>(s_kl + (kLds ? search_kl_words(L.n_lead) : 0));
-    __shared__ uint32_t s_next;
-
-    // Workgroups b and b + 8 share an XCD.  The template selection of a work item is cut into
-    // (rounds << cx) interleaved chunks -- chunk c holds the selected templates c, c + n_chunks, ..., so every
-    // chunk gets the same mix of cheap and expensive templates -- and an XCD only ever works on the chunks
-    // whose low cx bits equal its own: its share of the staged template table (about 1 KB per template) stays
-    // resident in its own 4 MB L2.  The structure a workgroup searches is copied into LDS once, so it does not
-    // matter which XCD that is.  Work items are ordered heaviest structure first, and heavy structures are cut
-    // into more rounds (host side), so that a few large structures in a batch do not become the tail.
-    const uint32_t bid = blockIdx.x;
-    const uint32_t xcd = bid & 7u;
-    const uint32_t cx = A.chunk_xcd_shift;
-    const uint32_t item_index = ((bid >> 3) << (3u - cx)) + (xcd >> cx);
-    if (item_index >= A.n_items) return;
-    const WorkItem item = A.work[item_index];
-    const uint32_t s = item.s;
-    const uint32_t chunk = ((uint32_t)item.round << cx) + (xcd & ((1u << cx) - 1u));
-    const uint32_t n_chunks = (uint32_t)item.rounds << cx;
-    if (chunk >= Q.n_sel) return;
-
-    if (B.tab_ok[s] != 1u) return;  // pair tables incomplete (pool overflow, reported with the result): nothing to search
-    const uint32_t a0 = B.s_off[s], n = B.s_off[s + 1] - a0;
-    const uint32_t r0 = B.s_roff[s], nres1 = B.s_roff[s + 1] - r0;  // n_res + 1 entries
-    const uint32_t *kl_off = B.kl_off + (size_t)s * (L.n_lead + 1);
-    bool pool_in_lds = false;
-    if (kLds) {
-        // the structure's atom records, residue starts, kind-list offsets and (when it fits) the
-        // kind lists themselves: after this the search reads global memory only for template data
-        const uint32_t p0 = kl_off[0], plen = kl_off[L.n_lead] - p0;
-        pool_in_lds = plen <= pool_cap;
-        const uint32_t rebase = pool_in_lds ? p0 : 0u;
-        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) s_rec[i] = B.q_rec[a0 + i];
-        for (uint32_t i = threadIdx.x; i < nres1; i += blockDim.x) s_res[i] = B.res_start[r0 + i];
-        for (uint32_t i = threadIdx.x; i <= L.n_lead; i += blockDim.x) s_kl[i] = kl_off[i] - rebase;
-        if (pool_in_lds)
-            for (uint32_t i = threadIdx.x; i < plen; i += blockDim.x) s_pool[i] = B.kl_pool[p0 + i];
-    }
-    if (threadIdx.x == 0) s_next = chunk;
-    TM_STAT(55, threadIdx.x == 0 ? 1 : 0);
-    TM_STAT(56, threadIdx.x == 0 && pool_in_lds ? 1 : 0);
-    TM_STAT(57, threadIdx.x == 0 ? kl_off[L.n_lead] - kl_off[0] : 0);
-    __syncthreads();
+    uint32_t &s_next = *s_next_p;
     const uint32_t t_end = Q.n_sel;
-
-    SearchCtx<kIgnoreChain> C;
+    (void)L;
+    SearchCtx<kIgnoreChain, kPoolLds> C;
     C.rec = kLds ? s_rec : B.q_rec + a0;
     C.res_start = kLds ? s_res : B.res_start + r0;
-    C.pool_lds = s_pool;
+    C.pool_lds = (const __attribute__((address_space(3))) uint16_t *)s_pool;
     C.pool_glb = B.kl_pool;
-    C.pool_in_lds = pool_in_lds;
     C.qchain = B.q_chain + a0;
     C.tab_rows = B.tab_rows;
     C.tab_ent = B.tab_ent;
@@ -1328,6 +1290,71 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
         }
         wave_sync();
     }
+}
+
+template <bool kLds, bool kIgnoreChain>
+__global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
+    const LibView &L = A.L;
+    const BatchView &B = A.B;
+    const QueryView &Q = A.Q;
+    const uint32_t max_atoms = A.max_atoms, max_res = A.max_res,
+                   pool_cap = A.pool_cap;
+    extern __shared__ __align__(16) unsigned char smem[];
+    // [WaveScratch x kSearchWaves][rec float4 x max_atoms][res_start u16 x (max_res+1)]
+    // [kind-list offsets u32 x (n_lead+1)][kind-list pool u16 x pool_cap]
+    WaveScratch *scratch = reinterpret_cast<WaveScratch *>(smem);
+    float4 *s_rec = reinterpret_cast<float4 *>(smem + sizeof(WaveScratch) * kSearchWaves);
+    uint16_t *s_res = reinterpret_cast<uint16_t *>(s_rec + (kLds ? max_atoms : 0));
+    uint32_t *s_kl = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(s_res) +
+                                                  (kLds ? search_res_bytes(max_res) : 0));
+    uint16_t *s_pool = reinterpret_cast<uint16_t *>(s_kl + (kLds ? search_kl_words(L.n_lead) : 0));
+    __shared__ uint32_t s_next;
+
+    // Workgroups b and b + 8 share an XCD.  The template selection of a work item is cut into
+    // (rounds << cx) interleaved chunks -- chunk c holds the selected templates c, c + n_chunks, ..., so every
+    // chunk gets the same mix of cheap and expensive templates -- and an XCD only ever works on the chunks
+    // whose low cx bits equal its own: its share of the staged template table (about 1 KB per template) stays
+    // resident in its own 4 MB L2.  The structure a workgroup searches is copied into LDS once, so it does not
+    // matter which XCD that is.  Work items are ordered heaviest structure first, and heavy structures are cut
+    // into more rounds (host side), so that a few large structures in a batch do not become the tail.
+    const uint32_t bid = blockIdx.x;
+    const uint32_t xcd = bid & 7u;
+    const uint32_t cx = A.chunk_xcd_shift;
+    const uint32_t item_index = ((bid >> 3) << (3u - cx)) + (xcd >> cx);
+    if (item_index >= A.n_items) return;
+    const WorkItem item = A.work[item_index];
+    const uint32_t s = item.s;
+    const uint32_t chunk = ((uint32_t)item.round << cx) + (xcd & ((1u << cx) - 1u));
+    const uint32_t n_chunks = (uint32_t)item.rounds << cx;
+    if (chunk >= Q.n_sel) return;
+
+    if (B.tab_ok[s] != 1u) return;  // pair tables incomplete (pool overflow, reported with the result): nothing to search
+    const uint32_t a0 = B.s_off[s], n = B.s_off[s + 1] - a0;
+    const uint32_t r0 = B.s_roff[s], nres1 = B.s_roff[s + 1] - r0;  // n_res + 1 entries
+    const uint32_t *kl_off = B.kl_off + (size_t)s * (L.n_lead + 1);
+    bool pool_in_lds = false;
+    if (kLds) {
+        // the structure's atom records, residue starts, kind-list offsets and (when it fits) the
+        // kind lists themselves: after this the search reads global memory only for template data
+        const uint32_t p0 = kl_off[0], plen = kl_off[L.n_lead] - p0;
+        pool_in_lds = plen <= pool_cap;
+        const uint32_t rebase = pool_in_lds ? p0 : 0u;
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) s_rec[i] = B.q_rec[a0 + i];
+        for (uint32_t i = threadIdx.x; i < nres1; i += blockDim.x) s_res[i] = B.res_start[r0 + i];
+        for (uint32_t i = threadIdx.x; i <= L.n_lead; i += blockDim.x) s_kl[i] = kl_off[i] - rebase;
+        if (pool_in_lds)
+            for (uint32_t i = threadIdx.x; i < plen; i += blockDim.x) s_pool[i] = B.kl_pool[p0 + i];
+    }
+    if (threadIdx.x == 0) s_next = chunk;
+    TM_STAT(55, threadIdx.x == 0 ? 1 : 0);
+    TM_STAT(56, threadIdx.x == 0 && pool_in_lds ? 1 : 0);
+    TM_STAT(57, threadIdx.x == 0 ? kl_off[L.n_lead] - kl_off[0] : 0);
+    __syncthreads();
+
+    if (pool_in_lds)
+        search_templates<kLds, kIgnoreChain, true>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, &s_next, s, a0, r0, n_chunks);
+    else
+        search_templates<kLds, kIgnoreChain, false>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, &s_next, s, a0, r0, n_chunks);
 }
 
 template __global__ void k_search<true, true>(SearchArgs);

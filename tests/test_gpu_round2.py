@@ -442,3 +442,26 @@ def test_rccl_gather_world_size_1():
     out = subprocess.run([sys.executable, str(helpers.ROOT / "tests" / "gpu_rccl_world1.py")], env=env, timeout=200,
                          capture_output=True, text=True)
     assert out.returncode == 0 and "RCCL world-size-1 gather ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_kind_lists_partly_outside_lds():
+    """k_search keeps a structure's atom records in LDS up to about 6 300 atoms per structure, its kind lists only while
+    they fit beside them (up to about 4 700 atoms): a batch whose largest structure lies in between runs the search
+    body that reads kind lists from global memory for that structure and the LDS one for the small ones."""
+    big = synthetic.complex_structure(5, 700)
+    big = big._subset(np.arange(5500))
+    mols = [synthetic.structure(3), big, synthetic.structure(4)]
+    jess, olib = _every(13)
+    table, cands = jess.query_batch(mols, 2.0, 1.5, 1.5, max_candidates=10000, ignore_chain=True, count_candidates=True,
+                                    return_raw=True)
+    total = 0
+    for s, mol in enumerate(mols):
+        r = oracle.query_library(helpers.to_oracle_molecule(mol), olib, 2.0, 1.5, 1.5, max_candidates=10000,
+                                 ignore_chain=True)
+        total += compare(table, cands, s, r, olib)
+    assert total > 3
+    # chains are compared on the other kernel variant
+    table_c = jess.query_batch(mols, 2.0, 1.5, 1.5, max_candidates=10000, ignore_chain=False, return_raw=True)
+    want = sum(int((oracle.query_library(helpers.to_oracle_molecule(m), olib, 2.0, 1.5, 1.5, max_candidates=10000,
+                                         ignore_chain=False)["hit"]).sum()) for m in mols)
+    assert len(table_c) == want
