@@ -157,7 +157,7 @@ def main():
     ap.add_argument("--streamed-passes", type=int, default=2,
                     help="extra passes with the batches uploaded from host memory under the timer (reported in "
                          "config.streamed_structures_per_s, never in value); 0 = skip")
-    ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2],
+    ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2, 3],
                     help="searches in flight per rank (2: launch j + 1 before fetching j's hit table; 1: one after the other)")
     ap.add_argument("--generator", default="v2", choices=["v2", "v1", "real"],
                     help="v2: natively packed synthetic globules (default); v1: the round-1 generator (under-dense, "
@@ -222,8 +222,9 @@ def main():
     # Two searches in flight must not share a batch (TM_FLAG_REBUILD_INDEX rebuilds its index and tables in place):
     # a rank with a single resident batch keeps a second copy of it and alternates.
     resident_sets = [list(zip(starts, batches))]
-    if len(batches) == 1 and args.pipeline > 1:
-        resident_sets.append([(starts[0], pyjess.make_batch(chunks[0], local_rank))])
+    if len(batches) < args.pipeline:  # fewer resident batches than searches in flight: more copies, used in turn
+        for _ in range(args.pipeline - 1):
+            resident_sets.append([(st, pyjess.make_batch(ch, local_rank)) for st, ch in zip(starts, chunks)])
     streams = [_native.Stream(local_rank) for _ in range(max(1, args.pipeline))]
     flags = _native.TM_FLAG_BEST_MATCH | _native.TM_FLAG_IGNORE_CHAIN | _native.TM_FLAG_REBUILD_INDEX
     capacity = max(4096, 64 * args.batch)
