@@ -485,3 +485,56 @@ def test_library_census_under_both_readings_of_one_letter_x():
     moved = collections.Counter((size_from_columns_18_20(t), t.effective_size) for t in lib
                                 if size_from_columns_18_20(t) != t.effective_size)
     assert moved == {(3, 2): 5, (4, 3): 3, (5, 4): 4, (6, 5): 3, (7, 6): 1, (8, 7): 1}
+
+
+def test_batches_merge_in_reference_order_and_lists_are_cut_by_count_and_atoms(monkeypatch):
+    """Host logic of the pipelined Matcher.run / run_files without a GPU: (1) Matcher._merged orders the molecules of
+    consecutive batches as one pass of the reference's per-size loop would (jess_run.py:930-988: first those that enter
+    the result in the largest size bucket, input order within a bucket); (2) ingest.iter_molecule_batches cuts a list
+    into consecutive batches by molecule count and by atoms, never an empty one, and closes what the consumer leaves."""
+    from enzymm_amd import ingest, jess_run
+
+    class Lazy(list):
+        def __init__(self, first_size):
+            super().__init__()
+            self.first_size = first_size
+
+    matcher = jess_run.Matcher.__new__(jess_run.Matcher)
+    monkeypatch.setattr(jess_run.Matcher, "_plan", lambda self: (None, None, None, None, None, {}, None, None, None))
+    mols = {n: n for n in "abcdefgh"}  # the keys are opaque to the merge
+    parts = [{mols["a"]: Lazy(4), mols["b"]: Lazy(3)}, {mols["c"]: Lazy(5), mols["d"]: Lazy(4), mols["e"]: Lazy(3)},
+             {mols["f"]: Lazy(5)}, {}, {mols["g"]: Lazy(3), mols["h"]: Lazy(8)}]
+    merged = matcher._merged(parts)
+    assert list(merged) == ["h", "c", "f", "a", "d", "b", "e", "g"]
+    assert matcher._merged([parts[1]]) is parts[1] and len(matcher._merged([])) == 0
+
+    made, closed = [], []
+
+    class FakeBatch:
+        def __init__(self, molecules, device=None):
+            self.molecules = list(molecules)
+            made.append(self)
+
+        def close(self):
+            closed.append(self)
+
+    monkeypatch.setattr(ingest, "MoleculeBatch", FakeBatch)
+
+    class Mol:
+        def __init__(self, n):
+            self.n = n
+
+        def __len__(self):
+            return self.n
+
+    sizes = [10, 10, 10, 95, 10, 200, 10, 10, 10, 10, 10]
+    items = [Mol(n) for n in sizes]
+    got = [[m.n for m in b.molecules] for b in ingest.iter_molecule_batches(items, batch_size=4, max_atoms=100)]
+    assert got == [[10, 10, 10], [95], [10], [200], [10, 10, 10, 10], [10]]  # 200 > max_atoms still travels, alone
+    assert [n for chunk in got for n in chunk] == sizes
+    made.clear(); closed.clear()
+    gen = ingest.iter_molecule_batches(items, batch_size=2, max_atoms=10 ** 9, prefetch=2)
+    first = next(gen)
+    gen.close()
+    assert first in made and first not in closed and all(b in closed for b in made if b is not first)
+    assert list(ingest.iter_molecule_batches([], batch_size=4)) == []
