@@ -292,6 +292,11 @@ struct StagedSelection {
     // then starts with the expensive templates and ends on the cheap ones); order[pos] is the caller's index.
     std::vector<uint32_t> order;
     DevBuf<uint32_t> d_order;
+    // What queries with this selection have needed so far, per 1000 atoms of their batches: candidates and
+    // (template, structure) pairs with candidates.  tm_query sizes a result's tables for 1.5 x that when the caller
+    // leaves the capacities to the library -- loose thresholds (enzymm's -j) produce orders of magnitude more
+    // candidates than the defaults allow for, and an overflow costs a whole second run.
+    std::atomic<unsigned long long> cands_per_katom{0}, pairs_per_katom{0};
     // pair tables the selection's templates read (see k_tab_* in tm_kernels.hip) and, per staged template, which ones
     std::vector<TableDesc> tables;
     DevBuf<TableDesc> d_tables;
@@ -413,6 +418,7 @@ struct tm_result {
     DevBuf<PairEntry> d_pairs;
     DevBuf<unsigned long long> d_counters;  // [0] hits, [1] candidates, [2] pairs
     std::shared_ptr<StagedSelection> selection;
+    unsigned long long n_atoms = 0;                                 // atoms of the batch (for the selection's per-atom needs)
     bool calibrates = false;                                        // this query clocks the selection's templates
     std::shared_ptr<IndexShared> index_shared;                      // the batch's (see tm_batch)
     DevBuf<unsigned long long> d_pool_used;                         // kind-list entries the index build needed
@@ -1652,9 +1658,12 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
     if (!stage_now) HIP_TRY(hipStreamWaitEvent(stream, S->ready, 0));  // staged on another stream, possibly
     trace.mark("selection");
     r->selection = S;
+    r->n_atoms = b->n_atoms;
     unsigned long long hcap = p->hit_capacity, ccap = p->candidate_capacity;
-    if (!hcap) hcap = std::max<unsigned long long>(4096, 64ull * b->n_structs);
-    if (!ccap) ccap = std::max<unsigned long long>(65536, 256ull * b->n_structs);
+    const unsigned long long katoms = (b->n_atoms + 999ull) / 1000ull;
+    if (!hcap) hcap = std::max<unsigned long long>({4096, 64ull * b->n_structs, S->pairs_per_katom.load() * katoms * 3 / 2});
+    if (!ccap) ccap = std::min<unsigned long long>(0xfffffffeull,
+        std::max<unsigned long long>({65536, 256ull * b->n_structs, S->cands_per_katom.load() * katoms * 3 / 2}));
     if (ccap > 0xfffffffeull) return fail(TM_E_UNSUPPORTED, "candidate_capacity must be below 2^32 - 1");
     r->hit_capacity = hcap; r->cand_capacity = ccap;
     HIP_TRY(r->d_hits.alloc(hcap));
@@ -1825,6 +1834,15 @@ int tm_result_wait(tm_result *r) {
         }
         r->n_hits = counters[0]; r->n_cands = counters[1]; r->n_pairs = counters[2];
         r->waited = true;
+        if (r->selection && r->n_atoms) {  // what this selection needs per 1000 atoms (sizes the next results)
+            auto raise = [](std::atomic<unsigned long long> &a, unsigned long long v) {
+                unsigned long long seen = a.load();
+                while (seen < v && !a.compare_exchange_weak(seen, v)) {}
+            };
+            const unsigned long long katoms = (r->n_atoms + 999ull) / 1000ull;
+            raise(r->selection->cands_per_katom, (r->n_cands + katoms - 1) / katoms);
+            raise(r->selection->pairs_per_katom, (std::max(r->n_pairs, r->n_hits) + katoms - 1) / katoms);
+        }
         if (r->calibrates && r->selection) {  // the measured cost of every template, back in the caller's numbering
             StagedSelection &S = *r->selection;
             std::vector<unsigned long long> ticks(S.sel.size());
