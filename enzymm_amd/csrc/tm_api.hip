@@ -271,12 +271,32 @@ struct PinnedBuf {
         if (p) PinnedPool::get().release(p, bytes);
     }
     hipError_t alloc(size_t count) {
+        const size_t need = std::max<size_t>(count, 1) * sizeof(T);
         n = count;
-        return PinnedPool::get().acquire(std::max<size_t>(count, 1) * sizeof(T), reinterpret_cast<void **>(&p), &bytes);
+        if (p && bytes >= need) return hipSuccess;  // still fits
+        if (p) PinnedPool::get().release(p, bytes);
+        p = nullptr;
+        return PinnedPool::get().acquire(need, reinterpret_cast<void **>(&p), &bytes);
     }
     T &operator[](size_t i) { return p[i]; }
     const T &operator[](size_t i) const { return p[i]; }
 };
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a ceiling: it is raised when a launch needs more dynamic LDS than any
+// launch of that kernel on that device before it, not set again with every query (the call costs as much as a launch).
+hipError_t allow_dynamic_lds(const void *kernel, size_t bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<const void *, int>, size_t> granted;
+    int device = 0;
+    hipError_t e = hipGetDevice(&device);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t &have = granted[{kernel, device}];
+    if (bytes <= have) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) have = bytes;
+    return e;
+}
 
 // A template selection with its thresholds, staged for the search kernel (k_stage_templates).
 // Batches are normally queried with the same selection over and over: the library keeps the last
@@ -378,6 +398,7 @@ struct tm_batch {
     bool has_residue_count = false;
     // search work items (structure, round), cached for the (cx, n_sel) they were planned for
     DevBuf<WorkItem> d_work;
+    PinnedBuf<WorkItem> h_work;      // page-locked source of d_work: uploaded on the query's stream without a host wait
     uint32_t work_items = 0, work_cx = 0xffffffffu, work_n_sel = 0;
     hipStream_t last_stream = nullptr;  // stream of the last query that read this batch
     bool queried = false;
@@ -391,6 +412,7 @@ struct tm_batch {
     DevBuf<uint4> d_tab_ref;
     DevBuf<unsigned long long> d_tab_cursors;  // [0] row slots, [1] entries handed out
     DevBuf<TabWork> d_tab_work;
+    PinnedBuf<TabWork> h_tab_work;   // likewise
     uint32_t tab_work_items = 0, tab_work_tables = 0xffffffffu;
     unsigned long long row_capacity = 0, ent_capacity = 0;
     // The index build is not waited for: a query whose build overflowed the kind-list pool finds out in
@@ -1250,8 +1272,7 @@ int tm_batch_create_from_pdb(int device, uint32_t n_files, const char *const *te
     }
     if (n_files) {
         const size_t key_lds = (size_t)kMaxSortedRuns * sizeof(uint64_t);
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pdb_residues),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)key_lds));
+        HIP_TRY(allow_dynamic_lds(reinterpret_cast<const void *>(k_pdb_residues), key_lds));
         hipLaunchKernelGGL(k_pdb_residues, dim3(n_files), dim3(256), key_lds, stream, d_s_off_tmp.p, d_key.p, d_runs.p,
                            d_needs_host.p);
     }
@@ -1476,8 +1497,12 @@ static int build_tables(const tm_library *lib, tm_batch *b, const StagedSelectio
         std::stable_sort(items.begin(), items.end(), [&](const TabWork &x, const TabWork &y) {
             return b->s_off[x.s + 1] - b->s_off[x.s] > b->s_off[y.s + 1] - b->s_off[y.s];
         });
+        // (a plain hipMemcpy from the vector would wait for everything enqueued so far -- the candidate index of this
+        // very query: the list goes through a page-locked copy owned by the batch, asynchronously on the stream)
         if (b->d_tab_work.p) HIP_TRY(hipStreamSynchronize(stream));  // a previous query may still read the old list
-        HIP_TRY(b->d_tab_work.upload(items));
+        HIP_TRY(b->h_tab_work.alloc(items.size()));
+        std::copy(items.begin(), items.end(), b->h_tab_work.p);
+        HIP_TRY(b->d_tab_work.upload_async(b->h_tab_work.p, items.size(), stream));
         b->tab_work_items = (uint32_t)items.size(); b->tab_work_tables = nt;
     }
     const BatchView B = b->view();
@@ -1491,8 +1516,7 @@ static int build_tables(const tm_library *lib, tm_batch *b, const StagedSelectio
 #ifdef TM_ABLATE
     if (const char *env = std::getenv("ENZYMM_AMD_TAB_DEBUG")) lr_arg |= (uint32_t)std::atoi(env) << 30;
 #endif
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tab_build), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds_bytes));
+    HIP_TRY(allow_dynamic_lds(reinterpret_cast<const void *>(k_tab_build), lds_bytes));
     hipLaunchKernelGGL(k_tab_layout, dim3(ns), dim3(256), 0, stream, lib->n_lead, B, S->d_tables.p, b->d_tab_dir.p,
                        b->d_tab_cursors.p, rows, b->d_tab_overflow.p, b->d_tab_ok.p);
     hipLaunchKernelGGL(k_tab_build, dim3(b->tab_work_items), dim3(kTabBlock), lds_bytes, stream, lib->n_lead, B,
@@ -1774,7 +1798,9 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
                 for (uint32_t r = 0; r < rounds; ++r) items.push_back(WorkItem{s, (uint16_t)r, (uint16_t)rounds});
             }
             if (b->d_work.p) HIP_TRY(hipStreamSynchronize(stream));  // a previous query may still read the old list
-            HIP_TRY(b->d_work.upload(items));
+            HIP_TRY(b->h_work.alloc(items.size()));
+            std::copy(items.begin(), items.end(), b->h_work.p);
+            HIP_TRY(b->d_work.upload_async(b->h_work.p, items.size(), stream));  // no host wait: see build_tables
             b->work_items = (uint32_t)items.size(); b->work_cx = cx; b->work_n_sel = n_sel;
         }
         const uint32_t per_group = 8u >> cx;  // work items per group of 8 consecutive workgroups
@@ -1790,8 +1816,7 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
         const bool ic = (p->flags & TM_FLAG_IGNORE_CHAIN) != 0;
         void (*kernel)(SearchArgs) = lds_path ? (ic ? k_search<true, true> : k_search<true, false>)
                                               : (ic ? k_search<false, true> : k_search<false, false>);
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds_bytes));
+        HIP_TRY(allow_dynamic_lds(reinterpret_cast<const void *>(kernel), lds_bytes));
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(kSearchBlock), lds_bytes, stream,
                            SearchArgs{lib->view(), b->view(), Q, O, b->d_work.p, b->work_items, cx, b->max_atoms, b->max_res, pool_cap});
         HIP_TRY(hipGetLastError());

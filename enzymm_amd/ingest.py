@@ -26,6 +26,23 @@ class LazyMolecule(pyjess.Molecule):
 
     _lock = threading.Lock()  # shared: the lazy ones are rarely flattened on the host (Molecule._encoded)
 
+    # Defaults live on the class: a batch of a thousand files makes a thousand of these on an ingest thread with the
+    # GIL held, while the main thread wants it to launch and collect searches.
+    _loaded = None
+    _atoms = None
+    _enc = None
+    #: filled by PdbBatch.annotate(): byte offset of every kept record in the text, and the number of
+    #: distinct residue numbers among the counted residue names (what a TSV row needs) -- with those a
+    #: match is reported without parsing the whole file on the host
+    _line_off = None
+    _residue_count = None
+    _picked = None  # {kept-record index: Atom}, made on first use
+    #: PdbBatch.annotate_hits: the records of the matched atoms, copied out of the batch's text buffer -- sorted
+    #: kept-record indices and, row for row, 96 bytes from the start of each record's line
+    _picked_idx = None
+    _picked_lines = None
+    _row = None
+
     def __init__(self, text: Optional[bytes], id: Optional[str], n_atoms: int, min_bfactor: float, ignore_endmdl: bool,
                  path: Optional[str] = None):
         #: the file's bytes; None for a molecule of a batch read natively (PdbBatch.from_paths) until something
@@ -33,22 +50,9 @@ class LazyMolecule(pyjess.Molecule):
         self._text_bytes = text
         self._path = path
         self.id = id
-        self._n = int(n_atoms)
-        self._min_bfactor = float(min_bfactor)
-        self._ignore_endmdl = bool(ignore_endmdl)
-        self._loaded = None
-        self._atoms = None
-        self._enc = None
-        #: filled by PdbBatch.annotate(): byte offset of every kept record in the text, and the number of
-        #: distinct residue numbers among the counted residue names (what a TSV row needs) -- with those a
-        #: match is reported without parsing the whole file on the host
-        self._line_off = None
-        self._residue_count = None
-        self._picked = None  # {kept-record index: Atom}, made on first use
-        #: PdbBatch.annotate_hits: the records of the matched atoms, copied out of the batch's text buffer -- sorted
-        #: kept-record indices and, row for row, 96 bytes from the start of each record's line
-        self._picked_idx = None
-        self._picked_lines = None
+        self._n = n_atoms
+        self._min_bfactor = min_bfactor
+        self._ignore_endmdl = ignore_endmdl
 
     @property
     def _text(self):
@@ -204,16 +208,17 @@ class PdbBatch:
     @classmethod
     def from_paths(cls, paths: Sequence, **kw) -> "PdbBatch":
         """Same id rule as load_molecules: the file stem, with _2, _3 ... for repeated stems."""
-        import collections
         import os
 
-        paths = [os.fspath(p) for p in paths]
-        seen = collections.Counter()
+        paths = [p if type(p) is str else os.fspath(p) for p in paths]
+        seen: dict = {}
         ids = []
         for p in paths:
-            stem = os.path.splitext(os.path.basename(p))[0]
-            seen[stem] += 1
-            ids.append(stem if seen[stem] == 1 else f"{stem}_{seen[stem]}")
+            name = p[p.rfind(os.sep) + 1:]
+            dot = name.rfind(".")
+            stem = name[:dot] if 0 < dot < len(name) - 1 else name  # pathlib's PurePath.stem
+            count = seen[stem] = seen.get(stem, 0) + 1
+            ids.append(stem if count == 1 else f"{stem}_{count}")
         return cls(None, ids, paths=paths, **kw)  # read, uploaded and parsed without passing through Python
 
     def __len__(self):
