@@ -317,6 +317,17 @@ struct StagedSelection {
     // leaves the capacities to the library -- loose thresholds (enzymm's -j) produce orders of magnitude more
     // candidates than the defaults allow for, and an overflow costs a whole second run.
     std::atomic<unsigned long long> cands_per_katom{0}, pairs_per_katom{0};
+    // The logistic model tables of the hit epilogue as last uploaded for this selection (enzymm passes the same ones
+    // with every query): a query whose tables are identical uses these instead of four blocking uploads of its own,
+    // each of which would wait for the index and table build it has just enqueued.
+    std::mutex models_mu;
+    std::vector<int32_t> h_model_set;
+    std::vector<uint32_t> h_model_offsets, h_model_votes;
+    std::vector<double> h_models;
+    DevBuf<int32_t> d_model_set;
+    DevBuf<uint32_t> d_model_offsets, d_model_votes;
+    DevBuf<double> d_models;
+    bool models_cached = false;
     // pair tables the selection's templates read (see k_tab_* in tm_kernels.hip) and, per staged template, which ones
     std::vector<TableDesc> tables;
     DevBuf<TableDesc> d_tables;
@@ -1747,16 +1758,30 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
         const uint32_t ns = p->n_model_sets, nm = p->model_offsets[ns];
         for (uint32_t i = 0; i < n_sel; ++i)
             if (p->model_set[i] >= (int32_t)ns) return fail(TM_E_INVALID, "model_set index out of range");
+        std::vector<int32_t> ms(n_sel);
+        for (uint32_t i = 0; i < n_sel; ++i) ms[i] = p->model_set[S->order[i]];
+        std::vector<uint32_t> mo(p->model_offsets, p->model_offsets + ns + 1), mv(p->model_votes, p->model_votes + ns);
+        std::vector<double> mm(p->models, p->models + 4 * (size_t)nm);
+        bool shared = false;
         {
-            std::vector<int32_t> ms(n_sel);
-            for (uint32_t i = 0; i < n_sel; ++i) ms[i] = p->model_set[S->order[i]];
-            HIP_TRY(r->d_model_set.upload(ms));
+            std::lock_guard<std::mutex> lock(S->models_mu);
+            if (!S->models_cached) {  // first query with models on this selection: upload once, keep
+                HIP_TRY(S->d_model_set.upload(ms)); HIP_TRY(S->d_model_offsets.upload(mo));
+                HIP_TRY(S->d_model_votes.upload(mv)); HIP_TRY(S->d_models.upload(mm));
+                S->h_model_set = ms; S->h_model_offsets = mo; S->h_model_votes = mv; S->h_models = mm;
+                S->models_cached = true;
+            }
+            shared = S->h_model_set == ms && S->h_model_offsets == mo && S->h_model_votes == mv && S->h_models == mm;
         }
-        HIP_TRY(r->d_model_offsets.upload(std::vector<uint32_t>(p->model_offsets, p->model_offsets + ns + 1)));
-        HIP_TRY(r->d_model_votes.upload(std::vector<uint32_t>(p->model_votes, p->model_votes + ns)));
-        HIP_TRY(r->d_models.upload(std::vector<double>(p->models, p->models + 4 * (size_t)nm)));
-        Q.model_set = r->d_model_set.p; Q.model_offsets = r->d_model_offsets.p;
-        Q.model_votes = r->d_model_votes.p; Q.models = r->d_models.p;
+        if (shared) {  // r->selection keeps S (and these buffers) alive for as long as the result exists
+            Q.model_set = S->d_model_set.p; Q.model_offsets = S->d_model_offsets.p;
+            Q.model_votes = S->d_model_votes.p; Q.models = S->d_models.p;
+        } else {  // other tables than the cached ones: this result carries its own
+            HIP_TRY(r->d_model_set.upload(ms)); HIP_TRY(r->d_model_offsets.upload(mo));
+            HIP_TRY(r->d_model_votes.upload(mv)); HIP_TRY(r->d_models.upload(mm));
+            Q.model_set = r->d_model_set.p; Q.model_offsets = r->d_model_offsets.p;
+            Q.model_votes = r->d_model_votes.p; Q.models = r->d_models.p;
+        }
     }
     OutView O;
     O.cands = r->d_cands.p; O.cand_rmsd = r->d_cand_rmsd.p; O.n_cands = r->d_counters.p + 1; O.cand_capacity = ccap;
