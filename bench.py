@@ -308,6 +308,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
+    # ---- not part of `value`: the same K steps three more times -- the timed region of the contract is a fraction
+    # of a second, these show how far one such measurement moves (config.repeats_structures_per_s)
+    repeats = []
+    for _ in range(3):  # record=False: the per-kernel timings and the kept hit table stay those of the timed region
+        fence()
+        r0 = time.perf_counter()
+        run_steps(args.steps, False)
+        fence()
+        rt = torch.tensor([time.perf_counter() - r0], dtype=torch.float64, device="cpu" if one_gpu else "cuda")
+        if world > 1:
+            dist.all_reduce(rt, op=dist.ReduceOp.MAX)
+        repeats.append(args.structures * world * args.steps / float(rt.item()))
+
     # ---- not part of `value`: the kernels' durations with ONE search in flight (nothing else on the GPU), for
     # roofline.exclusive -- with two in flight the HIP events of a search also span what the other search's kernels ran
     exclusive_ms = None
@@ -399,6 +412,7 @@ def main():
                                 "(BASELINE.json configs[3] when 8 x 12500)")),
                 "generator": args.generator,
                 "structures_per_gpu": args.structures, "batch": args.batch, "templates": int(len(idx)),
+                "repeats_structures_per_s": repeats,  # the same K steps timed three more times (not `value`)
                 "streamed_structures_per_s": streamed,  # upload-inclusive (host atom tables -> HBM overlapped with the search)
                 "atoms_per_structure": n_atoms / max(1, len(molecules)),
                 "parallelism": f"structures sharded over {world} GPU(s), hit-table gather to rank 0",
