@@ -1417,9 +1417,11 @@ static int build_index(const tm_library *lib, tm_batch *b, tm_result *r, hipStre
     HIP_TRY(hipMemsetAsync(b->d_cursor.p, 0, sizeof(unsigned long long), stream));
     HIP_TRY(hipMemsetAsync(b->d_overflow.p, 0, sizeof(uint32_t), stream));
     if (b->n_structs && lib->n_lead) {
-        // LDS for the per-name atom buckets: structures above the cap scan all atoms for every lead kind
-        const uint32_t bucket_cap = 12288;
+        // LDS for the per-name atom buckets (4 B per atom of the largest structure): structures above the cap scan all
+        // their atoms for every lead kind -- 3.5 ms per batch of 25 k-atom complexes when the cap was 12 288 atoms
+        const uint32_t bucket_cap = 38912;  // 152 KB
         const size_t lds = ((size_t)lib->n_lead + 1 + std::min<uint32_t>(b->max_atoms, bucket_cap)) * sizeof(uint32_t);
+        HIP_TRY(allow_dynamic_lds(reinterpret_cast<const void *>(k_kind_lists), lds));
         hipLaunchKernelGGL(k_kind_lists, dim3(b->n_structs), dim3(512), lds, stream,
                            lib->view(), b->view(), b->d_kl_off.p, b->d_kl_pool.p, b->d_cursor.p, cap,
                            b->d_overflow.p, bucket_cap);
@@ -1521,7 +1523,9 @@ static int build_tables(const tm_library *lib, tm_batch *b, const StagedSelectio
     // (a batch of mostly large structures would not use the copy: without it two workgroups fit a CU and hide the
     // latency of reading the records through L2 twice as well)
     const bool mostly_large = (size_t)b->n_atoms > (size_t)3800 * ns;
-    const uint32_t lr_cap = mostly_large ? 0u : (uint32_t)std::min<size_t>(9600, std::max<size_t>(1024, 3 * (size_t)b->max_atoms));
+    // (such a batch still reserves 4096 records = 64 KB, two workgroups per CU: the staging area for list B of the
+    // big tables its workgroups build together)
+    const uint32_t lr_cap = mostly_large ? 4096u : (uint32_t)std::min<size_t>(9600, std::max<size_t>(1024, 3 * (size_t)b->max_atoms));
     const size_t lds_bytes = (size_t)lr_cap * sizeof(float4) + ((size_t)lib->n_lead + 2 + nt) * sizeof(uint32_t);
     uint32_t lr_arg = lr_cap;
 #ifdef TM_ABLATE

@@ -348,6 +348,8 @@ __global__ __launch_bounds__(256) void k_tab_layout(uint32_t n_lead, BatchView B
     }
 }
 
+// a table with more than this many (position A, position B) pairs is built by all waves of its workgroup together
+constexpr unsigned long long kTabShared = 256ull * 1024ull;
 constexpr int kTabBlock = 1024;  // threads of a k_tab_build workgroup: 16 waves share one LDS copy of the lead records
 
 // One sweep over the tiles of one table.  A tile lays TI rows x TJ columns over the 64 lanes, row-major (TJ = the
@@ -360,14 +362,18 @@ constexpr int kTabBlock = 1024;  // threads of a k_tab_build workgroup: 16 waves
 // Two tiles are in flight per iteration (two independent chains of LDS read -> distance -> vote): the loop is bound
 // by those latencies, not by issue.  When list B fits one tile its operand is loaded once per table.
 // Returns the number of passing pairs.
-template <bool kFill, class Lead>
-__device__ __forceinline__ uint32_t tab_sweep(Lead lead, uint32_t a_lo, uint32_t n_a, uint32_t b_lo, uint32_t n_b,
-                                              float dmax2, uint32_t *rows, uint2 *ent) {
+// A sweep may cover a block of rows of a larger table (several waves share a big table): `rows` then points at the
+// block's first row slot, `i_base` is that row's number and `row_base` the number of passing pairs in the rows before
+// it -- entries and row offsets are written for the whole table's numbering.  The return value counts this block only.
+template <bool kFill, class Lead, class LeadB>
+__device__ __forceinline__ uint32_t tab_sweep(Lead lead, LeadB lead_b, uint32_t a_lo, uint32_t n_a, uint32_t b_lo,
+                                              uint32_t n_b, float dmax2, uint32_t *rows, uint2 *ent,
+                                              uint32_t row_base = 0u, uint32_t i_base = 0u) {
     const uint32_t lane = threadIdx.x & 63;
-    uint32_t running = 0;
+    uint32_t running = row_base;
     if (n_b == 0u || n_a == 0u) {  // nothing to pair with: every row is empty
         if (kFill)
-            for (uint32_t i = lane; i < n_a; i += 64u) rows[i] = 0u;
+            for (uint32_t i = lane; i < n_a; i += 64u) rows[i] = row_base;
         return 0u;
     }
     const uint32_t shift = n_b <= 1u ? 0u : min(6u, 32u - (uint32_t)__clz((int)(n_b - 1u)));
@@ -382,7 +388,7 @@ __device__ __forceinline__ uint32_t tab_sweep(Lead lead, uint32_t a_lo, uint32_t
     if (n_b <= TJ) {
         // ---- list B is one tile wide: the column operand never changes, rows go by 2 x TI
         const bool vj = lj < n_b;
-        const float4 rb = lead(b_lo + (vj ? lj : 0u));
+        const float4 rb = lead_b(b_lo + (vj ? lj : 0u));
         for (uint32_t i0 = 0; i0 < n_a; i0 += 2u * TI) {
             const uint32_t iA = i0 + li, iB = iA + TI;
             const bool vA = iA < n_a, vB = iB < n_a;
@@ -392,8 +398,8 @@ __device__ __forceinline__ uint32_t tab_sweep(Lead lead, uint32_t a_lo, uint32_t
             const unsigned long long allA = ballot64(okA), allB = ballot64(okB);
             const uint32_t nA = (uint32_t)__popcll(allA);
             if (kFill) {
-                if (okA) ent[running + rank_in(allA)] = make_uint2(iA | (lj << 16), __float_as_uint(dA));
-                if (okB) ent[running + nA + rank_in(allB)] = make_uint2(iB | (lj << 16), __float_as_uint(dB));
+                if (okA) ent[running + rank_in(allA)] = make_uint2((iA + i_base) | (lj << 16), __float_as_uint(dA));
+                if (okB) ent[running + nA + rank_in(allB)] = make_uint2((iB + i_base) | (lj << 16), __float_as_uint(dB));
                 if (lj == 0u) {
                     if (vA) rows[iA] = running + (uint32_t)__popcll(allA & below);
                     if (vB) rows[iB] = running + nA + (uint32_t)__popcll(allB & below);
@@ -401,7 +407,7 @@ __device__ __forceinline__ uint32_t tab_sweep(Lead lead, uint32_t a_lo, uint32_t
             }
             running += nA + (uint32_t)__popcll(allB);
         }
-        return running;
+        return running - row_base;
     }
     // ---- list B is longer than 64: one row per tile (TI = 1), columns go by 2 x 64
     for (uint32_t i = 0; i < n_a; ++i) {
@@ -411,19 +417,19 @@ __device__ __forceinline__ uint32_t tab_sweep(Lead lead, uint32_t a_lo, uint32_t
         for (uint32_t j0 = 0; j0 < n_b; j0 += 128u) {
             const uint32_t jA = j0 + lane, jB = jA + 64u;
             const bool vA = jA < n_b, vB = jB < n_b;
-            const float4 rbA = lead(b_lo + (vA ? jA : 0u)), rbB = lead(b_lo + (vB ? jB : 0u));
+            const float4 rbA = lead_b(b_lo + (vA ? jA : 0u)), rbB = lead_b(b_lo + (vB ? jB : 0u));
             float dA, dB;
             const bool okA = test(ra, rbA, vA, dA), okB = test(ra, rbB, vB, dB);
             const unsigned long long allA = ballot64(okA), allB = ballot64(okB);
             const uint32_t nA = (uint32_t)__popcll(allA);
             if (kFill) {
-                if (okA) ent[running + rank_in(allA)] = make_uint2(i | (jA << 16), __float_as_uint(dA));
-                if (okB) ent[running + nA + rank_in(allB)] = make_uint2(i | (jB << 16), __float_as_uint(dB));
+                if (okA) ent[running + rank_in(allA)] = make_uint2((i + i_base) | (jA << 16), __float_as_uint(dA));
+                if (okB) ent[running + nA + rank_in(allB)] = make_uint2((i + i_base) | (jB << 16), __float_as_uint(dB));
             }
             running += nA + (uint32_t)__popcll(allB);
         }
     }
-    return running;
+    return running - row_base;
 }
 
 // All tables of one work item (structure, part), one wave per table.  Entries are bump-allocated per WAVE in chunks of
@@ -445,7 +451,9 @@ __device__ __forceinline__ void tab_build_tables(const BatchView &B, const Table
                                                  uint32_t *__restrict__ tab_rows, uint2 *__restrict__ tab_ent,
                                                  uint2 *__restrict__ tab_seg, unsigned long long *__restrict__ cursors,
                                                  unsigned long long ent_capacity, uint32_t *__restrict__ overflow,
-                                                 uint32_t *__restrict__ tab_ok, uint32_t dbg_mode) {
+                                                 uint32_t *__restrict__ tab_ok, uint32_t dbg_mode, uint32_t *s_count,
+                                                 unsigned long long *s_first, uint32_t n_lead, float4 *s_stage,
+                                                 uint32_t stage_cap) {
     const uint32_t nt = B.n_tables;
     const uint32_t wave = uni(threadIdx.x >> 6), n_waves = blockDim.x >> 6, lane = threadIdx.x & 63;
     auto lead = [&](uint32_t p) -> float4 { return kLds ? s_lr[p] : rec[pool[p]]; };
@@ -472,6 +480,7 @@ __device__ __forceinline__ void tab_build_tables(const BatchView &B, const Table
                        n_b = uni(kl[T.li_b + 1]) - b_lo;
         uint32_t *rows = tab_rows + B.tab_dir[(size_t)w.s * nt + t];
         const unsigned long long bound = (unsigned long long)n_a * n_b;
+        if (bound > kTabShared) continue;  // a big table: all waves build it together, below
         unsigned long long first = 0;
         uint32_t total = 0;
         if (dbg_mode == 2u) {
@@ -483,20 +492,73 @@ __device__ __forceinline__ void tab_build_tables(const BatchView &B, const Table
             }
             if (chunk != ~0ull) {
                 first = chunk + used;
-                total = tab_sweep<true>(lead, a_lo, n_a, b_lo, n_b, T.dmax2, rows, tab_ent + first);
+                total = tab_sweep<true>(lead, lead, a_lo, n_a, b_lo, n_b, T.dmax2, rows, tab_ent + first);
                 used += total;
             } else {
                 first = ~0ull;
             }
         } else {
-            total = tab_sweep<false>(lead, a_lo, n_a, b_lo, n_b, T.dmax2, nullptr, nullptr);
+            total = tab_sweep<false>(lead, lead, a_lo, n_a, b_lo, n_b, T.dmax2, nullptr, nullptr);
             first = allocate(total);
-            if (first != ~0ull && dbg_mode == 0u) tab_sweep<true>(lead, a_lo, n_a, b_lo, n_b, T.dmax2, rows, tab_ent + first);
+            if (first != ~0ull && dbg_mode == 0u) tab_sweep<true>(lead, lead, a_lo, n_a, b_lo, n_b, T.dmax2, rows, tab_ent + first);
         }
         if (lane == 0) {
             tab_seg[(size_t)w.s * nt + t] = first == ~0ull ? make_uint2(0u, 0u) : make_uint2((uint32_t)first, (uint32_t)first + total);
             rows[n_a] = total;
         }
+    }
+    // ---- big tables of this part (kind lists of several hundred atoms: large complexes): the rows are cut into one
+    // block per wave; every wave counts its block, the counts are summed up in LDS, the entries allocated once and
+    // every wave fills its block behind the blocks before it.  One wave per table left a 25 k-atom complex waiting for
+    // its largest table (9 ms for a single structure).
+    // (a structure whose longest kind list squared stays below the limit has none: most have none, and looking at
+    // every table's descriptor to find that out cost more than the tables of a 300-residue structure take to build)
+    uint32_t longest = 0;
+    for (uint32_t k = lane; k < n_lead; k += 64u) longest = max(longest, kl[k + 1] - kl[k]);
+    longest = wave_scan_max(longest);
+    longest = (uint32_t)__builtin_amdgcn_readlane((int)longest, 63);
+    if ((unsigned long long)longest * longest <= kTabShared) return;  // the same in every wave of the workgroup
+    for (uint32_t t = w.part; t < nt; t += w.parts) {
+        const TableDesc T = tables[t];
+        const uint32_t a_lo = uni(kl[T.li_a]), n_a = uni(kl[T.li_a + 1]) - a_lo, b_lo = uni(kl[T.li_b]),
+                       n_b = uni(kl[T.li_b + 1]) - b_lo;
+        if ((unsigned long long)n_a * n_b <= kTabShared) continue;  // same value in every wave: the barriers below are safe
+        uint32_t *rows = tab_rows + B.tab_dir[(size_t)w.s * nt + t];
+        const uint32_t block = (n_a + n_waves - 1u) / n_waves;
+        const uint32_t i0 = min(n_a, wave * block), i1 = min(n_a, i0 + block);
+        // a structure too large for the LDS copy of all its lead records reads them through L2 (two dependent loads
+        // per operand): list B of a big table, which every row block sweeps in full, is staged in that unused LDS
+        const bool staged = !kLds && n_b <= stage_cap;
+        if (staged) {
+            for (uint32_t j = threadIdx.x; j < n_b; j += blockDim.x) s_stage[j] = rec[pool[b_lo + j]];
+            __syncthreads();
+        }
+        // (two instantiations: a run-time choice per operand load would compile into a flat load)
+        auto build = [&](auto lead_b) {
+            const uint32_t mine = dbg_mode == 2u ? 0u : tab_sweep<false>(lead, lead_b, a_lo + i0, i1 - i0, b_lo, n_b, T.dmax2, nullptr, nullptr);
+            if (lane == 0) s_count[wave] = mine;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                uint32_t run = 0;
+                for (uint32_t k = 0; k < n_waves; ++k) { const uint32_t c = s_count[k]; s_count[k] = run; run += c; }
+                unsigned long long first = atomicAdd(&cursors[1], (unsigned long long)run);
+                if (first + run > ent_capacity) {
+                    atomicOr(overflow, 2u);
+                    tab_ok[w.s] = 0u;
+                    first = ~0ull;
+                }
+                *s_first = first;
+                tab_seg[(size_t)w.s * nt + t] = first == ~0ull ? make_uint2(0u, 0u) : make_uint2((uint32_t)first, (uint32_t)first + run);
+                rows[n_a] = run;
+            }
+            __syncthreads();
+            const unsigned long long first = *s_first;
+            if (first != ~0ull && dbg_mode == 0u)
+                tab_sweep<true>(lead, lead_b, a_lo + i0, i1 - i0, b_lo, n_b, T.dmax2, rows + i0, tab_ent + first, s_count[wave], i0);
+        };
+        if (staged) build([&](uint32_t p) -> float4 { return s_stage[p - b_lo]; });
+        else build(lead);
+        __syncthreads();  // s_count, s_first and the staged list are reused by the next big table
     }
 }
 
@@ -510,6 +572,8 @@ __global__ __launch_bounds__(kTabBlock) void k_tab_build(uint32_t n_lead, BatchV
                                                           unsigned long long ent_capacity, uint32_t *__restrict__ overflow,
                                                           uint32_t lr_cap) {
     extern __shared__ __align__(16) unsigned char tab_smem[];
+    __shared__ uint32_t s_count[kTabBlock / 64];
+    __shared__ unsigned long long s_first;
     const TabWork w = work[blockIdx.x];
     if (tab_ok[w.s] == 0u) return;  // its row slots did not fit (k_tab_layout)
 #ifdef TM_ABLATE
@@ -528,10 +592,10 @@ __global__ __launch_bounds__(kTabBlock) void k_tab_build(uint32_t n_lead, BatchV
         for (uint32_t i = threadIdx.x; i <= n_lead; i += blockDim.x) s_kl[i] = kl[i] - p0;
         __syncthreads();
         tab_build_tables<true>(B, tables, w, rec, B.kl_pool, s_lr, s_kl, tab_rows, tab_ent, tab_seg, cursors,
-                               ent_capacity, overflow, tab_ok, dbg_mode);
+                               ent_capacity, overflow, tab_ok, dbg_mode, s_count, &s_first, n_lead, nullptr, 0u);
     } else {
         tab_build_tables<false>(B, tables, w, rec, B.kl_pool, nullptr, kl, tab_rows, tab_ent, tab_seg, cursors,
-                                ent_capacity, overflow, tab_ok, dbg_mode);
+                                ent_capacity, overflow, tab_ok, dbg_mode, s_count, &s_first, n_lead, s_lr, lr_cap);
     }
 }
 
