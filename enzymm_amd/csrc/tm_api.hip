@@ -1527,6 +1527,9 @@ static int build_tables(const tm_library *lib, tm_batch *b, const StagedSelectio
     // big tables its workgroups build together)
     const uint32_t lr_cap = mostly_large ? 4096u : (uint32_t)std::min<size_t>(9600, std::max<size_t>(1024, 3 * (size_t)b->max_atoms));
     const size_t lds_bytes = (size_t)lr_cap * sizeof(float4) + ((size_t)lib->n_lead + 2 + nt) * sizeof(uint32_t);
+    unsigned long long shared_limit = kTabShared;
+    if (const char *env = std::getenv("ENZYMM_AMD_TAB_SHARED"))  // test hook: smaller tables take the shared build too
+        shared_limit = std::max<unsigned long long>(1, std::strtoull(env, nullptr, 10));
     uint32_t lr_arg = lr_cap;
 #ifdef TM_ABLATE
     if (const char *env = std::getenv("ENZYMM_AMD_TAB_DEBUG")) lr_arg |= (uint32_t)std::atoi(env) << 30;
@@ -1536,7 +1539,7 @@ static int build_tables(const tm_library *lib, tm_batch *b, const StagedSelectio
                        b->d_tab_cursors.p, rows, b->d_tab_overflow.p, b->d_tab_ok.p);
     hipLaunchKernelGGL(k_tab_build, dim3(b->tab_work_items), dim3(kTabBlock), lds_bytes, stream, lib->n_lead, B,
                        S->d_tables.p, b->d_tab_work.p, b->d_tab_ok.p, b->d_tab_rows.p, b->d_tab_ent.p, b->d_tab_seg.p,
-                       b->d_tab_cursors.p, ents, b->d_tab_overflow.p, lr_arg);
+                       b->d_tab_cursors.p, ents, b->d_tab_overflow.p, lr_arg, shared_limit);
     {
         const uint32_t n_sel = (uint32_t)S->sel.size();
         hipLaunchKernelGGL(k_tab_refs, dim3(ns, (n_sel + 255) / 256), dim3(256), 0, stream, B, n_sel, S->d_staged.p, b->d_tab_ref.p);

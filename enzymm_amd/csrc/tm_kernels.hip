@@ -349,6 +349,7 @@ __global__ __launch_bounds__(256) void k_tab_layout(uint32_t n_lead, BatchView B
 }
 
 // a table with more than this many (position A, position B) pairs is built by all waves of its workgroup together
+// (k_tab_build's shared_limit; ENZYMM_AMD_TAB_SHARED overrides it -- tests send ordinary structures down that path)
 constexpr unsigned long long kTabShared = 256ull * 1024ull;
 constexpr int kTabBlock = 1024;  // threads of a k_tab_build workgroup: 16 waves share one LDS copy of the lead records
 
@@ -453,7 +454,7 @@ __device__ __forceinline__ void tab_build_tables(const BatchView &B, const Table
                                                  unsigned long long ent_capacity, uint32_t *__restrict__ overflow,
                                                  uint32_t *__restrict__ tab_ok, uint32_t dbg_mode, uint32_t *s_count,
                                                  unsigned long long *s_first, uint32_t n_lead, float4 *s_stage,
-                                                 uint32_t stage_cap) {
+                                                 uint32_t stage_cap, unsigned long long shared_limit) {
     const uint32_t nt = B.n_tables;
     const uint32_t wave = uni(threadIdx.x >> 6), n_waves = blockDim.x >> 6, lane = threadIdx.x & 63;
     auto lead = [&](uint32_t p) -> float4 { return kLds ? s_lr[p] : rec[pool[p]]; };
@@ -480,7 +481,7 @@ __device__ __forceinline__ void tab_build_tables(const BatchView &B, const Table
                        n_b = uni(kl[T.li_b + 1]) - b_lo;
         uint32_t *rows = tab_rows + B.tab_dir[(size_t)w.s * nt + t];
         const unsigned long long bound = (unsigned long long)n_a * n_b;
-        if (bound > kTabShared) continue;  // a big table: all waves build it together, below
+        if (bound > shared_limit) continue;  // a big table: all waves build it together, below
         unsigned long long first = 0;
         uint32_t total = 0;
         if (dbg_mode == 2u) {
@@ -517,12 +518,12 @@ __device__ __forceinline__ void tab_build_tables(const BatchView &B, const Table
     for (uint32_t k = lane; k < n_lead; k += 64u) longest = max(longest, kl[k + 1] - kl[k]);
     longest = wave_scan_max(longest);
     longest = (uint32_t)__builtin_amdgcn_readlane((int)longest, 63);
-    if ((unsigned long long)longest * longest <= kTabShared) return;  // the same in every wave of the workgroup
+    if ((unsigned long long)longest * longest <= shared_limit) return;  // the same in every wave of the workgroup
     for (uint32_t t = w.part; t < nt; t += w.parts) {
         const TableDesc T = tables[t];
         const uint32_t a_lo = uni(kl[T.li_a]), n_a = uni(kl[T.li_a + 1]) - a_lo, b_lo = uni(kl[T.li_b]),
                        n_b = uni(kl[T.li_b + 1]) - b_lo;
-        if ((unsigned long long)n_a * n_b <= kTabShared) continue;  // same value in every wave: the barriers below are safe
+        if ((unsigned long long)n_a * n_b <= shared_limit) continue;  // same value in every wave: the barriers below are safe
         uint32_t *rows = tab_rows + B.tab_dir[(size_t)w.s * nt + t];
         const uint32_t block = (n_a + n_waves - 1u) / n_waves;
         const uint32_t i0 = min(n_a, wave * block), i1 = min(n_a, i0 + block);
@@ -570,7 +571,7 @@ __global__ __launch_bounds__(kTabBlock) void k_tab_build(uint32_t n_lead, BatchV
                                                           uint2 *__restrict__ tab_seg,
                                                           unsigned long long *__restrict__ cursors,
                                                           unsigned long long ent_capacity, uint32_t *__restrict__ overflow,
-                                                          uint32_t lr_cap) {
+                                                          uint32_t lr_cap, unsigned long long shared_limit) {
     extern __shared__ __align__(16) unsigned char tab_smem[];
     __shared__ uint32_t s_count[kTabBlock / 64];
     __shared__ unsigned long long s_first;
@@ -592,10 +593,10 @@ __global__ __launch_bounds__(kTabBlock) void k_tab_build(uint32_t n_lead, BatchV
         for (uint32_t i = threadIdx.x; i <= n_lead; i += blockDim.x) s_kl[i] = kl[i] - p0;
         __syncthreads();
         tab_build_tables<true>(B, tables, w, rec, B.kl_pool, s_lr, s_kl, tab_rows, tab_ent, tab_seg, cursors,
-                               ent_capacity, overflow, tab_ok, dbg_mode, s_count, &s_first, n_lead, nullptr, 0u);
+                               ent_capacity, overflow, tab_ok, dbg_mode, s_count, &s_first, n_lead, nullptr, 0u, shared_limit);
     } else {
         tab_build_tables<false>(B, tables, w, rec, B.kl_pool, nullptr, kl, tab_rows, tab_ent, tab_seg, cursors,
-                                ent_capacity, overflow, tab_ok, dbg_mode, s_count, &s_first, n_lead, s_lr, lr_cap);
+                                ent_capacity, overflow, tab_ok, dbg_mode, s_count, &s_first, n_lead, s_lr, lr_cap, shared_limit);
     }
 }
 

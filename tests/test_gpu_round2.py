@@ -465,3 +465,27 @@ def test_kind_lists_partly_outside_lds():
     want = sum(int((oracle.query_library(helpers.to_oracle_molecule(m), olib, 2.0, 1.5, 1.5, max_candidates=10000,
                                          ignore_chain=False)["hit"]).sum()) for m in mols)
     assert len(table_c) == want
+
+
+def test_shared_table_build_equals_one_wave_per_table(amy, af, monkeypatch):
+    """k_tab_build builds a table of more than 256 Ki position pairs with all waves of its workgroup (row blocks, counts
+    summed in LDS, one allocation).  Large complexes take that path with their lead records read through L2
+    (test_config5_large_complex, test_kind_lists_partly_outside_lds); with the limit lowered (ENZYMM_AMD_TAB_SHARED)
+    ordinary structures take it with the records in LDS -- the hit tables and candidate counts must not change, and
+    they are checked against the oracle for one structure."""
+    idx, cut = helpers.default_selection()
+    jess = pyjess.Jess(helpers.product_library_templates())
+    mols = [amy] + synthetic.structures(20, start=60) + [af]
+    q = lambda: jess.query_batch(mols, 2.0, cut, cut, max_candidates=10000, ignore_chain=True, template_index=idx,
+                                 count_candidates=True, return_raw=True)
+    want, want_c = q()
+    for limit in ("1", "900", "20000"):  # every table / most / the larger ones
+        monkeypatch.setenv("ENZYMM_AMD_TAB_SHARED", limit)
+        got, got_c = q()
+        assert got.tobytes() == want.tobytes() and np.array_equal(got_c, want_c), limit
+    jess9, olib = _every(9)
+    table, cands = jess9.query_batch([amy], 2.0, 1.5, 1.5, max_candidates=10000, ignore_chain=True,
+                                     count_candidates=True, return_raw=True)
+    r = oracle.query_library(helpers.to_oracle_molecule(amy), olib, 2.0, 1.5, 1.5, max_candidates=10000, ignore_chain=True)
+    assert compare(table, cands, 0, r, olib) > 0
+    assert len(want) > 30
