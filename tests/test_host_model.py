@@ -538,3 +538,17 @@ def test_batches_merge_in_reference_order_and_lists_are_cut_by_count_and_atoms(m
     gen.close()
     assert first in made and first not in closed and all(b in closed for b in made if b is not first)
     assert list(ingest.iter_molecule_batches([], batch_size=4)) == []
+
+
+def test_header_is_plain_c():
+    """The drop-in boundary is a C ABI: include/enzymm_amd.h must compile as C99 on its own (what a cgo / JNI / FFI
+    binding of the reference's host language would include)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    header = helpers.ROOT / "include" / "enzymm_amd.h"
+    out = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-fsyntax-only", "-x", "c", str(header)],
+                         capture_output=True, text=True)
+    assert out.returncode == 0 and "warning" not in out.stderr, out.stderr
