@@ -97,11 +97,12 @@ struct __align__(16) Staged {
     uint16_t lead_li[kMaxK];  // lead levels: index among lead kinds; 0xffff otherwise
     uint32_t packed[kMaxK];   // group | ref << 8 | any << 13 | orig << 14 | tchain << 24 (see lvl_* in tm_kernels.hip)
     uint8_t orig[kMaxK];      // search position -> template (file) order, also part of `packed`
-    uint8_t k, n_groups;
+    // one word, one load per search: k | n_groups << 8 | triple_key << 16 (triple_key 0: rows of the triple table
+    // are positions of lead 0, 1: of lead 1)
+    uint32_t hdr;
     uint16_t pair_table;    // table (lead 0, lead 1); 0xffff: fewer than two residues
     uint16_t triple_table;  // table (lead 0 or 1, lead 2); 0xffff: fewer than three residues
-    uint8_t triple_key;     // 0: rows of the triple table are positions of lead 0, 1: of lead 1
-    uint8_t pad;
+    __host__ __device__ uint32_t k() const { return hdr & 0xffu; }
 };
 
 struct QueryView {

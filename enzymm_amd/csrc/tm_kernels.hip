@@ -139,12 +139,9 @@ __global__ __launch_bounds__(64) void k_stage_templates(LibView L, uint32_t n_se
     if (lane == 0) {
         uint8_t g = 0;
         for (int i = 0; i < k; ++i) g = max(g, (uint8_t)(L.a_group[off + i] + 1));
-        S.k = (uint8_t)k;
-        S.n_groups = g;
+        S.hdr = (uint32_t)k | ((uint32_t)g << 8) | ((uint32_t)triple_key[ti] << 16);
         S.pair_table = pair_table[ti];
         S.triple_table = triple_table[ti];
-        S.triple_key = triple_key[ti];
-        S.pad = 0;
     }
     for (int p = lane; p < npairs; p += 64) {
         int i, j;
@@ -1225,7 +1222,7 @@ __device__ __forceinline__ void load_template(const QueryView &Q, uint32_t ti, i
     R.nm_hi = (uint32_t)(nm >> 32);
     R.li = T.lead_li[l];
     R.bound = Q.bounds[(size_t)ti * kMaxPairs + lane];
-    R.hdr = (uint32_t)T.k | ((uint32_t)T.n_groups << 8) | ((uint32_t)T.triple_key << 16);
+    R.hdr = T.hdr;
 }
 
 // The template loop of one workgroup: its waves claim the templates of the workgroup's chunk one by one and search
@@ -1506,7 +1503,7 @@ __device__ double superpose_candidate(const LibView &L, const BatchView &B, cons
                                       double R[9], double T[3]) {
     const uint32_t off = L.t_off[Q.sel[c.ti]];
     const Staged &St = Q.staged[c.ti];
-    const int k = (int)St.k;
+    const int k = (int)St.k();
     const double *qx = B.q_xyz + 3 * (size_t)B.s_off[c.s];
     // candidate atoms are stored in TEMPLATE order, library coordinates in SEARCH order
     double qc[3] = {0, 0, 0}, pc[3] = {0, 0, 0};
@@ -1646,7 +1643,7 @@ __global__ __launch_bounds__(256) void k_select(LibView L, BatchView B, QueryVie
     for (unsigned long long e = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
         const PairEntry pe = O.pairs[e];
         const double thr = Q.rmsd_thr[pe.ti];
-        const int k = (int)Q.staged[pe.ti].k;
+        const int k = (int)Q.staged[pe.ti].k();
         const uint32_t *orig = B.q_orig + B.s_off[pe.s];
         uint32_t best = 0xffffffffu;
         double best_rmsd = 0.0;
