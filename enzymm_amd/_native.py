@@ -91,7 +91,7 @@ EXPORTS = (
     "tm_batch_residue_counts",
     "tm_batch_destroy", "tm_query", "tm_result_wait", "tm_result_needed", "tm_result_hit_count",
     "tm_result_copy_hits", "tm_result_copy_candidates", "tm_result_timing", "tm_result_device_hits",
-    "tm_result_destroy", "tm_pdb_count_host", "tm_pdb_parse_host", "tm_pdb_count_host_many",
+    "tm_result_append_hits", "tm_result_destroy", "tm_pdb_count_host", "tm_pdb_parse_host", "tm_pdb_count_host_many",
     "tm_pdb_parse_host_many", "tm_files_sizes", "tm_files_read", "tm_batch_create_from_files", "tm_batch_file_text",
     "tm_stream_create", "tm_stream_destroy", "tm_batch_text_layout",
 )
@@ -533,6 +533,12 @@ class Result:
 
     def device_hits_ptr(self) -> int:
         return load().tm_result_device_hits(self._h) or 0
+
+    def append_hits(self, rows_ptr: int, capacity: int, count_ptr: int, structure_offset: int = 0):
+        """Enqueue (on the query's stream, no host wait) the copy of this query's hit rows into a caller-owned device
+        table: ``rows_ptr`` tm_hit[capacity], ``count_ptr`` a uint64 row counter, both device addresses."""
+        _check(load().tm_result_append_hits(self._h, C.c_void_p(rows_ptr), C.c_uint64(capacity), C.c_void_p(count_ptr),
+                                            C.c_uint32(structure_offset)))
 
     def close(self):
         if getattr(self, "_h", None):

@@ -304,6 +304,7 @@ hipError_t allow_dynamic_lds(const void *kernel, size_t bytes) {
 struct StagedSelection {
     std::vector<uint32_t> sel;
     std::vector<double> rmsd, cut, maxdyn;
+    double slack = kPrefilterSlack;  // fp32 prefilter slack the windows and table classes were staged with
     DevBuf<uint32_t> d_sel;
     DevBuf<double> d_rmsd, d_cut, d_maxdyn;
     DevBuf<float2> d_bounds;
@@ -321,7 +322,7 @@ struct StagedSelection {
     // with every query): a query whose tables are identical uses these instead of four blocking uploads of its own,
     // each of which would wait for the index and table build it has just enqueued.
     std::mutex models_mu;
-    std::vector<int32_t> h_model_set;
+    std::vector<int32_t> h_model_set;  // CALLER order (d_model_set is in staged order: h_model_set[order[i]])
     std::vector<uint32_t> h_model_offsets, h_model_votes;
     std::vector<double> h_models;
     DevBuf<int32_t> d_model_set;
@@ -341,6 +342,10 @@ struct StagedSelection {
     DevBuf<unsigned long long> d_cost;
     std::vector<float> measured;           // per caller index, valid in state 2
     std::atomic<int> calibration{0};       // 0 not measured, 1 measuring query in flight, 2 measured, 3 staged by measured cost
+    // mean atoms per structure of the batch the costs were measured on (the relative cost of templates moves with the
+    // size of the structures: a selection calibrated on 300-residue chains is measured again when it meets batches
+    // whose mean differs by more than a quarter)
+    std::atomic<uint32_t> calibrated_on{0}, calibrating_on{0};
     hipEvent_t ready = nullptr;  // recorded after k_stage_templates
     ~StagedSelection() {
         if (ready) (void)hipEventDestroy(ready);
@@ -351,7 +356,11 @@ struct StagedSelection {
 
 struct tm_library {
     mutable std::mutex sel_mu;
-    mutable std::shared_ptr<StagedSelection> last_selection;
+    // staged selections of this library, most recently used first.  enzymm queries a library with ONE parameter set
+    // per size bucket, but a caller that alternates between a few (per-size queries through one Jess, a threshold
+    // sweep) would otherwise stage 6780 templates and plan their tables again with every call.
+    static constexpr size_t kSelectionsKept = 8;
+    mutable std::vector<std::shared_ptr<StagedSelection>> selections;
     int device = 0;
     uint32_t n_templates = 0, n_atoms = 0, n_kinds = 0, n_lead = 0;
     std::vector<uint32_t> t_off;
@@ -394,6 +403,7 @@ struct IndexShared {
 struct tm_batch {
     int device = 0;
     uint32_t n_structs = 0, n_atoms = 0, max_atoms = 0, max_res = 0;
+    float extent = 0.f;  // largest |centred coordinate| of any atom (A): sizes the fp32 prefilter slack of its queries
     std::vector<uint32_t> s_off;
     DevBuf<uint32_t> d_s_off, d_s_roff, d_orig, d_kl_off;
     DevBuf<double> d_xyz;
@@ -738,8 +748,10 @@ int batch_from_encoded(int device, const tm_batch_desc *d, const double *const *
     trace.mark("limits");
 
     // pass 2: the structures are independent; a small team of threads flattens them
+    std::atomic<uint32_t> extent_bits{0};  // largest |centred coordinate| (non-negative floats order like their bits)
     auto flatten = [&](uint32_t s_begin, uint32_t s_end) {
         std::vector<uint32_t> count, perm, fill;
+        float reach = 0.f;
         for (uint32_t s = s_begin; s < s_end; ++s) {
             const uint32_t o = d->atom_offsets[s], n = d->atom_offsets[s + 1] - o, nres = nres_of[s];
             // counting sort by residue ordinal: atoms of a residue become contiguous, file order kept inside
@@ -764,6 +776,7 @@ int batch_from_encoded(int device, const tm_batch_desc *d, const double *const *
                 r.x = (float)(px[0] - c[0]);
                 r.y = (float)(px[1] - c[1]);
                 r.z = (float)(px[2] - c[2]);
+                reach = std::max(reach, std::max(std::fabs(r.x), std::max(std::fabs(r.y), std::fabs(r.z))));
                 const uint32_t nm = std::min<uint32_t>(d->name_id[src], TM_NAME_OTHER);
                 const uint32_t rt = std::min<uint32_t>(d->res_type[src], TM_RES_OTHER);
                 const uint32_t m = meta_pack(d->residue[src], nm, rt);
@@ -773,6 +786,10 @@ int batch_from_encoded(int device, const tm_batch_desc *d, const double *const *
                 orig[dst] = perm[j];
             }
         }
+        if (!(reach <= 3.0e38f)) reach = 3.0e38f;  // a NaN or infinite coordinate: the widest slack there is
+        uint32_t bits, seen = extent_bits.load();
+        std::memcpy(&bits, &reach, 4);
+        while (seen < bits && !extent_bits.compare_exchange_weak(seen, bits)) {}
     };
     {
         const uint32_t team = std::min<uint32_t>(host_team(), std::max(1u, na / 65536u));  // ~64 k atoms per thread at least
@@ -798,6 +815,10 @@ int batch_from_encoded(int device, const tm_batch_desc *d, const double *const *
     if (!b) return fail(TM_E_NOMEM, "out of host memory");
     b->device = device;
     b->n_structs = ns; b->n_atoms = na; b->max_atoms = max_atoms; b->max_res = max_res;
+    {
+        const uint32_t bits = extent_bits.load();
+        std::memcpy(&b->extent, &bits, 4);
+    }
     b->s_off.assign(d->atom_offsets, d->atom_offsets + ns + 1);
     hipError_t e = hipSuccess;
     auto up = [&](hipError_t r) { if (e == hipSuccess) e = r; };
@@ -1350,7 +1371,20 @@ int tm_batch_create_from_pdb(int device, uint32_t n_files, const char *const *te
                                hipMemcpyHostToDevice, stream));
         HIP_TRY(hipMemcpyAsync(b->d_residue_count.p + h.file, &h.residue_count, sizeof(uint32_t), hipMemcpyHostToDevice, stream));
     }
+    // the batch's extent (tm_batch::extent), measured where the records are
+    DevBuf<uint32_t> d_extent;
+    PinnedBuf<uint32_t> h_extent;
+    HIP_TRY(d_extent.alloc(1)); HIP_TRY(h_extent.alloc(1));
+    h_extent[0] = 0;
+    HIP_TRY(hipMemsetAsync(d_extent.p, 0, sizeof(uint32_t), stream));
+    if (n_atoms) {
+        hipLaunchKernelGGL(k_extent, dim3(std::min<uint32_t>(1024u, (uint32_t)((n_atoms + 255) / 256))), dim3(256), 0, stream,
+                           b->d_rec.p, (uint32_t)n_atoms, d_extent.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(h_extent.p, d_extent.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    }
     HIP_TRY(hipStreamSynchronize(stream));
+    std::memcpy(&b->extent, h_extent.p, 4);
     trace.mark("sync3");
     guard.b = nullptr;
     *out = b;
@@ -1414,8 +1448,13 @@ static int build_index(const tm_library *lib, tm_batch *b, tm_result *r, hipStre
         HIP_TRY(b->d_kl_pool.alloc(cap));
     }
     b->pool_capacity = cap;
-    HIP_TRY(hipMemsetAsync(b->d_cursor.p, 0, sizeof(unsigned long long), stream));
-    HIP_TRY(hipMemsetAsync(b->d_overflow.p, 0, sizeof(uint32_t), stream));
+    {
+        ZeroList z = {};
+        z.p[0] = b->d_cursor.p; z.words[0] = 2;
+        z.p[1] = b->d_overflow.p; z.words[1] = 1;
+        hipLaunchKernelGGL(k_zero, dim3(1), dim3(256), 0, stream, z);
+        HIP_TRY(hipGetLastError());
+    }
     if (b->n_structs && lib->n_lead) {
         // LDS for the per-name atom buckets (4 B per atom of the largest structure): structures above the cap scan all
         // their atoms for every lead kind -- 3.5 ms per batch of 25 k-atom complexes when the cap was 12 288 atoms
@@ -1434,11 +1473,12 @@ static int build_index(const tm_library *lib, tm_batch *b, tm_result *r, hipStre
 // The outcome of the index build the query searches -- pool entries needed, overflow bit -- travels with EVERY query
 // that uses that index, not only with the one that launched the build: a second query issued before the first one
 // was waited for reuses the index, and must report the same TM_E_OVERFLOW instead of returning with hits missing.
-static int carry_index_outcome(tm_batch *b, tm_result *r, hipStream_t stream) {
-    HIP_TRY(hipMemcpyAsync(r->d_pool_used.p, b->d_cursor.p, sizeof(unsigned long long), hipMemcpyDeviceToDevice, stream));
-    hipLaunchKernelGGL(k_flag_index_overflow, dim3(1), dim3(1), 0, stream, b->d_overflow.p, r->d_overflow.p);
+static int carry_build_outcome(tm_batch *b, tm_result *r, hipStream_t stream) {
+    hipLaunchKernelGGL(k_carry_outcome, dim3(1), dim3(1), 0, stream, b->d_cursor.p, b->d_overflow.p,
+                       b->d_tab_cursors.p, b->d_tab_overflow.p, r->d_pool_used.p, r->d_tab_used.p, r->d_overflow.p);
     HIP_TRY(hipGetLastError());
     r->pool_capacity = b->pool_capacity;
+    r->row_capacity = b->row_capacity; r->ent_capacity = b->ent_capacity;
     return TM_OK;
 }
 
@@ -1489,9 +1529,14 @@ static int build_tables(const tm_library *lib, tm_batch *b, const StagedSelectio
         if (b->d_tab_ref.n != ref_n) HIP_TRY(b->d_tab_ref.alloc(ref_n));
     }
     b->row_capacity = rows; b->ent_capacity = ents;
-    HIP_TRY(hipMemsetAsync(b->d_tab_cursors.p, 0, 2 * sizeof(unsigned long long), stream));
-    HIP_TRY(hipMemsetAsync(b->d_tab_overflow.p, 0, sizeof(uint32_t), stream));
-    HIP_TRY(hipMemsetAsync(b->d_tab_ok.p, 0, std::max<uint32_t>(ns, 1) * sizeof(uint32_t), stream));
+    {
+        ZeroList z = {};
+        z.p[0] = b->d_tab_cursors.p; z.words[0] = 4;
+        z.p[1] = b->d_tab_overflow.p; z.words[1] = 1;
+        z.p[2] = b->d_tab_ok.p; z.words[2] = std::max<uint32_t>(ns, 1);
+        hipLaunchKernelGGL(k_zero, dim3(1), dim3(256), 0, stream, z);
+        HIP_TRY(hipGetLastError());
+    }
     b->tables_for = S->serial;
     if (!ns) return TM_OK;
     if (!nt) {  // no template of the selection has two residues: nothing to build, every structure is searchable
@@ -1526,7 +1571,7 @@ static int build_tables(const tm_library *lib, tm_batch *b, const StagedSelectio
     // (such a batch still reserves 4096 records = 64 KB, two workgroups per CU: the staging area for list B of the
     // big tables its workgroups build together)
     const uint32_t lr_cap = mostly_large ? 4096u : (uint32_t)std::min<size_t>(9600, std::max<size_t>(1024, 3 * (size_t)b->max_atoms));
-    const size_t lds_bytes = (size_t)lr_cap * sizeof(float4) + ((size_t)lib->n_lead + 2 + nt) * sizeof(uint32_t);
+    const size_t lds_bytes = (size_t)lr_cap * sizeof(float4) + ((size_t)lib->n_lead + 2) * sizeof(uint32_t);  // s_lr + s_kl
     unsigned long long shared_limit = kTabShared;
     if (const char *env = std::getenv("ENZYMM_AMD_TAB_SHARED"))  // test hook: smaller tables take the shared build too
         shared_limit = std::max<unsigned long long>(1, std::strtoull(env, nullptr, 10));
@@ -1545,15 +1590,6 @@ static int build_tables(const tm_library *lib, tm_batch *b, const StagedSelectio
         hipLaunchKernelGGL(k_tab_refs, dim3(ns, (n_sel + 255) / 256), dim3(256), 0, stream, B, n_sel, S->d_staged.p, b->d_tab_ref.p);
     }
     HIP_TRY(hipGetLastError());
-    return TM_OK;
-}
-
-// like carry_index_outcome, for the pair tables
-static int carry_table_outcome(tm_batch *b, tm_result *r, hipStream_t stream) {
-    HIP_TRY(hipMemcpyAsync(r->d_tab_used.p, b->d_tab_cursors.p, 2 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, stream));
-    hipLaunchKernelGGL(k_flag_table_overflow, dim3(1), dim3(1), 0, stream, b->d_tab_overflow.p, r->d_overflow.p);
-    HIP_TRY(hipGetLastError());
-    r->row_capacity = b->row_capacity; r->ent_capacity = b->ent_capacity;
     return TM_OK;
 }
 
@@ -1577,22 +1613,35 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
     const uint32_t n_sel = p->n_selected;
     for (auto &e : r->ev) HIP_TRY(hipEventCreate(&e));
 
-    // the staged selection: reused when this library was last queried with identical arguments
+    // fp32 prefilter slack: a property of the batch's extent (2e-3 A unless a structure reaches beyond 4096 A of its
+    // centroid) and, with the thresholds, of the staged windows and table classes
+    const double slack = prefilter_slack((double)b->extent);
+    // the staged selection: reused when this library was queried with identical arguments before (a few are kept)
     std::shared_ptr<StagedSelection> S;
     bool stage_now = false;
     {
         std::lock_guard<std::mutex> lock(lib->sel_mu);
-        const auto &last = lib->last_selection;
-        const bool same = last && last->sel.size() == n_sel &&
-            std::equal(last->sel.begin(), last->sel.end(), p->template_index) &&
-            std::equal(last->rmsd.begin(), last->rmsd.end(), p->rmsd_threshold) &&
-            std::equal(last->cut.begin(), last->cut.end(), p->distance_cutoff) &&
-            std::equal(last->maxdyn.begin(), last->maxdyn.end(), p->max_dynamic_distance);
+        std::shared_ptr<StagedSelection> last;
+        size_t found = lib->selections.size();
+        for (size_t i = 0; i < lib->selections.size(); ++i) {
+            const auto &c = lib->selections[i];
+            if (c->sel.size() == n_sel && c->slack == slack && std::equal(c->sel.begin(), c->sel.end(), p->template_index) &&
+                std::equal(c->rmsd.begin(), c->rmsd.end(), p->rmsd_threshold) &&
+                std::equal(c->cut.begin(), c->cut.end(), p->distance_cutoff) &&
+                std::equal(c->maxdyn.begin(), c->maxdyn.end(), p->max_dynamic_distance)) {
+                found = i;
+                last = c;
+                break;
+            }
+        }
+        const bool same = last != nullptr;
         const bool restage = same && last->calibration.load() == 2;  // measured: stage once more, in measured order
         if (same && !restage) {
             S = last;
+            if (found != 0) std::rotate(lib->selections.begin(), lib->selections.begin() + found, lib->selections.begin() + found + 1);
         } else {
             S = std::make_shared<StagedSelection>();
+            S->slack = slack;
             S->sel.assign(p->template_index, p->template_index + n_sel);
             S->rmsd.assign(p->rmsd_threshold, p->rmsd_threshold + n_sel);
             S->cut.assign(p->distance_cutoff, p->distance_cutoff + n_sel);
@@ -1603,6 +1652,10 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
                 const std::vector<float> &cost = last->measured;
                 std::stable_sort(S->order.begin(), S->order.end(), [&](uint32_t x, uint32_t y) { return cost[x] > cost[y]; });
                 S->calibration = 3;
+                S->calibrated_on = last->calibrating_on.load();
+                // what the selection has learned stays with it: the sizes its queries needed ...
+                S->cands_per_katom = last->cands_per_katom.load();
+                S->pairs_per_katom = last->pairs_per_katom.load();
             } else {
                 std::stable_sort(S->order.begin(), S->order.end(), [&](uint32_t x, uint32_t y) {
                     return lib->cost_weight[S->sel[x]] > lib->cost_weight[S->sel[y]];
@@ -1649,7 +1702,7 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
                             d2 += d * d;
                         }
                         const double thr = std::min(S->cut[o] + lib->h_w[off + x] + lib->h_w[off + y], S->maxdyn[o]);
-                        return std::sqrt(d2) + thr + kPrefilterSlack;
+                        return std::sqrt(d2) + thr + S->slack;
                     };
                     int id = 0;
                     if (G >= 2) {
@@ -1689,11 +1742,28 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
             if (n_sel) {
                 hipLaunchKernelGGL(k_stage_templates, dim3(n_sel), dim3(64), 0, stream, lib->view(), n_sel, S->d_sel.p,
                                    S->d_cut.p, S->d_maxdyn.p, S->d_pair_table.p, S->d_triple_table.p, S->d_triple_key.p,
-                                   S->d_staged.p, S->d_bounds.p);
+                                   S->d_staged.p, S->d_bounds.p, S->slack);
                 HIP_TRY(hipGetLastError());
             }
             HIP_TRY(hipEventRecord(S->ready, stream));
-            lib->last_selection = S;
+            if (restage) {
+                // ... and the logistic model tables of the hit epilogue (model_set follows the new order)
+                std::lock_guard<std::mutex> mlock(last->models_mu);
+                if (last->models_cached) {
+                    std::vector<int32_t> ms(n_sel);
+                    for (uint32_t i = 0; i < n_sel; ++i) ms[i] = last->h_model_set[S->order[i]];
+                    HIP_TRY(S->d_model_set.upload(ms)); HIP_TRY(S->d_model_offsets.upload(last->h_model_offsets));
+                    HIP_TRY(S->d_model_votes.upload(last->h_model_votes)); HIP_TRY(S->d_models.upload(last->h_models));
+                    S->h_model_set = last->h_model_set; S->h_model_offsets = last->h_model_offsets;
+                    S->h_model_votes = last->h_model_votes; S->h_models = last->h_models;
+                    S->models_cached = true;
+                }
+                lib->selections[found] = S;
+                if (found != 0) std::rotate(lib->selections.begin(), lib->selections.begin() + found, lib->selections.begin() + found + 1);
+            } else {
+                lib->selections.insert(lib->selections.begin(), S);
+                if (lib->selections.size() > tm_library::kSelectionsKept) lib->selections.pop_back();
+            }
             stage_now = true;
         }
     }
@@ -1716,10 +1786,16 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
     HIP_TRY(r->d_overflow.alloc(1));
     HIP_TRY(r->d_pool_used.alloc(1));
     HIP_TRY(r->d_tab_used.alloc(2));
-    HIP_TRY(hipMemsetAsync(r->d_pool_used.p, 0, sizeof(unsigned long long), stream));
     r->index_shared = b->index_shared;
-    HIP_TRY(hipMemsetAsync(r->d_counters.p, 0, 3 * sizeof(unsigned long long), stream));
-    HIP_TRY(hipMemsetAsync(r->d_overflow.p, 0, sizeof(uint32_t), stream));
+    {
+        ZeroList z = {};
+        z.p[0] = r->d_pool_used.p; z.words[0] = 2;
+        z.p[1] = r->d_counters.p; z.words[1] = 6;
+        z.p[2] = r->d_overflow.p; z.words[2] = 1;
+        z.p[3] = r->d_tab_used.p; z.words[3] = 4;
+        hipLaunchKernelGGL(k_zero, dim3(1), dim3(256), 0, stream, z);
+        HIP_TRY(hipGetLastError());
+    }
     if (p->flags & TM_FLAG_COUNT_CANDIDATES) {
         HIP_TRY(r->d_candidates.alloc((size_t)b->n_structs * n_sel));
         HIP_TRY(hipMemsetAsync(r->d_candidates.p, 0, (size_t)b->n_structs * n_sel * sizeof(uint32_t), stream));
@@ -1739,8 +1815,7 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
         if (rc != TM_OK) return rc;
     }
     {
-        int rc = carry_index_outcome(b, r, stream);
-        if (rc == TM_OK) rc = carry_table_outcome(b, r, stream);
+        int rc = carry_build_outcome(b, r, stream);
         if (rc != TM_OK) return rc;
     }
     HIP_TRY(hipEventRecord(r->ev[1], stream));
@@ -1753,7 +1828,14 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
     Q.cost = nullptr;
     {
         int expected = 0;
+        const uint32_t mean_atoms = b->n_structs ? (uint32_t)(b->n_atoms / b->n_structs) : 0u;
+        if (S->calibration.load() == 3) {  // measured before: once more when these structures are of another size
+            const uint32_t ref = S->calibrated_on.load();
+            const uint32_t off = mean_atoms > ref ? mean_atoms - ref : ref - mean_atoms;
+            if (ref && 4u * off > ref) expected = 3;
+        }
         if (n_sel && b->n_structs >= 64 && S->calibration.compare_exchange_strong(expected, 1)) {  // enough searches to average
+            S->calibrating_on = mean_atoms;
             HIP_TRY(S->d_cost.alloc(n_sel));
             HIP_TRY(hipMemsetAsync(S->d_cost.p, 0, n_sel * sizeof(unsigned long long), stream));
             Q.cost = S->d_cost.p;
@@ -1765,7 +1847,7 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
         const uint32_t ns = p->n_model_sets, nm = p->model_offsets[ns];
         for (uint32_t i = 0; i < n_sel; ++i)
             if (p->model_set[i] >= (int32_t)ns) return fail(TM_E_INVALID, "model_set index out of range");
-        std::vector<int32_t> ms(n_sel);
+        std::vector<int32_t> ms(n_sel), ms_caller(p->model_set, p->model_set + n_sel);
         for (uint32_t i = 0; i < n_sel; ++i) ms[i] = p->model_set[S->order[i]];
         std::vector<uint32_t> mo(p->model_offsets, p->model_offsets + ns + 1), mv(p->model_votes, p->model_votes + ns);
         std::vector<double> mm(p->models, p->models + 4 * (size_t)nm);
@@ -1775,10 +1857,10 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
             if (!S->models_cached) {  // first query with models on this selection: upload once, keep
                 HIP_TRY(S->d_model_set.upload(ms)); HIP_TRY(S->d_model_offsets.upload(mo));
                 HIP_TRY(S->d_model_votes.upload(mv)); HIP_TRY(S->d_models.upload(mm));
-                S->h_model_set = ms; S->h_model_offsets = mo; S->h_model_votes = mv; S->h_models = mm;
+                S->h_model_set = ms_caller; S->h_model_offsets = mo; S->h_model_votes = mv; S->h_models = mm;
                 S->models_cached = true;
             }
-            shared = S->h_model_set == ms && S->h_model_offsets == mo && S->h_model_votes == mv && S->h_models == mm;
+            shared = S->h_model_set == ms_caller && S->h_model_offsets == mo && S->h_model_votes == mv && S->h_models == mm;
         }
         if (shared) {  // r->selection keeps S (and these buffers) alive for as long as the result exists
             Q.model_set = S->d_model_set.p; Q.model_offsets = S->d_model_offsets.p;
@@ -1991,6 +2073,16 @@ int tm_result_timing(tm_result *r, float *index_ms, float *search_ms, float *fin
 }
 
 const void *tm_result_device_hits(tm_result *r) { return r ? r->d_hits.p : nullptr; }
+
+int tm_result_append_hits(tm_result *r, void *rows, uint64_t capacity, uint64_t *count, uint32_t structure_offset) {
+    if (!r || !count || (!rows && capacity)) return fail(TM_E_INVALID, "tm_result_append_hits: NULL argument");
+    HIP_TRY(hipSetDevice(r->device));
+    hipLaunchKernelGGL(k_append_hits, dim3(1), dim3(1024), 0, r->stream, r->d_hits.p, r->d_counters.p, r->hit_capacity,
+                       reinterpret_cast<tm_hit *>(rows), (unsigned long long)capacity,
+                       reinterpret_cast<unsigned long long *>(count), structure_offset);
+    HIP_TRY(hipGetLastError());
+    return TM_OK;
+}
 
 #ifdef TM_STATS
 // diagnostic build only (make stats): read and reset the search counters

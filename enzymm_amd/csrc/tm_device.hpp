@@ -26,12 +26,21 @@ struct TableDesc {
 constexpr int kTableClasses = 5;
 constexpr double kTableClassLimit[kTableClasses] = {8.0, 12.0, 16.0, 24.0, 1e30};  // upper window edge (A) per class
 
-// fp32 prefilter slack (Angstrom) added to every pair threshold.  Centred fp32
-// coordinates of a <= 300 A structure carry < 4e-5 A of rounding; anything the
-// slack lets through is re-checked in fp64 before it can become a candidate.
+// fp32 prefilter slack (Angstrom) added to every pair threshold; anything the slack lets through is re-checked in
+// fp64 before it can become a candidate.  What it has to cover is the rounding of the CENTRED fp32 coordinates: half
+// an ulp per coordinate, 2^-24 |c| -- for a structure whose atoms lie within kPrefilterExtent of its centroid at most
+// sqrt(3) x 2 x 2.44e-4 = 8.5e-4 A on a distance (a 300-residue protein: 1e-5 A), plus 2e-5 A for the squared-distance
+// arithmetic and the rounding of the window edges.  A batch with a structure beyond that extent (the upload measures
+// it, tm_batch::extent) is searched with the slack doubled per doubling of the extent: prefilter_slack().
 constexpr double kPrefilterSlack = 2e-3;
+constexpr double kPrefilterExtent = 4096.0;
+inline double prefilter_slack(double extent) {
+    double slack = kPrefilterSlack;
+    for (double reach = kPrefilterExtent; reach < extent; reach *= 2.0) slack *= 2.0;
+    return slack;
+}
 
-// best_match: RMSDs closer than this are a tie, resolved by the smaller atom-index tuple.
+// best_match: candidates within this of the (global) minimum RMSD are tied with it; the smallest atom-index tuple wins.
 constexpr double kTieEps = 1e-9;
 
 // bits of the packed per-atom meta word (float4.w of a target atom record)
@@ -84,7 +93,7 @@ struct BatchView {
     uint32_t n_tables;
     const uint32_t *tab_dir;   // [n_structs * n_tables] first row slot of the table
     const uint2 *tab_seg;      // [n_structs * n_tables] (first entry, one past the last entry) of the table
-    const uint32_t *tab_ok;    // [n_structs] 1: the structure's tables are complete
+    const uint32_t *tab_ok;    // [n_structs] 1: the structure's tables are complete (bit 0: row slots fit, bit 1: entries ran out)
     const uint4 *tab_ref;      // [n_structs * n_sel] per (structure, selected template): see k_tab_refs
     const uint32_t *tab_rows;  // row offsets (absolute entry indices); a table with n rows owns n + 1 slots
     const uint2 *tab_ent;      // {position in list A | position in list B << 16, squared distance (fp32 bits)}

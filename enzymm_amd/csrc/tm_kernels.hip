@@ -13,6 +13,8 @@
 // satisfies all pair-distance constraints, superpose each, keep the minimum-RMSD one.
 // The enumeration ORDER is this kernel's own (lead atoms of all template residues first); the
 // SET of complete assignments does not depend on it.
+#include <cstddef>
+
 #include "tm_device.hpp"
 
 namespace tmx {
@@ -111,7 +113,8 @@ __global__ __launch_bounds__(64) void k_stage_templates(LibView L, uint32_t n_se
                                                          const uint16_t *__restrict__ pair_table,
                                                          const uint16_t *__restrict__ triple_table,
                                                          const uint8_t *__restrict__ triple_key,
-                                                         Staged *__restrict__ staged, float2 *__restrict__ bounds) {
+                                                         Staged *__restrict__ staged, float2 *__restrict__ bounds,
+                                                         double slack) {
     const uint32_t ti = blockIdx.x;
     if (ti >= n_sel) return;
     const uint32_t t = sel[ti];
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(64) void k_stage_templates(LibView L, uint32_t n_se
         const double dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
         const double dt = sqrt(dx * dx + dy * dy + dz * dz);
         double thr = cut + L.a_w[off + i] + L.a_w[off + j];
-        thr = (thr < mx ? thr : mx) + kPrefilterSlack;
+        thr = (thr < mx ? thr : mx) + slack;
         const double lo = dt - thr, hi = dt + thr;
         const float lo2 = lo > 0.0 ? (float)(lo * lo) * (1.0f - 1e-6f) : 0.0f;
         const float hi2 = (float)(hi * hi) * (1.0f + 1e-6f);
@@ -284,9 +287,44 @@ __global__ __launch_bounds__(512) void k_kind_lists(LibView L, BatchView B, uint
     }
 }
 
-// one thread: carries the index build's overflow flag into the query's overflow word (bit 3)
-__global__ void k_flag_index_overflow(const uint32_t *__restrict__ index_overflow, uint32_t *__restrict__ query_overflow) {
-    if (*index_overflow) atomicOr(query_overflow, 8u);
+// Largest |centred coordinate| of a batch's atom records, as float bits (non-negative floats order like integers):
+// what the fp32 prefilter's slack must cover (tm_device.hpp, prefilter_slack).
+__global__ __launch_bounds__(256) void k_extent(const float4 *__restrict__ rec, uint32_t n, uint32_t *__restrict__ out) {
+    float m = 0.f;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 r = rec[i];
+        m = fmaxf(m, fmaxf(fabsf(r.x), fmaxf(fabsf(r.y), fabsf(r.z))));
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
+// A query resets a dozen counters and flags before its kernels run and copies a few afterwards; one small launch per
+// group instead of a hipMemsetAsync / hipMemcpyAsync per word (the host side of a single-structure query is enqueue
+// time: DESIGN.md 6, configs[1]).
+struct ZeroList {
+    void *p[6];
+    uint32_t words[6];  // 32-bit words to clear at p[i]
+};
+__global__ __launch_bounds__(256) void k_zero(ZeroList z) {
+    for (int i = 0; i < 6; ++i)
+        for (uint32_t w = threadIdx.x; w < z.words[i]; w += blockDim.x) reinterpret_cast<uint32_t *>(z.p[i])[w] = 0u;
+}
+
+// one thread: what the index and table builds this query searches needed and whether they overflowed, carried into the
+// query's own words (bits 3 and 4 of its overflow word; see carry_build_outcome in tm_api.hip)
+__global__ void k_carry_outcome(const unsigned long long *__restrict__ index_cursor, const uint32_t *__restrict__ index_overflow,
+                                const unsigned long long *__restrict__ tab_cursors, const uint32_t *__restrict__ tab_overflow,
+                                unsigned long long *__restrict__ pool_used, unsigned long long *__restrict__ tab_used,
+                                uint32_t *__restrict__ query_overflow) {
+    *pool_used = *index_cursor;
+    uint32_t bits = *index_overflow ? 8u : 0u;
+    if (tab_cursors) {
+        tab_used[0] = tab_cursors[0];
+        tab_used[1] = tab_cursors[1];
+        if (*tab_overflow) bits |= 16u;
+    }
+    if (bits) atomicOr(query_overflow, bits);
 }
 
 // ------------------------------------------------------------------ pair tables
@@ -451,7 +489,7 @@ __device__ __forceinline__ void tab_build_tables(const BatchView &B, const Table
                                                  unsigned long long ent_capacity, uint32_t *__restrict__ overflow,
                                                  uint32_t *__restrict__ tab_ok, uint32_t dbg_mode, uint32_t *s_count,
                                                  unsigned long long *s_first, uint32_t n_lead, float4 *s_stage,
-                                                 uint32_t stage_cap, unsigned long long shared_limit) {
+                                                 uint32_t stage_cap, unsigned long long shared_limit, bool rows_ok) {
     const uint32_t nt = B.n_tables;
     const uint32_t wave = uni(threadIdx.x >> 6), n_waves = blockDim.x >> 6, lane = threadIdx.x & 63;
     auto lead = [&](uint32_t p) -> float4 { return kLds ? s_lr[p] : rec[pool[p]]; };
@@ -462,7 +500,7 @@ __device__ __forceinline__ void tab_build_tables(const BatchView &B, const Table
             first = atomicAdd(&cursors[1], n);
             if (first + n > ent_capacity) {
                 atomicOr(overflow, 2u);
-                tab_ok[w.s] = 0u;
+                atomicOr(&tab_ok[w.s], 2u);
                 first = ~0ull;
             }
         }
@@ -488,19 +526,23 @@ __device__ __forceinline__ void tab_build_tables(const BatchView &B, const Table
                 chunk = allocate(kTabChunk);
                 used = 0;
             }
-            if (chunk != ~0ull) {
+            if (rows_ok && chunk != ~0ull) {
                 first = chunk + used;
                 total = tab_sweep<true>(lead, lead, a_lo, n_a, b_lo, n_b, T.dmax2, rows, tab_ent + first);
-                used += total;
             } else {
+                // no room (or no row slots): count only, and let the wave's chunk fill up exactly as it would have --
+                // the entry cursor then ends on what a build with room hands out, and ONE retry is sized right
                 first = ~0ull;
+                total = tab_sweep<false>(lead, lead, a_lo, n_a, b_lo, n_b, T.dmax2, nullptr, nullptr);
             }
+            used += total;
         } else {
             total = tab_sweep<false>(lead, lead, a_lo, n_a, b_lo, n_b, T.dmax2, nullptr, nullptr);
             first = allocate(total);
+            if (!rows_ok) first = ~0ull;
             if (first != ~0ull && dbg_mode == 0u) tab_sweep<true>(lead, lead, a_lo, n_a, b_lo, n_b, T.dmax2, rows, tab_ent + first);
         }
-        if (lane == 0) {
+        if (lane == 0 && rows_ok) {
             tab_seg[(size_t)w.s * nt + t] = first == ~0ull ? make_uint2(0u, 0u) : make_uint2((uint32_t)first, (uint32_t)first + total);
             rows[n_a] = total;
         }
@@ -542,12 +584,15 @@ __device__ __forceinline__ void tab_build_tables(const BatchView &B, const Table
                 unsigned long long first = atomicAdd(&cursors[1], (unsigned long long)run);
                 if (first + run > ent_capacity) {
                     atomicOr(overflow, 2u);
-                    tab_ok[w.s] = 0u;
+                    atomicOr(&tab_ok[w.s], 2u);
                     first = ~0ull;
                 }
+                if (!rows_ok) first = ~0ull;
                 *s_first = first;
-                tab_seg[(size_t)w.s * nt + t] = first == ~0ull ? make_uint2(0u, 0u) : make_uint2((uint32_t)first, (uint32_t)first + run);
-                rows[n_a] = run;
+                if (rows_ok) {
+                    tab_seg[(size_t)w.s * nt + t] = first == ~0ull ? make_uint2(0u, 0u) : make_uint2((uint32_t)first, (uint32_t)first + run);
+                    rows[n_a] = run;
+                }
             }
             __syncthreads();
             const unsigned long long first = *s_first;
@@ -573,7 +618,11 @@ __global__ __launch_bounds__(kTabBlock) void k_tab_build(uint32_t n_lead, BatchV
     __shared__ uint32_t s_count[kTabBlock / 64];
     __shared__ unsigned long long s_first;
     const TabWork w = work[blockIdx.x];
-    if (tab_ok[w.s] == 0u) return;  // its row slots did not fit (k_tab_layout)
+    // Bit 0 of tab_ok[s]: the structure's row slots fit (k_tab_layout; never changes while this kernel runs).  Bit 1 is
+    // set by whichever workgroup of the structure runs out of entries -- at any moment, so nothing here branches on it:
+    // a structure without row slots, or a wave whose entries do not fit, keeps sweeping in count-only mode, so that
+    // cursors[1] ends on what a build with room would have handed out.
+    const bool rows_ok = (tab_ok[w.s] & 1u) != 0u;
 #ifdef TM_ABLATE
     const uint32_t dbg_mode = lr_cap >> 30;  // timing experiments: 1 no fill sweep, 2 no sweeps at all
     lr_cap &= 0x3fffffffu;
@@ -590,10 +639,10 @@ __global__ __launch_bounds__(kTabBlock) void k_tab_build(uint32_t n_lead, BatchV
         for (uint32_t i = threadIdx.x; i <= n_lead; i += blockDim.x) s_kl[i] = kl[i] - p0;
         __syncthreads();
         tab_build_tables<true>(B, tables, w, rec, B.kl_pool, s_lr, s_kl, tab_rows, tab_ent, tab_seg, cursors,
-                               ent_capacity, overflow, tab_ok, dbg_mode, s_count, &s_first, n_lead, nullptr, 0u, shared_limit);
+                               ent_capacity, overflow, tab_ok, dbg_mode, s_count, &s_first, n_lead, nullptr, 0u, shared_limit, rows_ok);
     } else {
         tab_build_tables<false>(B, tables, w, rec, B.kl_pool, nullptr, kl, tab_rows, tab_ent, tab_seg, cursors,
-                                ent_capacity, overflow, tab_ok, dbg_mode, s_count, &s_first, n_lead, s_lr, lr_cap, shared_limit);
+                                ent_capacity, overflow, tab_ok, dbg_mode, s_count, &s_first, n_lead, s_lr, lr_cap, shared_limit, rows_ok);
     }
 }
 
@@ -624,11 +673,6 @@ __global__ __launch_bounds__(256) void k_tab_refs(BatchView B, uint32_t n_sel, c
         }
     }
     tab_ref[(size_t)s * n_sel + ti] = r;
-}
-
-// one thread: the pair-table build's overflow word into the query's (bit 4)
-__global__ void k_flag_table_overflow(const uint32_t *__restrict__ table_overflow, uint32_t *__restrict__ query_overflow) {
-    if (*table_overflow) atomicOr(query_overflow, 16u);
 }
 
 // ------------------------------------------------------------------ k_search
@@ -920,7 +964,9 @@ __device__ __forceinline__ bool on_complete(const Ctx &C, WaveRegs &W, PairState
 // Returns false when the pair was cut short by max_candidates.
 template <class Ctx>
 __device__ __forceinline__ bool dfs(const Ctx &C, WaveRegs &W, PairState &P, int floor) {
-    const int k = C.k;  // floor < k always: a template has at least 3 atoms per residue
+    const int k = C.k;
+    // every atom a lead and at most three of them (a template of one atom per residue): the tables placed them all
+    if (floor >= k) return on_complete(C, W, P);
     int level = floor;
     init_level(C, W, level);
     for (;;) {
@@ -1182,7 +1228,7 @@ __device__ __forceinline__ bool table_scan(const Ctx &C, WaveRegs &W, PairState 
                     const uint32_t ab = uni(S.queue3[q][0]), c = uni(S.queue3[q][1]);
                     const uint32_t x0 = ab & 0xffffu, x1 = ab >> 16;
                     const float4 q0 = C.rec[x0], q1 = C.rec[x1], q2 = C.rec[c];
-                    if (!level3_has_candidate(C, W, x0, x1, c, q0, q1, q2)) continue;
+                    if (C.k > 3 && !level3_has_candidate(C, W, x0, x1, c, q0, q1, q2)) continue;
 #if defined(TM_STATS) || defined(TM_ABLATE)
                     if (TR.flags & 0x800u) continue;  // phase timing: the look at level 3, but no search below it
 #endif
@@ -1645,20 +1691,53 @@ __global__ __launch_bounds__(256) void k_select(LibView L, BatchView B, QueryVie
         const double thr = Q.rmsd_thr[pe.ti];
         const int k = (int)Q.staged[pe.ti].k();
         const uint32_t *orig = B.q_orig + B.s_off[pe.s];
-        uint32_t best = 0xffffffffu;
-        double best_rmsd = 0.0;
+        if (!best_match) {
+            for (uint32_t c = pe.last; c != 0xffffffffu; c = O.cands[c].prev)
+                if (O.cand_rmsd[c] <= thr) emit_hit(L, B, Q, O, pe, O.cands[c], k);
+            continue;
+        }
+        // Two passes over the chain: the GLOBAL minimum first, then the smallest atom tuple among the candidates within
+        // kTieEps of it.  (One pass against a moving best depends on the order of the chain: of three candidates
+        // pairwise within eps but not all within eps of the minimum, which one survives would change with it.)
+        double min_rmsd = thr;
+        bool any = false;
         for (uint32_t c = pe.last; c != 0xffffffffu; c = O.cands[c].prev) {
             const double r = O.cand_rmsd[c];
-            if (!(r <= thr)) continue;
-            if (!best_match) {
-                emit_hit(L, B, Q, O, pe, O.cands[c], k);
-                continue;
-            }
-            bool better = best == 0xffffffffu || r < best_rmsd - kTieEps;
-            if (!better && r <= best_rmsd + kTieEps) better = tuple_less(orig, O.cands[c], O.cands[best], k);
-            if (better) { best = c; best_rmsd = r; }
+            if (r <= min_rmsd) { min_rmsd = r; any = true; }
         }
+        uint32_t best = 0xffffffffu;
+        if (any)
+            for (uint32_t c = pe.last; c != 0xffffffffu; c = O.cands[c].prev) {
+                if (!(O.cand_rmsd[c] <= min_rmsd + kTieEps) || !(O.cand_rmsd[c] <= thr)) continue;
+                if (best == 0xffffffffu || tuple_less(orig, O.cands[c], O.cands[best], k)) best = c;
+            }
         if (best != 0xffffffffu) emit_hit(L, B, Q, O, pe, O.cands[best], k);
+    }
+}
+
+
+// A query's hit rows appended to a table that collects a rank's hits over several queries (tm_result_append_hits).
+// ONE workgroup: one reservation, rows copied 8 bytes per lane (a hit table is a few thousand rows of 232 bytes).
+static_assert(sizeof(tm_hit) % 8 == 0 && offsetof(tm_hit, structure) == 0, "k_append_hits copies rows as 64-bit words");
+__global__ __launch_bounds__(1024) void k_append_hits(const tm_hit *__restrict__ src, const unsigned long long *__restrict__ n_src,
+                                                       unsigned long long src_capacity, tm_hit *__restrict__ dst,
+                                                       unsigned long long dst_capacity, unsigned long long *__restrict__ dst_count,
+                                                       uint32_t structure_offset) {
+    __shared__ unsigned long long s_base;
+    unsigned long long n = *n_src;
+    if (n > src_capacity) n = src_capacity;
+    if (threadIdx.x == 0) s_base = atomicAdd(dst_count, n);
+    __syncthreads();
+    const unsigned long long base = s_base;
+    constexpr uint32_t kWords = sizeof(tm_hit) / 8;
+    const unsigned long long total = n * kWords;
+    for (unsigned long long w = threadIdx.x; w < total; w += blockDim.x) {
+        const unsigned long long row = w / kWords;
+        const uint32_t col = (uint32_t)(w % kWords);
+        if (base + row >= dst_capacity) continue;
+        unsigned long long v = reinterpret_cast<const unsigned long long *>(src + row)[col];
+        if (col == 0) v += structure_offset;  // tm_hit.structure: the low word of a row's first 8 bytes
+        reinterpret_cast<unsigned long long *>(dst + base + row)[col] = v;
     }
 }
 

@@ -178,11 +178,98 @@ def gather_report(processed, group=None, predict_correctness: bool = True) -> Op
     return version + (header or "") + "".join("".join(r) for _, r in gathered)
 
 
-def gather_hit_table(result: "_native.Result", n_hits: int, structure_offset: int, world: int, rank: int,
-                     device: str):
-    """bench.py's per-step exchange: this rank's (sorted) hit table, gathered to rank 0 when world > 1
-    (``device`` "cuda:N" = staged in HBM and moved by RCCL)."""
-    table = result.hits()
-    if world == 1:
+class DeviceHitTable:
+    """A rank's hit table, collected in HBM over the queries of one pass and sent to rank 0 in ONE gather.
+
+    ``append(result, structure_offset)`` enqueues a device-side copy of the query's rows behind its kernels
+    (``tm_result_append_hits``: no host wait, no host copy); ``gather()`` is the pass's only exchange: the row counts
+    in one ``all_gather``, the rows -- straight from this table's memory -- in one padded ``gather`` to rank 0, which
+    sorts them into (structure, template) order.  This is north_star's "only a final RCCL gather of the hit table"
+    and the single merge of the reference's sharded flow (/root/reference/nextflow/template_matcher.nf:65-78).
+    With a backend that cannot move device tensors (gloo in the CPU/one-GPU tests) the rows are staged on the host
+    for the collective only."""
+
+    def __init__(self, capacity_rows: int, device=None):
+        import torch
+
+        self.capacity = int(capacity_rows)
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.width = _native.HIT_DTYPE.itemsize
+        self.rows = torch.zeros(max(1, self.capacity) * self.width, dtype=torch.uint8, device=self.device)
+        self.count = torch.zeros(1, dtype=torch.int64, device=self.device)
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)  # the zero fills ran on torch's stream; appends come on the library's
+
+    def reset(self):
+        """Empty the table (enqueued on torch's current stream; call when no append is in flight)."""
+        self.count.zero_()
+
+    def append(self, result: "_native.Result", structure_offset: int = 0):
+        result.append_hits(self.rows.data_ptr(), self.capacity, self.count.data_ptr(), structure_offset)
+
+    def append_rows(self, table: np.ndarray, structure_offset: int = 0):
+        """Host rows (``_native.HIT_DTYPE``) into the table -- for hit tables that already left the device, and for the
+        CPU tests of the gather (a table on ``device="cpu"``)."""
+        import torch
+
+        table = np.ascontiguousarray(table, dtype=_native.HIT_DTYPE).copy()
+        table["structure"] += np.uint32(structure_offset)
+        n0, n = int(self.count.item()), len(table)
+        if n0 + n <= self.capacity and n:
+            raw = torch.from_numpy(table.view(np.uint8).reshape(-1))
+            self.rows[n0 * self.width: (n0 + n) * self.width] = raw.to(self.device)
+        self.count += n
+
+    def gather(self, group=None, force_collective: bool = False, sort: bool = True):
+        """Every append must have completed (wait for the results first).  Returns rank 0's merged table (None on the
+        other ranks); ``sort=False`` leaves the rows in rank order, unsorted (rank 0 can sort later, off the
+        critical path, with ``sort_rows``)."""
+        import torch
+        import torch.distributed as dist
+
+        n_local = int(self.count.item())  # the pass's one read-back of a count
+        if n_local > self.capacity:
+            raise _native.NativeError(_native.TM_E_OVERFLOW, f"device hit table holds {self.capacity} rows, the pass produced {n_local}")
+        active = dist.is_available() and dist.is_initialized()
+        if not active or (dist.get_world_size(group) == 1 and not force_collective):
+            table = self.rows[: n_local * self.width].cpu().numpy().view(_native.HIT_DTYPE).copy()
+            return sort_rows(table) if sort else table
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        on_device = dist.get_backend(group) != "gloo"
+        comm = self.device if on_device else torch.device("cpu")
+        mine = torch.tensor([n_local], dtype=torch.int64, device=comm)
+        counts = torch.zeros(world, dtype=torch.int64, device=comm)
+        dist.all_gather_into_tensor(counts, mine, group=group)
+        counts = counts.cpu().tolist()
+        pad = max(counts + [1]) * self.width
+        if pad > self.rows.numel():
+            raise _native.NativeError(_native.TM_E_OVERFLOW, "a rank's hit table is larger than this rank's capacity")
+        send = self.rows[:pad] if on_device else self.rows[:pad].cpu()  # a view of the table itself: no staging copy
+        out = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
+        dist.gather(send, out, dst=0, group=group)
+        if rank != 0:
+            return None
+        parts = [out[r][: counts[r] * self.width].cpu().numpy().view(_native.HIT_DTYPE) for r in range(world)]
+        table = np.concatenate(parts) if parts else np.zeros(0, dtype=_native.HIT_DTYPE)
+        return sort_rows(table) if sort else table
+
+
+def sort_rows(table: np.ndarray) -> np.ndarray:
+    """Hit rows in (structure, template) order; several hits of one pair (best_match off) by ascending atom tuple,
+    like ``tm_result_copy_hits``."""
+    if len(table) < 2:
         return table
-    return gather_tables(table, structure_offset, device=device)
+    keys = [table["atoms"][:, c] for c in range(table["atoms"].shape[1] - 1, -1, -1)]
+    return table[np.lexsort(keys + [table["template_sel"], table["structure"]])]
+
+
+def table_digest(table: np.ndarray) -> str:
+    """Order-independent fingerprint of a hit table's identity columns (structure, template, matched atoms): what a
+    sharded run and the unsharded run of the same structures must agree on."""
+    import hashlib
+
+    t = sort_rows(np.ascontiguousarray(table, dtype=_native.HIT_DTYPE))
+    h = hashlib.sha256()
+    for col in ("structure", "template_sel", "n_atoms", "atoms"):
+        h.update(np.ascontiguousarray(t[col]).tobytes())
+    return h.hexdigest()[:16]

@@ -380,6 +380,35 @@ def _default_cpus() -> int:
     return len(os.sched_getaffinity(0)) if sys.platform == "linux" else (os.cpu_count() or 1)
 
 
+class _GcPaused:
+    """The cyclic garbage collector is a process-wide switch; pipelines that want it to rest share this counter: the
+    first one in turns it off (if it was on), the last one out turns it back on."""
+
+    def __init__(self):
+        import threading
+        self._lock = threading.Lock()
+        self._depth = 0
+        self._was_enabled = False
+
+    def enter(self):
+        import gc
+        with self._lock:
+            if self._depth == 0:
+                self._was_enabled = gc.isenabled()
+                gc.disable()
+            self._depth += 1
+
+    def leave(self):
+        import gc
+        with self._lock:
+            self._depth -= 1
+            if self._depth == 0 and self._was_enabled:
+                gc.enable()
+
+
+_gc_paused = _GcPaused()
+
+
 class Matcher:
     """Match query molecules against a list of templates (reference: jess_run.py:559-1000)."""
 
@@ -732,16 +761,16 @@ class Matcher:
         """Search device-resident batches (objects with ``native``, ``molecules`` and ``close()``) as they come out
         of ``batches``: batch i is searched on one of two streams while the matches of batch i - 1 are built here
         and whoever feeds the iterator prepares the next ones."""
-        import gc
         from . import _native
         parts: List[Dict[pyjess.Molecule, List[Match]]] = []
         streams = [_native.Stream(pyjess.default_device()) for _ in range(2)]
         in_flight = None  # (batch, submitted) of the previous batch
         # The pipeline builds no reference cycles, but its allocations do trigger full collections, and one of those
         # walks the quarter of a million objects of the template library with the GIL held: 90-300 ms in which none
-        # of the three stages moves (thirty batches' worth of search).  The cyclic collector rests until we return.
-        collecting = gc.isenabled()
-        gc.disable()
+        # of the three stages moves (thirty batches' worth of search).  The cyclic collector rests until we return
+        # (_gc_paused counts the pipelines that are running: two Matchers on two threads do not switch it back on
+        # under each other).
+        _gc_paused.enter()
         try:
             for n, batch in enumerate(batches):
                 try:
@@ -770,8 +799,7 @@ class Matcher:
                 in_flight[0].close()
             for st in streams:
                 st.close()
-            if collecting:
-                gc.enable()
+            _gc_paused.leave()
         return self._merged(parts)
 
     def _merged(self, parts: List[Dict[pyjess.Molecule, List[Match]]]) -> Dict[pyjess.Molecule, List[Match]]:

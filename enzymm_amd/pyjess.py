@@ -827,6 +827,21 @@ def register_vocabulary(templates) -> None:
                 pass
 
 
+_thread_streams = threading.local()
+_OWN_STREAM = -1  # query_batch(stream=...): "the calling thread's own stream" (resolved only when something is launched)
+
+
+def _thread_stream(device: int) -> int:
+    """This thread's own HIP stream on ``device`` (created on first use, destroyed with the thread)."""
+    streams = getattr(_thread_streams, "by_device", None)
+    if streams is None:
+        streams = _thread_streams.by_device = {}
+    st = streams.get(device)
+    if st is None:
+        st = streams[device] = _native.Stream(device)
+    return st.handle
+
+
 class Jess:
     query_batch_accepts_async = True  # Matcher pipelines batches through query_batch(_async=True)
 
@@ -891,6 +906,8 @@ class Jess:
                                  "template; create the Jess (or its templates) first, then the batch")
             if batch.n_structures != len(molecules):
                 raise ValueError("batch and molecule list differ in length")
+        if stream == _OWN_STREAM:
+            stream = _thread_stream(self._device)
         flags = _native.TM_FLAG_BEST_MATCH if best_match else 0
         if ignore_chain:
             flags |= _native.TM_FLAG_IGNORE_CHAIN
@@ -944,7 +961,11 @@ class Jess:
     def query(self, molecule: Molecule, rmsd_threshold: float, distance_cutoff: float,
               max_dynamic_distance: float, *, max_candidates: Optional[int] = None, ignore_chain: bool = False,
               best_match: bool = False) -> Query:
+        # enzymm maps this call over molecules from a thread pool (jess_run.py:919-921, 977-981): every calling thread
+        # gets a stream of its own, so the small kernels of concurrent single-molecule queries overlap on the GPU
+        # instead of queueing on the null stream
         hits = self.query_batch([molecule], rmsd_threshold, distance_cutoff, max_dynamic_distance,
-                                max_candidates=max_candidates, ignore_chain=ignore_chain, best_match=best_match)
+                                max_candidates=max_candidates, ignore_chain=ignore_chain, best_match=best_match,
+                                stream=_OWN_STREAM)
         return Query(self, molecule, rmsd_threshold, distance_cutoff, max_dynamic_distance, max_candidates,
                      ignore_chain, best_match, hits[0])

@@ -234,6 +234,13 @@ int tm_result_copy_candidates(tm_result *res, uint32_t *out, uint64_t n); /* [n_
 /* HIP-event durations on the launch stream: candidate index + template staging, k_search, superposition + selection */
 int tm_result_timing(tm_result *res, float *index_ms, float *search_ms, float *finish_ms);
 const void *tm_result_device_hits(tm_result *res);           /* device pointer to the unsorted tm_hit table */
+/* Appends this query's hit rows to a caller-owned DEVICE table (rows: tm_hit[capacity], *count: rows in use, both in
+ * device memory), adding structure_offset to tm_hit.structure -- enqueued on the query's stream behind its kernels,
+ * no host wait.  A rank of a sharded run (one process per GPU) collects the rows of all its batches this way and
+ * sends them to rank 0 in ONE gather per pass: the single merge step of the reference's sharded flow
+ * (nextflow/template_matcher.nf:65-78, collectFile).  Rows beyond capacity are dropped; *count still advances, so
+ * count > capacity tells the caller to grow the table. */
+int tm_result_append_hits(tm_result *res, void *rows, uint64_t capacity, uint64_t *count, uint32_t structure_offset);
 void tm_result_destroy(tm_result *res);
 
 /* ---- host-side PDB reader (no GPU involved) -----------------------------------------------------------

@@ -50,12 +50,15 @@
  *  - every complete assignment ("candidate") is superposed onto the template
  *    with the optimal PROPER rotation; RMSD = sqrt(sum |R q + t - p|^2 / k).
  *  - a candidate is a hit when RMSD <= rmsd_threshold.  best_match keeps, per
- *    template, the hit of minimum RMSD.  Two hits whose RMSDs differ by less
- *    than ORACLE_TIE_EPS (1e-9 A: exact symmetric copies of a site, e.g. the
- *    chains of a homo-oligomer built by symmetry operators) count as tied and
- *    the first in enumeration order -- the lexicographically smallest tuple of
- *    target atom indices -- is kept.  [UNPINNED: which of two tied sites PyJess
- *    reports depends on Jess's traversal order.]
+ *    template, the hit of minimum RMSD.  Hits whose RMSD lies within
+ *    ORACLE_TIE_EPS (1e-9 A) of that GLOBAL minimum (exact symmetric copies of
+ *    a site, e.g. the chains of a homo-oligomer built by symmetry operators)
+ *    count as tied with it and the first of them in enumeration order -- the
+ *    lexicographically smallest tuple of target atom indices -- is kept.  The
+ *    rule does not depend on the order in which candidates are met (a running
+ *    "better than the best so far by more than eps" comparison would).
+ *    [UNPINNED: which of two tied sites PyJess reports depends on Jess's
+ *    traversal order.]
  *  - max_candidates: at most that many candidates are evaluated per
  *    (template, molecule); if more exist the search stops and `truncated` is
  *    set.  Which candidates Jess would have seen first is [UNPINNED]; parity
@@ -262,6 +265,10 @@ typedef struct {
     int max_hits, nhits, candidates, truncated, stop;
     int *out_atoms;
     double *out_rmsd, *out_rot, *out_trans;
+    /* best_match: the hits within ORACLE_TIE_EPS of the minimum RMSD met so far, in enumeration order */
+    struct contender { double rmsd, rot[9], trans[3]; int atoms[ORACLE_MAXK]; } *tied;
+    int ntied, tied_cap, failed;
+    double min_rmsd;
 } search_t;
 
 static double dist3(const double a[3], const double b[3])
@@ -280,9 +287,26 @@ static void on_candidate(search_t *s)
     rmsd = superpose(s->k, (const double (*)[3])q, s->txyz, rot, trans);
     if (!(rmsd <= s->rmsd_thr)) return;
     if (s->best_match) {
-        if (s->nhits == 1 && !(rmsd < s->out_rmsd[0] - ORACLE_TIE_EPS)) return; /* ties keep the earlier */
-        slot = 0;
-        s->nhits = 1;
+        /* keep every hit within eps of the running minimum; a new minimum drops those it leaves behind.  At the
+         * end the list holds exactly the hits within eps of the global minimum, earliest first (query_one) */
+        int w = 0;
+        if (s->ntied == 0 || rmsd < s->min_rmsd) s->min_rmsd = rmsd;
+        for (i = 0; i < s->ntied; ++i)
+            if (s->tied[i].rmsd <= s->min_rmsd + ORACLE_TIE_EPS) { if (w != i) s->tied[w] = s->tied[i]; ++w; }
+        s->ntied = w;
+        if (!(rmsd <= s->min_rmsd + ORACLE_TIE_EPS)) return;
+        if (s->ntied == s->tied_cap) {
+            int cap = s->tied_cap ? 2 * s->tied_cap : 4;
+            struct contender *grown = realloc(s->tied, sizeof *grown * (size_t)cap);
+            if (!grown) { s->stop = 1; s->failed = 1; return; }
+            s->tied = grown; s->tied_cap = cap;
+        }
+        s->tied[s->ntied].rmsd = rmsd;
+        memcpy(s->tied[s->ntied].rot, rot, sizeof rot);
+        memcpy(s->tied[s->ntied].trans, trans, sizeof trans);
+        for (i = 0; i < s->k; ++i) s->tied[s->ntied].atoms[i] = s->assign[i];
+        ++s->ntied;
+        return;
     } else {
         if (s->nhits >= s->max_hits) { s->truncated = 1; s->stop = 1; return; }
         slot = s->nhits++;
@@ -432,10 +456,19 @@ static int query_one(
         }
     }
     descend(&s, 0);
+    if (s.failed) { rc = ORACLE_EINVAL; goto done; }
+    if (best_match && s.ntied > 0) { /* the earliest of the hits tied with the global minimum */
+        for (i = 0; i < k; ++i) out_atoms[i] = s.tied[0].atoms[i];
+        out_rmsd[0] = s.tied[0].rmsd;
+        memcpy(out_rot, s.tied[0].rot, sizeof s.tied[0].rot);
+        memcpy(out_trans, s.tied[0].trans, sizeof s.tied[0].trans);
+        s.nhits = 1;
+    }
     rc = s.nhits;
     if (out_candidates) *out_candidates = s.candidates;
     if (out_truncated) *out_truncated = s.truncated;
 done:
+    free(s.tied);
     if (!scratch)
         for (i = 0; i < k; ++i) free(s.cand[i]);
     return rc;

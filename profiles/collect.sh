@@ -4,26 +4,34 @@
 # Writes gpurun_out/<tag>/: the bench line, rocprofv3 --kernel-trace --stats of the same command, and separate --pmc
 # passes (SQ counters in groups of <= 8, FETCH_SIZE and WRITE_SIZE each alone -- MI355X_MICROARCH.md, PMC slots)
 # condensed by summarize_pmc.py.  Copy <tag>_* into profiles/ and point profiles/LATEST at them.
+# The box has no .git: profiles/run_collect.sh (run in the build container) refuses a dirty tree, writes the revision to
+# .build_head (git-ignored, travels with the snapshot) and calls this script through gpurun; every JSON written here
+# carries that revision, and this script refuses to run without it.
 set -u
 tag=${1:?tag}
+head=$(cat .build_head 2>/dev/null || true)
+if [ -z "$head" ]; then echo "no .build_head: start this through profiles/run_collect.sh" >&2; exit 2; fi
 out=gpurun_out/$tag
 mkdir -p "$out"
+echo "$head" > "$out/${tag}_git_head.txt"
+python3 tests/gpu_valu_ceiling.py "$tag" > "$out/valu.log" 2>&1 && mv "gpurun_out/${tag}_valu_ceiling.json" "$out/"
 export TMPDIR=/tmp ENZYMM_AMD_SYNTH_CACHE=/tmp/synth
-timeout 300 python3 bench.py --steps 10 --warmup 2 > "$out/${tag}_bench1000.json" 2> "$out/bench.err"
-timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o run -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --streamed-passes 0 > "$out/trace.log" 2>&1
+timeout 600 python3 bench.py --steps 10 --warmup 2 > "$out/${tag}_bench1000.json" 2> "$out/bench.err"
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o run -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras --streamed-passes 0 > "$out/trace.log" 2>&1
 stats=$(find "$out/trace" -name "*kernel_stats.csv" | head -1)
 [ -n "$stats" ] && cp "$stats" "$out/${tag}_bench1000_kernel_stats.csv"
 # the same with ONE search in flight: kernel durations with nothing else on the GPU (roofline.exclusive, and the
 # duration the per-search instruction figures of summarize_pmc.py are set against)
-timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace1" -o run -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --streamed-passes 0 --pipeline 1 > "$out/trace1.log" 2>&1
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace1" -o run -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras --streamed-passes 0 --pipeline 1 > "$out/trace1.log" 2>&1
 stats=$(find "$out/trace1" -name "*kernel_stats.csv" | head -1)
 [ -n "$stats" ] && cp "$stats" "$out/${tag}_bench1000_pipeline1_kernel_stats.csv"
-pass() { timeout 200 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$out/pmc_$1" -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --streamed-passes 0 --pipeline 1 > "$out/pmc_$1.log" 2>&1; }
+pass() { timeout 200 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$out/pmc_$1" -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --streamed-passes 0 --pipeline 1 > "$out/pmc_$1.log" 2>&1; }
 pass SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES
 pass SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT
 pass SQ_INSTS_BRANCH SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU
 pass FETCH_SIZE
 pass WRITE_SIZE
+pass TCC_HIT_sum TCC_MISS_sum
 for kernel in k_search k_tab_build; do
     kms=0
     if [ -f "$out/${tag}_bench1000_pipeline1_kernel_stats.csv" ]; then
@@ -35,7 +43,8 @@ PY
 )
     fi
     python3 profiles/summarize_pmc.py "$kernel" "$out/${tag}_${kernel}_pmc.json" --searches 6780000 --kernel-ms "$kms" \
-        "$out"/pmc_SQ_INSTS_VALU "$out"/pmc_SQ_ACTIVE_INST_ANY "$out"/pmc_SQ_INSTS_BRANCH "$out"/pmc_FETCH_SIZE "$out"/pmc_WRITE_SIZE >> "$out/summary.log" 2>&1
+        --valu-ceiling "$out/${tag}_valu_ceiling.json" --head "$head" \
+        "$out"/pmc_SQ_INSTS_VALU "$out"/pmc_SQ_ACTIVE_INST_ANY "$out"/pmc_SQ_INSTS_BRANCH "$out"/pmc_FETCH_SIZE "$out"/pmc_WRITE_SIZE "$out"/pmc_TCC_HIT_sum >> "$out/summary.log" 2>&1
 done
 cat "$out/${tag}_bench1000.json" "$out/summary.log"
 [ -f "$out/${tag}_bench1000_kernel_stats.csv" ] && head -8 "$out/${tag}_bench1000_kernel_stats.csv"

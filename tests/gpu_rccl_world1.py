@@ -27,5 +27,11 @@ got = distributed.gather_result(res, n, 1000, device="cuda:0", force_collective=
 want = res.hits()
 want["structure"] += np.uint32(1000)
 assert n > 20 and got.tobytes() == want.tobytes(), (n, len(got))
+# the pass table of bench.py's N > 1 loop over the same backend: rows appended on the device, one gather
+table = distributed.DeviceHitTable(8192, device="cuda:0")
+table.append(res, 1000)
+res.wait()
+again = table.gather(force_collective=True)
+assert again.tobytes() == want.tobytes(), len(again)
 print("RCCL world-size-1 gather ok:", n, "rows")
 dist.destroy_process_group()

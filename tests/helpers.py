@@ -181,3 +181,75 @@ def check_completeness_vector(Matcher, jess_factory, amy, af):
     loose = {s: {"rmsd": 2.0, "distance": 1.2, "max_dynamic_distance": 1.2} for s in range(3, 9)}
     out = Matcher(tpls, jess_params=loose, filter_matches=False, jess_factory=jess_factory).run([amy, af])
     assert summary(out[amy]) == summary(out[af]) == [(1, 1, True), (1, 2, True)]
+
+
+# ---------------------------------------------------------------------------------------------
+# constructed cases of round 3
+
+
+def _kabsch_rmsd(q, p):
+    """RMSD of q onto p after the optimal proper rotation (numpy SVD; fp64)."""
+    qc, pc = q - q.mean(0), p - p.mean(0)
+    u, s, vt = np.linalg.svd(qc.T @ pc)
+    d = np.sign(np.linalg.det(u @ vt))
+    e = (qc * qc).sum() + (pc * pc).sum() - 2.0 * (s[0] + s[1] + d * s[2])
+    return float(np.sqrt(max(e, 0.0) / len(q)))
+
+
+def subset_molecule(mol, index, xyz=None, id=None, residue_offset=0, chain=None):
+    """A pyjess.Molecule of the atoms ``index`` of ``mol`` (file order kept), optionally with other coordinates,
+    residue numbers shifted and another chain id."""
+    from enzymm_amd import pyjess
+    c = {k: v[index].copy() for k, v in mol._cols.items()}
+    c["residue_number"] = c["residue_number"] + residue_offset
+    if chain is not None:
+        c["chain_id"][:] = chain.rjust(2).encode()
+    return pyjess.Molecule.from_columns(id=id or mol.id, xyz=np.asarray(mol._xyz[index] if xyz is None else xyz, dtype=np.float64),
+                                        **{k: v for k, v in c.items() if k != "serial"})
+
+
+def concat_molecules(mols, id="joined"):
+    from enzymm_amd import pyjess
+    cols = {k: np.concatenate([m._cols[k] for m in mols]) for k in mols[0]._cols if k != "serial"}
+    return pyjess.Molecule.from_columns(id=id, xyz=np.concatenate([m._xyz for m in mols]), **cols)
+
+
+def tie_case(golden):
+    """Three copies of the site that template G1 hits in 1AMY (tests/test_jess_run.py:24-44), 40 A apart, each scaled
+    about its centroid by a hair so that the copies' RMSDs are r + 1.2e-9, r + 0.6e-9 and r (file order).  The copies
+    are pairwise closer than the 1e-9 tie width but only the second and third lie within it of the MINIMUM: the
+    global-minimum rule (oracle/jess_oracle.c header, k_select) picks the second copy -- the smallest atom tuple among
+    the candidates tied with the minimum.  A running "better than the best so far by more than eps" comparison picks
+    the third or the first, depending on the order in which it meets them.
+    Returns (molecule, template, atoms per copy, index of the expected copy = 1)."""
+    from enzymm_amd import pyjess, template
+    from oracle import oracle, parse
+    g = golden["G1"]
+    amy = pyjess.Molecule.load(GOLDEN / g["molecule"])
+    tpl = template.Template.load(GOLDEN / "templates" / g["template"])
+    otpl = parse.parse_template((GOLDEN / "templates" / g["template"]).read_text())
+    hits, _, _ = oracle.query(to_oracle_molecule(amy), otpl, g["rmsd_threshold"], g["distance_cutoff"],
+                              g["max_dynamic_distance"], max_candidates=g["max_candidates"], best_match=True)
+    site = np.sort(hits[0].atoms)  # file order
+    pos_of = {int(a): i for i, a in enumerate(site)}
+    in_template_order = [pos_of[int(a)] for a in hits[0].atoms]
+    txyz = np.array([[a.x, a.y, a.z] for a in tpl])
+    base = amy._xyz[site]
+    centre = base.mean(0)
+
+    def rmsd_at(scale):
+        return _kabsch_rmsd(((base - centre) * (1.0 + scale) + centre)[in_template_order], txyz)
+
+    r0 = rmsd_at(0.0)
+    slope = (rmsd_at(1e-6) - r0) / 1e-6
+    copies = []
+    for c, delta in enumerate((1.2e-9, 0.6e-9, 0.0)):
+        scale = delta / slope
+        for _ in range(4):  # secant refinement: the RMSD is smooth in the scale
+            scale -= (rmsd_at(scale) - (r0 + delta)) / slope
+        assert abs(rmsd_at(scale) - (r0 + delta)) < 2e-11
+        xyz = (base - centre) * (1.0 + scale) + centre + np.array([40.0 * c, 0.0, 0.0])
+        copies.append(subset_molecule(amy, site, xyz=xyz, residue_offset=1000 * c))
+    mol = concat_molecules(copies, id="tied_sites")
+    n = len(site)
+    return mol, tpl, [np.arange(c * n, (c + 1) * n) for c in range(3)], 1

@@ -149,3 +149,57 @@ def test_sharded_file_run_world_size_2(tmp_path):
     assert by_mol(got[2:]) == by_mol(want[2:])
     # one rank: the same text without a process group
     assert distributed.gather_report(whole) == buf.getvalue()
+
+
+def _pass_table_worker(rank, world, port, out_path):
+    """One gather per pass (distributed.DeviceHitTable): each rank appends the rows of TWO queries of its shard to its
+    table (kept in host memory here; in HBM on a GPU), then the table goes to rank 0 in one exchange."""
+    import torch.distributed as dist
+    from enzymm_amd import pyjess, synthetic
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mols = [pyjess.Molecule.load(helpers.GOLDEN / "1AMY.pdb"),
+                pyjess.Molecule.load(helpers.GOLDEN / "AF-P0DUB6-F1-model_v4.pdb")] + synthetic.structures(2)
+        lo, hi = distributed.shard_range(len(mols), rank, world)
+        table = distributed.DeviceHitTable(64, device="cpu")
+        for i in range(lo, hi):  # one "query" per molecule: several appends per pass
+            table.append_rows(_oracle_table(mols[i:i + 1], i), i)
+        merged = table.gather()
+        if rank == 0:
+            np.save(out_path, merged)
+        else:
+            assert merged is None
+        table.reset()
+        assert int(table.count.item()) == 0
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_gather_per_pass_world_size_2(tmp_path):
+    import torch.multiprocessing as mp
+    from enzymm_amd import pyjess, synthetic
+    out = tmp_path / "pass_table.npy"
+    mp.spawn(_pass_table_worker, args=(2, _free_port(), str(out)), nprocs=2, join=True)
+    got = np.load(out)
+    mols = [pyjess.Molecule.load(helpers.GOLDEN / "1AMY.pdb"),
+            pyjess.Molecule.load(helpers.GOLDEN / "AF-P0DUB6-F1-model_v4.pdb")] + synthetic.structures(2)
+    want = _oracle_table(mols, 0)
+    assert len(got) == len(want) > 0
+    assert got.tobytes() == want.tobytes()
+    assert distributed.table_digest(got) == distributed.table_digest(want[::-1])  # the digest ignores the order of rows
+
+
+def test_pass_table_without_process_group_and_overflow():
+    rows = np.zeros(5, dtype=_native.HIT_DTYPE)
+    rows["structure"] = [3, 1, 1, 0, 2]
+    rows["template_sel"] = [0, 7, 2, 5, 1]
+    t = distributed.DeviceHitTable(8, device="cpu")
+    t.append_rows(rows[:2], 10)
+    t.append_rows(rows[2:], 10)
+    out = t.gather()
+    assert out["structure"].tolist() == [10, 11, 11, 12, 13] and out["template_sel"].tolist() == [5, 2, 7, 1, 0]
+    small = distributed.DeviceHitTable(4, device="cpu")
+    small.append_rows(rows)
+    with pytest.raises(_native.NativeError):
+        small.gather()

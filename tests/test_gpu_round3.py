@@ -1,0 +1,248 @@
+"""GPU parity tests added in round 3: the two parity hazards VERDICT r02 named (tie rule, extent of the fp32
+prefilter), the pair-table overflow path, templates of one atom per residue, the selection cache, the
+device-side hit table of a sharded pass, and bench.py's N > 1 loop as the driver launches it (a fresh
+torch.distributed.run child with two ranks).  Every test calls through the C ABI."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests import helpers
+from enzymm_amd import _native, distributed, pyjess, synthetic, template
+from oracle import oracle, parse
+
+pytestmark = pytest.mark.gpu
+
+TPL = helpers.GOLDEN / "templates"
+RMSD_TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def amy():
+    return pyjess.Molecule.load(helpers.GOLDEN / "1AMY.pdb")
+
+
+def _a1_templates():
+    """The six templates of the reference's A1 vector (tests/test_jess_run.py:186-193) plus the 5/4-residue sets."""
+    tpls = list(template.load_templates(TPL / "5_residues")) + list(template.load_templates(TPL / "4_residues")) + \
+        list(template.load_templates(TPL / "3_residues" / "results" / "csa3d_0285"))
+    tpls.sort(key=lambda t: (t.effective_size, t.template_id_string, str(t.cluster)))
+    return tpls
+
+
+def _oracle_lib(tpls):
+    return oracle.OracleLibrary([helpers.to_oracle_template(t) for t in tpls])
+
+
+def _same_as_oracle(table, r, lib, s=0):
+    mine = {int(h["template_sel"]): h for h in table if int(h["structure"]) == s}
+    theirs = set(np.nonzero(r["hit"])[0].tolist())
+    assert set(mine) == theirs
+    for t in theirs:
+        k = lib.templates[t].k
+        assert np.array_equal(mine[t]["atoms"][:k], r["atoms"][t][:k]), t
+        assert abs(mine[t]["rmsd"] - r["rmsd"][t]) < RMSD_TOL
+    return len(theirs)
+
+
+# ------------------------------------------------------------------------------------------- parity hazards
+
+
+def test_tie_rule_global_minimum_on_gpu(golden):
+    """Three near-tied symmetric sites (r + 1.2e-9, r + 0.6e-9, r): k_select picks what the oracle picks, the second."""
+    mol, tpl, copies, expected = helpers.tie_case(golden)
+    hits = list(pyjess.Jess([tpl]).query(mol, 2.0, 1.5, 1.5, max_candidates=10000, best_match=True, ignore_chain=True))
+    assert len(hits) == 1
+    assert set(hits[0]._atom_index) == set(copies[expected].tolist())
+    g = golden["G1"]
+    otpl = parse.parse_template((TPL / g["template"]).read_text())
+    ohits, _, _ = oracle.query(helpers.to_oracle_molecule(mol), otpl, 2.0, 1.5, 1.5, max_candidates=10000, best_match=True)
+    assert list(hits[0]._atom_index) == ohits[0].atoms.tolist()
+    assert abs(hits[0].rmsd - ohits[0].rmsd) < 1e-12 * 100
+    # the same three sites in the opposite file order: the rule, not the enumeration order, decides
+    n = len(copies[0])
+    rev = helpers.concat_molecules([helpers.subset_molecule(mol, copies[c]) for c in (2, 1, 0)], id="tied_reversed")
+    hits = list(pyjess.Jess([tpl]).query(rev, 2.0, 1.5, 1.5, max_candidates=10000, best_match=True, ignore_chain=True))
+    ohits, _, _ = oracle.query(helpers.to_oracle_molecule(rev), otpl, 2.0, 1.5, 1.5, max_candidates=10000, best_match=True)
+    assert list(hits[0]._atom_index) == ohits[0].atoms.tolist()
+    assert set(hits[0]._atom_index) == set(range(0, n))  # r is now first in the file: the smallest tuple among {r, r + 0.6e-9}
+
+
+def test_extent_of_the_fp32_prefilter(amy):
+    """The fp32 prefilter works on coordinates centred per structure, with a slack sized for atoms within 4096 A of
+    the centroid; a batch reaching further is searched with a wider slack (tm_device.hpp, prefilter_slack).
+    (a) 1AMY translated to +-9000 A: centring removes the translation, same hits as at the origin;
+    (b) one molecule made of two copies of 1AMY 9000 A apart (centred extent 4500 A, fp32 spacing 4.9e-4 A): the
+    wider slack class, hits equal to the oracle's."""
+    tpls = _a1_templates()
+    lib = _oracle_lib(tpls)
+    jess = pyjess.Jess(tpls)
+    base = jess.query_batch([amy], 2.0, 1.7, 1.7, max_candidates=10000, ignore_chain=True, return_raw=True)
+    far = helpers.subset_molecule(amy, np.arange(len(amy)), xyz=amy._xyz + np.array([9000.0, -9000.0, 9000.0]), id="far")
+    moved = jess.query_batch([far], 2.0, 1.7, 1.7, max_candidates=10000, ignore_chain=True, return_raw=True)
+    assert len(base) == len(moved) > 3
+    assert np.array_equal(base["atoms"], moved["atoms"]) and np.array_equal(base["template_sel"], moved["template_sel"])
+    assert np.abs(base["rmsd"] - moved["rmsd"]).max() < 1e-9
+    r = oracle.query_library(helpers.to_oracle_molecule(far), lib, 2.0, 1.7, 1.7, max_candidates=10000, ignore_chain=True)
+    assert _same_as_oracle(moved, r, lib) == len(base)
+
+    second = helpers.subset_molecule(amy, np.arange(len(amy)), xyz=amy._xyz + np.array([9000.0, 0.0, 0.0]),
+                                     residue_offset=5000, chain="B")
+    wide = helpers.concat_molecules([amy, second], id="two_domains_9000A_apart")
+    assert np.abs(wide._xyz - wide._xyz.mean(0)).max() > 4096.0
+    table = jess.query_batch([wide, amy], 2.0, 1.7, 1.7, max_candidates=10000, ignore_chain=True, return_raw=True)
+    r = oracle.query_library(helpers.to_oracle_molecule(wide), lib, 2.0, 1.7, 1.7, max_candidates=10000, ignore_chain=True)
+    assert _same_as_oracle(table, r, lib, s=0) == len(base)  # the first copy wins every tie: same templates as 1AMY alone
+    r1 = oracle.query_library(helpers.to_oracle_molecule(amy), lib, 2.0, 1.7, 1.7, max_candidates=10000, ignore_chain=True)
+    assert _same_as_oracle(table, r1, lib, s=1) == len(base)
+
+
+# ------------------------------------------------------------------------------------------- ADVICE r02
+
+
+def _query_once(packed, batch, sel, cut):
+    flags = _native.TM_FLAG_BEST_MATCH | _native.TM_FLAG_IGNORE_CHAIN
+    return _native.query(packed.native, batch, sel, 2.0, cut, cut, 10000, flags, retry=False)
+
+
+@pytest.mark.parametrize("n_structures", [1, 96])
+def test_pair_table_pool_overflow_takes_one_retry(n_structures, monkeypatch):
+    """The pair-table entry pool starts far too small (ENZYMM_AMD_TABLE_POOL=64): the first query reports
+    TM_E_OVERFLOW, every workgroup having kept COUNTING what it could not store, so the second query -- one retry --
+    has room for everything and returns the hit table of an undisturbed run, byte for byte."""
+    idx, cut = helpers.default_selection()
+    every = np.arange(0, len(idx), 7)
+    tpls = [helpers.product_library_templates()[i] for i in idx[every]]
+    jess = pyjess.Jess(tpls)
+    packed = pyjess._packed(jess._templates, jess._device)
+    sel = np.arange(len(tpls), dtype=np.uint32)
+    mols = synthetic.structures(n_structures, start=300)
+    want_batch = pyjess.make_batch(mols, jess._device)
+    res = _query_once(packed, want_batch, sel, cut[every])
+    want = res.hits()
+    res.close(); want_batch.close()
+    assert len(want) > 0
+    monkeypatch.setenv("ENZYMM_AMD_TABLE_POOL", "64")
+    batch = pyjess.make_batch(mols, jess._device)
+    first = _query_once(packed, batch, sel, cut[every])
+    with pytest.raises(_native.NativeError) as exc:
+        first.wait()
+    assert exc.value.code == _native.TM_E_OVERFLOW and "pair-table" in str(exc.value)
+    first.close()
+    second = _query_once(packed, batch, sel, cut[every])
+    got = second.hits()  # raises if the pools overflowed again
+    second.close(); batch.close()
+    assert got.tobytes() == want.tobytes()
+
+
+def test_templates_of_one_atom_per_residue(amy):
+    """Templates whose residues contribute a single atom each (k == number of residues; legal for Jess, absent from
+    the shipped library): 1 to 5 atoms, every atom a "lead" for the search -- the level-3 look and the depth-first
+    search below the tables have nothing left to place for k <= 3."""
+    src = template.Template.load(TPL / "5_residues" / "results" / "csa3d_0285" /
+                                 "csa3d_0285.cluster_1_1_1.1uh3_A396-A262-A356-A471-A472.template.pdb")
+    atoms = list(src)
+    tpls = []
+    for k in (1, 2, 3, 4, 5):
+        picked = [atoms[3 * r] for r in range(k)]  # the first atom of k different residues
+        tpls.append(pyjess.Template([a.copy() for a in picked], id=f"one_per_residue_{k}"))
+    lib = _oracle_lib(tpls)
+    for cutoff in (0.6, 1.5):
+        table, cands = pyjess.Jess(tpls).query_batch([amy], 2.0, cutoff, cutoff, max_candidates=2000000, ignore_chain=True,
+                                                     return_raw=True, count_candidates=True)
+        r = oracle.query_library(helpers.to_oracle_molecule(amy), lib, 2.0, cutoff, cutoff, max_candidates=2000000,
+                                 ignore_chain=True)
+        assert np.array_equal(cands[0] & 0x7FFFFFFF, r["candidates"])
+        assert _same_as_oracle(table, r, lib) >= 4
+
+
+def test_selection_cache_keeps_several_parameter_sets(amy):
+    """One library queried with three parameter sets in turn (what per-size queries through one Jess look like): every
+    set is staged once and found again; results do not depend on what was staged in between."""
+    tpls = _a1_templates()
+    jess = pyjess.Jess(tpls)
+    sets = [(2.0, 1.2, 1.2), (2.0, 1.7, 1.7), (1.0, 2.0, 2.5)]
+    first = [jess.query_batch([amy], *p, max_candidates=10000, ignore_chain=True, return_raw=True) for p in sets]
+    for _ in range(3):
+        for p, want in zip(sets, first):
+            got = jess.query_batch([amy], *p, max_candidates=10000, ignore_chain=True, return_raw=True)
+            assert got.tobytes() == want.tobytes()
+    lib = _oracle_lib(tpls)
+    for p, table in zip(sets, first):
+        r = oracle.query_library(helpers.to_oracle_molecule(amy), lib, *p, max_candidates=10000, ignore_chain=True)
+        _same_as_oracle(table, r, lib)
+
+
+# ------------------------------------------------------------------------------------------- sharded pass
+
+
+def test_device_hit_table_collects_a_pass(amy):
+    """tm_result_append_hits: the rows of several queries appended to one table in HBM (global structure indices),
+    equal to the concatenation of the queries' own tables; count > capacity flags a table that is too small."""
+    import torch
+    tpls = _a1_templates()
+    jess = pyjess.Jess(tpls)
+    packed = pyjess._packed(jess._templates, jess._device)
+    sel = np.arange(len(tpls), dtype=np.uint32)
+    mols = [amy] + synthetic.structures(5, start=40)
+    flags = _native.TM_FLAG_BEST_MATCH | _native.TM_FLAG_IGNORE_CHAIN
+    table = distributed.DeviceHitTable(4096, device=f"cuda:{jess._device}")
+    streams = [_native.Stream(jess._device) for _ in range(2)]
+    parts, results, batches = [], [], []
+    for j, (lo, hi) in enumerate([(0, 2), (2, 3), (3, 6)]):
+        b = pyjess.make_batch(mols[lo:hi], jess._device)
+        res = _native.query(packed.native, b, sel, 2.0, 1.7, 1.7, 10000, flags, retry=False, stream=streams[j % 2].handle)
+        table.append(res, 100 + lo)
+        results.append(res); batches.append(b)
+    for (lo, hi), res in zip([(0, 2), (2, 3), (3, 6)], results):
+        t = res.hits()
+        t["structure"] += np.uint32(100 + lo)
+        parts.append(t)
+    want = distributed.sort_rows(np.concatenate(parts))
+    got = table.gather()
+    assert len(got) == len(want) > 0 and got.tobytes() == want.tobytes()
+    small = distributed.DeviceHitTable(1, device=f"cuda:{jess._device}")
+    small.append(results[0], 0)
+    results[0].wait()
+    torch.cuda.synchronize()
+    with pytest.raises(_native.NativeError):
+        small.gather()
+    for r in results:
+        r.close()
+    for b in batches:
+        b.close()
+    for s in streams:
+        s.close()
+
+
+def _bench_line(args, env_extra, nproc=None, timeout=900):
+    env = dict(os.environ)
+    env.update(env_extra)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable]
+    if nproc:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+                "--master-port", "29671"]
+    cmd += [str(helpers.ROOT / "bench.py")] + args
+    out = subprocess.run(cmd, cwd=str(helpers.ROOT), env=env, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_as_the_driver_launches_it():
+    """bench.py --gpus 2 under torch.distributed.run in a FRESH child process (both ranks on this box's one GPU, gloo
+    for the collective: ENZYMM_AMD_BENCH_ONE_GPU=1): one JSON line, n_gpus 2, and the gathered hit table of the two
+    shards equals the table of the unsharded run over the same 128 structures."""
+    common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--streamed-passes", "0"]
+    two = _bench_line(["--gpus", "2", "--structures", "64"] + common, {"ENZYMM_AMD_BENCH_ONE_GPU": "1"}, nproc=2)
+    one = _bench_line(["--gpus", "1", "--structures", "128"] + common, {})
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1 and two["scaling"] == "weak"
+    assert two["config"]["hits_total"] == one["config"]["hits_total"] > 0
+    assert two["config"]["hit_table_digest"] == one["config"]["hit_table_digest"]
+    assert two["value"] > 0 and two["config"]["gather_ms_per_pass"] is not None
+    assert "roofline" in two and two["roofline"]["kernel"] == "k_search"

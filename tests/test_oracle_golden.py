@@ -190,3 +190,21 @@ def test_report_writers_match_the_cli_layout(amy, af, tmp_path):
     assert text.count("HEADER MOLECULE_ID 1AMY") == 1 and text.count("REMARK MATCH INDEX") == 2
     with pytest.raises(FileExistsError):
         report.write_pdbs(processed, tmp_path / "pdbs")
+
+
+def test_tie_rule_is_the_global_minimum(golden):
+    """best_match among near-tied candidates (exact symmetric copies of a site differ by rounding only): the winner is
+    the smallest atom tuple among the candidates within 1e-9 A of the GLOBAL minimum RMSD -- independent of the order
+    in which candidates are met.  Three copies at r + 1.2e-9, r + 0.6e-9, r: the second wins (tests/helpers.tie_case).
+    Unpinned by the reference; the rule is this build's, stated in the oracle's header."""
+    from oracle import oracle, parse
+    mol, tpl, copies, expected = helpers.tie_case(golden)
+    g = golden["G1"]
+    otpl = parse.parse_template((helpers.GOLDEN / "templates" / g["template"]).read_text())
+    om = helpers.to_oracle_molecule(mol)
+    every, n, _ = oracle.query(om, otpl, 2.0, 1.5, 1.5, max_candidates=10000, best_match=False)
+    best = sorted(h.rmsd for h in every)[:3]
+    assert 1.1e-9 < best[2] - best[0] < 1.3e-9 and 0.5e-9 < best[1] - best[0] < 0.7e-9
+    hits, _, _ = oracle.query(om, otpl, 2.0, 1.5, 1.5, max_candidates=10000, best_match=True)
+    assert len(hits) == 1 and set(hits[0].atoms.tolist()) == set(copies[expected].tolist())
+    assert abs(hits[0].rmsd - best[1]) < 1e-12
