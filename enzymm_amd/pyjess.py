@@ -682,6 +682,75 @@ def make_batch(molecules: Sequence[Molecule], device: int) -> "_native.Batch":
     return batch
 
 
+class _SingleBatches:
+    """Device copies of molecules that are queried one at a time, kept between queries (most recently used last) up to
+    a budget of atoms: enzymm's call pattern asks for the same molecule once per template size.  An entry is lent to
+    one query at a time (a tm_batch carries the candidate index of its last query); a second concurrent query of the
+    same molecule builds a batch of its own."""
+
+    BUDGET_ATOMS = 48_000_000  # about 2.5 GB of HBM
+
+    def __init__(self):
+        self._lock = threading.Lock()
+        self._entries: "collections.OrderedDict[tuple, list]" = collections.OrderedDict()
+        self._atoms = 0
+
+    def borrow(self, molecule, device):
+        import weakref
+        key = (id(molecule), device)
+        with self._lock:
+            e = self._entries.get(key)
+            if e is not None and (e[0]() is not molecule or e[1].vocab_version != VOCAB.version):
+                self._drop(key)  # another object at that address now, or names registered since
+                e = None
+            if e is not None:
+                if e[2]:
+                    return None, None  # on loan
+                e[2] = True
+                self._entries.move_to_end(key)
+                return e[1], lambda: self._give_back(key)
+        batch = make_batch([molecule], device)
+        with self._lock:
+            if key in self._entries:  # another thread was faster: this one stays private
+                return batch, None
+            try:
+                ref = weakref.ref(molecule)
+            except TypeError:
+                return batch, None
+            self._entries[key] = [ref, batch, True, len(molecule)]
+            self._atoms += len(molecule)
+            while self._atoms > self.BUDGET_ATOMS and len(self._entries) > 1:
+                oldest = next(iter(self._entries))
+                if self._entries[oldest][2]:
+                    break
+                self._drop(oldest)
+        return batch, lambda: self._give_back(key)
+
+    def _give_back(self, key):
+        with self._lock:
+            e = self._entries.get(key)
+            if e is not None:
+                e[2] = False
+
+    def _drop(self, key):
+        e = self._entries.pop(key)
+        self._atoms -= e[3]
+        if not e[2]:
+            e[1].close()
+
+
+_single_batches = _SingleBatches()
+
+
+def _single_batch(molecule, device):
+    """(batch, release) for a one-molecule query: a kept device copy when there is one to lend (release hands it
+    back), else a fresh batch the caller owns (release None)."""
+    batch, release = _single_batches.borrow(molecule, device)
+    if batch is None:
+        return make_batch([molecule], device), None
+    return batch, release
+
+
 # ---------------------------------------------------------------------------------- Hit / Query / Jess
 
 
@@ -763,9 +832,11 @@ class _PendingQuery:
     waits for it and builds what ``query_batch`` returns.  If a result table overflowed, the query is repeated with the
     sizes the first run reported."""
 
-    def __init__(self, jess, molecules, sel, args, models, owned_batch, count_candidates, return_raw, stream=0):
+    def __init__(self, jess, molecules, sel, args, models, owned_batch, count_candidates, return_raw, stream=0,
+                 release=None):
         self._jess, self._molecules, self._sel, self._args, self._models = jess, molecules, sel, args, models
         self._owned_batch, self._count, self._raw, self._stream = owned_batch, count_candidates, return_raw, stream
+        self._release = release  # hands a cached single-molecule batch back (see _single_batch)
         self._res = _native.query(*args, models=models, retry=False, stream=stream)
 
     def result(self):
@@ -786,6 +857,9 @@ class _PendingQuery:
             self._res.close()
             if self._owned_batch is not None:
                 self._owned_batch.close()
+            if self._release is not None:
+                self._release()
+                self._release = None
         self.table = table  # the raw rows, for callers that post-process in bulk (ingest.PdbBatch.annotate_hits)
         if self._raw:
             return (table, cands) if self._count else table
@@ -827,6 +901,7 @@ def register_vocabulary(templates) -> None:
                 pass
 
 
+_jess_cache: "dict[tuple, tuple]" = {}  # (id(template list), device) -> (tuple of its templates, _PackedLibrary or None)
 _thread_streams = threading.local()
 _OWN_STREAM = -1  # query_batch(stream=...): "the calling thread's own stream" (resolved only when something is launched)
 
@@ -855,10 +930,24 @@ class Jess:
             _packed(templates, self._device)  # registers the library's vocabulary
             return
         self._templates = tuple(templates)
+        # enzymm builds Jess(templates) anew for every (molecule, size) call with the SAME list object
+        # (jess_run.py:800, templates_by_effective_size[size]): a list seen before, holding the same objects (tuple
+        # comparison stops at identity, at C speed), needs neither the type checks nor a new device library
+        self._cache_key = (id(templates), self._device) if isinstance(templates, (list, tuple)) else None
+        known = _jess_cache.get(self._cache_key) if self._cache_key is not None else None
+        if known is not None and known[0] == self._templates:
+            self._templates = known[0]
+            if known[1] is not None and known[1].vocab_version == VOCAB.version:
+                self._packed_ref = known[1]
+            return
         for t in self._templates:
             if not isinstance(t, Template):
                 raise TypeError(f"expected Template, found {type(t).__name__}")
         register_vocabulary(self._templates)
+        if self._cache_key is not None and self._templates:
+            _jess_cache[self._cache_key] = (self._templates, None)
+            while len(_jess_cache) > _PACK_CACHE_SIZE:
+                _jess_cache.pop(next(iter(_jess_cache)))
 
     def __len__(self):
         return len(self._templates)
@@ -896,8 +985,16 @@ class Jess:
         packed = getattr(self, "_packed_ref", None)
         if packed is None or packed.vocab_version != VOCAB.version:
             packed = self._packed_ref = _packed(self._templates, self._device)
+            key = getattr(self, "_cache_key", None)
+            if key is not None and key in _jess_cache and _jess_cache[key][0] is self._templates:
+                _jess_cache[key] = (self._templates, packed)
         own_batch = batch is None
-        if own_batch:
+        release = None
+        if own_batch and len(molecules) == 1:
+            # the reference queries one molecule six times, once per size bucket: its device copy is kept
+            batch, release = _single_batch(molecules[0], self._device)
+            own_batch = release is None
+        elif own_batch:
             batch = make_batch(molecules, self._device)
         else:
             batch = getattr(batch, "native", batch)  # an ingest.PdbBatch or a raw _native.Batch
@@ -915,8 +1012,13 @@ class Jess:
             flags |= _native.TM_FLAG_COUNT_CANDIDATES
         cap = _UNLIMITED if max_candidates is None else max(0, min(int(max_candidates), _UNLIMITED))
         args = (packed.native, batch, sel, rmsd_threshold, distance_cutoff, max_dynamic_distance, cap, flags)
-        pending = _PendingQuery(self, molecules, sel, args, models, batch if own_batch else None, count_candidates,
-                                return_raw, stream)
+        try:
+            pending = _PendingQuery(self, molecules, sel, args, models, batch if own_batch else None, count_candidates,
+                                    return_raw, stream, release)
+        except BaseException:
+            if release is not None:
+                release()
+            raise
         return pending if _async else pending.result()
 
     def _hits_from_table(self, table: np.ndarray, sel: np.ndarray, molecules: Sequence[Molecule]) -> List[List[Hit]]:
