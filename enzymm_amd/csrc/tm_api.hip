@@ -309,6 +309,12 @@ struct StagedSelection {
     DevBuf<double> d_rmsd, d_cut, d_maxdyn;
     DevBuf<float2> d_bounds;
     DevBuf<Staged> d_staged;
+    DevBuf<BlockHdr> d_hdr;      // per staged template: the record of the table-driven stages (k_search reads 64 at a time)
+    DevBuf<uint16_t> d_lead8;    // per staged template: lead-kind index of each of its residues (0xffff: none)
+    // staged positions the template-at-a-time launch looks at: templates of fewer than three residues, and (for batches
+    // with a structure large enough for a pair table of 2^25 entries) all of them
+    std::vector<uint32_t> small;
+    DevBuf<uint32_t> d_small, d_all;
     // The device works on the selection sorted by descending estimated cost (every workgroup's dynamic queue
     // then starts with the expensive templates and ends on the cheap ones); order[pos] is the caller's index.
     std::vector<uint32_t> order;
@@ -1587,7 +1593,8 @@ static int build_tables(const tm_library *lib, tm_batch *b, const StagedSelectio
                        b->d_tab_cursors.p, ents, b->d_tab_overflow.p, lr_arg, shared_limit);
     {
         const uint32_t n_sel = (uint32_t)S->sel.size();
-        hipLaunchKernelGGL(k_tab_refs, dim3(ns, (n_sel + 255) / 256), dim3(256), 0, stream, B, n_sel, S->d_staged.p, b->d_tab_ref.p);
+        hipLaunchKernelGGL(k_tab_refs, dim3(ns, (n_sel + 255) / 256), dim3(256), 0, stream, B, lib->n_lead, n_sel, S->d_pair_table.p,
+                           S->d_triple_table.p, S->d_lead8.p, b->d_tab_ref.p);
     }
     HIP_TRY(hipGetLastError());
     return TM_OK;
@@ -1732,17 +1739,26 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
                     for (int c = 0; c < kTableClasses; ++c) std::fprintf(stderr, " %d", per_class[c]);
                     std::fprintf(stderr, "\n");
                 }
+                for (uint32_t i = 0; i < n_sel; ++i)
+                    if (tt[i] == 0xffffu) S->small.push_back(i);
+                {
+                    std::vector<uint32_t> all(n_sel);
+                    std::iota(all.begin(), all.end(), 0u);
+                    HIP_TRY(S->d_small.upload(S->small)); HIP_TRY(S->d_all.upload(all));
+                }
                 HIP_TRY(S->d_tables.upload(S->tables)); HIP_TRY(S->d_pair_table.upload(tp));
                 HIP_TRY(S->d_triple_table.upload(tt)); HIP_TRY(S->d_triple_key.upload(key));
                 S->serial = ++g_serial;
             }
             HIP_TRY(S->d_bounds.alloc((size_t)n_sel * kMaxPairs));
             HIP_TRY(S->d_staged.alloc(n_sel));
+            HIP_TRY(S->d_hdr.alloc(n_sel));
+            HIP_TRY(S->d_lead8.alloc((size_t)n_sel * kMaxG));
             HIP_TRY(hipEventCreateWithFlags(&S->ready, hipEventDisableTiming));
             if (n_sel) {
                 hipLaunchKernelGGL(k_stage_templates, dim3(n_sel), dim3(64), 0, stream, lib->view(), n_sel, S->d_sel.p,
                                    S->d_cut.p, S->d_maxdyn.p, S->d_pair_table.p, S->d_triple_table.p, S->d_triple_key.p,
-                                   S->d_staged.p, S->d_bounds.p, S->slack);
+                                   S->d_staged.p, S->d_bounds.p, S->d_hdr.p, S->d_lead8.p, S->slack);
                 HIP_TRY(hipGetLastError());
             }
             HIP_TRY(hipEventRecord(S->ready, stream));
@@ -1823,7 +1839,7 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
 
     QueryView Q;
     Q.n_sel = n_sel; Q.sel = S->d_sel.p; Q.rmsd_thr = S->d_rmsd.p; Q.cutoff = S->d_cut.p; Q.maxdyn = S->d_maxdyn.p;
-    Q.staged = S->d_staged.p; Q.bounds = S->d_bounds.p; Q.order = S->d_order.p; Q.max_candidates = p->max_candidates; Q.flags = p->flags;
+    Q.staged = S->d_staged.p; Q.hdr = S->d_hdr.p; Q.bounds = S->d_bounds.p; Q.order = S->d_order.p; Q.max_candidates = p->max_candidates; Q.flags = p->flags;
     Q.n_tables = (uint32_t)S->tables.size(); Q.tables = S->d_tables.p;
     Q.cost = nullptr;
     {
@@ -1928,12 +1944,23 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
         const uint32_t pool_cap = lds_path ? (uint32_t)((lds_limit - base) / sizeof(uint16_t)) : 0u;
         const size_t lds_bytes = lds_path ? lds_limit : scratch;
         const bool ic = (p->flags & TM_FLAG_IGNORE_CHAIN) != 0;
-        void (*kernel)(SearchArgs) = lds_path ? (ic ? k_search<true, true> : k_search<true, false>)
-                                              : (ic ? k_search<false, true> : k_search<false, false>);
+        void (*kernel)(SearchArgs) = lds_path ? (ic ? k_search<true, true, false> : k_search<true, false, false>)
+                                              : (ic ? k_search<false, true, false> : k_search<false, false, false>);
+        SearchArgs args{lib->view(), b->view(), Q, O, b->d_work.p, b->work_items, cx, b->max_atoms, b->max_res, pool_cap, nullptr, 0u};
         HIP_TRY(allow_dynamic_lds(reinterpret_cast<const void *>(kernel), lds_bytes));
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(kSearchBlock), lds_bytes, stream,
-                           SearchArgs{lib->view(), b->view(), Q, O, b->d_work.p, b->work_items, cx, b->max_atoms, b->max_res, pool_cap});
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(kSearchBlock), lds_bytes, stream, args);
         HIP_TRY(hipGetLastError());
+        // templates the block search leaves out (k_tab_refs marks them kRefSingly), one template per wave at a time
+        const bool huge = (uint64_t)b->max_atoms * b->max_atoms >= (uint64_t)kRefLenMask;
+        if (huge || !S->small.empty()) {
+            args.singly = huge ? S->d_all.p : S->d_small.p;
+            args.n_singly = huge ? n_sel : (uint32_t)S->small.size();
+            void (*singly)(SearchArgs) = lds_path ? (ic ? k_search<true, true, true> : k_search<true, false, true>)
+                                                  : (ic ? k_search<false, true, true> : k_search<false, false, true>);
+            HIP_TRY(allow_dynamic_lds(reinterpret_cast<const void *>(singly), lds_bytes));
+            hipLaunchKernelGGL(singly, dim3(grid), dim3(kSearchBlock), lds_bytes, stream, args);
+            HIP_TRY(hipGetLastError());
+        }
     }
     HIP_TRY(hipEventRecord(r->ev[2], stream));
     trace.mark("search launch");

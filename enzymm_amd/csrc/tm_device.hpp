@@ -14,7 +14,7 @@ constexpr int kWave = 64;
 constexpr int kSearchWaves = 16;  // waves per search workgroup (one structure copy in LDS serves all)
 constexpr int kSearchBlock = kWave * kSearchWaves;
 constexpr int kPairQueue = 128;   // pair-table survivors buffered per wave
-constexpr int kTripleQueue = 64;  // triple survivors of one pass, waiting for their subtrees
+constexpr int kTripleQueue = 128;  // triple survivors waiting for their subtrees
 
 // Pair tables (see k_tab_* in tm_kernels.hip): for an ordered pair of lead kinds (A, B) and a distance limit, every
 // pair (i, j) of list positions -- i in the structure's kind list A, j in list B -- whose atoms lie in different
@@ -114,6 +114,18 @@ struct __align__(16) Staged {
     __host__ __device__ uint32_t k() const { return hdr & 0xffu; }
 };
 
+// What the table-driven stages of the search (the lead atoms of the first three template residues) need of a staged
+// template, 32 bytes: k_search reads these 64 templates at a time, one per lane (search_block in tm_kernels.hip).
+struct __align__(16) BlockHdr {
+    float2 w10;      // fp32 window (lo^2, hi^2) of the pair (lead 1, lead 0)
+    float2 wkey;     // ... of (lead 2, key lead): the stored distance of a triple-table entry is tested against it
+    float2 wother;   // ... of (lead 2, the other of leads 0 and 1): computed from the atom records
+    uint16_t li[3];  // lead-kind indices of leads 0, 1, 2 (0xffff: the template has fewer residues)
+    uint16_t flags;  // bit 0: rows of the triple table are positions of lead 1 (else lead 0); bits 1-3: template chains of
+                     // (1,0), (2,0), (2,1) equal; bits 4-7: residues; bits 8-12: atoms
+};
+static_assert(sizeof(BlockHdr) == 32, "BlockHdr layout");
+
 struct QueryView {
     uint32_t n_sel;
     const uint32_t *sel;        // [n_sel] template indices
@@ -121,6 +133,7 @@ struct QueryView {
     const double *cutoff;       // [n_sel]
     const double *maxdyn;       // [n_sel]
     const Staged *staged;       // [n_sel]
+    const BlockHdr *hdr;        // [n_sel]
     const float2 *bounds;       // [n_sel*kMaxPairs] (lo^2, hi^2) fp32 prefilter bounds, search order
     const uint32_t *order;      // [n_sel] every per-selection array above is sorted by descending estimated cost;
                                 // order[pos] = the caller's selection index (reported in tm_hit / candidate counts)

@@ -114,6 +114,7 @@ __global__ __launch_bounds__(64) void k_stage_templates(LibView L, uint32_t n_se
                                                          const uint16_t *__restrict__ triple_table,
                                                          const uint8_t *__restrict__ triple_key,
                                                          Staged *__restrict__ staged, float2 *__restrict__ bounds,
+                                                         BlockHdr *__restrict__ hdr, uint16_t *__restrict__ lead8,
                                                          double slack) {
     const uint32_t ti = blockIdx.x;
     if (ti >= n_sel) return;
@@ -146,9 +147,7 @@ __global__ __launch_bounds__(64) void k_stage_templates(LibView L, uint32_t n_se
         S.pair_table = pair_table[ti];
         S.triple_table = triple_table[ti];
     }
-    for (int p = lane; p < npairs; p += 64) {
-        int i, j;
-        pair_of(p, i, j);
+    auto window = [&](int i, int j) {  // fp32 (lo^2, hi^2) of the pair constraint (i, j), slack included
         const double *a = L.a_xyz + 3 * (size_t)(off + i), *b = L.a_xyz + 3 * (size_t)(off + j);
         const double dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
         const double dt = sqrt(dx * dx + dy * dy + dz * dz);
@@ -157,7 +156,27 @@ __global__ __launch_bounds__(64) void k_stage_templates(LibView L, uint32_t n_se
         const double lo = dt - thr, hi = dt + thr;
         const float lo2 = lo > 0.0 ? (float)(lo * lo) * (1.0f - 1e-6f) : 0.0f;
         const float hi2 = (float)(hi * hi) * (1.0f + 1e-6f);
-        bounds[(size_t)ti * kMaxPairs + p] = make_float2(lo2, hi2);
+        return make_float2(lo2, hi2);
+    };
+    for (int p = lane; p < npairs; p += 64) {
+        int i, j;
+        pair_of(p, i, j);
+        bounds[(size_t)ti * kMaxPairs + p] = window(i, j);
+    }
+    if (lane == 0) {
+        // the compact record of the table-driven stages (leads 0, 1, 2 are search positions 0, 1, 2)
+        int g = 0;
+        for (int i = 0; i < k; ++i) g = max(g, (int)L.a_group[off + i] + 1);
+        BlockHdr h;
+        const uint32_t key = triple_key[ti];
+        h.w10 = g >= 2 ? window(1, 0) : make_float2(0.f, 0.f);
+        h.wkey = g >= 3 ? window(2, (int)key) : make_float2(0.f, 0.f);
+        h.wother = g >= 3 ? window(2, 1 - (int)key) : make_float2(0.f, 0.f);
+        for (int i = 0; i < 3; ++i) h.li[i] = i < g ? (uint16_t)L.k_lead[L.a_kind[off + i]] : (uint16_t)0xffffu;
+        const auto tc = [&](int i, int j) { return i < k && j < k && L.a_chain[off + i] == L.a_chain[off + j] ? 1u : 0u; };
+        h.flags = (uint16_t)(key | (tc(1, 0) << 1) | (tc(2, 0) << 2) | (tc(2, 1) << 3) | ((uint32_t)g << 4) | ((uint32_t)k << 8));
+        hdr[ti] = h;
+        for (int i = 0; i < kMaxG; ++i) lead8[(size_t)ti * kMaxG + i] = i < g ? (uint16_t)L.k_lead[L.a_kind[off + i]] : (uint16_t)0xffffu;
     }
 }
 
@@ -647,29 +666,39 @@ __global__ __launch_bounds__(kTabBlock) void k_tab_build(uint32_t n_lead, BatchV
 }
 
 constexpr uint32_t kRefLenMask = (1u << 25) - 1u;
+constexpr uint32_t kRefSingly = 1u << 31;
 // Where every (structure, selected template) search finds its tables: {first entry of its pair table, number of
-// entries (25 bits) | entries of the triple table to prefetch (7 bits), first row slot of its triple table, first
-// entry of its triple table}.  One 16-byte load at an address
-// known the moment a template is claimed, instead of three loads that depend on the template's record.
-__global__ __launch_bounds__(256) void k_tab_refs(BatchView B, uint32_t n_sel, const Staged *__restrict__ staged,
-                                                   uint4 *__restrict__ tab_ref) {
+// entries (25 bits) | kRefSingly, first row slot of its triple table, first entry of its triple table}.  One 16-byte
+// load per search, lane = template.  A template with an empty lead list in this structure cannot match: it gets an
+// empty pair segment and costs nothing further.  kRefSingly marks the searches the block search hands to the
+// template-at-a-time path: templates of fewer than three residues (enzymm's match_small_templates) and pair tables
+// of 2^25 entries or more.
+__global__ __launch_bounds__(256) void k_tab_refs(BatchView B, uint32_t n_lead, uint32_t n_sel,
+                                                   const uint16_t *__restrict__ pair_table,
+                                                   const uint16_t *__restrict__ triple_table,
+                                                   const uint16_t *__restrict__ lead8, uint4 *__restrict__ tab_ref) {
     const uint32_t s = blockIdx.x;
     const uint32_t ti = blockIdx.y * blockDim.x + threadIdx.x;
     if (ti >= n_sel) return;
     const size_t base = (size_t)s * B.n_tables;
-    const uint32_t tp = staged[ti].pair_table, tt = staged[ti].triple_table;
+    const uint32_t tp = pair_table[ti], tt = triple_table[ti];
+    const uint32_t *kl = B.kl_off + (size_t)s * (n_lead + 1);
+    bool feasible = true;
+    for (int g = 0; g < kMaxG; ++g) {
+        const uint32_t li = lead8[(size_t)ti * kMaxG + g];
+        if (li != 0xffffu && kl[li + 1] == kl[li]) feasible = false;
+    }
     uint4 r = make_uint4(0u, 0u, 0u, 0u);
-    if (B.tab_ok[s] == 1u) {
-        if (tp != 0xffffu) {
-            const uint2 seg = B.tab_seg[base + tp];
+    if (B.tab_ok[s] == 1u && feasible) {
+        if (tt == 0xffffu) {
+            r.y = kRefSingly;
+        } else {
+            const uint2 seg = B.tab_seg[base + tp], seg3 = B.tab_seg[base + tt];
             r.x = seg.x;
-            r.y = min(seg.y - seg.x, kRefLenMask);  // kRefLenMask itself: "longer, see tab_seg" (never seen so far)
-        }
-        if (tt != 0xffffu) {
-            const uint2 seg = B.tab_seg[base + tt];
+            r.y = seg.y - seg.x;
+            if (r.y >= kRefLenMask) r.y = kRefSingly;
             r.z = B.tab_dir[base + tt];
-            r.w = seg.x;
-            r.y |= min(seg.y - seg.x, 64u) << 25;  // how many of the triple table's entries a search prefetches
+            r.w = seg3.x;
         }
     }
     tab_ref[(size_t)s * n_sel + ti] = r;
@@ -685,9 +714,9 @@ constexpr int kBoundsLds = kBoundRowsLds * (kBoundRowsLds + 1) / 2;  // 55 entri
 struct __align__(16) WaveScratch {
     float2 bnd[64];                            // the first kBoundsLds pair bounds of the template (all of them for k <= 11)
     uint16_t surv[kMaxG][64];                  // per template residue: one 64-entry chunk of its lead list
-    uint32_t queue[kPairQueue];                // pair-table survivors (position in list 0 | position in list 1 << 16)
-    uint32_t queue3[kTripleQueue][2];          // survivors of one triple pass ((a0 | a1 << 16), a2) waiting for their subtree
-    uint32_t owner[64];                        // triple stage: queued pair owning the item at which its row starts
+    uint2 pairs[kPairQueue];                   // pair-table survivors {position in list 0 | position in list 1 << 16, slot}
+    uint2 triples[kTripleQueue];               // triple survivors {a0 | a1 << 16, a2 | slot << 16} waiting for their subtrees
+    uint32_t owner[64];                        // item-parallel stages: who owns the item at which its segment / row starts
 };
 
 // Search state of one wave, held in VGPRs and indexed BY LANE: lane L holds the entry of search
@@ -882,6 +911,10 @@ struct SearchArgs {
     uint32_t n_items;
     uint32_t chunk_xcd_shift;  // template chunks of an item: (1 << chunk_xcd_shift) spread over the XCDs x item.rounds
     uint32_t max_atoms, max_res, pool_cap;
+    // k_search<..., kSingly = true>: staged templates that may need the template-at-a-time search (those of fewer than
+    // three residues; every template when a structure is large enough for a pair table of 2^25 entries)
+    const uint32_t *singly;
+    uint32_t n_singly;
 };
 typedef const __attribute__((address_space(4))) SearchArgs *ColdArgsPtr;
 __device__ __forceinline__ ColdArgsPtr cold_args() {
@@ -1094,6 +1127,9 @@ template <class Ctx>
 __device__ __forceinline__ bool table_scan(const Ctx &C, WaveRegs &W, PairState &P, const TableRefs &TR,
                                            const TablePrefetch &F) {
     WaveScratch &S = *C.S;
+    // (the template-at-a-time path keeps its own layout of the two queues inside the block search's)
+    uint32_t *queue = reinterpret_cast<uint32_t *>(S.pairs);
+    uint32_t (*queue3)[2] = reinterpret_cast<uint32_t (*)[2]>(S.triples);
     const int lane = C.lane;
     const int G = C.n_groups;
     const uint32_t lo0 = RL(W.lo, 0), lo1 = RL(W.lo, 1), lo2 = RL(W.lo, 2);
@@ -1136,7 +1172,7 @@ __device__ __forceinline__ bool table_scan(const Ctx &C, WaveRegs &W, PairState 
             const unsigned long long m = ballot64(ok);
             TM_STAT(52, 1);
             if (m) {
-                if (ok) S.queue[nq + rank_in(m)] = ent.x;
+                if (ok) queue[nq + rank_in(m)] = ent.x;
                 nq += (uint32_t)__popcll(m);
             }
             e += 64u;
@@ -1152,7 +1188,7 @@ __device__ __forceinline__ bool table_scan(const Ctx &C, WaveRegs &W, PairState 
         wave_sync();
         if (G == 2) {
             for (uint32_t q = 0; q < nq; ++q) {
-                const uint32_t pos = uni(S.queue[q]);
+                const uint32_t pos = uni(queue[q]);
                 const uint32_t a0 = C.pool_at(lo0 + (pos & 0xffffu)), a1 = C.pool_at(lo1 + (pos >> 16));
                 const float4 r0 = C.rec[a0], r1 = C.rec[a1];
                 assign_record(C, W, 0, a0, r0);
@@ -1165,7 +1201,7 @@ __device__ __forceinline__ bool table_scan(const Ctx &C, WaveRegs &W, PairState 
         for (uint32_t p0 = 0; p0 < nq; p0 += 64u) {
             const uint32_t np = min(64u, nq - p0);
             const bool vp = (uint32_t)lane < np;
-            const uint32_t pos_p = vp ? S.queue[p0 + (uint32_t)lane] : 0u;
+            const uint32_t pos_p = vp ? queue[p0 + (uint32_t)lane] : 0u;
             const uint32_t key = key1 ? pos_p >> 16 : pos_p & 0xffffu;
             // the row of the key atom: offsets from the prefetched slots (lanes key, key + 1), or from memory
             uint32_t r0 = lane_get(F.triple_row, key), r1 = lane_get(F.triple_row, key + 1u);
@@ -1219,13 +1255,13 @@ __device__ __forceinline__ bool table_scan(const Ctx &C, WaveRegs &W, PairState 
                 if (m == 0ull) continue;
                 if (ok) {
                     const uint32_t slot = rank_in(m);
-                    S.queue3[slot][0] = a0 | (a1 << 16);
-                    S.queue3[slot][1] = c2;
+                    queue3[slot][0] = a0 | (a1 << 16);
+                    queue3[slot][1] = c2;
                 }
                 const uint32_t nq3 = (uint32_t)__popcll(m);
                 wave_sync();
                 for (uint32_t q = 0; q < nq3; ++q) {
-                    const uint32_t ab = uni(S.queue3[q][0]), c = uni(S.queue3[q][1]);
+                    const uint32_t ab = uni(queue3[q][0]), c = uni(queue3[q][1]);
                     const uint32_t x0 = ab & 0xffffu, x1 = ab >> 16;
                     const float4 q0 = C.rec[x0], q1 = C.rec[x1], q2 = C.rec[c];
                     if (C.k > 3 && !level3_has_candidate(C, W, x0, x1, c, q0, q1, q2)) continue;
@@ -1249,9 +1285,8 @@ __host__ __device__ inline size_t search_res_bytes(uint32_t max_res) {
 }
 __host__ __device__ inline size_t search_kl_words(uint32_t n_lead) { return ((size_t)n_lead + 1 + 3) & ~size_t(3); }
 
-// One template's per-level constants as loaded by lane L for level L (plus one lead-pair bound).
-// Held in registers one template ahead of the search, so that the global-memory latency of the
-// next template overlaps the current search.
+// One template's per-level constants as loaded by lane L for level L (plus one lead-pair bound): what the
+// depth-first part of a search needs.  Loaded only for templates with a triple that survived the tables.
 struct TemplateRegs {
     uint32_t pk, resmask, nm_lo, nm_hi, li;
     float2 bound;  // bounds[lane]
@@ -1271,19 +1306,401 @@ __device__ __forceinline__ void load_template(const QueryView &Q, uint32_t ti, i
     R.hdr = T.hdr;
 }
 
-// The template loop of one workgroup: its waves claim the templates of the workgroup's chunk one by one and search
+// Lane L < k takes level L's constants of the template in R: the search state machine (dfs, eval_chunk,
+// level3_has_candidate) runs on W.  Returns false when a lead list of the template is empty in this structure.
+template <class Ctx>
+__device__ __forceinline__ bool setup_template(Ctx &C, WaveRegs &W, const TemplateRegs &R, const uint32_t *kl,
+                                               const QueryView &Q, uint32_t ti) {
+    const int lane = C.lane;
+    const uint32_t hdr = uni(R.hdr);
+    const int k = (int)(hdr & 0xffu);
+    C.k = k;
+    C.n_groups = (int)((hdr >> 8) & 0xffu);
+    C.bnd = Q.bounds + (size_t)ti * kMaxPairs;
+    W = {};
+    W.surv_base = 0xffffffffu;
+    bool empty = false;
+    if (lane < k) {
+        W.pk = R.pk;
+        W.resmask = R.resmask;
+        W.nm_lo = R.nm_lo;
+        W.nm_hi = R.nm_hi;
+        W.lead = R.li != 0xffffu ? 1u : 0u;
+        if (W.lead) {
+            const uint32_t o0 = kl[R.li], o1 = kl[R.li + 1];
+            W.lo = o0;
+            W.cnt = o1 - o0;
+            empty = o1 == o0;
+        }
+    }
+    C.S->bnd[lane] = R.bound;  // rows of bounds for eval_chunk (LDS); the first windows are read from the registers
+    W.bnd_lo = R.bound.x;
+    W.bnd_hi = R.bound.y;
+    wave_sync();
+    return ballot64(empty) == 0ull;
+}
+
+// The outcome of one (structure, template) search: its candidate count (optional table) and, when it produced
+// candidates or was cut short, one entry of the pair table (k_superpose / k_select work from those).
+__device__ __forceinline__ void write_outcome(uint32_t s, uint32_t ti, uint32_t packed, uint32_t prev, bool count_candidates,
+                                              int lane) {
+    if (packed == 0u || lane != 0) return;
+    ColdArgsPtr cold = cold_args();
+    if (count_candidates) cold->O.candidates[(size_t)s * cold->Q.n_sel + cold->Q.order[ti]] = packed;
+    const unsigned long long slot = atomicAdd(cold->O.n_pairs, 1ull);
+    if (slot >= cold->O.pair_capacity) atomicOr(cold->O.overflow, 2u);
+    else cold->O.pairs[slot] = PairEntry{s, ti, prev, packed};
+}
+
+// Template-at-a-time search (the round-2 path): templates of one or two residues, which have no triple table, and
+// pair tables too long for a block's 25-bit segment length.
+template <class Ctx>
+__device__ __forceinline__ void search_singly(Ctx &C, const SearchArgs &A, WaveRegs &W, uint32_t s, uint32_t ti, const uint32_t *kl) {
+    const QueryView &Q = A.Q;
+    const BatchView &B = A.B;
+    const int lane = C.lane;
+    TemplateRegs R;
+    load_template(Q, ti, lane, R);
+    const bool feasible = setup_template(C, W, R, kl, Q, ti);
+    const uint32_t hdr = uni(R.hdr);
+    const int G = C.n_groups;
+    TableRefs TR = {};
+    TablePrefetch F = {};
+    const Staged &T = Q.staged[ti];
+    const uint32_t tp = T.pair_table, tt = T.triple_table;
+    uint32_t pair_len = 0, triple_len = 0;
+    if (tp != 0xffffu) {
+        const uint2 seg = B.tab_seg[(size_t)s * B.n_tables + tp];
+        TR.pair_begin = uni(seg.x);
+        pair_len = uni(seg.y - seg.x);
+    }
+    TR.pair_end = TR.pair_begin + pair_len;
+    if (tt != 0xffffu) {
+        const uint2 seg = B.tab_seg[(size_t)s * B.n_tables + tt];
+        TR.triple_rows = uni(B.tab_dir[(size_t)s * B.n_tables + tt]);
+        TR.triple_begin = uni(seg.x);
+        triple_len = uni(min(seg.y - seg.x, 64u));
+    }
+    TR.key_is_1 = hdr >> 16;
+    TR.flags = Q.flags;
+    F.pair_ent = B.tab_ent[TR.pair_begin + min((uint32_t)lane, max(pair_len, 1u) - 1u)];
+    F.triple_row = B.tab_rows[TR.triple_rows + min((uint32_t)lane, G >= 3 ? RL(W.cnt, (int)TR.key_is_1) : 0u)];
+    F.triple_ent = B.tab_ent[TR.triple_begin + min((uint32_t)lane, max(triple_len, 1u) - 1u)];
+    PairState P;
+    P.s = s; P.ti = ti;
+    P.ncand = 0; P.prev = 0xffffffffu; P.truncated = false;
+    TM_STAT(49, 1);
+    if (feasible) table_scan(C, W, P, TR, F);
+    write_outcome(s, ti, P.ncand | (P.truncated ? 0x80000000u : 0u), P.prev, A.O.candidates != nullptr, lane);
+    wave_sync();
+}
+
+// ------------------------------------------------------------------ block search
+//
+// A wave searches a BLOCK of up to 64 templates of its workgroup's structure at a time.  The lead atoms of the first
+// three template residues come from the structure's pair tables, and those stages are data-parallel over the whole
+// block: the work items of all its templates are laid end to end over the lanes, so a pass of 64 lanes is full
+// whatever the sizes of the individual templates' table segments (14 entries on average).
+//
+//   A  lane = template: its table references (16 B) and its BlockHdr (32 B) are loaded; prefix sum of the pair-segment
+//      lengths.  What later stages need of a template stays in that lane's registers (SlotRegs) and is fetched by
+//      the lanes that work on its items with ds_bpermute.
+//   B  lane = entry of a pair segment: the stored squared distance against the template's window (1, 0); survivors
+//      {positions, slot} are queued in LDS.
+//   C  (per 64 queued pairs) lane = pair: its row of the (key, lead 2) table; then lane = item of a row: window
+//      (2, key) on the stored distance, window (2, other) computed from the atom records; survivors {atoms, slot} are
+//      queued in LDS.
+//   D  (per 64 queued triples) one triple at a time, wave-cooperative as before: the template's per-level constants
+//      are loaded when a triple of another template comes up (triples arrive grouped by template), a quick look at
+//      level 3, then the depth-first search below.
+//
+// Round 2 searched one template at a time: every search paid the set-up of the per-level constants (1 KB from L2
+// per search: 4.7 GB per launch), one exposed round trip to its tables, and ran its pair and triple stages with a
+// quarter of the lanes.  Here the set-up is paid by the templates that reach stage D, a block pays the table round
+// trips once, and stages B and C run on full waves.
+
+struct SlotRegs {  // lane = template slot of the block
+    uint32_t ti;                // staged template index
+    uint32_t base;              // first entry of its pair segment - items of the block before it (mod 2^32)
+    uint32_t trows, tbegin;     // triple table: first row slot, first entry
+    uint32_t lo0, lo1, lo2;     // kind lists of leads 0, 1, 2: first pool position
+    uint32_t flags;             // BlockHdr::flags
+    float w10lo, w10hi, wklo, wkhi, wolo, wohi;
+    uint32_t ncand;             // verified candidates so far | cut short << 31
+    uint32_t prev;              // last emitted candidate slot
+};
+
+__device__ __forceinline__ float lane_getf(float v, uint32_t src) { return __uint_as_float(lane_get(__float_as_uint(v), src)); }
+
+// The template whose per-level constants sit in W (stage D), and the one being fetched behind it.
+struct DeepState {
+    uint32_t slot;        // 0xffffffff: none
+    PairState P;
+    bool feasible;
+    TemplateRegs next;    // constants of the template of the next queued triple that belongs to another template
+    uint32_t next_ti;     // 0xffffffff: nothing fetched
+    unsigned long long since;  // calibration query: shader clock when this template's turn began
+};
+
+template <class Ctx>
+__device__ __forceinline__ void deep_leave(const Ctx &C, const QueryView &Q, SlotRegs &R, DeepState &D) {
+    if (D.slot == 0xffffffffu) return;
+    WL(R.ncand, (int)D.slot, D.P.ncand | (D.P.truncated ? 0x80000000u : 0u));
+    WL(R.prev, (int)D.slot, D.P.prev);
+    if (Q.cost && C.lane == 0) atomicAdd(&Q.cost[D.P.ti], __builtin_amdgcn_s_memtime() - D.since);
+    D.slot = 0xffffffffu;
+}
+
+// Stage D over the first `nt` queued triples.
+template <class Ctx>
+__device__ __forceinline__ void block_triples(Ctx &C, const SearchArgs &A, WaveRegs &W, SlotRegs &R, DeepState &D, uint32_t s,
+                                              const uint32_t *kl, uint32_t nt) {
+    const QueryView &Q = A.Q;
+    WaveScratch &S = *C.S;
+    const uint32_t lane = (uint32_t)C.lane;
+    uint2 t = make_uint2(0u, 0xffff0000u);
+    if (lane < nt) t = S.triples[lane];
+    for (uint32_t q = 0; q < nt; ++q) {
+        const uint32_t a01 = RL(t.x, (int)q), cs = RL(t.y, (int)q);
+        const uint32_t slot = cs >> 16, c = cs & 0xffffu, x0 = a01 & 0xffffu, x1 = a01 >> 16;
+        if (slot != D.slot) {  // a triple of another template: its constants take over W
+            deep_leave(C, Q, R, D);
+            const uint32_t ti = RL(R.ti, (int)slot);
+            TemplateRegs T;
+            if (D.next_ti == ti) T = D.next;
+            else load_template(Q, ti, (int)lane, T);
+            D.feasible = setup_template(C, W, T, kl, Q, ti);
+            D.slot = slot;
+            const uint32_t packed = RL(R.ncand, (int)slot);
+            D.P.s = s; D.P.ti = ti;
+            D.P.ncand = packed & 0x7fffffffu;
+            D.P.prev = RL(R.prev, (int)slot);
+            D.P.truncated = (packed >> 31) != 0u;
+            D.since = Q.cost ? __builtin_amdgcn_s_memtime() : 0ull;
+            // the next template in the queue starts loading now
+            const unsigned long long later = ballot64(lane > q && lane < nt && (t.y >> 16) != slot);
+            D.next_ti = 0xffffffffu;
+            if (later) {
+                D.next_ti = RL(R.ti, (int)(RL(t.y, __ffsll((long long)later) - 1) >> 16));
+                load_template(Q, D.next_ti, (int)lane, D.next);
+            }
+        }
+        if (D.P.truncated || !D.feasible) continue;
+        const float4 q0 = C.rec[x0], q1 = C.rec[x1], q2 = C.rec[c];
+        if (C.k > 3 && !level3_has_candidate(C, W, x0, x1, c, q0, q1, q2)) continue;
+#if defined(TM_STATS) || defined(TM_ABLATE)
+        if (Q.flags & 0x800u) continue;  // phase timing: the look at level 3, but no search below it
+#endif
+        assign_record(C, W, 0, x0, q0);
+        assign_record(C, W, 1, x1, q1);
+        assign_record(C, W, 2, c, q2);
+        dfs(C, W, D.P, 3);  // false: cut short by max_candidates (D.P.truncated is set)
+    }
+}
+
+// Moves queue entries [from, from + n) to the front (n < 64).
+__device__ __forceinline__ void queue_shift(uint2 *queue, uint32_t from, uint32_t n, uint32_t lane) {
+    uint2 v = make_uint2(0u, 0u);
+    if (lane < n) v = queue[from + lane];
+    wave_sync();
+    if (lane < n) queue[lane] = v;
+    wave_sync();
+}
+
+// Stage C over the first `np` queued pairs; survivors go to the triple queue (nq3 entries in it), which is worked
+// off (stage D) whenever it holds 64.
+template <class Ctx>
+__device__ __forceinline__ void block_pairs(Ctx &C, const SearchArgs &A, WaveRegs &W, SlotRegs &R, DeepState &D, uint32_t s,
+                                            const uint32_t *kl, uint32_t np, uint32_t &nq3) {
+    WaveScratch &S = *C.S;
+    const uint32_t lane = (uint32_t)C.lane;
+    const bool vp = lane < np;
+    uint2 pq = make_uint2(0u, 0u);
+    if (vp) pq = S.pairs[lane];
+    const uint32_t slot = pq.y, pos = pq.x;
+    const uint32_t flags = lane_get(R.flags, slot);
+    const bool key1 = (flags & 1u) != 0u;
+    const uint32_t key = key1 ? pos >> 16 : pos & 0xffffu;
+    const uint32_t trows = lane_get(R.trows, slot);
+    // the row of the key atom (lanes without a pair read slot 0's first row: a valid address)
+    const uint32_t r0 = C.tab_rows[trows + key], r1 = C.tab_rows[trows + key + 1u];
+    const uint32_t a0 = C.pool_at(lane_get(R.lo0, slot) + (pos & 0xffffu)), a1 = C.pool_at(lane_get(R.lo1, slot) + (pos >> 16));
+    const float4 ro = C.rec[key1 ? a0 : a1];  // the lead that is NOT the key: its distance to lead 2 is computed
+    const uint32_t a01 = a0 | (a1 << 16);
+    const uint32_t lo2 = lane_get(R.lo2, slot);
+    const float wklo = lane_getf(R.wklo, slot), wkhi = lane_getf(R.wkhi, slot);
+    const float wolo = lane_getf(R.wolo, slot), wohi = lane_getf(R.wohi, slot);
+    const uint32_t len = vp ? r1 - r0 : 0u;
+    const uint32_t incl = wave_scan_add(len), excl = incl - len;
+    const uint32_t total = RL(incl, 63);
+    const uint32_t row_base = lane_get(R.tbegin, slot) + r0 - excl;  // entry of item w of this pair's row: row_base + w
+    for (uint32_t w0 = 0; w0 < total; w0 += 64u) {
+        // owner of item w: each pair writes its lane where its row starts (or at item w0), a running maximum spreads it
+        S.owner[lane] = 0u;
+        {
+            const uint32_t start = max(excl, w0);
+            if (len != 0u && start < w0 + 64u && incl > w0) S.owner[start - w0] = lane;
+        }
+        wave_sync();
+        const uint32_t p = wave_scan_max(S.owner[lane]);
+        wave_sync();
+        const uint32_t w = min(w0 + lane, total - 1u);  // lanes past the last item repeat it and are masked out of the vote
+        const uint2 ent = C.tab_ent[lane_get(row_base, p) + w];
+        const float dk2 = __uint_as_float(ent.y);
+        bool ok = (w0 + lane < total) & (dk2 >= lane_getf(wklo, p)) & (dk2 <= lane_getf(wkhi, p));
+        const uint32_t c2 = C.pool_at(lane_get(lo2, p) + (ent.x >> 16));
+        const float4 rc = C.rec[c2];
+        const float ox = lane_getf(ro.x, p), oy = lane_getf(ro.y, p), oz = lane_getf(ro.z, p);
+        const uint32_t ores = meta_res(lane_get(__float_as_uint(ro.w), p));
+        const float dx = rc.x - ox, dy = rc.y - oy, dz = rc.z - oz;
+        const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+        ok = ok & (d2 >= lane_getf(wolo, p)) & (d2 <= lane_getf(wohi, p)) & (meta_res(__float_as_uint(rc.w)) != ores);
+        const uint32_t pa01 = lane_get(a01, p), pslot = lane_get(slot, p);
+        if (!C.ignore_chain) {
+            const uint32_t pf = lane_get(flags, p);  // (every lane takes part in the exchange: not under `if (ok)`)
+            if (ok) {
+                const uint8_t qc = C.qchain[c2];
+                ok = ((qc == C.qchain[pa01 & 0xffffu]) == (((pf >> 2) & 1u) != 0u)) &
+                     ((qc == C.qchain[pa01 >> 16]) == (((pf >> 3) & 1u) != 0u));
+            }
+        }
+        unsigned long long m = ballot64(ok);
+        TM_STAT(2, 1);
+        TM_STAT(24 + 2, __popcll(m));
+#if defined(TM_STATS) || defined(TM_ABLATE)
+        if (A.Q.flags & 0x400u) m = 0ull;
+#endif
+        if (m == 0ull) continue;
+        if (ok) S.triples[nq3 + rank_in(m)] = make_uint2(pa01, c2 | (pslot << 16));
+        nq3 += (uint32_t)__popcll(m);
+        if (nq3 >= 64u) {
+            wave_sync();
+            block_triples(C, A, W, R, D, s, kl, 64u);
+            queue_shift(S.triples, 64u, nq3 - 64u, lane);
+            nq3 -= 64u;
+        }
+    }
+}
+
+// One block: templates chunk + n_chunks * (m0 .. m0 + count - 1) of the staged selection against structure s.
+template <class Ctx>
+__device__ __forceinline__ void search_block(Ctx &C, const SearchArgs &A, WaveRegs &W, uint32_t s, uint32_t m0, uint32_t count,
+                                             uint32_t chunk, uint32_t n_chunks, const uint32_t *kl, const uint4 *tab_ref) {
+    const QueryView &Q = A.Q;
+    WaveScratch &S = *C.S;
+    const uint32_t lane = (uint32_t)C.lane;
+    const unsigned long long t_block = Q.cost ? __builtin_amdgcn_s_memtime() : 0ull;
+
+    // ---- A: lane = template
+    const bool valid = lane < count;
+    SlotRegs R;
+    R.ti = chunk + n_chunks * (m0 + (valid ? lane : 0u));
+    const uint4 ref = tab_ref[R.ti];
+    const BlockHdr H = Q.hdr[R.ti];
+    const bool singly = valid && (ref.y & kRefSingly) != 0u;
+    const uint32_t len = valid && !singly ? ref.y & kRefLenMask : 0u;
+    R.trows = ref.z; R.tbegin = ref.w;
+    R.flags = H.flags;
+    R.w10lo = H.w10.x; R.w10hi = H.w10.y;
+    R.wklo = H.wkey.x; R.wkhi = H.wkey.y;
+    R.wolo = H.wother.x; R.wohi = H.wother.y;
+    R.lo0 = kl[min((uint32_t)H.li[0], A.L.n_lead)];
+    R.lo1 = kl[min((uint32_t)H.li[1], A.L.n_lead)];
+    R.lo2 = kl[min((uint32_t)H.li[2], A.L.n_lead)];
+    R.ncand = 0u; R.prev = 0xffffffffu;
+    const uint32_t incl = wave_scan_add(len), excl = incl - len;
+    const uint32_t total = RL(incl, 63);
+    R.base = ref.x - excl;
+    TM_STAT(49, count);
+
+    DeepState D;
+    D.slot = 0xffffffffu; D.next_ti = 0xffffffffu; D.feasible = false; D.since = 0ull;
+    D.P.s = s; D.P.ti = 0; D.P.ncand = 0; D.P.prev = 0xffffffffu; D.P.truncated = false;
+
+    // (templates marked kRefSingly are searched by the k_search<..., kSingly = true> launch)
+
+    // ---- B: lane = entry of a pair segment
+    uint32_t nq = 0, nq3 = 0;
+    bool skip = false;
+#if defined(TM_STATS) || defined(TM_ABLATE)
+    skip = (Q.flags & 0x200u) != 0u;
+#endif
+    for (uint32_t w0 = 0; w0 < total && !skip; w0 += 64u) {
+        S.owner[lane] = 0u;
+        {
+            const uint32_t start = max(excl, w0);
+            if (len != 0u && start < w0 + 64u && incl > w0) S.owner[start - w0] = lane;
+        }
+        wave_sync();
+        const uint32_t p = wave_scan_max(S.owner[lane]);
+        wave_sync();
+        const uint32_t w = min(w0 + lane, total - 1u);
+        const uint2 ent = C.tab_ent[lane_get(R.base, p) + w];
+        const float d2 = __uint_as_float(ent.y);
+        bool ok = (w0 + lane < total) & (d2 >= lane_getf(R.w10lo, p)) & (d2 <= lane_getf(R.w10hi, p));
+        if (!C.ignore_chain) {
+            const uint32_t l0 = lane_get(R.lo0, p), l1 = lane_get(R.lo1, p), pf = lane_get(R.flags, p);
+            if (ok) ok = (C.qchain[C.pool_at(l0 + (ent.x & 0xffffu))] == C.qchain[C.pool_at(l1 + (ent.x >> 16))]) == (((pf >> 1) & 1u) != 0u);
+        }
+        unsigned long long m = ballot64(ok);
+        TM_STAT(52, 1);
+        TM_STAT(53, __popcll(m));
+#if defined(TM_STATS) || defined(TM_ABLATE)
+        if (Q.flags & 0x100u) m = 0ull;
+#endif
+        if (m == 0ull) continue;
+        if (ok) S.pairs[nq + rank_in(m)] = make_uint2(ent.x, p);
+        nq += (uint32_t)__popcll(m);
+        if (nq >= 64u) {
+            wave_sync();
+            block_pairs(C, A, W, R, D, s, kl, 64u, nq3);
+            queue_shift(S.pairs, 64u, nq - 64u, lane);
+            nq -= 64u;
+        }
+    }
+    if (nq != 0u) {
+        wave_sync();
+        block_pairs(C, A, W, R, D, s, kl, nq, nq3);
+    }
+    if (nq3 != 0u) {
+        wave_sync();
+        block_triples(C, A, W, R, D, s, kl, nq3);
+    }
+    deep_leave(C, Q, R, D);
+
+    // ---- the block's outcomes, lane = template
+    const uint32_t packed = valid && !singly ? R.ncand : 0u;
+    const unsigned long long with = ballot64(packed != 0u);
+    if (with) {
+        ColdArgsPtr cold = cold_args();
+        unsigned long long first = 0;
+        if (lane == 0) first = atomicAdd(cold->O.n_pairs, (unsigned long long)__popcll(with));
+        first = uni64(first);
+        if (packed != 0u) {
+            if (cold->O.candidates) cold->O.candidates[(size_t)s * Q.n_sel + cold->Q.order[R.ti]] = packed;
+            const unsigned long long slot = first + rank_in(with);
+            if (slot >= cold->O.pair_capacity) atomicOr(cold->O.overflow, 2u);
+            else cold->O.pairs[slot] = PairEntry{s, R.ti, R.prev, packed};
+        }
+    }
+    if (Q.cost && valid) {  // calibration query: the table-driven stages are shared out evenly over the block's templates
+        unsigned long long spent = __builtin_amdgcn_s_memtime() - t_block;
+        atomicAdd(&Q.cost[R.ti], spent / (64ull * count));
+    }
+    wave_sync();
+}
+
+// The template loop of one workgroup: its waves claim blocks of the workgroup's chunk of the staged selection and search
 // the structure staged in LDS.  kPoolLds: the structure's kind lists are in LDS too (the rule), else in global memory.
-template <bool kLds, bool kIgnoreChain, bool kPoolLds>
+// Block sizes are guided: 64 templates while much is left, fewer towards the end of the chunk (down to 8), so that
+// the sixteen waves run out of work at about the same time.
+template <bool kLds, bool kIgnoreChain, bool kPoolLds, bool kSingly>
 __device__ __forceinline__ void search_templates(const SearchArgs &A, WaveScratch *scratch, const float4 *s_rec,
                                                  const uint16_t *s_res, const uint32_t *s_kl, const uint16_t *s_pool,
                                                  const uint32_t *kl_off, uint32_t *s_next_p, uint32_t s, uint32_t a0,
-                                                 uint32_t r0, uint32_t n_chunks) {
-    const LibView &L = A.L;
+                                                 uint32_t r0, uint32_t chunk, uint32_t n_chunks) {
     const BatchView &B = A.B;
     const QueryView &Q = A.Q;
-    uint32_t &s_next = *s_next_p;
-    const uint32_t t_end = Q.n_sel;
-    (void)L;
     SearchCtx<kIgnoreChain, kPoolLds> C;
     C.rec = kLds ? s_rec : B.q_rec + a0;
     C.res_start = kLds ? s_res : B.res_start + r0;
@@ -1294,113 +1711,42 @@ __device__ __forceinline__ void search_templates(const SearchArgs &A, WaveScratc
     C.tab_ent = B.tab_ent;
     C.S = scratch + (threadIdx.x >> 6);
     C.lane = lane_id();
-    const bool count_candidates = A.O.candidates != nullptr;
-    WaveScratch &S = *C.S;
+    C.k = 0; C.n_groups = 0; C.bnd = Q.bounds;
     const int lane = C.lane;
     const uint32_t *kl = kLds ? s_kl : kl_off;
-
-    uint32_t ti = 0;
-    if (lane == 0) ti = atomicAdd(&s_next, n_chunks);
-    ti = uni(ti);
-    TemplateRegs R;
-    load_template(Q, min(ti, Q.n_sel - 1u), lane, R);
     const uint4 *tab_ref = B.tab_ref + (size_t)s * Q.n_sel;
-    uint4 ref = tab_ref[min(ti, Q.n_sel - 1u)];
-
-    while (ti < t_end) {
-        // claim the next template first: the LDS atomic's round trip runs under the set-up of the current one
-        uint32_t claimed = 0;
-        if (lane == 0) claimed = atomicAdd(&s_next, n_chunks);
-        const uint32_t hdr = uni(R.hdr);
-        const int k = (int)(hdr & 0xffu);
-        const int G = (int)((hdr >> 8) & 0xffu);
-        C.k = k;
-        C.n_groups = G;
-        C.bnd = Q.bounds + (size_t)ti * kMaxPairs;
-        TM_STAT(49, 1);
-
-        // ---- lane L < k takes level L's constants
-        WaveRegs W = {};
-        W.surv_base = 0xffffffffu;
-        bool empty = false;
-        if (lane < k) {
-            W.pk = R.pk;
-            W.resmask = R.resmask;
-            W.nm_lo = R.nm_lo;
-            W.nm_hi = R.nm_hi;
-            W.lead = R.li != 0xffffu ? 1u : 0u;
-            if (W.lead) {
-                const uint32_t o0 = kl[R.li], o1 = kl[R.li + 1];
-                W.lo = o0;
-                W.cnt = o1 - o0;
-                empty = o1 == o0;
-            }
+    const uint32_t n_mine = (Q.n_sel - chunk + n_chunks - 1u) / n_chunks;  // templates chunk, chunk + n_chunks, ...
+    WaveRegs W = {};
+    if (kSingly) {
+        // the template-at-a-time launch: the waves take the listed templates of this chunk one by one and search those
+        // whose table reference says so
+        for (;;) {
+            uint32_t m = 0;
+            if (lane == 0) m = atomicAdd(s_next_p, 1u);
+            m = uni(m);
+            const uint32_t at = chunk + n_chunks * m;
+            if (at >= A.n_singly) break;
+            const uint32_t ti = A.singly[at];
+            if ((uni(tab_ref[ti].y) & kRefSingly) != 0u) search_singly(C, A, W, s, ti, kl);
         }
-        const bool feasible = ballot64(empty) == 0ull;  // an empty lead list: no assignment exists
-        bool feasible_override = true;
-        // this template's tables (their whereabouts arrived with the template's constants); what the search reads
-        // of them first is fetched now, one value per lane, and is there when table_scan starts after the set-up
-        TableRefs TR;
-        TR.pair_begin = uni(ref.x);
-        uint32_t pair_len = uni(ref.y) & kRefLenMask;
-        const uint32_t triple_prefetch = uni(ref.y) >> 25;
-        if (pair_len == kRefLenMask) {  // a pair table of 2^25 entries or more: its true end is in the segment table
-            const uint2 seg = B.tab_seg[(size_t)s * B.n_tables + Q.staged[ti].pair_table];
-            pair_len = uni(seg.y - seg.x);
+        return;
+    }
+    for (;;) {
+        uint32_t m0 = 0, count = 0;
+        if (lane == 0) {
+            const uint32_t seen = __atomic_load_n(s_next_p, __ATOMIC_RELAXED);
+            const uint32_t left = seen < n_mine ? n_mine - seen : 0u;
+            count = min(64u, max(8u, (left / (2u * kSearchWaves)) & ~7u));
+            m0 = atomicAdd(s_next_p, count);
         }
-        TR.pair_end = TR.pair_begin + pair_len;
-        TR.triple_rows = uni(ref.z);
-        TR.triple_begin = uni(ref.w);
-        TR.key_is_1 = hdr >> 16;
-        TR.flags = Q.flags;
-        // only what exists is fetched: lanes past a table's end (or past the key list's rows) repeat its last
-        // element -- the same cache line, no extra traffic, and no divergent branch around the loads
-        TablePrefetch F;
-        F.pair_ent = B.tab_ent[TR.pair_begin + min((uint32_t)lane, max(pair_len, 1u) - 1u)];
-        F.triple_row = B.tab_rows[TR.triple_rows + min((uint32_t)lane, G >= 3 ? RL(W.cnt, (int)TR.key_is_1) : 0u)];
-        F.triple_ent = B.tab_ent[TR.triple_begin + min((uint32_t)lane, max(triple_prefetch, 1u) - 1u)];
-        S.bnd[lane] = R.bound;  // rows of bounds for eval_chunk (LDS); the first windows are read from the registers
-        W.bnd_lo = R.bound.x;
-        W.bnd_hi = R.bound.y;
-        wave_sync();
-
-        // ---- the next template (claimed at the top of this iteration) starts loading
-        const uint32_t ti_cur = ti;
-        ti = uni(claimed);
-        load_template(Q, min(ti, Q.n_sel - 1u), lane, R);
-        ref = tab_ref[min(ti, Q.n_sel - 1u)];
-
-        // calibration query: how long does this template's search take?  (orders the next staging of the selection)
-        const unsigned long long t_start = Q.cost ? __builtin_amdgcn_s_memtime() : 0ull;
-        PairState P;
-        P.s = s; P.ti = ti_cur;
-        P.ncand = 0; P.prev = 0xffffffffu; P.truncated = false;
-
-#if defined(TM_STATS) || defined(TM_ABLATE)
-        if (Q.flags & 0x200u) feasible_override = false;
-#endif
-        if (feasible && feasible_override) {
-            table_scan(C, W, P, TR, F);
-        }
-
-        if (Q.cost && lane == 0) atomicAdd(&Q.cost[ti_cur], __builtin_amdgcn_s_memtime() - t_start);
-        // ---- the pair's outcome
-        const uint32_t packed = P.ncand | (P.truncated ? 0x80000000u : 0u);
-        if (count_candidates && lane == 0) {
-            ColdArgsPtr cold = cold_args();
-            cold->O.candidates[(size_t)s * Q.n_sel + cold->Q.order[ti_cur]] = packed;
-        }
-        if (packed != 0u && lane == 0) {
-            ColdArgsPtr cold = cold_args();
-            const unsigned long long slot = atomicAdd(cold->O.n_pairs, 1ull);
-            if (slot >= cold->O.pair_capacity) atomicOr(cold->O.overflow, 2u);
-            else cold->O.pairs[slot] = PairEntry{s, ti_cur, P.prev, packed};
-        }
-        wave_sync();
+        m0 = uni(m0);
+        count = uni(count);
+        if (m0 >= n_mine) break;
+        search_block(C, A, W, s, m0, min(count, n_mine - m0), chunk, n_chunks, kl, tab_ref);
     }
 }
 
-template <bool kLds, bool kIgnoreChain>
+template <bool kLds, bool kIgnoreChain, bool kSingly>
 __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
     const LibView &L = A.L;
     const BatchView &B = A.B;
@@ -1434,7 +1780,7 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
     const uint32_t s = item.s;
     const uint32_t chunk = ((uint32_t)item.round << cx) + (xcd & ((1u << cx) - 1u));
     const uint32_t n_chunks = (uint32_t)item.rounds << cx;
-    if (chunk >= Q.n_sel) return;
+    if (chunk >= (kSingly ? A.n_singly : Q.n_sel)) return;
 
     if (B.tab_ok[s] != 1u) return;  // pair tables incomplete (pool overflow, reported with the result): nothing to search
     const uint32_t a0 = B.s_off[s], n = B.s_off[s + 1] - a0;
@@ -1453,22 +1799,26 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
         if (pool_in_lds)
             for (uint32_t i = threadIdx.x; i < plen; i += blockDim.x) s_pool[i] = B.kl_pool[p0 + i];
     }
-    if (threadIdx.x == 0) s_next = chunk;
+    if (threadIdx.x == 0) s_next = 0u;
     TM_STAT(55, threadIdx.x == 0 ? 1 : 0);
     TM_STAT(56, threadIdx.x == 0 && pool_in_lds ? 1 : 0);
     TM_STAT(57, threadIdx.x == 0 ? kl_off[L.n_lead] - kl_off[0] : 0);
     __syncthreads();
 
     if (pool_in_lds)
-        search_templates<kLds, kIgnoreChain, true>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, &s_next, s, a0, r0, n_chunks);
+        search_templates<kLds, kIgnoreChain, true, kSingly>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, &s_next, s, a0, r0, chunk, n_chunks);
     else
-        search_templates<kLds, kIgnoreChain, false>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, &s_next, s, a0, r0, n_chunks);
+        search_templates<kLds, kIgnoreChain, false, kSingly>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, &s_next, s, a0, r0, chunk, n_chunks);
 }
 
-template __global__ void k_search<true, true>(SearchArgs);
-template __global__ void k_search<true, false>(SearchArgs);
-template __global__ void k_search<false, true>(SearchArgs);
-template __global__ void k_search<false, false>(SearchArgs);
+template __global__ void k_search<true, true, false>(SearchArgs);
+template __global__ void k_search<true, false, false>(SearchArgs);
+template __global__ void k_search<false, true, false>(SearchArgs);
+template __global__ void k_search<false, false, false>(SearchArgs);
+template __global__ void k_search<true, true, true>(SearchArgs);
+template __global__ void k_search<true, false, true>(SearchArgs);
+template __global__ void k_search<false, true, true>(SearchArgs);
+template __global__ void k_search<false, false, true>(SearchArgs);
 
 size_t search_scratch_bytes() { return sizeof(WaveScratch) * kSearchWaves; }
 
