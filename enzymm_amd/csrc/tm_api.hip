@@ -310,6 +310,12 @@ struct StagedSelection {
     DevBuf<float2> d_bounds;
     DevBuf<Staged> d_staged;
     DevBuf<BlockHdr> d_hdr;      // per staged template: the record of the table-driven stages (k_search reads 64 at a time)
+    DevBuf<LookHdr> d_look;      // per staged template: the record of the look at search level 3
+    // Directory of the pages of triples waiting for k_deep: a structure of n atoms owns one entry per wave that works on
+    // it (the partly filled last page of each) + dir_milli * n^2 / 1e7 entries for its full pages.  Starts at 0.1 page
+    // per 1e4 atoms^2 (a 300-residue structure under the default thresholds fills about twenty pages); raised to what a
+    // query that overflowed needed.
+    std::atomic<unsigned long long> dir_milli{100};
     DevBuf<uint16_t> d_lead8;    // per staged template: lead-kind index of each of its residues (0xffff: none)
     // staged positions the template-at-a-time launch looks at: templates of fewer than three residues, and (for batches
     // with a structure large enough for a pair table of 2^25 entries) all of them
@@ -465,7 +471,17 @@ struct tm_result {
     DevBuf<tm_hit> d_hits;
     DevBuf<Cand> d_cands;
     DevBuf<PairEntry> d_pairs;
-    DevBuf<unsigned long long> d_counters;  // [0] hits, [1] candidates, [2] pairs
+    DevBuf<unsigned long long> d_counters;  // [0] hits, [1] candidates, [2] pairs, [3] pages of triples
+    // shared state of every (structure, template) pair: candidate count | cut short << 31, last candidate + 1
+    DevBuf<uint32_t> d_pair_count, d_pair_last;
+    // triples between k_search and k_deep: pages, their per-structure directory, its cursors
+    DevBuf<DeepEntry> d_pages;
+    DevBuf<uint2> d_dir;
+    DevBuf<uint32_t> d_dir_off, d_dir_n, d_dir_head;
+    PinnedBuf<uint32_t> h_dir_off;
+    std::vector<uint32_t> atoms_of, dir_base;  // per structure: atoms, fixed part of its directory share (read again after an overflow)
+    unsigned long long page_capacity = 0;
+    bool count_candidates = false;
     std::shared_ptr<StagedSelection> selection;
     unsigned long long n_atoms = 0;                                 // atoms of the batch (for the selection's per-atom needs)
     bool calibrates = false;                                        // this query clocks the selection's templates
@@ -473,7 +489,7 @@ struct tm_result {
     DevBuf<unsigned long long> d_pool_used;                         // kind-list entries the index build needed
     DevBuf<unsigned long long> d_tab_used;                          // pair-table row slots, entries the build needed
     unsigned long long pool_capacity = 0, row_capacity = 0, ent_capacity = 0;
-    DevBuf<uint32_t> d_overflow, d_candidates;
+    DevBuf<uint32_t> d_overflow;
     DevBuf<double> d_cand_rmsd, d_models;
     DevBuf<int32_t> d_model_set;
     DevBuf<uint32_t> d_model_offsets, d_model_votes;
@@ -1663,6 +1679,7 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
                 // what the selection has learned stays with it: the sizes its queries needed ...
                 S->cands_per_katom = last->cands_per_katom.load();
                 S->pairs_per_katom = last->pairs_per_katom.load();
+                S->dir_milli = last->dir_milli.load();
             } else {
                 std::stable_sort(S->order.begin(), S->order.end(), [&](uint32_t x, uint32_t y) {
                     return lib->cost_weight[S->sel[x]] > lib->cost_weight[S->sel[y]];
@@ -1753,12 +1770,13 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
             HIP_TRY(S->d_bounds.alloc((size_t)n_sel * kMaxPairs));
             HIP_TRY(S->d_staged.alloc(n_sel));
             HIP_TRY(S->d_hdr.alloc(n_sel));
+            HIP_TRY(S->d_look.alloc(n_sel));
             HIP_TRY(S->d_lead8.alloc((size_t)n_sel * kMaxG));
             HIP_TRY(hipEventCreateWithFlags(&S->ready, hipEventDisableTiming));
             if (n_sel) {
                 hipLaunchKernelGGL(k_stage_templates, dim3(n_sel), dim3(64), 0, stream, lib->view(), n_sel, S->d_sel.p,
                                    S->d_cut.p, S->d_maxdyn.p, S->d_pair_table.p, S->d_triple_table.p, S->d_triple_key.p,
-                                   S->d_staged.p, S->d_bounds.p, S->d_hdr.p, S->d_lead8.p, S->slack);
+                                   S->d_staged.p, S->d_bounds.p, S->d_hdr.p, S->d_look.p, S->d_lead8.p, S->slack);
                 HIP_TRY(hipGetLastError());
             }
             HIP_TRY(hipEventRecord(S->ready, stream));
@@ -1798,23 +1816,33 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
     HIP_TRY(r->d_pairs.alloc(hcap));
     HIP_TRY(r->d_cands.alloc(ccap));
     HIP_TRY(r->d_cand_rmsd.alloc(ccap));
-    HIP_TRY(r->d_counters.alloc(3));
+    HIP_TRY(r->d_counters.alloc(4));
     HIP_TRY(r->d_overflow.alloc(1));
     HIP_TRY(r->d_pool_used.alloc(1));
     HIP_TRY(r->d_tab_used.alloc(2));
     r->index_shared = b->index_shared;
+    r->count_candidates = (p->flags & TM_FLAG_COUNT_CANDIDATES) != 0;
+    // the shared state of the (structure, template) pairs, the pages of triples between k_search and k_deep and their
+    // per-structure directory (every structure's share from its atom count and what the selection has needed so far)
+    const size_t n_pairs_all = (size_t)b->n_structs * n_sel;
+    HIP_TRY(r->d_pair_count.alloc(n_pairs_all));
+    HIP_TRY(r->d_pair_last.alloc(n_pairs_all));
+    HIP_TRY(r->d_dir_n.alloc(b->n_structs));
+    HIP_TRY(r->d_dir_head.alloc(b->n_structs));
     {
         ZeroList z = {};
         z.p[0] = r->d_pool_used.p; z.words[0] = 2;
-        z.p[1] = r->d_counters.p; z.words[1] = 6;
+        z.p[1] = r->d_counters.p; z.words[1] = 8;
         z.p[2] = r->d_overflow.p; z.words[2] = 1;
         z.p[3] = r->d_tab_used.p; z.words[3] = 4;
+        z.p[4] = r->d_dir_n.p; z.words[4] = b->n_structs;
+        z.p[5] = r->d_dir_head.p; z.words[5] = b->n_structs;
         hipLaunchKernelGGL(k_zero, dim3(1), dim3(256), 0, stream, z);
         HIP_TRY(hipGetLastError());
     }
-    if (p->flags & TM_FLAG_COUNT_CANDIDATES) {
-        HIP_TRY(r->d_candidates.alloc((size_t)b->n_structs * n_sel));
-        HIP_TRY(hipMemsetAsync(r->d_candidates.p, 0, (size_t)b->n_structs * n_sel * sizeof(uint32_t), stream));
+    if (n_pairs_all) {
+        HIP_TRY(hipMemsetAsync(r->d_pair_count.p, 0, n_pairs_all * sizeof(uint32_t), stream));
+        HIP_TRY(hipMemsetAsync(r->d_pair_last.p, 0, n_pairs_all * sizeof(uint32_t), stream));
     }
 
     if (b->queried && b->last_stream != stream) HIP_TRY(hipStreamSynchronize(b->last_stream));
@@ -1839,7 +1867,7 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
 
     QueryView Q;
     Q.n_sel = n_sel; Q.sel = S->d_sel.p; Q.rmsd_thr = S->d_rmsd.p; Q.cutoff = S->d_cut.p; Q.maxdyn = S->d_maxdyn.p;
-    Q.staged = S->d_staged.p; Q.hdr = S->d_hdr.p; Q.bounds = S->d_bounds.p; Q.order = S->d_order.p; Q.max_candidates = p->max_candidates; Q.flags = p->flags;
+    Q.staged = S->d_staged.p; Q.hdr = S->d_hdr.p; Q.look = S->d_look.p; Q.bounds = S->d_bounds.p; Q.order = S->d_order.p; Q.max_candidates = p->max_candidates; Q.flags = p->flags;
     Q.n_tables = (uint32_t)S->tables.size(); Q.tables = S->d_tables.p;
     Q.cost = nullptr;
     {
@@ -1850,7 +1878,11 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
             const uint32_t off = mean_atoms > ref ? mean_atoms - ref : ref - mean_atoms;
             if (ref && 4u * off > ref) expected = 3;
         }
-        if (n_sel && b->n_structs >= 64 && S->calibration.compare_exchange_strong(expected, 1)) {  // enough searches to average
+        // (Round 2 searched a template per wave and ordered the selection by measured cost.  The block search spreads a
+        // block's items over the lanes and k_deep shares the triples: the order matters little, and sorting by cost puts
+        // all the heavy templates into the same blocks.  Measuring stays available for experiments.)
+        static const bool calibrate = std::getenv("ENZYMM_AMD_CALIBRATE") != nullptr;
+        if (calibrate && n_sel && b->n_structs >= 64 && S->calibration.compare_exchange_strong(expected, 1)) {  // enough searches to average
             S->calibrating_on = mean_atoms;
             HIP_TRY(S->d_cost.alloc(n_sel));
             HIP_TRY(hipMemsetAsync(S->d_cost.p, 0, n_sel * sizeof(unsigned long long), stream));
@@ -1892,7 +1924,9 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
     O.cands = r->d_cands.p; O.cand_rmsd = r->d_cand_rmsd.p; O.n_cands = r->d_counters.p + 1; O.cand_capacity = ccap;
     O.pairs = r->d_pairs.p; O.n_pairs = r->d_counters.p + 2; O.pair_capacity = hcap;
     O.hits = r->d_hits.p; O.n_hits = r->d_counters.p; O.hit_capacity = hcap; O.overflow = r->d_overflow.p;
-    O.candidates = (p->flags & TM_FLAG_COUNT_CANDIDATES) ? r->d_candidates.p : nullptr;
+    O.pair_count = r->d_pair_count.p; O.pair_last = r->d_pair_last.p;
+    O.n_pages = r->d_counters.p + 3; O.dir_n = r->d_dir_n.p; O.dir_head = r->d_dir_head.p;
+    O.pages = nullptr; O.page_capacity = 0; O.dir = nullptr; O.dir_off = nullptr;  // sized below, with the work items
     if (n_sel && b->n_structs) {
         // enough workgroups to fill 256 CUs several times over
         const uint32_t min_chunk = 2 * kSearchWaves;
@@ -1933,6 +1967,31 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
             HIP_TRY(b->d_work.upload_async(b->h_work.p, items.size(), stream));  // no host wait: see build_tables
             b->work_items = (uint32_t)items.size(); b->work_cx = cx; b->work_n_sel = n_sel;
         }
+        // The page directory of the depth-first stage.  A structure lists one partly filled page per wave that worked on
+        // it (its workgroups are known now) plus its full pages: from its atom count and what the selection has needed.
+        {
+            const uint32_t ns = b->n_structs;
+            HIP_TRY(r->h_dir_off.alloc((size_t)ns + 1));
+            r->atoms_of.resize(ns);
+            r->dir_base.assign(ns, 16u);
+            for (uint32_t i = 0; i < b->work_items; ++i) r->dir_base[b->h_work[i].s] += (uint32_t)kSearchWaves << cx;
+            const double milli = (double)S->dir_milli.load();
+            unsigned long long total = 0;
+            for (uint32_t s = 0; s < ns; ++s) {
+                const double n = (double)(b->s_off[s + 1] - b->s_off[s]);
+                r->atoms_of[s] = b->s_off[s + 1] - b->s_off[s];
+                r->h_dir_off[s] = (uint32_t)total;
+                total += (unsigned long long)r->dir_base[s] + (unsigned long long)std::ceil(milli * n * n / 1e7);
+                if (total > 0xfffffff0ull) return fail(TM_E_UNSUPPORTED, "page directory beyond 2^32 entries: split the batch");
+            }
+            r->h_dir_off[ns] = (uint32_t)total;
+            r->page_capacity = total;
+            HIP_TRY(r->d_dir.alloc(r->page_capacity));
+            HIP_TRY(r->d_pages.alloc((size_t)r->page_capacity * kPageTriples));
+            HIP_TRY(r->d_dir_off.upload_async(r->h_dir_off.p, (size_t)ns + 1, stream));
+            O.pages = r->d_pages.p; O.page_capacity = r->page_capacity;
+            O.dir = r->d_dir.p; O.dir_off = r->d_dir_off.p;
+        }
         const uint32_t per_group = 8u >> cx;  // work items per group of 8 consecutive workgroups
         const uint32_t grid = (b->work_items + per_group - 1) / per_group * 8u;
         const size_t scratch = search_scratch_bytes();
@@ -1944,8 +2003,8 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
         const uint32_t pool_cap = lds_path ? (uint32_t)((lds_limit - base) / sizeof(uint16_t)) : 0u;
         const size_t lds_bytes = lds_path ? lds_limit : scratch;
         const bool ic = (p->flags & TM_FLAG_IGNORE_CHAIN) != 0;
-        void (*kernel)(SearchArgs) = lds_path ? (ic ? k_search<true, true, false> : k_search<true, false, false>)
-                                              : (ic ? k_search<false, true, false> : k_search<false, false, false>);
+        void (*kernel)(SearchArgs) = lds_path ? (ic ? k_search<true, true, kModeBlocks> : k_search<true, false, kModeBlocks>)
+                                              : (ic ? k_search<false, true, kModeBlocks> : k_search<false, false, kModeBlocks>);
         SearchArgs args{lib->view(), b->view(), Q, O, b->d_work.p, b->work_items, cx, b->max_atoms, b->max_res, pool_cap, nullptr, 0u};
         HIP_TRY(allow_dynamic_lds(reinterpret_cast<const void *>(kernel), lds_bytes));
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(kSearchBlock), lds_bytes, stream, args);
@@ -1955,12 +2014,19 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
         if (huge || !S->small.empty()) {
             args.singly = huge ? S->d_all.p : S->d_small.p;
             args.n_singly = huge ? n_sel : (uint32_t)S->small.size();
-            void (*singly)(SearchArgs) = lds_path ? (ic ? k_search<true, true, true> : k_search<true, false, true>)
-                                                  : (ic ? k_search<false, true, true> : k_search<false, false, true>);
+            void (*singly)(SearchArgs) = lds_path ? (ic ? k_search<true, true, kModeSingly> : k_search<true, false, kModeSingly>)
+                                                  : (ic ? k_search<false, true, kModeSingly> : k_search<false, false, kModeSingly>);
             HIP_TRY(allow_dynamic_lds(reinterpret_cast<const void *>(singly), lds_bytes));
             hipLaunchKernelGGL(singly, dim3(grid), dim3(kSearchBlock), lds_bytes, stream, args);
             HIP_TRY(hipGetLastError());
         }
+        // the depth-first search below the triples the block search paged out: the same work items (every workgroup
+        // of a structure takes triples of that structure until none are left)
+        void (*deep)(SearchArgs) = lds_path ? (ic ? k_search<true, true, kModeDeep> : k_search<true, false, kModeDeep>)
+                                            : (ic ? k_search<false, true, kModeDeep> : k_search<false, false, kModeDeep>);
+        HIP_TRY(allow_dynamic_lds(reinterpret_cast<const void *>(deep), lds_bytes));
+        hipLaunchKernelGGL(deep, dim3(grid), dim3(kSearchBlock), lds_bytes, stream, args);
+        HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(r->ev[2], stream));
     trace.mark("search launch");
@@ -1982,7 +2048,7 @@ int tm_result_wait(tm_result *r) {
     if (!r) return fail(TM_E_INVALID, "result is NULL");
     if (!r->waited) {
         HIP_TRY(hipSetDevice(r->device));
-        unsigned long long counters[3] = {0, 0, 0};
+        unsigned long long counters[4] = {0, 0, 0, 0};
         HIP_TRY(hipMemcpyAsync(counters, r->d_counters.p, sizeof counters, hipMemcpyDeviceToHost, r->stream));
         unsigned long long pool_used = 0, tab_used[2] = {0, 0};
         HIP_TRY(hipMemcpyAsync(&r->overflow, r->d_overflow.p, sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
@@ -2000,6 +2066,21 @@ int tm_result_wait(tm_result *r) {
         }
         r->n_hits = counters[0]; r->n_cands = counters[1]; r->n_pairs = counters[2];
         r->waited = true;
+        if ((r->overflow & 32u) && r->selection && !r->atoms_of.empty()) {
+            // the page directory (or the page pool behind it) was too small: what did the structures list?
+            std::vector<uint32_t> listed(r->atoms_of.size());
+            HIP_TRY(hipMemcpyAsync(listed.data(), r->d_dir_n.p, listed.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
+            HIP_TRY(hipStreamSynchronize(r->stream));
+            double need = 0.0;
+            for (size_t s = 0; s < listed.size(); ++s) {
+                const double n = std::max(64.0, (double)r->atoms_of[s]);
+                const double fixed = (double)r->dir_base[s];
+                if ((double)listed[s] > fixed) need = std::max(need, ((double)listed[s] - fixed) * 1e7 / (n * n));
+            }
+            const unsigned long long want = (unsigned long long)(need * 1.25) + 1ull;
+            unsigned long long seen = r->selection->dir_milli.load();
+            while (seen < want && !r->selection->dir_milli.compare_exchange_weak(seen, want)) {}
+        }
         if (r->selection && r->n_atoms) {  // what this selection needs per 1000 atoms (sizes the next results)
             auto raise = [](std::atomic<unsigned long long> &a, unsigned long long v) {
                 unsigned long long seen = a.load();
@@ -2033,6 +2114,9 @@ int tm_result_wait(tm_result *r) {
     if (r->overflow & 8u)
         return fail(TM_E_OVERFLOW, "candidate index pool too small (" + std::to_string(r->pool_capacity) +
                                        " entries): query again, the batch now reserves what this build needed");
+    if (r->overflow & 32u)
+        return fail(TM_E_OVERFLOW, "page directory of the depth-first stage too small (" + std::to_string(r->page_capacity) +
+                                       " pages): query again, the selection now reserves what this query needed");
     if (r->overflow)
         return fail(TM_E_OVERFLOW, "result tables too small: " + std::to_string(r->n_cands) + " candidates (capacity " +
                                        std::to_string(r->cand_capacity) + "), " + std::to_string(r->n_pairs) +
@@ -2078,10 +2162,10 @@ int tm_result_copy_hits(tm_result *r, tm_hit *out, uint64_t capacity) {
 int tm_result_copy_candidates(tm_result *r, uint32_t *out, uint64_t n) {
     int rc = tm_result_wait(r);
     if (rc != TM_OK && rc != TM_E_OVERFLOW) return rc;
-    if (!r->d_candidates.p) return fail(TM_E_INVALID, "query was not run with TM_FLAG_COUNT_CANDIDATES");
+    if (!r->count_candidates) return fail(TM_E_INVALID, "query was not run with TM_FLAG_COUNT_CANDIDATES");
     const uint64_t need = (uint64_t)r->n_structs * r->n_sel;
     if (n < need || !out) return fail(TM_E_INVALID, "output buffer too small");
-    if (need) HIP_TRY(hipMemcpy(out, r->d_candidates.p, need * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (need) HIP_TRY(hipMemcpy(out, r->d_pair_count.p, need * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return TM_OK;
 }
 

@@ -126,6 +126,31 @@ struct __align__(16) BlockHdr {
 };
 static_assert(sizeof(BlockHdr) == 32, "BlockHdr layout");
 
+// What the quick look at search level 3 needs of a staged template (48 bytes; k_search, stage D1): the windows of the
+// fourth search position against the three placed leads and where its candidates come from -- the kind list of a
+// fourth lead, or the atoms of the target residue one of the three leads was assigned to.
+struct __align__(16) LookHdr {
+    float2 w30, w31, w32;
+    uint32_t nm_lo, nm_hi;  // residue-type level 3: admissible atom names ...
+    uint32_t resmask;       // ... and residue types
+    uint16_t li3;           // lead-kind index when level 3 is the lead of a fourth residue, else 0xffff
+    uint8_t ref;            // else: which of leads 0, 1, 2 shares its residue
+    uint8_t flags;          // bit 0: any residue type; bit 1: the template has no level 3 (three atoms)
+    uint32_t pad[2];
+};
+static_assert(sizeof(LookHdr) == 48, "LookHdr layout");
+
+// A triple (lead atoms of the first three template residues) that survived the tables and the look at level 3, waiting
+// for the depth-first search below it (k_deep).  k_search writes them in pages of kPageTriples; a structure's pages
+// are listed in its share of the page directory.
+struct DeepEntry {
+    uint32_t a01;  // target atoms of leads 0 and 1 (device order), 16 bits each
+    uint32_t c;    // ... of lead 2
+    uint32_t ti;   // staged template
+};
+constexpr uint32_t kPageTriples = 64;
+constexpr uint32_t kDeepRun = 4;  // triples a wave of k_deep claims at a time
+
 struct QueryView {
     uint32_t n_sel;
     const uint32_t *sel;        // [n_sel] template indices
@@ -134,6 +159,7 @@ struct QueryView {
     const double *maxdyn;       // [n_sel]
     const Staged *staged;       // [n_sel]
     const BlockHdr *hdr;        // [n_sel]
+    const LookHdr *look;        // [n_sel]
     const float2 *bounds;       // [n_sel*kMaxPairs] (lo^2, hi^2) fp32 prefilter bounds, search order
     const uint32_t *order;      // [n_sel] every per-selection array above is sorted by descending estimated cost;
                                 // order[pos] = the caller's selection index (reported in tm_hit / candidate counts)
@@ -158,9 +184,11 @@ struct __align__(16) Cand {
 };
 static_assert(sizeof(Cand) == 64, "Cand layout");
 
-// A (structure, template) pair that produced at least one candidate (or was cut short).
+// A (structure, template) pair that produced at least one candidate (or was cut short).  Its candidate count and the
+// head of its candidate chain live in OutView::pair_count / pair_last: candidates of one pair are found by any number
+// of waves (k_deep shares a structure's triples among all waves working on it), so both are updated atomically.
 struct PairEntry {
-    uint32_t s, ti, last, count;  // count: candidates | truncated << 31
+    uint32_t s, ti;
 };
 
 struct OutView {
@@ -174,8 +202,19 @@ struct OutView {
     tm_hit *hits;
     unsigned long long *n_hits;
     unsigned long long hit_capacity;
-    uint32_t *overflow;      // bit 0: candidate buffer, bit 1: pair table, bit 2: hit table
-    uint32_t *candidates;    // optional [n_structs*n_sel]: count | truncated<<31
+    uint32_t *overflow;      // bit 0: candidate buffer, bit 1: pair table, bit 2: hit table, bit 5: deep pages / directory
+    // per (structure, CALLER's selection index): verified candidates | cut short << 31, and the last candidate of the
+    // pair's chain + 1 (0: none).  Zeroed per query; pair_count doubles as the TM_FLAG_COUNT_CANDIDATES table.
+    uint32_t *pair_count;    // [n_structs * n_sel]
+    uint32_t *pair_last;     // [n_structs * n_sel]
+    // triples waiting for k_deep
+    DeepEntry *pages;                 // [page_capacity * kPageTriples]
+    unsigned long long *n_pages;      // pages handed out
+    unsigned long long page_capacity;
+    uint2 *dir;                       // page directory: {page, triples in it}; structure s owns [dir_off[s], dir_off[s + 1])
+    const uint32_t *dir_off;          // [n_structs + 1]
+    uint32_t *dir_n;                  // [n_structs] pages listed (may exceed the share: overflow)
+    uint32_t *dir_head;               // [n_structs] k_deep: next run of kDeepRun triples to claim, counted over the listed pages
 };
 
 }  // namespace tmx

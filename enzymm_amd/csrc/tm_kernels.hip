@@ -114,8 +114,8 @@ __global__ __launch_bounds__(64) void k_stage_templates(LibView L, uint32_t n_se
                                                          const uint16_t *__restrict__ triple_table,
                                                          const uint8_t *__restrict__ triple_key,
                                                          Staged *__restrict__ staged, float2 *__restrict__ bounds,
-                                                         BlockHdr *__restrict__ hdr, uint16_t *__restrict__ lead8,
-                                                         double slack) {
+                                                         BlockHdr *__restrict__ hdr, LookHdr *__restrict__ look,
+                                                         uint16_t *__restrict__ lead8, double slack) {
     const uint32_t ti = blockIdx.x;
     if (ti >= n_sel) return;
     const uint32_t t = sel[ti];
@@ -176,6 +176,23 @@ __global__ __launch_bounds__(64) void k_stage_templates(LibView L, uint32_t n_se
         const auto tc = [&](int i, int j) { return i < k && j < k && L.a_chain[off + i] == L.a_chain[off + j] ? 1u : 0u; };
         h.flags = (uint16_t)(key | (tc(1, 0) << 1) | (tc(2, 0) << 2) | (tc(2, 1) << 3) | ((uint32_t)g << 4) | ((uint32_t)k << 8));
         hdr[ti] = h;
+        // ... and of the look at level 3 (search position 3: the lead of a fourth residue, or another atom of one of
+        // the first three)
+        LookHdr q = {};
+        if (k > 3) {
+            const uint32_t kind = L.a_kind[off + 3];
+            const uint32_t ref = L.a_ref[off + 3];
+            q.w30 = window(3, 0); q.w31 = window(3, 1); q.w32 = window(3, 2);
+            q.nm_lo = (uint32_t)L.k_namemask[kind]; q.nm_hi = (uint32_t)(L.k_namemask[kind] >> 32);
+            q.resmask = L.k_resmask[kind];
+            q.li3 = ref == 3u ? (uint16_t)L.k_lead[kind] : (uint16_t)0xffffu;
+            q.ref = (uint8_t)(ref == 3u ? 0u : ref);
+            q.flags = L.k_any[kind] ? 1u : 0u;
+        } else {
+            q.li3 = 0xffffu;
+            q.flags = 2u;
+        }
+        look[ti] = q;
         for (int i = 0; i < kMaxG; ++i) lead8[(size_t)ti * kMaxG + i] = i < g ? (uint16_t)L.k_lead[L.a_kind[off + i]] : (uint16_t)0xffffu;
     }
 }
@@ -923,11 +940,12 @@ __device__ __forceinline__ ColdArgsPtr cold_args() {
     return p;
 }
 
-// Everything the wave needs to know about the (structure, template) pair it is searching.
+// The (structure, template) pair a wave is searching.  How many candidates the pair has and where its chain of
+// candidates ends is shared state (OutView::pair_count / pair_last), not the wave's: the triples of one pair may be
+// searched by several waves at once (k_deep).
 struct PairState {
-    uint32_t s, ti;           // structure, selected-template index
-    uint32_t ncand, prev;     // verified candidates so far, last emitted candidate slot
-    bool truncated;
+    uint32_t s, ti;           // structure, staged-template index
+    bool truncated;           // this wave met the pair's max_candidates limit
 };
 
 // A complete assignment passed the fp32 prefilter: re-check every pair in fp64
@@ -966,11 +984,29 @@ __device__ __forceinline__ bool on_complete(const Ctx &C, WaveRegs &W, PairState
         TM_STAT(51, 1);
         return true;
     }
-    if (P.ncand >= max_candidates) {
+    // The pair's candidate count: every verified assignment takes a number; those beyond max_candidates give it back
+    // and mark the pair as cut short (so the count ends on min(assignments found, max_candidates) whatever the order
+    // in which the waves working on the pair get here).
+    const size_t pair = (size_t)P.s * A->Q.n_sel + A->Q.order[P.ti];
+    uint32_t number = 0, first_mark = 0;
+    if (lane == 0) {
+        number = atomicAdd(&A->O.pair_count[pair], 1u) & 0x7fffffffu;
+        if (number >= max_candidates) {
+            atomicSub(&A->O.pair_count[pair], 1u);
+            first_mark = (atomicOr(&A->O.pair_count[pair], 0x80000000u) >> 31) ^ 1u;
+        }
+    }
+    number = uni(number);
+    if (number >= max_candidates) {
         P.truncated = true;
+        // a pair cut short before its first candidate (max_candidates == 0) is still reported
+        if (lane == 0 && first_mark && max_candidates == 0u) {
+            const unsigned long long e = atomicAdd(A->O.n_pairs, 1ull);
+            if (e >= A->O.pair_capacity) atomicOr(A->O.overflow, 2u);
+            else A->O.pairs[e] = PairEntry{P.s, P.ti};
+        }
         return false;
     }
-    ++P.ncand;
     unsigned long long slot = 0;
     if (lane == 0) slot = atomicAdd(A->O.n_cands, 1ull);
     slot = uni64(slot);
@@ -980,16 +1016,22 @@ __device__ __forceinline__ bool on_complete(const Ctx &C, WaveRegs &W, PairState
     }
     Cand *c = A->O.cands + slot;
     if (lane == 0) {
+        // the candidate becomes the new end of the pair's chain; whoever links the first one lists the pair
+        const uint32_t before = atomicExch(&A->O.pair_last[pair], (uint32_t)slot + 1u);
         c->s = P.s;
         c->ti = P.ti;
-        c->prev = P.prev;
+        c->prev = before - 1u;  // 0 -> 0xffffffff: none
         c->pad = 0;
+        if (before == 0u) {
+            const unsigned long long e = atomicAdd(A->O.n_pairs, 1ull);
+            if (e >= A->O.pair_capacity) atomicOr(A->O.overflow, 2u);
+            else A->O.pairs[e] = PairEntry{P.s, P.ti};
+        }
     }
     if (lane < kMaxK) {
         if (lane < k) c->atoms[lvl_orig(W.pk)] = (uint16_t)W.aidx;
         else c->atoms[lane] = 0xffffu;
     }
-    P.prev = (uint32_t)slot;
     return true;
 }
 
@@ -1340,22 +1382,10 @@ __device__ __forceinline__ bool setup_template(Ctx &C, WaveRegs &W, const Templa
     return ballot64(empty) == 0ull;
 }
 
-// The outcome of one (structure, template) search: its candidate count (optional table) and, when it produced
-// candidates or was cut short, one entry of the pair table (k_superpose / k_select work from those).
-__device__ __forceinline__ void write_outcome(uint32_t s, uint32_t ti, uint32_t packed, uint32_t prev, bool count_candidates,
-                                              int lane) {
-    if (packed == 0u || lane != 0) return;
-    ColdArgsPtr cold = cold_args();
-    if (count_candidates) cold->O.candidates[(size_t)s * cold->Q.n_sel + cold->Q.order[ti]] = packed;
-    const unsigned long long slot = atomicAdd(cold->O.n_pairs, 1ull);
-    if (slot >= cold->O.pair_capacity) atomicOr(cold->O.overflow, 2u);
-    else cold->O.pairs[slot] = PairEntry{s, ti, prev, packed};
-}
-
 // Template-at-a-time search (the round-2 path): templates of one or two residues, which have no triple table, and
 // pair tables too long for a block's 25-bit segment length.
 template <class Ctx>
-__device__ __forceinline__ void search_singly(Ctx &C, const SearchArgs &A, WaveRegs &W, uint32_t s, uint32_t ti, const uint32_t *kl) {
+__device__ void search_singly(Ctx &C, const SearchArgs &A, WaveRegs &W, uint32_t s, uint32_t ti, const uint32_t *kl) {
     const QueryView &Q = A.Q;
     const BatchView &B = A.B;
     const int lane = C.lane;
@@ -1388,36 +1418,39 @@ __device__ __forceinline__ void search_singly(Ctx &C, const SearchArgs &A, WaveR
     F.triple_ent = B.tab_ent[TR.triple_begin + min((uint32_t)lane, max(triple_len, 1u) - 1u)];
     PairState P;
     P.s = s; P.ti = ti;
-    P.ncand = 0; P.prev = 0xffffffffu; P.truncated = false;
+    P.truncated = false;
     TM_STAT(49, 1);
     if (feasible) table_scan(C, W, P, TR, F);
-    write_outcome(s, ti, P.ncand | (P.truncated ? 0x80000000u : 0u), P.prev, A.O.candidates != nullptr, lane);
     wave_sync();
 }
 
-// ------------------------------------------------------------------ block search
+// ------------------------------------------------------------------ block search (k_search)
 //
 // A wave searches a BLOCK of up to 64 templates of its workgroup's structure at a time.  The lead atoms of the first
 // three template residues come from the structure's pair tables, and those stages are data-parallel over the whole
 // block: the work items of all its templates are laid end to end over the lanes, so a pass of 64 lanes is full
 // whatever the sizes of the individual templates' table segments (14 entries on average).
 //
-//   A  lane = template: its table references (16 B) and its BlockHdr (32 B) are loaded; prefix sum of the pair-segment
-//      lengths.  What later stages need of a template stays in that lane's registers (SlotRegs) and is fetched by
-//      the lanes that work on its items with ds_bpermute.
-//   B  lane = entry of a pair segment: the stored squared distance against the template's window (1, 0); survivors
-//      {positions, slot} are queued in LDS.
-//   C  (per 64 queued pairs) lane = pair: its row of the (key, lead 2) table; then lane = item of a row: window
-//      (2, key) on the stored distance, window (2, other) computed from the atom records; survivors {atoms, slot} are
-//      queued in LDS.
-//   D  (per 64 queued triples) one triple at a time, wave-cooperative as before: the template's per-level constants
-//      are loaded when a triple of another template comes up (triples arrive grouped by template), a quick look at
-//      level 3, then the depth-first search below.
+//   A   lane = template: its table references (16 B) and its BlockHdr (32 B) are loaded; prefix sum of the pair-segment
+//       lengths.  What later stages need of a template stays in that lane's registers (SlotRegs) and is fetched by
+//       the lanes that work on its items with ds_bpermute.
+//   B   lane = entry of a pair segment: the stored squared distance against the template's window (1, 0); survivors
+//       {positions, slot} are queued in LDS.
+//   C   (per 64 queued pairs) lane = pair: its row of the (key, lead 2) table; then lane = item of a row: window
+//       (2, key) on the stored distance, window (2, other) computed from the atom records; survivors {atoms, slot} are
+//       queued in LDS.
+//   D1  (per 64 queued triples) lane = triple: the candidates for the template's fourth search position -- the kind
+//       list of a fourth lead, or the atoms of an assigned residue -- then lane = candidate: the three windows against
+//       the placed atoms.  A triple with no candidate at all ends here (four in five do).
 //
-// Round 2 searched one template at a time: every search paid the set-up of the per-level constants (1 KB from L2
-// per search: 4.7 GB per launch), one exposed round trip to its tables, and ran its pair and triple stages with a
-// quarter of the lanes.  Here the set-up is paid by the templates that reach stage D, a block pays the table round
-// trips once, and stages B and C run on full waves.
+// What survives goes to global memory in pages of 64 triples, listed per structure, and k_deep searches below them:
+// any wave of any workgroup that has the structure in LDS takes the next run of triples.  One long search -- a
+// template with thousands of surviving triples in a large complex under loose thresholds -- is thereby shared out
+// over as many waves as work on its structure, instead of being one wave's tail.
+//
+// Round 2 searched one template at a time in one wave: every search paid the set-up of the per-level constants
+// (1 KB from L2 per search: 4.7 GB per launch), an exposed round trip to its tables, ran its pair and triple stages
+// with a quarter of the lanes and its look at level 3 one triple at a time.
 
 struct SlotRegs {  // lane = template slot of the block
     uint32_t ti;                // staged template index
@@ -1426,76 +1459,177 @@ struct SlotRegs {  // lane = template slot of the block
     uint32_t lo0, lo1, lo2;     // kind lists of leads 0, 1, 2: first pool position
     uint32_t flags;             // BlockHdr::flags
     float w10lo, w10hi, wklo, wkhi, wolo, wohi;
-    uint32_t ncand;             // verified candidates so far | cut short << 31
-    uint32_t prev;              // last emitted candidate slot
 };
 
 __device__ __forceinline__ float lane_getf(float v, uint32_t src) { return __uint_as_float(lane_get(__float_as_uint(v), src)); }
 
-// The template whose per-level constants sit in W (stage D), and the one being fetched behind it.
-struct DeepState {
-    uint32_t slot;        // 0xffffffff: none
-    PairState P;
-    bool feasible;
-    TemplateRegs next;    // constants of the template of the next queued triple that belongs to another template
-    uint32_t next_ti;     // 0xffffffff: nothing fetched
-    unsigned long long since;  // calibration query: shader clock when this template's turn began
+// The page of surviving triples a wave is filling (uniform values).
+struct PageWriter {
+    uint32_t page;   // 0xffffffff: none yet
+    uint32_t fill;
 };
 
-template <class Ctx>
-__device__ __forceinline__ void deep_leave(const Ctx &C, const QueryView &Q, SlotRegs &R, DeepState &D) {
-    if (D.slot == 0xffffffffu) return;
-    WL(R.ncand, (int)D.slot, D.P.ncand | (D.P.truncated ? 0x80000000u : 0u));
-    WL(R.prev, (int)D.slot, D.P.prev);
-    if (Q.cost && C.lane == 0) atomicAdd(&Q.cost[D.P.ti], __builtin_amdgcn_s_memtime() - D.since);
-    D.slot = 0xffffffffu;
+constexpr uint32_t kNoPage = 0xffffffffu, kVirtualPage = 0xfffffffeu;
+
+// Lists the wave's current page in its structure's share of the directory.  A page that could not be had (the pool ran
+// out: kVirtualPage) is still COUNTED, like a page that does not fit the share: dir_n[s] ends on what the structure
+// needed, and the one retry the overflow costs is sized right.
+__device__ __forceinline__ void page_publish(PageWriter &PW, uint32_t s, uint32_t lane) {
+    if (PW.page == kNoPage || PW.fill == 0u) return;
+    if (lane == 0) {
+        ColdArgsPtr cold = cold_args();
+        const uint32_t at = atomicAdd(&cold->O.dir_n[s], 1u);
+        const uint32_t lo = cold->O.dir_off[s], hi = cold->O.dir_off[s + 1];
+        // (an entry inside the share is written whatever happened: k_deep of an overflowed query must not read garbage)
+        if (at < hi - lo) cold->O.dir[lo + at] = PW.page != kVirtualPage ? make_uint2(PW.page, PW.fill) : make_uint2(0u, 0u);
+        if (at >= hi - lo || PW.page == kVirtualPage) atomicOr(cold->O.overflow, 32u);
+    }
+    PW.page = kNoPage;
+    PW.fill = 0u;
 }
 
-// Stage D over the first `nt` queued triples.
+// Appends the triples of the lanes in `m` (each lane holds one: a01, c, ti) to the wave's page(s).
+__device__ __forceinline__ void page_append(PageWriter &PW, uint32_t s, uint32_t lane, unsigned long long m, uint32_t a01,
+                                            uint32_t c, uint32_t ti) {
+    const bool mine = ((m >> lane) & 1ull) != 0ull;
+    uint32_t rank = rank_in(m), left = (uint32_t)__popcll(m);
+    while (left != 0u) {
+        if (PW.page == kNoPage) {
+            ColdArgsPtr cold = cold_args();
+            unsigned long long page = 0;
+            if (lane == 0) page = atomicAdd(cold->O.n_pages, 1ull);
+            page = uni64(page);
+            PW.page = page < cold->O.page_capacity ? (uint32_t)page : kVirtualPage;  // (the query then reports TM_E_OVERFLOW)
+            PW.fill = 0u;
+        }
+        const uint32_t room = kPageTriples - PW.fill, take = min(room, left);
+        if (mine && rank < take && PW.page != kVirtualPage) {
+            DeepEntry *e = cold_args()->O.pages + (size_t)PW.page * kPageTriples + PW.fill + rank;
+            e->a01 = a01; e->c = c; e->ti = ti;
+        }
+        rank -= take;  // lanes already written wrap to huge ranks: never < take again
+        PW.fill += take;
+        left -= take;
+        if (PW.fill == kPageTriples) page_publish(PW, s, lane);
+    }
+}
+
+// Stage D1 over the first `nt` queued triples: those with a candidate for level 3 go to the wave's page.
 template <class Ctx>
-__device__ __forceinline__ void block_triples(Ctx &C, const SearchArgs &A, WaveRegs &W, SlotRegs &R, DeepState &D, uint32_t s,
-                                              const uint32_t *kl, uint32_t nt) {
-    const QueryView &Q = A.Q;
+__device__ __forceinline__ void block_look(Ctx &C, const SearchArgs &A, SlotRegs &R, PageWriter &PW, uint32_t s,
+                                           const uint32_t *kl, uint32_t nt) {
     WaveScratch &S = *C.S;
     const uint32_t lane = (uint32_t)C.lane;
-    uint2 t = make_uint2(0u, 0xffff0000u);
-    if (lane < nt) t = S.triples[lane];
-    for (uint32_t q = 0; q < nt; ++q) {
-        const uint32_t a01 = RL(t.x, (int)q), cs = RL(t.y, (int)q);
-        const uint32_t slot = cs >> 16, c = cs & 0xffffu, x0 = a01 & 0xffffu, x1 = a01 >> 16;
-        if (slot != D.slot) {  // a triple of another template: its constants take over W
-            deep_leave(C, Q, R, D);
-            const uint32_t ti = RL(R.ti, (int)slot);
-            TemplateRegs T;
-            if (D.next_ti == ti) T = D.next;
-            else load_template(Q, ti, (int)lane, T);
-            D.feasible = setup_template(C, W, T, kl, Q, ti);
-            D.slot = slot;
-            const uint32_t packed = RL(R.ncand, (int)slot);
-            D.P.s = s; D.P.ti = ti;
-            D.P.ncand = packed & 0x7fffffffu;
-            D.P.prev = RL(R.prev, (int)slot);
-            D.P.truncated = (packed >> 31) != 0u;
-            D.since = Q.cost ? __builtin_amdgcn_s_memtime() : 0ull;
-            // the next template in the queue starts loading now
-            const unsigned long long later = ballot64(lane > q && lane < nt && (t.y >> 16) != slot);
-            D.next_ti = 0xffffffffu;
-            if (later) {
-                D.next_ti = RL(R.ti, (int)(RL(t.y, __ffsll((long long)later) - 1) >> 16));
-                load_template(Q, D.next_ti, (int)lane, D.next);
+    const bool vt = lane < nt;
+    uint2 t = make_uint2(0u, 0u);
+    if (vt) t = S.triples[lane];
+    const uint32_t slot = t.y >> 16, c = t.y & 0xffffu, x0 = t.x & 0xffffu, x1 = t.x >> 16;
+    const uint32_t ti = lane_get(R.ti, slot);
+    const LookHdr H = A.Q.look[ti];
+    const float4 q0 = C.rec[x0], q1 = C.rec[x1], q2 = C.rec[c];
+    const bool lead3 = H.li3 != 0xffffu;
+    const bool nolook = (H.flags & 2u) != 0u;
+    // where the candidates come from: a kind list (pool positions) or the atoms of an assigned residue (atom indices)
+    uint32_t first, n_c, own;
+    if (lead3) {
+        first = kl[H.li3];
+        n_c = kl[H.li3 + 1u] - first;
+        own = 0xffffffffu;
+    } else {
+        const uint32_t res = meta_res(__float_as_uint(H.ref == 0u ? q0.w : H.ref == 1u ? q1.w : q2.w));
+        first = C.res_start[res];
+        n_c = C.res_start[res + 1u] - first;
+        own = H.ref == 0u ? x0 : H.ref == 1u ? x1 : c;
+    }
+    if (!vt || nolook) n_c = 0u;
+    bool pass = vt && nolook;
+
+    // ---- the lead of a fourth residue: its kind list is long (a hundred atoms is common), so the triples of this sort
+    // go one at a time with their atoms and windows as wave-uniform values and the LANES over the candidates -- a
+    // candidate then costs its record and nine multiply-adds, nothing is exchanged between lanes.
+    unsigned long long found_lead = 0ull;
+    for (unsigned long long todo = ballot64(lead3 && n_c != 0u); todo; todo &= todo - 1ull) {
+        const int q = __ffsll((long long)todo) - 1;
+        const float ax = RLf(q0.x, q), ay = RLf(q0.y, q), az = RLf(q0.z, q);
+        const float bx = RLf(q1.x, q), by = RLf(q1.y, q), bz = RLf(q1.z, q);
+        const float cx = RLf(q2.x, q), cy = RLf(q2.y, q), cz = RLf(q2.z, q);
+        const float2 wa = make_float2(RLf(H.w30.x, q), RLf(H.w30.y, q)), wb = make_float2(RLf(H.w31.x, q), RLf(H.w31.y, q)),
+                     wc = make_float2(RLf(H.w32.x, q), RLf(H.w32.y, q));
+        const uint32_t lo = RL(first, q), cnt = RL(n_c, q);
+        for (uint32_t base = 0; base < cnt; base += 64u) {
+            const uint32_t idx = base + lane;
+            const float4 r = C.rec[C.pool_at(lo + min(idx, cnt - 1u))];
+            float dx = r.x - ax, dy = r.y - ay, dz = r.z - az;
+            const float da = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            dx = r.x - bx; dy = r.y - by; dz = r.z - bz;
+            const float db = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            dx = r.x - cx; dy = r.y - cy; dz = r.z - cz;
+            const float dc = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            const bool ok = (idx < cnt) & (da >= wa.x) & (da <= wa.y) & (db >= wb.x) & (db <= wb.y) & (dc >= wc.x) & (dc <= wc.y);
+            if (ballot64(ok) != 0ull) {
+                found_lead |= 1ull << q;
+                break;
             }
         }
-        if (D.P.truncated || !D.feasible) continue;
-        const float4 q0 = C.rec[x0], q1 = C.rec[x1], q2 = C.rec[c];
-        if (C.k > 3 && !level3_has_candidate(C, W, x0, x1, c, q0, q1, q2)) continue;
-#if defined(TM_STATS) || defined(TM_ABLATE)
-        if (Q.flags & 0x800u) continue;  // phase timing: the look at level 3, but no search below it
-#endif
-        assign_record(C, W, 0, x0, q0);
-        assign_record(C, W, 1, x1, q1);
-        assign_record(C, W, 2, c, q2);
-        dfs(C, W, D.P, 3);  // false: cut short by max_candidates (D.P.truncated is set)
     }
+    pass = pass | (((found_lead >> lane) & 1ull) != 0ull);
+
+    // ---- another atom of an assigned residue: a dozen atoms at most, of which the masks leave one or two.  These go
+    // lane = (triple, atom), laid end to end like the table stages.
+    if (lead3) n_c = 0u;
+    const uint32_t anyres = H.flags & 1u;
+    const uint32_t incl = wave_scan_add(n_c), excl = incl - n_c;
+    const uint32_t total = RL(incl, 63);
+    const uint32_t cbase = first - excl;  // candidate atom of item w of this triple: cbase + w
+    for (uint32_t w0 = 0; w0 < total; w0 += 64u) {
+        S.owner[lane] = 0u;
+        {
+            const uint32_t start = max(excl, w0);
+            if (n_c != 0u && start < w0 + 64u && incl > w0) S.owner[start - w0] = lane;
+        }
+        wave_sync();
+        const uint32_t p = wave_scan_max(S.owner[lane]);
+        wave_sync();
+        const uint32_t w = min(w0 + lane, total - 1u);
+        const uint32_t atom = lane_get(cbase, p) + w;
+        const float4 r = C.rec[atom];
+        const uint32_t m = __float_as_uint(r.w);
+        bool ok = w0 + lane < total;
+        {
+            const float dx = r.x - lane_getf(q0.x, p), dy = r.y - lane_getf(q0.y, p), dz = r.z - lane_getf(q0.z, p);
+            const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            ok = ok & (d2 >= lane_getf(H.w30.x, p)) & (d2 <= lane_getf(H.w30.y, p));
+        }
+        {
+            const float dx = r.x - lane_getf(q1.x, p), dy = r.y - lane_getf(q1.y, p), dz = r.z - lane_getf(q1.z, p);
+            const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            ok = ok & (d2 >= lane_getf(H.w31.x, p)) & (d2 <= lane_getf(H.w31.y, p));
+        }
+        {
+            const float dx = r.x - lane_getf(q2.x, p), dy = r.y - lane_getf(q2.y, p), dz = r.z - lane_getf(q2.z, p);
+            const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            ok = ok & (d2 >= lane_getf(H.w32.x, p)) & (d2 <= lane_getf(H.w32.y, p));
+        }
+        // it must also carry an admissible name and residue type and not be the lead itself (a superset is all a filter
+        // needs: the search proper repeats every test)
+        const unsigned long long nm = ((unsigned long long)lane_get(H.nm_hi, p) << 32) | lane_get(H.nm_lo, p);
+        const uint32_t rm = lane_get(H.resmask, p), pown = lane_get(own, p), pany = lane_get(anyres, p);
+        ok = ok & (((nm >> meta_name(m)) & 1ull) != 0ull) & ((pany != 0u) | (((rm >> meta_rtype(m)) & 1u) != 0u)) & (atom != pown);
+        const unsigned long long found = ballot64(ok);
+        // does any of MY triple's items of this pass carry a vote?  (items [max(excl, w0), min(incl, w0 + 64)) - w0)
+        if (n_c != 0u && incl > w0 && excl < w0 + 64u) {
+            const uint32_t lo = max(excl, w0) - w0, hi = min(incl, w0 + 64u) - w0;  // 0 <= lo < hi <= 64
+            const unsigned long long span = (hi == 64u ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
+            pass = pass | ((found & span) != 0ull);
+        }
+    }
+    unsigned long long keep = ballot64(pass);
+    TM_STAT(3, 1);
+    TM_STAT(24 + 3, __popcll(keep));
+#if defined(TM_STATS) || defined(TM_ABLATE)
+    if (A.Q.flags & 0x800u) keep = 0ull;  // phase timing: the look at level 3, nothing below it
+#endif
+    if (keep) page_append(PW, s, lane, keep, t.x, c, ti);
 }
 
 // Moves queue entries [from, from + n) to the front (n < 64).
@@ -1508,9 +1642,9 @@ __device__ __forceinline__ void queue_shift(uint2 *queue, uint32_t from, uint32_
 }
 
 // Stage C over the first `np` queued pairs; survivors go to the triple queue (nq3 entries in it), which is worked
-// off (stage D) whenever it holds 64.
+// off (stage D1) whenever it holds 64.
 template <class Ctx>
-__device__ __forceinline__ void block_pairs(Ctx &C, const SearchArgs &A, WaveRegs &W, SlotRegs &R, DeepState &D, uint32_t s,
+__device__ __forceinline__ void block_pairs(Ctx &C, const SearchArgs &A, SlotRegs &R, PageWriter &PW, uint32_t s,
                                             const uint32_t *kl, uint32_t np, uint32_t &nq3) {
     WaveScratch &S = *C.S;
     const uint32_t lane = (uint32_t)C.lane;
@@ -1575,7 +1709,7 @@ __device__ __forceinline__ void block_pairs(Ctx &C, const SearchArgs &A, WaveReg
         nq3 += (uint32_t)__popcll(m);
         if (nq3 >= 64u) {
             wave_sync();
-            block_triples(C, A, W, R, D, s, kl, 64u);
+            block_look(C, A, R, PW, s, kl, 64u);
             queue_shift(S.triples, 64u, nq3 - 64u, lane);
             nq3 -= 64u;
         }
@@ -1584,7 +1718,7 @@ __device__ __forceinline__ void block_pairs(Ctx &C, const SearchArgs &A, WaveReg
 
 // One block: templates chunk + n_chunks * (m0 .. m0 + count - 1) of the staged selection against structure s.
 template <class Ctx>
-__device__ __forceinline__ void search_block(Ctx &C, const SearchArgs &A, WaveRegs &W, uint32_t s, uint32_t m0, uint32_t count,
+__device__ __forceinline__ void search_block(Ctx &C, const SearchArgs &A, PageWriter &PW, uint32_t s, uint32_t m0, uint32_t count,
                                              uint32_t chunk, uint32_t n_chunks, const uint32_t *kl, const uint4 *tab_ref) {
     const QueryView &Q = A.Q;
     WaveScratch &S = *C.S;
@@ -1597,8 +1731,8 @@ __device__ __forceinline__ void search_block(Ctx &C, const SearchArgs &A, WaveRe
     R.ti = chunk + n_chunks * (m0 + (valid ? lane : 0u));
     const uint4 ref = tab_ref[R.ti];
     const BlockHdr H = Q.hdr[R.ti];
-    const bool singly = valid && (ref.y & kRefSingly) != 0u;
-    const uint32_t len = valid && !singly ? ref.y & kRefLenMask : 0u;
+    // (templates marked kRefSingly are searched by the k_search<..., kSingly = true> launch)
+    const uint32_t len = valid && (ref.y & kRefSingly) == 0u ? ref.y & kRefLenMask : 0u;
     R.trows = ref.z; R.tbegin = ref.w;
     R.flags = H.flags;
     R.w10lo = H.w10.x; R.w10hi = H.w10.y;
@@ -1607,17 +1741,10 @@ __device__ __forceinline__ void search_block(Ctx &C, const SearchArgs &A, WaveRe
     R.lo0 = kl[min((uint32_t)H.li[0], A.L.n_lead)];
     R.lo1 = kl[min((uint32_t)H.li[1], A.L.n_lead)];
     R.lo2 = kl[min((uint32_t)H.li[2], A.L.n_lead)];
-    R.ncand = 0u; R.prev = 0xffffffffu;
     const uint32_t incl = wave_scan_add(len), excl = incl - len;
     const uint32_t total = RL(incl, 63);
     R.base = ref.x - excl;
     TM_STAT(49, count);
-
-    DeepState D;
-    D.slot = 0xffffffffu; D.next_ti = 0xffffffffu; D.feasible = false; D.since = 0ull;
-    D.P.s = s; D.P.ti = 0; D.P.ncand = 0; D.P.prev = 0xffffffffu; D.P.truncated = false;
-
-    // (templates marked kRefSingly are searched by the k_search<..., kSingly = true> launch)
 
     // ---- B: lane = entry of a pair segment
     uint32_t nq = 0, nq3 = 0;
@@ -1653,47 +1780,30 @@ __device__ __forceinline__ void search_block(Ctx &C, const SearchArgs &A, WaveRe
         nq += (uint32_t)__popcll(m);
         if (nq >= 64u) {
             wave_sync();
-            block_pairs(C, A, W, R, D, s, kl, 64u, nq3);
+            block_pairs(C, A, R, PW, s, kl, 64u, nq3);
             queue_shift(S.pairs, 64u, nq - 64u, lane);
             nq -= 64u;
         }
     }
     if (nq != 0u) {
         wave_sync();
-        block_pairs(C, A, W, R, D, s, kl, nq, nq3);
+        block_pairs(C, A, R, PW, s, kl, nq, nq3);
     }
     if (nq3 != 0u) {
         wave_sync();
-        block_triples(C, A, W, R, D, s, kl, nq3);
-    }
-    deep_leave(C, Q, R, D);
-
-    // ---- the block's outcomes, lane = template
-    const uint32_t packed = valid && !singly ? R.ncand : 0u;
-    const unsigned long long with = ballot64(packed != 0u);
-    if (with) {
-        ColdArgsPtr cold = cold_args();
-        unsigned long long first = 0;
-        if (lane == 0) first = atomicAdd(cold->O.n_pairs, (unsigned long long)__popcll(with));
-        first = uni64(first);
-        if (packed != 0u) {
-            if (cold->O.candidates) cold->O.candidates[(size_t)s * Q.n_sel + cold->Q.order[R.ti]] = packed;
-            const unsigned long long slot = first + rank_in(with);
-            if (slot >= cold->O.pair_capacity) atomicOr(cold->O.overflow, 2u);
-            else cold->O.pairs[slot] = PairEntry{s, R.ti, R.prev, packed};
-        }
+        block_look(C, A, R, PW, s, kl, nq3);
     }
     if (Q.cost && valid) {  // calibration query: the table-driven stages are shared out evenly over the block's templates
-        unsigned long long spent = __builtin_amdgcn_s_memtime() - t_block;
+        const unsigned long long spent = __builtin_amdgcn_s_memtime() - t_block;
         atomicAdd(&Q.cost[R.ti], spent / (64ull * count));
     }
     wave_sync();
 }
 
-// The template loop of one workgroup: its waves claim blocks of the workgroup's chunk of the staged selection and search
-// the structure staged in LDS.  kPoolLds: the structure's kind lists are in LDS too (the rule), else in global memory.
-// Block sizes are guided: 64 templates while much is left, fewer towards the end of the chunk (down to 8), so that
-// the sixteen waves run out of work at about the same time.
+// The template loop of one workgroup of k_search: its waves claim blocks of the workgroup's chunk of the staged
+// selection and search the structure staged in LDS.  kPoolLds: the structure's kind lists are in LDS too (the rule),
+// else in global memory.  Block sizes are guided: 64 templates while much is left, fewer towards the end of the chunk
+// (down to 8), so that the sixteen waves run out of work at about the same time.
 template <bool kLds, bool kIgnoreChain, bool kPoolLds, bool kSingly>
 __device__ __forceinline__ void search_templates(const SearchArgs &A, WaveScratch *scratch, const float4 *s_rec,
                                                  const uint16_t *s_res, const uint32_t *s_kl, const uint16_t *s_pool,
@@ -1715,11 +1825,10 @@ __device__ __forceinline__ void search_templates(const SearchArgs &A, WaveScratc
     const int lane = C.lane;
     const uint32_t *kl = kLds ? s_kl : kl_off;
     const uint4 *tab_ref = B.tab_ref + (size_t)s * Q.n_sel;
-    const uint32_t n_mine = (Q.n_sel - chunk + n_chunks - 1u) / n_chunks;  // templates chunk, chunk + n_chunks, ...
-    WaveRegs W = {};
     if (kSingly) {
         // the template-at-a-time launch: the waves take the listed templates of this chunk one by one and search those
         // whose table reference says so
+        WaveRegs W = {};
         for (;;) {
             uint32_t m = 0;
             if (lane == 0) m = atomicAdd(s_next_p, 1u);
@@ -1731,6 +1840,9 @@ __device__ __forceinline__ void search_templates(const SearchArgs &A, WaveScratc
         }
         return;
     }
+    const uint32_t n_mine = (Q.n_sel - chunk + n_chunks - 1u) / n_chunks;  // templates chunk, chunk + n_chunks, ...
+    PageWriter PW;
+    PW.page = kNoPage; PW.fill = 0u;
     for (;;) {
         uint32_t m0 = 0, count = 0;
         if (lane == 0) {
@@ -1742,12 +1854,104 @@ __device__ __forceinline__ void search_templates(const SearchArgs &A, WaveScratc
         m0 = uni(m0);
         count = uni(count);
         if (m0 >= n_mine) break;
-        search_block(C, A, W, s, m0, min(count, n_mine - m0), chunk, n_chunks, kl, tab_ref);
+        search_block(C, A, PW, s, m0, min(count, n_mine - m0), chunk, n_chunks, kl, tab_ref);
     }
+    page_publish(PW, s, (uint32_t)lane);
 }
 
-template <bool kLds, bool kIgnoreChain, bool kSingly>
+// ------------------------------------------------------------------ depth-first part (k_deep)
+
+// The template whose per-level constants sit in W, and the one being fetched behind it.
+struct DeepState {
+    uint32_t ti;          // 0xffffffff: none
+    PairState P;
+    bool feasible;
+    TemplateRegs next;    // constants of the template of the next triple of the run that belongs to another template
+    uint32_t next_ti;     // 0xffffffff: nothing fetched
+    unsigned long long since;  // calibration query: shader clock when this template's turn began
+};
+
+// The triples of one structure, searched below level 2 by whichever waves have the structure in LDS: every wave of every
+// workgroup of the structure claims runs of kDeepRun triples from the structure's pages through one counter.
+template <bool kLds, bool kIgnoreChain, bool kPoolLds>
+__device__ __forceinline__ void deep_templates(const SearchArgs &A, WaveScratch *scratch, const float4 *s_rec,
+                                               const uint16_t *s_res, const uint32_t *s_kl, const uint16_t *s_pool,
+                                               const uint32_t *kl_off, uint32_t s, uint32_t a0, uint32_t r0, uint32_t n_listed) {
+    const BatchView &B = A.B;
+    const QueryView &Q = A.Q;
+    SearchCtx<kIgnoreChain, kPoolLds> C;
+    C.rec = kLds ? s_rec : B.q_rec + a0;
+    C.res_start = kLds ? s_res : B.res_start + r0;
+    C.pool_lds = (const __attribute__((address_space(3))) uint16_t *)s_pool;
+    C.pool_glb = B.kl_pool;
+    C.qchain = B.q_chain + a0;
+    C.tab_rows = B.tab_rows;
+    C.tab_ent = B.tab_ent;
+    C.S = scratch + (threadIdx.x >> 6);
+    C.lane = lane_id();
+    C.k = 0; C.n_groups = 0; C.bnd = Q.bounds;
+    const uint32_t lane = (uint32_t)C.lane;
+    const uint32_t *kl = kLds ? s_kl : kl_off;
+    const uint2 *dir = A.O.dir + A.O.dir_off[s];
+    constexpr uint32_t kRunsPerPage = kPageTriples / kDeepRun;
+    const uint32_t n_runs = n_listed * kRunsPerPage;
+    WaveRegs W = {};
+    DeepState D;
+    D.ti = 0xffffffffu; D.next_ti = 0xffffffffu; D.feasible = false; D.since = 0ull;
+    D.P.s = s; D.P.ti = 0; D.P.truncated = false;
+    uint32_t run = 0;
+    if (lane == 0) run = atomicAdd(&A.O.dir_head[s], 1u);
+    run = uni(run);
+    while (run < n_runs) {
+        uint32_t claimed = 0;  // the next run is claimed now: the atomic's round trip runs under this run's searches
+        if (lane == 0) claimed = atomicAdd(&A.O.dir_head[s], 1u);
+        const uint2 pg = dir[run / kRunsPerPage];  // {page, triples in it}
+        const uint32_t e0 = (run % kRunsPerPage) * kDeepRun;
+        const uint32_t nt = uni(pg.y) > e0 ? min(kDeepRun, uni(pg.y) - e0) : 0u;
+        DeepEntry t;
+        t.a01 = 0u; t.c = 0u; t.ti = 0xffffffffu;
+        if (lane < nt) t = A.O.pages[(size_t)uni(pg.x) * kPageTriples + e0 + lane];
+        for (uint32_t q = 0; q < nt; ++q) {
+            const uint32_t a01 = RL(t.a01, (int)q), c = RL(t.c, (int)q), ti = RL(t.ti, (int)q);
+            const uint32_t x0 = a01 & 0xffffu, x1 = a01 >> 16;
+            if (ti != D.ti) {  // a triple of another template: its constants take over W
+                if (D.ti != 0xffffffffu && Q.cost && lane == 0) atomicAdd(&Q.cost[D.ti], __builtin_amdgcn_s_memtime() - D.since);
+                TemplateRegs T;
+                if (D.next_ti == ti) T = D.next;
+                else load_template(Q, ti, (int)lane, T);
+                D.feasible = setup_template(C, W, T, kl, Q, ti);
+                D.ti = ti;
+                D.P.ti = ti;
+                // cut short already (by any wave)?  then nothing below this template's triples is searched
+                D.P.truncated = (A.O.pair_count[(size_t)s * Q.n_sel + Q.order[ti]] >> 31) != 0u;
+                D.since = Q.cost ? __builtin_amdgcn_s_memtime() : 0ull;
+                // the next template of the run starts loading now
+                const unsigned long long later = ballot64(lane > q && lane < nt && t.ti != ti);
+                D.next_ti = 0xffffffffu;
+                if (later) {
+                    D.next_ti = RL(t.ti, __ffsll((long long)later) - 1);
+                    load_template(Q, D.next_ti, (int)lane, D.next);
+                }
+            }
+            if (D.P.truncated || !D.feasible) continue;
+            const float4 q0 = C.rec[x0], q1 = C.rec[x1], q2 = C.rec[c];
+            assign_record(C, W, 0, x0, q0);
+            assign_record(C, W, 1, x1, q1);
+            assign_record(C, W, 2, c, q2);
+            dfs(C, W, D.P, 3);  // false: cut short by max_candidates (D.P.truncated is set)
+        }
+        run = uni(claimed);
+    }
+    if (D.ti != 0xffffffffu && Q.cost && lane == 0) atomicAdd(&Q.cost[D.ti], __builtin_amdgcn_s_memtime() - D.since);
+}
+
+// kMode 0: the block search (stages A - D1, surviving triples to pages); 1: the template-at-a-time search of the
+// templates the block search leaves out; 2: the depth-first search below the paged triples (k_deep).  All three stage
+// the structure of their work item in LDS the same way.
+constexpr int kModeBlocks = 0, kModeSingly = 1, kModeDeep = 2;
+template <bool kLds, bool kIgnoreChain, int kMode>
 __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
+    constexpr bool kSingly = kMode == kModeSingly;
     const LibView &L = A.L;
     const BatchView &B = A.B;
     const QueryView &Q = A.Q;
@@ -1783,6 +1987,11 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
     if (chunk >= (kSingly ? A.n_singly : Q.n_sel)) return;
 
     if (B.tab_ok[s] != 1u) return;  // pair tables incomplete (pool overflow, reported with the result): nothing to search
+    uint32_t n_listed = 0;
+    if (kMode == kModeDeep) {  // pages of triples the block search left for this structure (its share of the directory)
+        n_listed = min(A.O.dir_n[s], A.O.dir_off[s + 1] - A.O.dir_off[s]);
+        if (n_listed == 0u) return;
+    }
     const uint32_t a0 = B.s_off[s], n = B.s_off[s + 1] - a0;
     const uint32_t r0 = B.s_roff[s], nres1 = B.s_roff[s + 1] - r0;  // n_res + 1 entries
     const uint32_t *kl_off = B.kl_off + (size_t)s * (L.n_lead + 1);
@@ -1805,20 +2014,26 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
     TM_STAT(57, threadIdx.x == 0 ? kl_off[L.n_lead] - kl_off[0] : 0);
     __syncthreads();
 
+    if (kMode == kModeDeep) {
+        if (pool_in_lds) deep_templates<kLds, kIgnoreChain, true>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, s, a0, r0, n_listed);
+        else deep_templates<kLds, kIgnoreChain, false>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, s, a0, r0, n_listed);
+        return;
+    }
     if (pool_in_lds)
         search_templates<kLds, kIgnoreChain, true, kSingly>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, &s_next, s, a0, r0, chunk, n_chunks);
     else
         search_templates<kLds, kIgnoreChain, false, kSingly>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, &s_next, s, a0, r0, chunk, n_chunks);
 }
 
-template __global__ void k_search<true, true, false>(SearchArgs);
-template __global__ void k_search<true, false, false>(SearchArgs);
-template __global__ void k_search<false, true, false>(SearchArgs);
-template __global__ void k_search<false, false, false>(SearchArgs);
-template __global__ void k_search<true, true, true>(SearchArgs);
-template __global__ void k_search<true, false, true>(SearchArgs);
-template __global__ void k_search<false, true, true>(SearchArgs);
-template __global__ void k_search<false, false, true>(SearchArgs);
+#define TM_INSTANTIATE(mode)                                       \
+    template __global__ void k_search<true, true, mode>(SearchArgs);   \
+    template __global__ void k_search<true, false, mode>(SearchArgs);  \
+    template __global__ void k_search<false, true, mode>(SearchArgs);  \
+    template __global__ void k_search<false, false, mode>(SearchArgs);
+TM_INSTANTIATE(kModeBlocks)
+TM_INSTANTIATE(kModeSingly)
+TM_INSTANTIATE(kModeDeep)
+#undef TM_INSTANTIATE
 
 size_t search_scratch_bytes() { return sizeof(WaveScratch) * kSearchWaves; }
 
@@ -1968,8 +2183,9 @@ __device__ void emit_hit(const LibView &L, const BatchView &B, const QueryView &
     for (int a = 0; a < 3; ++a) h->trans[a] = T[a];
     h->structure = pe.s;
     h->template_sel = Q.order[pe.ti];
-    h->n_candidates = pe.count & 0x7fffffffu;
-    h->flags = (pe.count >> 31) ? TM_HIT_TRUNCATED : 0u;
+    const uint32_t count = O.pair_count[(size_t)pe.s * Q.n_sel + Q.order[pe.ti]];
+    h->n_candidates = count & 0x7fffffffu;
+    h->flags = (count >> 31) ? TM_HIT_TRUNCATED : 0u;
     h->n_atoms = (uint32_t)k;
     h->reserved = 0;
     const uint32_t a0 = B.s_off[pe.s];
@@ -2041,8 +2257,9 @@ __global__ __launch_bounds__(256) void k_select(LibView L, BatchView B, QueryVie
         const double thr = Q.rmsd_thr[pe.ti];
         const int k = (int)Q.staged[pe.ti].k();
         const uint32_t *orig = B.q_orig + B.s_off[pe.s];
+        const uint32_t last = O.pair_last[(size_t)pe.s * Q.n_sel + Q.order[pe.ti]] - 1u;  // 0 - 1: no candidate
         if (!best_match) {
-            for (uint32_t c = pe.last; c != 0xffffffffu; c = O.cands[c].prev)
+            for (uint32_t c = last; c != 0xffffffffu; c = O.cands[c].prev)
                 if (O.cand_rmsd[c] <= thr) emit_hit(L, B, Q, O, pe, O.cands[c], k);
             continue;
         }
@@ -2051,13 +2268,13 @@ __global__ __launch_bounds__(256) void k_select(LibView L, BatchView B, QueryVie
         // pairwise within eps but not all within eps of the minimum, which one survives would change with it.)
         double min_rmsd = thr;
         bool any = false;
-        for (uint32_t c = pe.last; c != 0xffffffffu; c = O.cands[c].prev) {
+        for (uint32_t c = last; c != 0xffffffffu; c = O.cands[c].prev) {
             const double r = O.cand_rmsd[c];
             if (r <= min_rmsd) { min_rmsd = r; any = true; }
         }
         uint32_t best = 0xffffffffu;
         if (any)
-            for (uint32_t c = pe.last; c != 0xffffffffu; c = O.cands[c].prev) {
+            for (uint32_t c = last; c != 0xffffffffu; c = O.cands[c].prev) {
                 if (!(O.cand_rmsd[c] <= min_rmsd + kTieEps) || !(O.cand_rmsd[c] <= thr)) continue;
                 if (best == 0xffffffffu || tuple_less(orig, O.cands[c], O.cands[best], k)) best = c;
             }

@@ -1,10 +1,9 @@
-"""Phase ablation of k_search with the timing-only build (make -C enzymm_amd/csrc ablate). Not a test."""
+"""k_search duration (HIP events of the query) for the bench batch under a few query settings. Not a test."""
 import os
 import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
-os.environ.setdefault("ENZYMM_AMD_LIB", str(ROOT / "enzymm_amd" / "libenzymm_amd_ablate.so"))
 sys.path.insert(0, str(ROOT))
 from tests import helpers  # noqa: E402
 from enzymm_amd import pyjess, synthetic, _native  # noqa: E402
@@ -16,11 +15,10 @@ mols = synthetic.structures(n)
 packed = pyjess._packed(jess._templates, jess._device)
 batch = pyjess.make_batch(mols, jess._device)
 base = _native.TM_FLAG_BEST_MATCH | _native.TM_FLAG_IGNORE_CHAIN
-for label, extra in (("full: k_search blocks + k_deep", 0), ("stages A-D1, nothing paged (no k_deep work)", 0x800),
-                     ("stages A-C (no look at level 3)", 0x400), ("stages A-B (pair stage only)", 0x100), ("stage A only", 0x200)):
-    times = []
-    for _ in range(4):
+for label, extra in (("cached index", 0), ("rebuild index", _native.TM_FLAG_REBUILD_INDEX), ("cached again", 0)):
+    for i in range(4):
         res = _native.query(packed.native, batch, idx, 2.0, cut, cut, 10000, base | extra)
-        times.append(res.timing()[1])
+        t = res.timing()
+        nh = res.hit_count()
         res.close()
-    print("k_search ms (%s): %.3f" % (label, min(times)), flush=True)
+        print("%s #%d: index %.3f search %.3f finish %.3f ms, %d hits" % (label, i, t[0], t[1], t[2], nh), flush=True)
