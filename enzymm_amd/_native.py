@@ -134,6 +134,13 @@ def load() -> C.CDLL:
     return _lib
 
 
+def _finalizing() -> bool:
+    """True while the interpreter shuts down: destructors then leave device objects to the process exit (the HIP runtime
+    may already be gone, and calling into it crashes)."""
+    import sys
+    return sys is None or sys.is_finalizing()
+
+
 def _check(rc: int):
     if rc != TM_OK:
         raise NativeError(rc, (load().tm_last_error() or b"").decode(errors="replace"))
@@ -288,7 +295,7 @@ class Stream:
         self.handle = h.value
 
     def close(self):
-        if getattr(self, "handle", None):
+        if getattr(self, "handle", None) and not _finalizing():
             load().tm_stream_destroy(C.c_int(self.device), C.c_void_p(self.handle))
             self.handle = None
 
@@ -325,7 +332,7 @@ class Library:
         self.device = device
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and not _finalizing():
             load().tm_library_destroy(self._h)
             self._h = None
 
@@ -485,7 +492,7 @@ class Batch:
         return out
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and not _finalizing():
             load().tm_batch_destroy(self._h)
             self._h = None
 
@@ -541,7 +548,7 @@ class Result:
                                             C.c_uint32(structure_offset)))
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and not _finalizing():
             load().tm_result_destroy(self._h)
             self._h = None
 

@@ -473,7 +473,8 @@ struct tm_result {
     DevBuf<PairEntry> d_pairs;
     DevBuf<unsigned long long> d_counters;  // [0] hits, [1] candidates, [2] pairs, [3] pages of triples
     // shared state of every (structure, template) pair: candidate count | cut short << 31, last candidate + 1
-    DevBuf<uint32_t> d_pair_count, d_pair_last;
+    DevBuf<uint32_t> d_pair_count, d_pair_last, d_pair_tie;
+    DevBuf<unsigned long long> d_pair_min;  // (both initialised on the device per listed pair, not per query)
     // triples between k_search and k_deep: pages, their per-structure directory, its cursors
     DevBuf<DeepEntry> d_pages;
     DevBuf<uint2> d_dir;
@@ -1827,6 +1828,7 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
     const size_t n_pairs_all = (size_t)b->n_structs * n_sel;
     HIP_TRY(r->d_pair_count.alloc(n_pairs_all));
     HIP_TRY(r->d_pair_last.alloc(n_pairs_all));
+    if (p->flags & TM_FLAG_BEST_MATCH) { HIP_TRY(r->d_pair_min.alloc(n_pairs_all)); HIP_TRY(r->d_pair_tie.alloc(n_pairs_all)); }
     HIP_TRY(r->d_dir_n.alloc(b->n_structs));
     HIP_TRY(r->d_dir_head.alloc(b->n_structs));
     {
@@ -1925,6 +1927,7 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
     O.pairs = r->d_pairs.p; O.n_pairs = r->d_counters.p + 2; O.pair_capacity = hcap;
     O.hits = r->d_hits.p; O.n_hits = r->d_counters.p; O.hit_capacity = hcap; O.overflow = r->d_overflow.p;
     O.pair_count = r->d_pair_count.p; O.pair_last = r->d_pair_last.p;
+    O.pair_min = r->d_pair_min.p; O.pair_tie = r->d_pair_tie.p;
     O.n_pages = r->d_counters.p + 3; O.dir_n = r->d_dir_n.p; O.dir_head = r->d_dir_head.p;
     O.pages = nullptr; O.page_capacity = 0; O.dir = nullptr; O.dir_off = nullptr;  // sized below, with the work items
     if (n_sel && b->n_structs) {
@@ -1994,39 +1997,42 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
         }
         const uint32_t per_group = 8u >> cx;  // work items per group of 8 consecutive workgroups
         const uint32_t grid = (b->work_items + per_group - 1) / per_group * 8u;
-        const size_t scratch = search_scratch_bytes();
-        const size_t base = scratch + (size_t)b->max_atoms * sizeof(float4) + search_res_bytes(b->max_res) +
-                            search_kl_words(lib->view().n_lead) * sizeof(uint32_t);
-        const size_t lds_limit = 160 * 1024 - 64;
-        const bool lds_path = base <= lds_limit;
-        // whatever LDS is left holds the structure's kind lists (one workgroup per CU either way)
-        const uint32_t pool_cap = lds_path ? (uint32_t)((lds_limit - base) / sizeof(uint16_t)) : 0u;
-        const size_t lds_bytes = lds_path ? lds_limit : scratch;
         const bool ic = (p->flags & TM_FLAG_IGNORE_CHAIN) != 0;
-        void (*kernel)(SearchArgs) = lds_path ? (ic ? k_search<true, true, kModeBlocks> : k_search<true, false, kModeBlocks>)
-                                              : (ic ? k_search<false, true, kModeBlocks> : k_search<false, false, kModeBlocks>);
-        SearchArgs args{lib->view(), b->view(), Q, O, b->d_work.p, b->work_items, cx, b->max_atoms, b->max_res, pool_cap, nullptr, 0u};
-        HIP_TRY(allow_dynamic_lds(reinterpret_cast<const void *>(kernel), lds_bytes));
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(kSearchBlock), lds_bytes, stream, args);
-        HIP_TRY(hipGetLastError());
+        SearchArgs args{lib->view(), b->view(), Q, O, b->d_work.p, b->work_items, cx, b->max_atoms, b->max_res, 0u, nullptr, 0u};
+        // One launch of k_search in `mode`: the structure of a workgroup goes to LDS when the mode's per-wave scratch
+        // leaves room for the largest structure of the batch; whatever LDS is left after that holds the structure's
+        // kind lists (one workgroup per CU either way).
+        auto launch = [&](int mode) -> int {
+            const size_t scratch = search_scratch_bytes(mode);
+            const size_t base = scratch + (size_t)b->max_atoms * sizeof(float4) + search_res_bytes(b->max_res) +
+                                search_kl_words(lib->view().n_lead) * sizeof(uint32_t);
+            const size_t lds_limit = 160 * 1024 - 64;
+            const bool lds_path = base <= lds_limit;
+            args.pool_cap = lds_path ? (uint32_t)((lds_limit - base) / sizeof(uint16_t)) : 0u;
+            const size_t lds_bytes = lds_path ? lds_limit : scratch;
+            void (*kernel)(SearchArgs) = nullptr;
+#define TM_PICK(m) (lds_path ? (ic ? k_search<true, true, m> : k_search<true, false, m>) : (ic ? k_search<false, true, m> : k_search<false, false, m>))
+            kernel = mode == kModeBlocks ? TM_PICK(kModeBlocks) : mode == kModeSingly ? TM_PICK(kModeSingly) : TM_PICK(kModeDeep);
+#undef TM_PICK
+            HIP_TRY(allow_dynamic_lds(reinterpret_cast<const void *>(kernel), lds_bytes));
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(kSearchBlock), lds_bytes, stream, args);
+            HIP_TRY(hipGetLastError());
+            return TM_OK;
+        };
+        int rc = launch(kModeBlocks);
+        if (rc != TM_OK) return rc;
         // templates the block search leaves out (k_tab_refs marks them kRefSingly), one template per wave at a time
         const bool huge = (uint64_t)b->max_atoms * b->max_atoms >= (uint64_t)kRefLenMask;
         if (huge || !S->small.empty()) {
             args.singly = huge ? S->d_all.p : S->d_small.p;
             args.n_singly = huge ? n_sel : (uint32_t)S->small.size();
-            void (*singly)(SearchArgs) = lds_path ? (ic ? k_search<true, true, kModeSingly> : k_search<true, false, kModeSingly>)
-                                                  : (ic ? k_search<false, true, kModeSingly> : k_search<false, false, kModeSingly>);
-            HIP_TRY(allow_dynamic_lds(reinterpret_cast<const void *>(singly), lds_bytes));
-            hipLaunchKernelGGL(singly, dim3(grid), dim3(kSearchBlock), lds_bytes, stream, args);
-            HIP_TRY(hipGetLastError());
+            rc = launch(kModeSingly);
+            if (rc != TM_OK) return rc;
         }
         // the depth-first search below the triples the block search paged out: the same work items (every workgroup
         // of a structure takes triples of that structure until none are left)
-        void (*deep)(SearchArgs) = lds_path ? (ic ? k_search<true, true, kModeDeep> : k_search<true, false, kModeDeep>)
-                                            : (ic ? k_search<false, true, kModeDeep> : k_search<false, false, kModeDeep>);
-        HIP_TRY(allow_dynamic_lds(reinterpret_cast<const void *>(deep), lds_bytes));
-        hipLaunchKernelGGL(deep, dim3(grid), dim3(kSearchBlock), lds_bytes, stream, args);
-        HIP_TRY(hipGetLastError());
+        rc = launch(kModeDeep);
+        if (rc != TM_OK) return rc;
     }
     HIP_TRY(hipEventRecord(r->ev[2], stream));
     trace.mark("search launch");
@@ -2034,6 +2040,10 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
         // candidate and pair counts live on the device: fixed grids with grid-stride loops, no host sync
         hipLaunchKernelGGL(k_superpose, dim3(512), dim3(256), 0, stream, lib->view(), b->view(), Q, O);
         HIP_TRY(hipGetLastError());
+        if (p->flags & TM_FLAG_BEST_MATCH) {
+            hipLaunchKernelGGL(k_ties, dim3(512), dim3(256), 0, stream, Q, O);
+            HIP_TRY(hipGetLastError());
+        }
         hipLaunchKernelGGL(k_select, dim3(256), dim3(256), 0, stream, lib->view(), b->view(), Q, O);
         HIP_TRY(hipGetLastError());
     }
@@ -2199,8 +2209,8 @@ int tm_result_append_hits(tm_result *r, void *rows, uint64_t capacity, uint64_t 
 // diagnostic build only (make stats): read and reset the search counters
 int tm_debug_stats(unsigned long long *out) {
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(tmx::g_stats), 64 * sizeof(unsigned long long)));
-    unsigned long long zero[64] = {0};
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(tmx::g_stats), 96 * sizeof(unsigned long long)));
+    unsigned long long zero[96] = {0};
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(tmx::g_stats), zero, sizeof zero));
     return TM_OK;
 }

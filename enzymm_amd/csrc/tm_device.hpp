@@ -149,7 +149,10 @@ struct DeepEntry {
     uint32_t ti;   // staged template
 };
 constexpr uint32_t kPageTriples = 64;
-constexpr uint32_t kDeepRun = 4;  // triples a wave of k_deep claims at a time
+#ifndef TM_DEEP_RUN
+#define TM_DEEP_RUN 4
+#endif
+constexpr uint32_t kDeepRun = TM_DEEP_RUN;  // triples a wave of k_deep claims at a time
 
 struct QueryView {
     uint32_t n_sel;
@@ -179,7 +182,7 @@ struct QueryView {
 struct __align__(16) Cand {
     uint32_t s, ti;
     uint32_t prev;               // previous candidate of the same (s, ti) pair, 0xffffffff = none
-    uint32_t pad;
+    uint32_t tie_next;           // best_match: next candidate (+ 1; 0: none) of the pair's list of candidates tied with its minimum RMSD
     uint16_t atoms[kMaxK];       // target atom (device order) per template atom, TEMPLATE order
 };
 static_assert(sizeof(Cand) == 64, "Cand layout");
@@ -207,6 +210,12 @@ struct OutView {
     // pair's chain + 1 (0: none).  Zeroed per query; pair_count doubles as the TM_FLAG_COUNT_CANDIDATES table.
     uint32_t *pair_count;    // [n_structs * n_sel]
     uint32_t *pair_last;     // [n_structs * n_sel]
+    // best_match, per listed pair (initialised by whoever lists the pair, not per query): the minimum RMSD within the
+    // threshold among its candidates (bits of a non-negative double: they order like integers; k_superpose), and the
+    // list of the candidates within kTieEps of it (k_ties) -- k_select looks at those one or two candidates instead of
+    // walking a chain of up to max_candidates
+    unsigned long long *pair_min;  // [n_structs * n_sel]
+    uint32_t *pair_tie;            // [n_structs * n_sel] last linked tied candidate + 1 (0: none)
     // triples waiting for k_deep
     DeepEntry *pages;                 // [page_capacity * kPageTriples]
     unsigned long long *n_pages;      // pages handed out

@@ -22,9 +22,11 @@ namespace tmx {
 #ifdef TM_STATS
 // diagnostic build only: [0..23] chunk evaluations per level, [24..47] survivors per level,
 // [48] complete assignments, [49] searches, [50] pair tests (j-loop trips), [51] fp64 rejects,
-// [52] joint-scan tiles, [53] joint-scan survivors, [55] workgroups, [56] workgroups with their kind lists in LDS,
+// [52] pair-stage passes, [53] pair survivors, [67] triple-stage passes, [68] triple survivors, [64] look flushes,
+// [66] triples looked at, [65] triples paged out, [60] / [62] triples whose level 3 is a lead / a residue atom, [61] candidate chunks of the
+// former, [63] items of the latter, [55] workgroups, [56] workgroups with their kind lists in LDS,
 // [57] kind-list entries of their structures
-__device__ unsigned long long g_stats[64];
+__device__ unsigned long long g_stats[96];
 #define TM_STAT(i, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_stats[i], (unsigned long long)(v)); } while (0)
 // Ablation (diagnostic and timing builds): query flag bit 8 (0x100) drops the pair-scan survivors, bit 9 (0x200)
 // skips the search after template staging, bit 10 (0x400) drops the triple-scan survivors.
@@ -77,6 +79,8 @@ __device__ __forceinline__ uint32_t wave_scan_max(uint32_t x) {  // identity 0
 __device__ __forceinline__ uint32_t lane_get(uint32_t v, uint32_t src) {
     return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)v);
 }
+
+__device__ __forceinline__ float lane_getf(float v, uint32_t src) { return __uint_as_float(lane_get(__float_as_uint(v), src)); }
 
 // Orders this wave's LDS traffic: lanes exchange data through LDS without a workgroup barrier.
 __device__ __forceinline__ void wave_sync() {
@@ -723,17 +727,21 @@ __global__ __launch_bounds__(256) void k_tab_refs(BatchView B, uint32_t n_lead, 
 
 // ------------------------------------------------------------------ k_search
 
-// Per-wave LDS: only what lanes exchange.  All search state lives in registers (see WaveRegs).
-// Pair-bound rows 1..kBoundRowsLds (row L = bounds of level L against levels 0..L-1, at tri(L)) are kept in LDS.
-constexpr int kBoundRowsLds = 10;
-constexpr int kBoundsLds = kBoundRowsLds * (kBoundRowsLds + 1) / 2;  // 55 entries: one per lane
+// kMode of k_search: 0 the block search (stages A - D1, surviving triples to pages); 1 the template-at-a-time search of
+// the templates the block search leaves out; 2 the depth-first search below the paged triples (k_deep).
+constexpr int kModeBlocks = 0, kModeSingly = 1, kModeDeep = 2;
 
-struct __align__(16) WaveScratch {
-    float2 bnd[64];                            // the first kBoundsLds pair bounds of the template (all of them for k <= 11)
-    uint16_t surv[kMaxG][64];                  // per template residue: one 64-entry chunk of its lead list
-    uint2 pairs[kPairQueue];                   // pair-table survivors {position in list 0 | position in list 1 << 16, slot}
-    uint2 triples[kTripleQueue];               // triple survivors {a0 | a1 << 16, a2 | slot << 16} waiting for their subtrees
-    uint32_t owner[64];                        // item-parallel stages: who owns the item at which its segment / row starts
+// Per-wave LDS: only what lanes exchange.  All search state lives in registers (see WaveRegs).  What a launch mode
+// does not use is not reserved: the block search has no template constants in LDS, the depth-first part no queues.
+template <int kMode>
+struct __align__(16) WaveScratchT {
+    static constexpr bool kSearches = kMode != kModeBlocks;  // runs the per-level search (dfs, eval_chunk, completion)
+    static constexpr bool kQueues = kMode != kModeDeep;      // runs the table stages
+    float2 bnd[kSearches ? kMaxPairs : 1];           // every pair bound of the current template (pair (i, j < i) at tri(i) + j)
+    uint16_t surv[kSearches ? kMaxG : 1][64];        // per template residue: one 64-entry chunk of its lead list
+    uint2 pairs[kQueues ? kPairQueue : 1];           // pair-table survivors {position in list 0 | position in list 1 << 16, slot}
+    uint2 triples[kQueues ? kTripleQueue : 1];       // triple survivors {a0 | a1 << 16, a2 | slot << 16} waiting for the look at level 3
+    uint32_t owner[64];                              // item-parallel stages: who owns the item at which its segment / row starts
 };
 
 // Search state of one wave, held in VGPRs and indexed BY LANE: lane L holds the entry of search
@@ -764,7 +772,7 @@ __device__ __forceinline__ void WLf(float &v, int lane, float x) { v = lane_id()
 
 // kIgnoreChain is a compile-time property of the launch: the default (ignore_chain=True in enzymm) drops
 // every chain test from the instruction stream.
-template <bool kIgnoreChain, bool kPoolLds>
+template <bool kIgnoreChain, bool kPoolLds, int kMode>
 struct SearchCtx {
     const float4 *rec;          // structure atom records (LDS or global)
     const uint16_t *res_start;  // residue -> first atom (LDS or global)
@@ -782,7 +790,7 @@ struct SearchCtx {
     const uint32_t *tab_rows;   // pair tables: row offsets (global) ...
     const uint2 *tab_ent;       // ... and entries
     const float2 *bnd;          // this template's pair bounds (global)
-    WaveScratch *S;
+    WaveScratchT<kMode> *S;
     int lane, k, n_groups;
     static constexpr bool ignore_chain = kIgnoreChain;
 };
@@ -798,22 +806,16 @@ struct SearchCtx {
 // candidate, not per assigned level.
 template <class Ctx>
 __device__ __forceinline__ unsigned long long eval_chunk(const Ctx &C, WaveRegs &W, int level, uint32_t base) {
-    WaveScratch &S = *C.S;
+    auto &S = *C.S;
     const int lane = C.lane;
     const uint32_t cnt = RL(W.cnt, level), lo = RL(W.lo, level);
     const bool lead = RL(W.lead, level) != 0;
     const uint32_t mygroup = lvl_group(RL(W.pk, level));
     // this level's row of pair bounds, one entry per lane j < level, loaded before the candidate gather
     float2 brow = make_float2(0.f, 0.f);
-    if (level <= kBoundRowsLds) {
-        // read through a pointer that carries the LDS address space: from two generic pointers the compiler makes
-        // one flat_load through a selected address
-        if (lane < level) {
-            const unsigned long long raw = ((const __attribute__((address_space(3))) unsigned long long *)S.bnd)[tri(level) + lane];
-            brow = make_float2(__uint_as_float((uint32_t)raw), __uint_as_float((uint32_t)(raw >> 32)));
-        }
-    } else {
-        if (lane < level) brow = C.bnd[tri(level) + lane];
+    if (lane < level) {  // (read through a pointer that carries the LDS address space)
+        const unsigned long long raw = ((const __attribute__((address_space(3))) unsigned long long *)S.bnd)[tri(level) + lane];
+        brow = make_float2(__uint_as_float((uint32_t)raw), __uint_as_float((uint32_t)(raw >> 32)));
     }
     const uint32_t idx = base + lane;
     bool ok = idx < cnt;
@@ -1001,6 +1003,7 @@ __device__ __forceinline__ bool on_complete(const Ctx &C, WaveRegs &W, PairState
         P.truncated = true;
         // a pair cut short before its first candidate (max_candidates == 0) is still reported
         if (lane == 0 && first_mark && max_candidates == 0u) {
+            if (A->O.pair_min) { A->O.pair_min[pair] = ~0ull; A->O.pair_tie[pair] = 0u; }
             const unsigned long long e = atomicAdd(A->O.n_pairs, 1ull);
             if (e >= A->O.pair_capacity) atomicOr(A->O.overflow, 2u);
             else A->O.pairs[e] = PairEntry{P.s, P.ti};
@@ -1021,8 +1024,9 @@ __device__ __forceinline__ bool on_complete(const Ctx &C, WaveRegs &W, PairState
         c->s = P.s;
         c->ti = P.ti;
         c->prev = before - 1u;  // 0 -> 0xffffffff: none
-        c->pad = 0;
+        c->tie_next = 0;
         if (before == 0u) {
+            if (A->O.pair_min) { A->O.pair_min[pair] = ~0ull; A->O.pair_tie[pair] = 0u; }  // (read by later kernels only)
             const unsigned long long e = atomicAdd(A->O.n_pairs, 1ull);
             if (e >= A->O.pair_capacity) atomicOr(A->O.overflow, 2u);
             else A->O.pairs[e] = PairEntry{P.s, P.ti};
@@ -1168,7 +1172,7 @@ struct TablePrefetch {
 template <class Ctx>
 __device__ __forceinline__ bool table_scan(const Ctx &C, WaveRegs &W, PairState &P, const TableRefs &TR,
                                            const TablePrefetch &F) {
-    WaveScratch &S = *C.S;
+    auto &S = *C.S;
     // (the template-at-a-time path keeps its own layout of the two queues inside the block search's)
     uint32_t *queue = reinterpret_cast<uint32_t *>(S.pairs);
     uint32_t (*queue3)[2] = reinterpret_cast<uint32_t (*)[2]>(S.triples);
@@ -1375,7 +1379,10 @@ __device__ __forceinline__ bool setup_template(Ctx &C, WaveRegs &W, const Templa
             empty = o1 == o0;
         }
     }
-    C.S->bnd[lane] = R.bound;  // rows of bounds for eval_chunk (LDS); the first windows are read from the registers
+    // every pair bound of the template goes to LDS (the first 64 came with the template's constants, the rest is fetched
+    // now); the first windows are also read from the registers
+    C.S->bnd[lane] = R.bound;
+    for (int p = 64 + lane; p < tri(k); p += 64) C.S->bnd[p] = C.bnd[p];
     W.bnd_lo = R.bound.x;
     W.bnd_hi = R.bound.y;
     wave_sync();
@@ -1461,7 +1468,6 @@ struct SlotRegs {  // lane = template slot of the block
     float w10lo, w10hi, wklo, wkhi, wolo, wohi;
 };
 
-__device__ __forceinline__ float lane_getf(float v, uint32_t src) { return __uint_as_float(lane_get(__float_as_uint(v), src)); }
 
 // The page of surviving triples a wave is filling (uniform values).
 struct PageWriter {
@@ -1518,7 +1524,7 @@ __device__ __forceinline__ void page_append(PageWriter &PW, uint32_t s, uint32_t
 template <class Ctx>
 __device__ __forceinline__ void block_look(Ctx &C, const SearchArgs &A, SlotRegs &R, PageWriter &PW, uint32_t s,
                                            const uint32_t *kl, uint32_t nt) {
-    WaveScratch &S = *C.S;
+    auto &S = *C.S;
     const uint32_t lane = (uint32_t)C.lane;
     const bool vt = lane < nt;
     uint2 t = make_uint2(0u, 0u);
@@ -1548,6 +1554,15 @@ __device__ __forceinline__ void block_look(Ctx &C, const SearchArgs &A, SlotRegs
     // go one at a time with their atoms and windows as wave-uniform values and the LANES over the candidates -- a
     // candidate then costs its record and nine multiply-adds, nothing is exchanged between lanes.
     unsigned long long found_lead = 0ull;
+#ifdef TM_STATS
+    {
+        const uint32_t n_lead3 = (uint32_t)__popcll(ballot64(lead3 && n_c != 0u)), n_res3 = (uint32_t)__popcll(ballot64(!lead3 && n_c != 0u));
+        const uint32_t n_empty = (uint32_t)__popcll(ballot64(vt && !nolook && n_c == 0u));
+        TM_STAT(60, n_lead3);
+        TM_STAT(62, n_res3);
+        TM_STAT(69, n_empty);
+    }
+#endif
     for (unsigned long long todo = ballot64(lead3 && n_c != 0u); todo; todo &= todo - 1ull) {
         const int q = __ffsll((long long)todo) - 1;
         const float ax = RLf(q0.x, q), ay = RLf(q0.y, q), az = RLf(q0.z, q);
@@ -1557,6 +1572,7 @@ __device__ __forceinline__ void block_look(Ctx &C, const SearchArgs &A, SlotRegs
                      wc = make_float2(RLf(H.w32.x, q), RLf(H.w32.y, q));
         const uint32_t lo = RL(first, q), cnt = RL(n_c, q);
         for (uint32_t base = 0; base < cnt; base += 64u) {
+            TM_STAT(61, 1);
             const uint32_t idx = base + lane;
             const float4 r = C.rec[C.pool_at(lo + min(idx, cnt - 1u))];
             float dx = r.x - ax, dy = r.y - ay, dz = r.z - az;
@@ -1581,6 +1597,7 @@ __device__ __forceinline__ void block_look(Ctx &C, const SearchArgs &A, SlotRegs
     const uint32_t incl = wave_scan_add(n_c), excl = incl - n_c;
     const uint32_t total = RL(incl, 63);
     const uint32_t cbase = first - excl;  // candidate atom of item w of this triple: cbase + w
+    TM_STAT(63, total);
     for (uint32_t w0 = 0; w0 < total; w0 += 64u) {
         S.owner[lane] = 0u;
         {
@@ -1624,8 +1641,13 @@ __device__ __forceinline__ void block_look(Ctx &C, const SearchArgs &A, SlotRegs
         }
     }
     unsigned long long keep = ballot64(pass);
-    TM_STAT(3, 1);
-    TM_STAT(24 + 3, __popcll(keep));
+    {
+        const uint32_t n_keep = (uint32_t)__popcll(keep);
+        (void)n_keep;
+        TM_STAT(64, 1);
+        TM_STAT(65, n_keep);
+        TM_STAT(66, nt);
+    }
 #if defined(TM_STATS) || defined(TM_ABLATE)
     if (A.Q.flags & 0x800u) keep = 0ull;  // phase timing: the look at level 3, nothing below it
 #endif
@@ -1646,7 +1668,7 @@ __device__ __forceinline__ void queue_shift(uint2 *queue, uint32_t from, uint32_
 template <class Ctx>
 __device__ __forceinline__ void block_pairs(Ctx &C, const SearchArgs &A, SlotRegs &R, PageWriter &PW, uint32_t s,
                                             const uint32_t *kl, uint32_t np, uint32_t &nq3) {
-    WaveScratch &S = *C.S;
+    auto &S = *C.S;
     const uint32_t lane = (uint32_t)C.lane;
     const bool vp = lane < np;
     uint2 pq = make_uint2(0u, 0u);
@@ -1699,8 +1721,12 @@ __device__ __forceinline__ void block_pairs(Ctx &C, const SearchArgs &A, SlotReg
             }
         }
         unsigned long long m = ballot64(ok);
-        TM_STAT(2, 1);
-        TM_STAT(24 + 2, __popcll(m));
+        {
+            const uint32_t n_m = (uint32_t)__popcll(m);
+            (void)n_m;
+            TM_STAT(67, 1);
+            TM_STAT(68, n_m);
+        }
 #if defined(TM_STATS) || defined(TM_ABLATE)
         if (A.Q.flags & 0x400u) m = 0ull;
 #endif
@@ -1721,7 +1747,7 @@ template <class Ctx>
 __device__ __forceinline__ void search_block(Ctx &C, const SearchArgs &A, PageWriter &PW, uint32_t s, uint32_t m0, uint32_t count,
                                              uint32_t chunk, uint32_t n_chunks, const uint32_t *kl, const uint4 *tab_ref) {
     const QueryView &Q = A.Q;
-    WaveScratch &S = *C.S;
+    auto &S = *C.S;
     const uint32_t lane = (uint32_t)C.lane;
     const unsigned long long t_block = Q.cost ? __builtin_amdgcn_s_memtime() : 0ull;
 
@@ -1770,8 +1796,12 @@ __device__ __forceinline__ void search_block(Ctx &C, const SearchArgs &A, PageWr
             if (ok) ok = (C.qchain[C.pool_at(l0 + (ent.x & 0xffffu))] == C.qchain[C.pool_at(l1 + (ent.x >> 16))]) == (((pf >> 1) & 1u) != 0u);
         }
         unsigned long long m = ballot64(ok);
-        TM_STAT(52, 1);
-        TM_STAT(53, __popcll(m));
+        {
+            const uint32_t n_m = (uint32_t)__popcll(m);
+            (void)n_m;
+            TM_STAT(52, 1);
+            TM_STAT(53, n_m);
+        }
 #if defined(TM_STATS) || defined(TM_ABLATE)
         if (Q.flags & 0x100u) m = 0ull;
 #endif
@@ -1805,13 +1835,13 @@ __device__ __forceinline__ void search_block(Ctx &C, const SearchArgs &A, PageWr
 // else in global memory.  Block sizes are guided: 64 templates while much is left, fewer towards the end of the chunk
 // (down to 8), so that the sixteen waves run out of work at about the same time.
 template <bool kLds, bool kIgnoreChain, bool kPoolLds, bool kSingly>
-__device__ __forceinline__ void search_templates(const SearchArgs &A, WaveScratch *scratch, const float4 *s_rec,
+__device__ __forceinline__ void search_templates(const SearchArgs &A, WaveScratchT<kSingly ? kModeSingly : kModeBlocks> *scratch, const float4 *s_rec,
                                                  const uint16_t *s_res, const uint32_t *s_kl, const uint16_t *s_pool,
                                                  const uint32_t *kl_off, uint32_t *s_next_p, uint32_t s, uint32_t a0,
                                                  uint32_t r0, uint32_t chunk, uint32_t n_chunks) {
     const BatchView &B = A.B;
     const QueryView &Q = A.Q;
-    SearchCtx<kIgnoreChain, kPoolLds> C;
+    SearchCtx<kIgnoreChain, kPoolLds, kSingly ? kModeSingly : kModeBlocks> C;
     C.rec = kLds ? s_rec : B.q_rec + a0;
     C.res_start = kLds ? s_res : B.res_start + r0;
     C.pool_lds = (const __attribute__((address_space(3))) uint16_t *)s_pool;
@@ -1825,7 +1855,7 @@ __device__ __forceinline__ void search_templates(const SearchArgs &A, WaveScratc
     const int lane = C.lane;
     const uint32_t *kl = kLds ? s_kl : kl_off;
     const uint4 *tab_ref = B.tab_ref + (size_t)s * Q.n_sel;
-    if (kSingly) {
+    if constexpr (kSingly) {
         // the template-at-a-time launch: the waves take the listed templates of this chunk one by one and search those
         // whose table reference says so
         WaveRegs W = {};
@@ -1838,8 +1868,7 @@ __device__ __forceinline__ void search_templates(const SearchArgs &A, WaveScratc
             const uint32_t ti = A.singly[at];
             if ((uni(tab_ref[ti].y) & kRefSingly) != 0u) search_singly(C, A, W, s, ti, kl);
         }
-        return;
-    }
+    } else {
     const uint32_t n_mine = (Q.n_sel - chunk + n_chunks - 1u) / n_chunks;  // templates chunk, chunk + n_chunks, ...
     PageWriter PW;
     PW.page = kNoPage; PW.fill = 0u;
@@ -1857,6 +1886,7 @@ __device__ __forceinline__ void search_templates(const SearchArgs &A, WaveScratc
         search_block(C, A, PW, s, m0, min(count, n_mine - m0), chunk, n_chunks, kl, tab_ref);
     }
     page_publish(PW, s, (uint32_t)lane);
+    }
 }
 
 // ------------------------------------------------------------------ depth-first part (k_deep)
@@ -1874,12 +1904,12 @@ struct DeepState {
 // The triples of one structure, searched below level 2 by whichever waves have the structure in LDS: every wave of every
 // workgroup of the structure claims runs of kDeepRun triples from the structure's pages through one counter.
 template <bool kLds, bool kIgnoreChain, bool kPoolLds>
-__device__ __forceinline__ void deep_templates(const SearchArgs &A, WaveScratch *scratch, const float4 *s_rec,
+__device__ __forceinline__ void deep_templates(const SearchArgs &A, WaveScratchT<kModeDeep> *scratch, const float4 *s_rec,
                                                const uint16_t *s_res, const uint32_t *s_kl, const uint16_t *s_pool,
                                                const uint32_t *kl_off, uint32_t s, uint32_t a0, uint32_t r0, uint32_t n_listed) {
     const BatchView &B = A.B;
     const QueryView &Q = A.Q;
-    SearchCtx<kIgnoreChain, kPoolLds> C;
+    SearchCtx<kIgnoreChain, kPoolLds, kModeDeep> C;
     C.rec = kLds ? s_rec : B.q_rec + a0;
     C.res_start = kLds ? s_res : B.res_start + r0;
     C.pool_lds = (const __attribute__((address_space(3))) uint16_t *)s_pool;
@@ -1914,6 +1944,9 @@ __device__ __forceinline__ void deep_templates(const SearchArgs &A, WaveScratch 
         for (uint32_t q = 0; q < nt; ++q) {
             const uint32_t a01 = RL(t.a01, (int)q), c = RL(t.c, (int)q), ti = RL(t.ti, (int)q);
             const uint32_t x0 = a01 & 0xffffu, x1 = a01 >> 16;
+#if defined(TM_STATS) || defined(TM_ABLATE)
+            if (Q.flags & 0x2000u) continue;  // phase timing: runs claimed and read, nothing else
+#endif
             if (ti != D.ti) {  // a triple of another template: its constants take over W
                 if (D.ti != 0xffffffffu && Q.cost && lane == 0) atomicAdd(&Q.cost[D.ti], __builtin_amdgcn_s_memtime() - D.since);
                 TemplateRegs T;
@@ -1922,8 +1955,9 @@ __device__ __forceinline__ void deep_templates(const SearchArgs &A, WaveScratch 
                 D.feasible = setup_template(C, W, T, kl, Q, ti);
                 D.ti = ti;
                 D.P.ti = ti;
-                // cut short already (by any wave)?  then nothing below this template's triples is searched
-                D.P.truncated = (A.O.pair_count[(size_t)s * Q.n_sel + Q.order[ti]] >> 31) != 0u;
+                // (whether another wave already met the pair's max_candidates limit is not looked up here -- two dependent
+                // loads from HBM per triple; a wave learns it with its own first completion, on_complete)
+                D.P.truncated = false;
                 D.since = Q.cost ? __builtin_amdgcn_s_memtime() : 0ull;
                 // the next template of the run starts loading now
                 const unsigned long long later = ballot64(lane > q && lane < nt && t.ti != ti);
@@ -1934,10 +1968,19 @@ __device__ __forceinline__ void deep_templates(const SearchArgs &A, WaveScratch 
                 }
             }
             if (D.P.truncated || !D.feasible) continue;
-            const float4 q0 = C.rec[x0], q1 = C.rec[x1], q2 = C.rec[c];
-            assign_record(C, W, 0, x0, q0);
-            assign_record(C, W, 1, x1, q1);
-            assign_record(C, W, 2, c, q2);
+#if defined(TM_STATS) || defined(TM_ABLATE)
+            if (Q.flags & 0x1000u) continue;  // phase timing: template constants set up, no search
+#endif
+            {  // the three placed leads: lane L < 3 fetches and keeps the entry of level L (lane = level)
+                const uint32_t mine = lane == 0u ? x0 : lane == 1u ? x1 : c;
+                const float4 r = C.rec[mine];
+                if (lane < 3u) {
+                    W.aidx = mine;
+                    W.ax = r.x; W.ay = r.y; W.az = r.z;
+                    W.ameta = __float_as_uint(r.w);
+                    if (!C.ignore_chain) W.achain = (uint32_t)C.qchain[mine];
+                }
+            }
             dfs(C, W, D.P, 3);  // false: cut short by max_candidates (D.P.truncated is set)
         }
         run = uni(claimed);
@@ -1945,10 +1988,7 @@ __device__ __forceinline__ void deep_templates(const SearchArgs &A, WaveScratch 
     if (D.ti != 0xffffffffu && Q.cost && lane == 0) atomicAdd(&Q.cost[D.ti], __builtin_amdgcn_s_memtime() - D.since);
 }
 
-// kMode 0: the block search (stages A - D1, surviving triples to pages); 1: the template-at-a-time search of the
-// templates the block search leaves out; 2: the depth-first search below the paged triples (k_deep).  All three stage
-// the structure of their work item in LDS the same way.
-constexpr int kModeBlocks = 0, kModeSingly = 1, kModeDeep = 2;
+// All three launch modes (kModeBlocks, kModeSingly, kModeDeep) stage the structure of their work item in LDS the same way.
 template <bool kLds, bool kIgnoreChain, int kMode>
 __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
     constexpr bool kSingly = kMode == kModeSingly;
@@ -1958,10 +1998,10 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
     const uint32_t max_atoms = A.max_atoms, max_res = A.max_res,
                    pool_cap = A.pool_cap;
     extern __shared__ __align__(16) unsigned char smem[];
-    // [WaveScratch x kSearchWaves][rec float4 x max_atoms][res_start u16 x (max_res+1)]
+    // [WaveScratchT<kMode> x kSearchWaves][rec float4 x max_atoms][res_start u16 x (max_res+1)]
     // [kind-list offsets u32 x (n_lead+1)][kind-list pool u16 x pool_cap]
-    WaveScratch *scratch = reinterpret_cast<WaveScratch *>(smem);
-    float4 *s_rec = reinterpret_cast<float4 *>(smem + sizeof(WaveScratch) * kSearchWaves);
+    WaveScratchT<kMode> *scratch = reinterpret_cast<WaveScratchT<kMode> *>(smem);
+    float4 *s_rec = reinterpret_cast<float4 *>(smem + sizeof(WaveScratchT<kMode>) * kSearchWaves);
     uint16_t *s_res = reinterpret_cast<uint16_t *>(s_rec + (kLds ? max_atoms : 0));
     uint32_t *s_kl = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(s_res) +
                                                   (kLds ? search_res_bytes(max_res) : 0));
@@ -1975,6 +2015,9 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
     // resident in its own 4 MB L2.  The structure a workgroup searches is copied into LDS once, so it does not
     // matter which XCD that is.  Work items are ordered heaviest structure first, and heavy structures are cut
     // into more rounds (host side), so that a few large structures in a batch do not become the tail.
+#ifdef TM_STATS
+    const unsigned long long t_wg = __builtin_amdgcn_s_memtime();
+#endif
     const uint32_t bid = blockIdx.x;
     const uint32_t xcd = bid & 7u;
     const uint32_t cx = A.chunk_xcd_shift;
@@ -2014,15 +2057,35 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
     TM_STAT(57, threadIdx.x == 0 ? kl_off[L.n_lead] - kl_off[0] : 0);
     __syncthreads();
 
-    if (kMode == kModeDeep) {
+#ifdef TM_STATS
+    // how long the workgroup's waves work against how long the workgroup holds its CU: [70 + 4 mode] sum of the waves'
+    // working ticks, [71 + 4 mode] sum over workgroups of (last wave's end - start) x waves, [72 + 4 mode] staging ticks x waves
+    __shared__ unsigned long long s_end;
+    const unsigned long long t_work = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) s_end = 0ull;
+    __syncthreads();
+#endif
+    if constexpr (kMode == kModeDeep) {
         if (pool_in_lds) deep_templates<kLds, kIgnoreChain, true>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, s, a0, r0, n_listed);
         else deep_templates<kLds, kIgnoreChain, false>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, s, a0, r0, n_listed);
-        return;
+    } else {
+        if (pool_in_lds)
+            search_templates<kLds, kIgnoreChain, true, kSingly>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, &s_next, s, a0, r0, chunk, n_chunks);
+        else
+            search_templates<kLds, kIgnoreChain, false, kSingly>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, &s_next, s, a0, r0, chunk, n_chunks);
     }
-    if (pool_in_lds)
-        search_templates<kLds, kIgnoreChain, true, kSingly>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, &s_next, s, a0, r0, chunk, n_chunks);
-    else
-        search_templates<kLds, kIgnoreChain, false, kSingly>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, &s_next, s, a0, r0, chunk, n_chunks);
+#ifdef TM_STATS
+    {
+        const unsigned long long t_done = __builtin_amdgcn_s_memtime();
+        TM_STAT(70 + 4 * kMode, t_done - t_work);
+        if ((threadIdx.x & 63) == 0) atomicMax(&s_end, t_done);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            atomicAdd(&g_stats[71 + 4 * kMode], (s_end - t_work) * (unsigned long long)kSearchWaves);
+            atomicAdd(&g_stats[72 + 4 * kMode], (t_work - t_wg) * (unsigned long long)kSearchWaves);
+        }
+    }
+#endif
 }
 
 #define TM_INSTANTIATE(mode)                                       \
@@ -2035,7 +2098,10 @@ TM_INSTANTIATE(kModeSingly)
 TM_INSTANTIATE(kModeDeep)
 #undef TM_INSTANTIATE
 
-size_t search_scratch_bytes() { return sizeof(WaveScratch) * kSearchWaves; }
+size_t search_scratch_bytes(int mode) {
+    return (mode == kModeBlocks ? sizeof(WaveScratchT<kModeBlocks>) : mode == kModeSingly ? sizeof(WaveScratchT<kModeSingly>)
+                                                                                         : sizeof(WaveScratchT<kModeDeep>)) * kSearchWaves;
+}
 
 // ------------------------------------------------------------------ superposition (fp64)
 
@@ -2156,7 +2222,28 @@ __global__ __launch_bounds__(256) void k_superpose(LibView L, BatchView B, Query
     const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
     for (unsigned long long c = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += stride) {
         double R[9], T[3];
-        O.cand_rmsd[c] = superpose_candidate(L, B, Q, O.cands[c], R, T);
+        const Cand &cand = O.cands[c];
+        const double r = superpose_candidate(L, B, Q, cand, R, T);
+        O.cand_rmsd[c] = r;
+        // the pair's minimum within the threshold (non-negative doubles order like their bit patterns)
+        if (O.pair_min && r <= Q.rmsd_thr[cand.ti])
+            atomicMin(&O.pair_min[(size_t)cand.s * Q.n_sel + Q.order[cand.ti]], (unsigned long long)__double_as_longlong(r));
+    }
+}
+
+// best_match: the candidates within kTieEps of their pair's minimum RMSD are linked into the pair's tie list (one or two
+// per pair; a homo-oligomer built by symmetry operators gives a few more).  One lane per candidate.
+__global__ __launch_bounds__(256) void k_ties(QueryView Q, OutView O) {
+    unsigned long long n = *O.n_cands;
+    if (n > O.cand_capacity) n = O.cand_capacity;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long c = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += stride) {
+        Cand &cand = O.cands[c];
+        const double r = O.cand_rmsd[c];
+        const size_t pair = (size_t)cand.s * Q.n_sel + Q.order[cand.ti];
+        const unsigned long long low = O.pair_min[pair];
+        if (low == ~0ull || !(r <= Q.rmsd_thr[cand.ti]) || !(r <= __longlong_as_double((long long)low) + kTieEps)) continue;
+        cand.tie_next = atomicExch(&O.pair_tie[pair], (uint32_t)c + 1u);
     }
 }
 
@@ -2263,21 +2350,14 @@ __global__ __launch_bounds__(256) void k_select(LibView L, BatchView B, QueryVie
                 if (O.cand_rmsd[c] <= thr) emit_hit(L, B, Q, O, pe, O.cands[c], k);
             continue;
         }
-        // Two passes over the chain: the GLOBAL minimum first, then the smallest atom tuple among the candidates within
-        // kTieEps of it.  (One pass against a moving best depends on the order of the chain: of three candidates
-        // pairwise within eps but not all within eps of the minimum, which one survives would change with it.)
-        double min_rmsd = thr;
-        bool any = false;
-        for (uint32_t c = last; c != 0xffffffffu; c = O.cands[c].prev) {
-            const double r = O.cand_rmsd[c];
-            if (r <= min_rmsd) { min_rmsd = r; any = true; }
-        }
+        // The candidates within kTieEps of the pair's GLOBAL minimum RMSD were listed by k_ties; the smallest atom tuple
+        // among them wins.  (A comparison against a moving best while walking the chain depends on the order of the chain:
+        // of three candidates pairwise within eps but not all within eps of the minimum, which one survives would change
+        // with it -- and a chain of max_candidates candidates is a long walk for one lane.)
+        (void)last;
         uint32_t best = 0xffffffffu;
-        if (any)
-            for (uint32_t c = last; c != 0xffffffffu; c = O.cands[c].prev) {
-                if (!(O.cand_rmsd[c] <= min_rmsd + kTieEps) || !(O.cand_rmsd[c] <= thr)) continue;
-                if (best == 0xffffffffu || tuple_less(orig, O.cands[c], O.cands[best], k)) best = c;
-            }
+        for (uint32_t c = O.pair_tie[(size_t)pe.s * Q.n_sel + Q.order[pe.ti]]; c != 0u; c = O.cands[c - 1u].tie_next)
+            if (best == 0xffffffffu || tuple_less(orig, O.cands[c - 1u], O.cands[best], k)) best = c - 1u;
         if (best != 0xffffffffu) emit_hit(L, B, Q, O, pe, O.cands[best], k);
     }
 }

@@ -914,7 +914,44 @@ def _thread_stream(device: int) -> int:
     st = streams.get(device)
     if st is None:
         st = streams[device] = _native.Stream(device)
+        _all_thread_streams.append(st)
     return st.handle
+
+
+_all_thread_streams: list = []
+
+
+def _shutdown():
+    """Release what this module keeps alive between queries (device copies of single molecules, per-thread streams,
+    device libraries) while the HIP runtime is still there: left to interpreter finalisation, their destructors run in
+    arbitrary order, some after the runtime has gone."""
+    with _single_batches._lock:
+        for e in _single_batches._entries.values():
+            try:
+                e[1].close()
+            except Exception:
+                pass
+        _single_batches._entries.clear()
+        _single_batches._atoms = 0
+    for st in _all_thread_streams:
+        try:
+            st.close()
+        except Exception:
+            pass
+    _all_thread_streams.clear()
+    with _pack_lock:
+        for _, packed in _pack_cache.values():
+            try:
+                packed.native.close()
+            except Exception:
+                pass
+        _pack_cache.clear()
+    _jess_cache.clear()
+
+
+import atexit  # noqa: E402
+
+atexit.register(_shutdown)
 
 
 class Jess:

@@ -16,7 +16,8 @@ mols = synthetic.structures(n)
 packed = pyjess._packed(jess._templates, jess._device)
 batch = pyjess.make_batch(mols, jess._device)
 base = _native.TM_FLAG_BEST_MATCH | _native.TM_FLAG_IGNORE_CHAIN
-for label, extra in (("full: k_search blocks + k_deep", 0), ("stages A-D1, nothing paged (no k_deep work)", 0x800),
+for label, extra in (("full: k_search blocks + k_deep", 0), ("k_deep sets templates up but does not search", 0x1000),
+                     ("k_deep only claims and reads its runs", 0x2000), ("stages A-D1, nothing paged (no k_deep work)", 0x800),
                      ("stages A-C (no look at level 3)", 0x400), ("stages A-B (pair stage only)", 0x100), ("stage A only", 0x200)):
     times = []
     for _ in range(4):

@@ -15,10 +15,14 @@ from enzymm_amd import pyjess, synthetic, _native  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 idx, cut = helpers.default_selection()
 jess = pyjess.Jess(helpers.product_library_templates())
-mols = synthetic.structures(n)
+if len(sys.argv) > 2 and sys.argv[2] == "complexes":  # BASELINE.json configs[4]: large complexes, loosened thresholds
+    mols = [synthetic.complex_structure(i, 6000).conserved(70) for i in range(n)]
+    cut = np.full(len(idx), 2.5)
+else:
+    mols = synthetic.structures(n)
 lib = _native.load()
 print("loaded", flush=True)
-buf = (C.c_ulonglong * 64)()
+buf = (C.c_ulonglong * 96)()
 print("stats0", lib.tm_debug_stats(buf), flush=True)
 t0 = time.time()
 table = jess.query_batch(mols, 2.0, cut, cut, max_candidates=10000, ignore_chain=True, template_index=idx,
@@ -27,21 +31,26 @@ print("query s", time.time() - t0, "hits", len(table))
 lib.tm_debug_stats(buf)
 s = np.array(list(buf), dtype=np.float64)
 searches = s[49]
-print("searches", int(searches), "chunk evals/search", s[:24].sum() / searches, "pair tests/search", s[50] / searches,
-      "survivors/search", s[24:48].sum() / searches, "completes", int(s[48]), "fp64 rejects", int(s[51]))
-print("evals per level  ", np.round(s[:24] / searches, 2))
-print("surv per level   ", np.round(s[24:48] / searches, 2))
-print("joint tiles/search", s[52] / searches, "joint survivors/search", s[53] / searches,
-      "searches with survivor", s[54] / searches)
-print("pair rounds with a survivor / search", s[54] / searches, "one-tile segments / search", s[58] / searches,
-      "one-tile segments without survivor / search", s[59] / searches)
+print("searches", int(searches), "completes", int(s[48]), "fp64 rejects", int(s[51]))
+print("per search: pair passes %.3f  pair survivors %.3f  triple passes %.3f  triple survivors %.3f" %
+      (s[52] / searches, s[53] / searches, s[67] / searches, s[68] / searches))
+print("per search: look flushes %.4f  triples with a lead at level 3 %.3f (chunks each %.2f)  with a residue atom %.3f (items each %.2f)  paged out %.3f" %
+      (s[64] / searches, s[60] / searches, s[61] / max(s[60], 1), s[62] / searches, s[63] / max(s[62], 1), s[65] / searches))
+print("triples looked at per search %.3f, of them with an empty candidate source %.3f" % (s[66] / searches, s[69] / searches))
+paged = max(s[65], 1)
+print("k_deep chunk evaluations per level (per paged triple)", np.round(s[3:24] / paged, 2))
+print("k_deep survivors per level (per paged triple)        ", np.round(s[27:48] / paged, 2))
+print("pair tests (j-loop trips) per paged triple", s[50] / paged)
+for mode, name in ((0, "k_search blocks"), (2, "k_deep")):
+    busy, held, staging = s[70 + 4 * mode], s[71 + 4 * mode], s[72 + 4 * mode]
+    print("%s: waves working %.1f %% of the time their workgroup holds its CU after staging; staging %.1f %% of that time" %
+          (name, 100.0 * busy / max(held, 1), 100.0 * staging / max(held, 1)))
 print("workgroups", int(s[55]), "with kind lists in LDS", int(s[56]), "mean kind-list pool entries", s[57] / max(s[55], 1))
-
 # ablation: k_search time with (a) everything, (b) no subtrees below the joint scan, (c) staging only
 packed = pyjess._packed(jess._templates, jess._device)
 batch = pyjess.make_batch(mols, jess._device)
 base = _native.TM_FLAG_BEST_MATCH | _native.TM_FLAG_IGNORE_CHAIN
-for label, extra in (("full", 0), ("no subtrees", 0x100), ("staging only", 0x200)):
+for label, extra in (("full", 0), ("no k_deep work", 0x800), ("stage A only", 0x200)):
     times = []
     for _ in range(3):
         res = _native.query(packed.native, batch, idx, 2.0, cut, cut, 10000, base | extra)
