@@ -368,6 +368,7 @@ def main():
     cand_capacity = max(65536, 256 * args.batch)
 
     search_ms, index_ms, finish_ms, hit_total = [], [], [], 0
+    front_ms, deep_ms = [], []  # search_ms split: block search over the pair tables, depth-first part
     last_hits = None
 
     def search(batch, stream=None):
@@ -404,7 +405,7 @@ def main():
             t["structure"] += np.uint32(start - lo)
             st[0].append(t)
             if record:
-                st[1].append(res.timing())
+                st[1].append(res.timing() + res.search_split())
             res.close()
             st[3] -= 1
             if st[3] == 0:  # the step is complete
@@ -413,6 +414,8 @@ def main():
                     index_ms.extend(t[0] for t in times)
                     search_ms.extend(t[1] for t in times)
                     finish_ms.extend(t[2] for t in times)
+                    front_ms.extend(t[3] for t in times)
+                    deep_ms.extend(t[4] for t in times)
                     hit_total = n_local
                     last_hits = np.concatenate(tables) if len(tables) > 1 else tables[0]
 
@@ -427,6 +430,8 @@ def main():
                 for res in results:
                     a, b_, c = res.timing()
                     index_ms.append(a); search_ms.append(b_); finish_ms.append(c)
+                    f_, d_ = res.search_split()
+                    front_ms.append(f_); deep_ms.append(d_)
                 hit_total = int(table.count.item())
                 last_hits = gathered
             for res in results:
@@ -495,14 +500,15 @@ def main():
     # roofline.exclusive -- with two in flight the HIP events of a search also span what the other search's kernels ran
     exclusive_ms = None
     if len(streams) > 1:
-        timed = (list(index_ms), list(search_ms), list(finish_ms), hit_total, last_hits)
+        timed = (list(index_ms), list(search_ms), list(finish_ms), list(front_ms), list(deep_ms), hit_total, last_hits)
         saved, streams = streams, streams[:1]
-        index_ms, search_ms, finish_ms = [], [], []
+        index_ms, search_ms, finish_ms, front_ms, deep_ms = [], [], [], [], []
         run_steps(3, True)
         fence()
-        exclusive_ms = {"index": float(np.mean(index_ms)), "search": float(np.mean(search_ms)), "finish": float(np.mean(finish_ms))}
+        exclusive_ms = {"index": float(np.mean(index_ms)), "search": float(np.mean(search_ms)), "finish": float(np.mean(finish_ms)),
+                        "front": float(np.mean(front_ms)), "deep": float(np.mean(deep_ms))}
         streams = saved
-        index_ms, search_ms, finish_ms, hit_total, last_hits = timed
+        index_ms, search_ms, finish_ms, front_ms, deep_ms, hit_total, last_hits = timed
 
     # ---- not part of `value`: the same pass with the structures coming from HOST memory (encoded atom tables), batch
     # i + 1 flattened and uploaded on a worker thread while batch i is searched -- the PCIe-inclusive rate
@@ -565,19 +571,23 @@ def main():
         algo_bytes = (n_atoms * 16 + hit_total * 128) / len(batches) + lib_bytes  # per launch = per resident batch
         k_ms = float(np.mean(search_ms))
         achieved = algo_bytes / (k_ms * 1e-3) / 1e9
-        # HBM traffic of one k_search launch from the committed PMC passes of this workload (rocprofv3 cannot run
-        # inside the timed process); null when no summary is present
+        # HBM traffic of one search (its two launches: the block search k_search and the depth-first part k_deep) from the
+        # committed PMC passes of this workload (rocprofv3 cannot run inside the timed process); null when no summary is
+        # present.  profiles/LATEST names the summaries of the CURRENT kernels (profiles/collect.sh).
         traffic, traffic_src, secondary = None, None, None
-        latest = ROOT / "profiles" / "LATEST"  # names the PMC summary of the CURRENT kernel (profiles/collect.sh)
+        latest = ROOT / "profiles" / "LATEST"
         if latest.exists() and args.structures == 1000 and args.generator == "v2":
             try:
                 pointer = json.loads(latest.read_text())
-                pmc = json.loads((ROOT / "profiles" / pointer["k_search_pmc"]).read_text())
-                traffic = pmc["hbm_traffic_bytes_per_launch"]["total_corrected"]
-                traffic_src = f"profiles/{pointer['k_search_pmc']} (FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
-                secondary = pmc.get("secondary")
+                traffic, secondary, names = 0.0, {}, []
+                for key in ("k_search_pmc", "k_deep_pmc"):
+                    pmc = json.loads((ROOT / "profiles" / pointer[key]).read_text())
+                    traffic += pmc["hbm_traffic_bytes_per_launch"]["total_corrected"]
+                    secondary[key[:-4]] = pmc.get("secondary")
+                    names.append(f"profiles/{pointer[key]}")
+                traffic_src = " + ".join(names) + " (FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
             except (KeyError, ValueError, OSError):
-                pass
+                traffic, traffic_src, secondary = None, None, None
         out = {
             "metric": "structures_per_sec_vs_full_mcsa_library",
             "value": total_structs / (elapsed / args.steps),
@@ -613,14 +623,18 @@ def main():
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "k_search",
+                         # one search = two launches back to back on the search's stream: the block search over the pair tables
+                         # (k_search<mode 0>) and the depth-first part below the surviving triples (k_deep = k_search<mode 2>)
+                         "kernel": "k_search + k_deep",
                          "algorithmic_bytes_per_launch": algo_bytes,
-                         # average k_search launch over the timed region (HIP events on the search's own stream)
+                         # average duration of the pair over the timed region (HIP events on the search's own stream), and its parts
                          "kernel_ms": k_ms,
+                         "kernel_ms_parts": {"k_search": float(np.mean(front_ms)), "k_deep": float(np.mean(deep_ms))},
                          # the same kernel with one search in flight, measured after the timed region, and the
                          # fraction of peak that duration gives
                          "exclusive": None if exclusive_ms is None else {
-                             "kernel_ms": exclusive_ms["search"], "index_ms": exclusive_ms["index"],
+                             "kernel_ms": exclusive_ms["search"], "k_search_ms": exclusive_ms["front"], "k_deep_ms": exclusive_ms["deep"],
+                             "index_ms": exclusive_ms["index"],
                              "finish_ms": exclusive_ms["finish"],
                              "frac": algo_bytes / (exclusive_ms["search"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
                          # what actually bounds the kernel (instruction issue of a divergent search), from the same

@@ -6,6 +6,7 @@ MI355X is visible, every entry point raises.
 from __future__ import annotations
 
 import ctypes as C
+import sys as _sys
 import threading
 from pathlib import Path
 
@@ -90,7 +91,7 @@ EXPORTS = (
     "tm_batch_create", "tm_batch_create_from_columns", "tm_batch_create_from_structures", "tm_batch_create_from_pdb", "tm_batch_atom_counts", "tm_batch_line_offsets",
     "tm_batch_residue_counts",
     "tm_batch_destroy", "tm_query", "tm_result_wait", "tm_result_needed", "tm_result_hit_count",
-    "tm_result_copy_hits", "tm_result_copy_candidates", "tm_result_timing", "tm_result_device_hits",
+    "tm_result_copy_hits", "tm_result_copy_candidates", "tm_result_timing", "tm_result_search_split", "tm_result_device_hits",
     "tm_result_append_hits", "tm_result_destroy", "tm_pdb_count_host", "tm_pdb_parse_host", "tm_pdb_count_host_many",
     "tm_pdb_parse_host_many", "tm_files_sizes", "tm_files_read", "tm_batch_create_from_files", "tm_batch_file_text",
     "tm_stream_create", "tm_stream_destroy", "tm_batch_text_layout",
@@ -137,8 +138,10 @@ def load() -> C.CDLL:
 def _finalizing() -> bool:
     """True while the interpreter shuts down: destructors then leave device objects to the process exit (the HIP runtime
     may already be gone, and calling into it crashes)."""
-    import sys
-    return sys is None or sys.is_finalizing()
+    try:
+        return _sys.is_finalizing()
+    except Exception:  # module globals already torn down
+        return True
 
 
 def _check(rc: int):
@@ -531,6 +534,13 @@ class Result:
         a, b, c = C.c_float(0), C.c_float(0), C.c_float(0)
         _check(load().tm_result_timing(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
+
+    def search_split(self):
+        """(front_ms, deep_ms): the search time of ``timing()`` split into the block search over the pair tables and the
+        depth-first part below the surviving triples."""
+        a, b = C.c_float(0), C.c_float(0)
+        _check(load().tm_result_search_split(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def needed(self):
         """(candidates, pairs) this query produced -- the capacities a retry after TM_E_OVERFLOW needs."""

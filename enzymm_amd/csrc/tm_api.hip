@@ -478,7 +478,7 @@ struct tm_result {
     // triples between k_search and k_deep: pages, their per-structure directory, its cursors
     DevBuf<DeepEntry> d_pages;
     DevBuf<uint2> d_dir;
-    DevBuf<uint32_t> d_dir_off, d_dir_n, d_dir_head;
+    DevBuf<uint32_t> d_dir_off, d_dir_n, d_dir_head, d_dir_triples;
     PinnedBuf<uint32_t> h_dir_off;
     std::vector<uint32_t> atoms_of, dir_base;  // per structure: atoms, fixed part of its directory share (read again after an overflow)
     unsigned long long page_capacity = 0;
@@ -494,7 +494,7 @@ struct tm_result {
     DevBuf<double> d_cand_rmsd, d_models;
     DevBuf<int32_t> d_model_set;
     DevBuf<uint32_t> d_model_offsets, d_model_votes;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // [4]: between the table stages and the depth-first part
     bool waited = false;
     uint32_t overflow = 0;
     unsigned long long n_hits = 0, n_cands = 0, n_pairs = 0;
@@ -1666,6 +1666,8 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
         } else {
             S = std::make_shared<StagedSelection>();
             S->slack = slack;
+            if (const char *env = std::getenv("ENZYMM_AMD_DIR_MILLI"))  // test hook: start from a page directory that is too small
+                S->dir_milli = std::strtoull(env, nullptr, 10);
             S->sel.assign(p->template_index, p->template_index + n_sel);
             S->rmsd.assign(p->rmsd_threshold, p->rmsd_threshold + n_sel);
             S->cut.assign(p->distance_cutoff, p->distance_cutoff + n_sel);
@@ -1831,6 +1833,7 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
     if (p->flags & TM_FLAG_BEST_MATCH) { HIP_TRY(r->d_pair_min.alloc(n_pairs_all)); HIP_TRY(r->d_pair_tie.alloc(n_pairs_all)); }
     HIP_TRY(r->d_dir_n.alloc(b->n_structs));
     HIP_TRY(r->d_dir_head.alloc(b->n_structs));
+    HIP_TRY(r->d_dir_triples.alloc(b->n_structs));
     {
         ZeroList z = {};
         z.p[0] = r->d_pool_used.p; z.words[0] = 2;
@@ -1839,6 +1842,7 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
         z.p[3] = r->d_tab_used.p; z.words[3] = 4;
         z.p[4] = r->d_dir_n.p; z.words[4] = b->n_structs;
         z.p[5] = r->d_dir_head.p; z.words[5] = b->n_structs;
+        z.p[6] = r->d_dir_triples.p; z.words[6] = b->n_structs;
         hipLaunchKernelGGL(k_zero, dim3(1), dim3(256), 0, stream, z);
         HIP_TRY(hipGetLastError());
     }
@@ -1928,7 +1932,7 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
     O.hits = r->d_hits.p; O.n_hits = r->d_counters.p; O.hit_capacity = hcap; O.overflow = r->d_overflow.p;
     O.pair_count = r->d_pair_count.p; O.pair_last = r->d_pair_last.p;
     O.pair_min = r->d_pair_min.p; O.pair_tie = r->d_pair_tie.p;
-    O.n_pages = r->d_counters.p + 3; O.dir_n = r->d_dir_n.p; O.dir_head = r->d_dir_head.p;
+    O.n_pages = r->d_counters.p + 3; O.dir_n = r->d_dir_n.p; O.dir_head = r->d_dir_head.p; O.dir_triples = r->d_dir_triples.p;
     O.pages = nullptr; O.page_capacity = 0; O.dir = nullptr; O.dir_off = nullptr;  // sized below, with the work items
     if (n_sel && b->n_structs) {
         // enough workgroups to fill 256 CUs several times over
@@ -1978,6 +1982,7 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
             r->atoms_of.resize(ns);
             r->dir_base.assign(ns, 16u);
             for (uint32_t i = 0; i < b->work_items; ++i) r->dir_base[b->h_work[i].s] += (uint32_t)kSearchWaves << cx;
+            if (std::getenv("ENZYMM_AMD_DIR_MILLI")) r->dir_base.assign(ns, 0u);  // test hook: nothing but the learned part
             const double milli = (double)S->dir_milli.load();
             unsigned long long total = 0;
             for (uint32_t s = 0; s < ns; ++s) {
@@ -2029,6 +2034,7 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
             rc = launch(kModeSingly);
             if (rc != TM_OK) return rc;
         }
+        HIP_TRY(hipEventRecord(r->ev[4], stream));
         // the depth-first search below the triples the block search paged out: the same work items (every workgroup
         // of a structure takes triples of that structure until none are left)
         rc = launch(kModeDeep);
@@ -2190,6 +2196,20 @@ int tm_result_timing(tm_result *r, float *index_ms, float *search_ms, float *fin
     if (index_ms) *index_ms = a;
     if (search_ms) *search_ms = s;
     if (finish_ms) *finish_ms = f;
+    return TM_OK;
+}
+
+int tm_result_search_split(tm_result *r, float *front_ms, float *deep_ms) {
+    if (!r) return fail(TM_E_INVALID, "result is NULL");
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipEventSynchronize(r->ev[3]));
+    float a = 0, d = 0;
+    if (hipEventQuery(r->ev[4]) == hipSuccess) {  // recorded (a query with templates and structures)
+        HIP_TRY(hipEventElapsedTime(&a, r->ev[1], r->ev[4]));
+        HIP_TRY(hipEventElapsedTime(&d, r->ev[4], r->ev[2]));
+    }
+    if (front_ms) *front_ms = a;
+    if (deep_ms) *deep_ms = d;
     return TM_OK;
 }
 

@@ -223,6 +223,7 @@ struct OutView {
     uint2 *dir;                       // page directory: {page, triples in it}; structure s owns [dir_off[s], dir_off[s + 1])
     const uint32_t *dir_off;          // [n_structs + 1]
     uint32_t *dir_n;                  // [n_structs] pages listed (may exceed the share: overflow)
+    uint32_t *dir_triples;            // [n_structs] triples in them
     uint32_t *dir_head;               // [n_structs] k_deep: next run of kDeepRun triples to claim, counted over the listed pages
 };
 

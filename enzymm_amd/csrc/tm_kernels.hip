@@ -343,11 +343,11 @@ __global__ __launch_bounds__(256) void k_extent(const float4 *__restrict__ rec, 
 // group instead of a hipMemsetAsync / hipMemcpyAsync per word (the host side of a single-structure query is enqueue
 // time: DESIGN.md 6, configs[1]).
 struct ZeroList {
-    void *p[6];
-    uint32_t words[6];  // 32-bit words to clear at p[i]
+    void *p[8];
+    uint32_t words[8];  // 32-bit words to clear at p[i]
 };
 __global__ __launch_bounds__(256) void k_zero(ZeroList z) {
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < 8; ++i)
         for (uint32_t w = threadIdx.x; w < z.words[i]; w += blockDim.x) reinterpret_cast<uint32_t *>(z.p[i])[w] = 0u;
 }
 
@@ -1485,6 +1485,7 @@ __device__ __forceinline__ void page_publish(PageWriter &PW, uint32_t s, uint32_
     if (lane == 0) {
         ColdArgsPtr cold = cold_args();
         const uint32_t at = atomicAdd(&cold->O.dir_n[s], 1u);
+        atomicAdd(&cold->O.dir_triples[s], PW.fill);
         const uint32_t lo = cold->O.dir_off[s], hi = cold->O.dir_off[s + 1];
         // (an entry inside the share is written whatever happened: k_deep of an overflowed query must not read garbage)
         if (at < hi - lo) cold->O.dir[lo + at] = PW.page != kVirtualPage ? make_uint2(PW.page, PW.fill) : make_uint2(0u, 0u);
@@ -1923,7 +1924,11 @@ __device__ __forceinline__ void deep_templates(const SearchArgs &A, WaveScratchT
     const uint32_t lane = (uint32_t)C.lane;
     const uint32_t *kl = kLds ? s_kl : kl_off;
     const uint2 *dir = A.O.dir + A.O.dir_off[s];
-    constexpr uint32_t kRunsPerPage = kPageTriples / kDeepRun;
+    // Triples are claimed kDeepRun at a time: fewer claims on the structure's one counter, and the next template's
+    // constants load under the current triple's search.  (One at a time is slower even for a lone structure: the claims
+    // of a thousand waves on one address are what that case waits for.)
+    constexpr uint32_t run_len = kDeepRun;
+    constexpr uint32_t kRunsPerPage = kPageTriples / run_len;
     const uint32_t n_runs = n_listed * kRunsPerPage;
     WaveRegs W = {};
     DeepState D;
@@ -1936,8 +1941,8 @@ __device__ __forceinline__ void deep_templates(const SearchArgs &A, WaveScratchT
         uint32_t claimed = 0;  // the next run is claimed now: the atomic's round trip runs under this run's searches
         if (lane == 0) claimed = atomicAdd(&A.O.dir_head[s], 1u);
         const uint2 pg = dir[run / kRunsPerPage];  // {page, triples in it}
-        const uint32_t e0 = (run % kRunsPerPage) * kDeepRun;
-        const uint32_t nt = uni(pg.y) > e0 ? min(kDeepRun, uni(pg.y) - e0) : 0u;
+        const uint32_t e0 = (run % kRunsPerPage) * run_len;
+        const uint32_t nt = uni(pg.y) > e0 ? min(run_len, uni(pg.y) - e0) : 0u;
         DeepEntry t;
         t.a01 = 0u; t.c = 0u; t.ti = 0xffffffffu;
         if (lane < nt) t = A.O.pages[(size_t)uni(pg.x) * kPageTriples + e0 + lane];
@@ -2034,6 +2039,9 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
     if (kMode == kModeDeep) {  // pages of triples the block search left for this structure (its share of the directory)
         n_listed = min(A.O.dir_n[s], A.O.dir_off[s + 1] - A.O.dir_off[s]);
         if (n_listed == 0u) return;
+        // a structure with few triples is not worth all its workgroups (each stages the structure in LDS and queues at the
+        // structure's counter): as many take part as there are 8 triples per wave for
+        if ((unsigned long long)chunk * (8u * kSearchWaves) >= A.O.dir_triples[s]) return;
     }
     const uint32_t a0 = B.s_off[s], n = B.s_off[s + 1] - a0;
     const uint32_t r0 = B.s_roff[s], nres1 = B.s_roff[s + 1] - r0;  // n_res + 1 entries

@@ -233,6 +233,9 @@ int tm_result_copy_hits(tm_result *res, tm_hit *out, uint64_t capacity); /* sort
 int tm_result_copy_candidates(tm_result *res, uint32_t *out, uint64_t n); /* [n_structures * n_selected], needs TM_FLAG_COUNT_CANDIDATES */
 /* HIP-event durations on the launch stream: candidate index + template staging, k_search, superposition + selection */
 int tm_result_timing(tm_result *res, float *index_ms, float *search_ms, float *finish_ms);
+/* search_ms split into its two launches: the block search over the pair tables (k_search; with the template-at-a-time
+ * launch, when the selection needs one) and the depth-first part below the surviving triples (k_deep) */
+int tm_result_search_split(tm_result *res, float *front_ms, float *deep_ms);
 const void *tm_result_device_hits(tm_result *res);           /* device pointer to the unsorted tm_hit table */
 /* Appends this query's hit rows to a caller-owned DEVICE table (rows: tm_hit[capacity], *count: rows in use, both in
  * device memory), adding structure_offset to tm_hit.structure -- enqueued on the query's stream behind its kernels,

@@ -32,7 +32,11 @@ pass SQ_INSTS_BRANCH SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU
 pass FETCH_SIZE
 pass WRITE_SIZE
 pass TCC_HIT_sum TCC_MISS_sum
-for kernel in k_search k_tab_build; do
+# one summary per kernel: the two launches of a search (block search = k_search<..., 0>, depth-first part = k_deep =
+# k_search<..., 2>) and the table build
+for spec in "k_search:k_search<true, true, 0>" "k_deep:k_search<true, true, 2>" "k_tab_build:k_tab_build"; do
+    short=${spec%%:*}
+    kernel=${spec#*:}
     kms=0
     if [ -f "$out/${tag}_bench1000_pipeline1_kernel_stats.csv" ]; then
         kms=$(python3 - "$out/${tag}_bench1000_pipeline1_kernel_stats.csv" "$kernel" <<'PY'
@@ -42,7 +46,7 @@ print(float(rows[0]["AverageNs"]) / 1e6 if rows else 0.0)
 PY
 )
     fi
-    python3 profiles/summarize_pmc.py "$kernel" "$out/${tag}_${kernel}_pmc.json" --searches 6780000 --kernel-ms "$kms" \
+    python3 profiles/summarize_pmc.py "$kernel" "$out/${tag}_${short}_pmc.json" --searches 6780000 --kernel-ms "$kms" \
         --valu-ceiling "$out/${tag}_valu_ceiling.json" --head "$head" \
         "$out"/pmc_SQ_INSTS_VALU "$out"/pmc_SQ_ACTIVE_INST_ANY "$out"/pmc_SQ_INSTS_BRANCH "$out"/pmc_FETCH_SIZE "$out"/pmc_WRITE_SIZE "$out"/pmc_TCC_HIT_sum >> "$out/summary.log" 2>&1
 done

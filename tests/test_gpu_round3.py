@@ -138,6 +138,43 @@ def test_pair_table_pool_overflow_takes_one_retry(n_structures, monkeypatch):
     assert got.tobytes() == want.tobytes()
 
 
+def test_page_directory_overflow_takes_one_retry(monkeypatch):
+    """The directory of the pages of triples between k_search and k_deep starts without room for a single full page
+    (ENZYMM_AMD_DIR_MILLI=0): the first query reports TM_E_OVERFLOW -- k_deep having searched only what was listed --,
+    the structures kept COUNTING their pages, so the second query has room and returns the undisturbed hit table."""
+    idx, cut = helpers.default_selection()
+    mols = [pyjess.Molecule.load(helpers.GOLDEN / "1AMY.pdb")] + synthetic.structures(40, start=700)
+    flags = _native.TM_FLAG_BEST_MATCH | _native.TM_FLAG_IGNORE_CHAIN
+
+    jess = pyjess.Jess(helpers.product_library_templates())
+    packed = pyjess._packed(jess._templates, jess._device)
+    rmsd = 1.875  # a threshold no other test uses: this library has not staged the selection yet
+
+    def run(retry_expected):
+        batch = pyjess.make_batch(mols, jess._device)
+        res = _native.query(packed.native, batch, idx, rmsd, cut, cut, 10000, flags, retry=False)
+        if retry_expected:
+            with pytest.raises(_native.NativeError) as exc:
+                res.wait()
+            assert exc.value.code == _native.TM_E_OVERFLOW and "page directory" in str(exc.value)
+            res.close()
+            res = _native.query(packed.native, batch, idx, rmsd, cut, cut, 10000, flags, retry=False)
+        table = res.hits()
+        res.close(); batch.close()
+        return table
+
+    monkeypatch.setenv("ENZYMM_AMD_DIR_MILLI", "0")  # (the hook also drops the per-wave part of a structure's share)
+    got = run(True)     # stages the selection with an empty directory, overflows, learns, succeeds
+    again = run(False)  # the selection remembers what it needed
+    monkeypatch.delenv("ENZYMM_AMD_DIR_MILLI")
+    assert len(got) > 20 and got.tobytes() == again.tobytes()
+    # and the same hits as the oracle's for the first structure
+    otpl = helpers.oracle_library_templates()
+    lib = oracle.OracleLibrary([otpl[i] for i in idx])
+    r = oracle.query_library(helpers.to_oracle_molecule(mols[0]), lib, rmsd, cut, cut, max_candidates=10000, ignore_chain=True)
+    assert _same_as_oracle(got, r, lib) > 5
+
+
 def test_templates_of_one_atom_per_residue(amy):
     """Templates whose residues contribute a single atom each (k == number of residues; legal for Jess, absent from
     the shipped library): 1 to 5 atoms, every atom a "lead" for the search -- the level-3 look and the depth-first
