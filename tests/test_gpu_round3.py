@@ -282,4 +282,4 @@ def test_bench_two_ranks_as_the_driver_launches_it():
     assert two["config"]["hits_total"] == one["config"]["hits_total"] > 0
     assert two["config"]["hit_table_digest"] == one["config"]["hit_table_digest"]
     assert two["value"] > 0 and two["config"]["gather_ms_per_pass"] is not None
-    assert "roofline" in two and two["roofline"]["kernel"] == "k_search"
+    assert "roofline" in two and two["roofline"]["kernel"] == "k_search + k_deep"
