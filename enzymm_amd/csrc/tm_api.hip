@@ -2014,7 +2014,7 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
             const size_t lds_limit = 160 * 1024 - 64;
             const bool lds_path = base <= lds_limit;
             args.pool_cap = lds_path ? (uint32_t)((lds_limit - base) / sizeof(uint16_t)) : 0u;
-            const size_t lds_bytes = lds_path ? lds_limit : scratch;
+            const size_t lds_bytes = lds_path ? lds_limit : scratch + (mode == kModeDeep ? search_cache_bytes() : 0);
             void (*kernel)(SearchArgs) = nullptr;
 #define TM_PICK(m) (lds_path ? (ic ? k_search<true, true, m> : k_search<true, false, m>) : (ic ? k_search<false, true, m> : k_search<false, false, m>))
             kernel = mode == kModeBlocks ? TM_PICK(kModeBlocks) : mode == kModeSingly ? TM_PICK(kModeSingly) : TM_PICK(kModeDeep);

@@ -742,6 +742,8 @@ struct __align__(16) WaveScratchT {
     uint2 pairs[kQueues ? kPairQueue : 1];           // pair-table survivors {position in list 0 | position in list 1 << 16, slot}
     uint2 triples[kQueues ? kTripleQueue : 1];       // triple survivors {a0 | a1 << 16, a2 | slot << 16} waiting for the look at level 3
     uint32_t owner[64];                              // item-parallel stages: who owns the item at which its segment / row starts
+    // candidate slots this wave has reserved: {next, end, size of the next reservation} (on_complete, slab_release)
+    uint32_t slab[4];
 };
 
 // Search state of one wave, held in VGPRs and indexed BY LANE: lane L holds the entry of search
@@ -772,8 +774,23 @@ __device__ __forceinline__ void WLf(float &v, int lane, float x) { v = lane_id()
 
 // kIgnoreChain is a compile-time property of the launch: the default (ignore_chain=True in enzymm) drops
 // every chain test from the instruction stream.
-template <bool kIgnoreChain, bool kPoolLds, int kMode>
+// A structure too large for LDS (a complex of tens of thousands of atoms) is searched with its records in global
+// memory: every step of the depth-first part then waits for L2 or HBM two or three times over.  What that part touches
+// below the lead levels is small, though -- the other atoms of the residues the leads were assigned to --, so k_deep
+// keeps those residues in LDS (per wave: one slot per template residue, filled when a non-lead level of that residue
+// is first prepared and valid for as long as the residue's lead stays the same atom).
+constexpr uint32_t kResCacheAtoms = 32;
+struct __align__(16) ResCache {
+    float4 rec[kMaxG][kResCacheAtoms];
+    uint32_t tag[kMaxG];    // lead atom whose residue sits in the slot (0xffffffff: none)
+    uint32_t first[kMaxG];  // first atom of that residue
+    uint32_t count[kMaxG];  // its atoms
+};
+
+template <bool kIgnoreChain, bool kPoolLds, int kMode, bool kCache = false>
 struct SearchCtx {
+    static constexpr bool kResCache = kCache;
+    ResCache *rc;               // kResCache: this wave's slots
     const float4 *rec;          // structure atom records (LDS or global)
     const uint16_t *res_start;  // residue -> first atom (LDS or global)
     // kind lists of this structure in LDS (when they fit: kPoolLds) or the batch-wide pool in global memory (offsets
@@ -830,7 +847,7 @@ __device__ __forceinline__ unsigned long long eval_chunk(const Ctx &C, WaveRegs 
     } else {
         cand = ok ? lo + idx : lo;
     }
-    const float4 r = C.rec[cand];
+    const float4 r = lead ? C.rec[cand] : residue_record(C, mygroup, cand);
     const uint32_t m = __float_as_uint(r.w);
     uint32_t cchain = 0, mychain = 0;
     if (!C.ignore_chain) {
@@ -889,11 +906,40 @@ __device__ __forceinline__ void init_level(const Ctx &C, WaveRegs &W, int level)
     WL(W.pend_hi, level, 0u);
     if (RL(W.lead, level) == 0) {
         // same template residue as an already placed lead atom: scan the atoms of that target residue
-        const uint32_t res = meta_res(RL(W.ameta, (int)lvl_ref(RL(W.pk, level))));
-        const uint32_t s0 = C.res_start[res], s1 = C.res_start[res + 1];  // uniform address: same value in every lane
-        WL(W.lo, level, s0);
-        WL(W.cnt, level, s1 - s0);
+        const uint32_t pk = RL(W.pk, level);
+        const int ref = (int)lvl_ref(pk);
+        if constexpr (Ctx::kResCache) {
+            const uint32_t g = lvl_group(pk), lead_atom = RL(W.aidx, ref);
+            ResCache &R = *C.rc;
+            if (uni(R.tag[g]) != lead_atom) {  // the slot holds another residue (or none): fetch this one
+                const uint32_t res = meta_res(RL(W.ameta, ref));
+                const uint32_t s0 = C.res_start[res], n = C.res_start[res + 1] - s0;
+                wave_sync();  // (earlier reads of the slot are done)
+                if ((uint32_t)C.lane < min(n, kResCacheAtoms)) R.rec[g][C.lane] = C.rec[s0 + (uint32_t)C.lane];
+                if (C.lane == 0) { R.tag[g] = lead_atom; R.first[g] = s0; R.count[g] = n; }
+                wave_sync();
+            }
+            WL(W.lo, level, uni(R.first[g]));
+            WL(W.cnt, level, uni(R.count[g]));
+        } else {
+            const uint32_t res = meta_res(RL(W.ameta, ref));
+            const uint32_t s0 = C.res_start[res], s1 = C.res_start[res + 1];  // uniform address: same value in every lane
+            WL(W.lo, level, s0);
+            WL(W.cnt, level, s1 - s0);
+        }
     }
+}
+
+// The record of atom `atom`, which belongs to the target residue of template residue `g` (a non-lead level's candidate):
+// from the residue cache when there is one and the residue fits a slot.
+template <class Ctx>
+__device__ __forceinline__ float4 residue_record(const Ctx &C, uint32_t g, uint32_t atom) {
+    if constexpr (Ctx::kResCache) {
+        const ResCache &R = *C.rc;
+        const uint32_t first = uni(R.first[g]);
+        if (uni(R.count[g]) <= kResCacheAtoms) return R.rec[g][min(atom - first, kResCacheAtoms - 1u)];
+    }
+    return C.rec[atom];
 }
 
 template <class Ctx>
@@ -908,7 +954,9 @@ __device__ __forceinline__ void assign_record(const Ctx &C, WaveRegs &W, int lev
 
 template <class Ctx>
 __device__ __forceinline__ void assign_level(const Ctx &C, WaveRegs &W, int level, uint32_t cand) {
-    assign_record(C, W, level, cand, C.rec[cand]);  // uniform address: every lane receives the same record
+    // uniform address: every lane receives the same record
+    if (Ctx::kResCache && RL(W.lead, level) == 0u) assign_record(C, W, level, cand, residue_record(C, lvl_group(RL(W.pk, level)), cand));
+    else assign_record(C, W, level, cand, C.rec[cand]);
 }
 
 // All arguments of k_search as one kernel-argument struct.  Code that runs rarely (a complete
@@ -1010,13 +1058,28 @@ __device__ __forceinline__ bool on_complete(const Ctx &C, WaveRegs &W, PairState
         }
         return false;
     }
-    unsigned long long slot = 0;
-    if (lane == 0) slot = atomicAdd(A->O.n_cands, 1ull);
-    slot = uni64(slot);
-    if (slot >= A->O.cand_capacity) {
-        if (lane == 0) atomicOr(A->O.overflow, 1u);
-        return true;
+    // A slot of the candidate buffer: waves reserve slots in slabs (1, 2, 4 ... 64 at a time) -- one counter for every
+    // candidate of the launch is what millions of completions (large complexes under loose thresholds) would queue at.
+    // What a wave leaves unused of its last slab is marked invalid when the wave is done (slab_release).
+    auto &S = *C.S;
+    wave_sync();  // (lane 0 keeps the wave's slab cursor in LDS)
+    uint32_t next = uni(S.slab[0]);
+    const uint32_t end = uni(S.slab[1]);
+    if (next == end) {
+        const uint32_t want = uni(S.slab[2]);
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(A->O.n_cands, (unsigned long long)want);
+        base = uni64(base);
+        if (base + want > A->O.cand_capacity) {
+            if (lane == 0) atomicOr(A->O.overflow, 1u);  // (the query is run again with room: tm_result_needed)
+            return true;
+        }
+        next = (uint32_t)base;
+        if (lane == 0) { S.slab[1] = next + want; S.slab[2] = min(64u, 2u * want); }
     }
+    const unsigned long long slot = next;
+    if (lane == 0) S.slab[0] = next + 1u;
+    wave_sync();
     Cand *c = A->O.cands + slot;
     if (lane == 0) {
         // the candidate becomes the new end of the pair's chain; whoever links the first one lists the pair
@@ -1037,6 +1100,20 @@ __device__ __forceinline__ bool on_complete(const Ctx &C, WaveRegs &W, PairState
         else c->atoms[lane] = 0xffffu;
     }
     return true;
+}
+
+// A wave starts without reserved candidate slots, and marks what it leaves unused invalid when it is done.
+template <class Ctx>
+__device__ __forceinline__ void slab_init(const Ctx &C) {
+    if (C.lane == 0) { C.S->slab[0] = 0u; C.S->slab[1] = 0u; C.S->slab[2] = 1u; }
+    wave_sync();
+}
+template <class Ctx>
+__device__ __forceinline__ void slab_release(const Ctx &C) {
+    wave_sync();
+    const uint32_t next = uni(C.S->slab[0]), end = uni(C.S->slab[1]);
+    Cand *cands = cold_args()->O.cands;
+    for (uint32_t i = next + (uint32_t)C.lane; i < end; i += 64u) cands[i].s = 0xffffffffu;
 }
 
 // Depth-first search over levels >= floor (levels < floor are already assigned).
@@ -1843,6 +1920,7 @@ __device__ __forceinline__ void search_templates(const SearchArgs &A, WaveScratc
     const BatchView &B = A.B;
     const QueryView &Q = A.Q;
     SearchCtx<kIgnoreChain, kPoolLds, kSingly ? kModeSingly : kModeBlocks> C;
+    C.rc = nullptr;
     C.rec = kLds ? s_rec : B.q_rec + a0;
     C.res_start = kLds ? s_res : B.res_start + r0;
     C.pool_lds = (const __attribute__((address_space(3))) uint16_t *)s_pool;
@@ -1860,6 +1938,7 @@ __device__ __forceinline__ void search_templates(const SearchArgs &A, WaveScratc
         // the template-at-a-time launch: the waves take the listed templates of this chunk one by one and search those
         // whose table reference says so
         WaveRegs W = {};
+        slab_init(C);
         for (;;) {
             uint32_t m = 0;
             if (lane == 0) m = atomicAdd(s_next_p, 1u);
@@ -1869,6 +1948,7 @@ __device__ __forceinline__ void search_templates(const SearchArgs &A, WaveScratc
             const uint32_t ti = A.singly[at];
             if ((uni(tab_ref[ti].y) & kRefSingly) != 0u) search_singly(C, A, W, s, ti, kl);
         }
+        slab_release(C);
     } else {
     const uint32_t n_mine = (Q.n_sel - chunk + n_chunks - 1u) / n_chunks;  // templates chunk, chunk + n_chunks, ...
     PageWriter PW;
@@ -1907,10 +1987,16 @@ struct DeepState {
 template <bool kLds, bool kIgnoreChain, bool kPoolLds>
 __device__ __forceinline__ void deep_templates(const SearchArgs &A, WaveScratchT<kModeDeep> *scratch, const float4 *s_rec,
                                                const uint16_t *s_res, const uint32_t *s_kl, const uint16_t *s_pool,
-                                               const uint32_t *kl_off, uint32_t s, uint32_t a0, uint32_t r0, uint32_t n_listed) {
+                                               const uint32_t *kl_off, uint32_t s, uint32_t a0, uint32_t r0, uint32_t n_listed,
+                                               ResCache *cache) {
     const BatchView &B = A.B;
     const QueryView &Q = A.Q;
-    SearchCtx<kIgnoreChain, kPoolLds, kModeDeep> C;
+    SearchCtx<kIgnoreChain, kPoolLds, kModeDeep, !kLds> C;
+    C.rc = cache ? cache + (threadIdx.x >> 6) : nullptr;
+    if (!kLds) {
+        if (lane_id() < kMaxG) C.rc->tag[lane_id()] = 0xffffffffu;
+        wave_sync();
+    }
     C.rec = kLds ? s_rec : B.q_rec + a0;
     C.res_start = kLds ? s_res : B.res_start + r0;
     C.pool_lds = (const __attribute__((address_space(3))) uint16_t *)s_pool;
@@ -1934,6 +2020,7 @@ __device__ __forceinline__ void deep_templates(const SearchArgs &A, WaveScratchT
     DeepState D;
     D.ti = 0xffffffffu; D.next_ti = 0xffffffffu; D.feasible = false; D.since = 0ull;
     D.P.s = s; D.P.ti = 0; D.P.truncated = false;
+    slab_init(C);
     uint32_t run = 0;
     if (lane == 0) run = atomicAdd(&A.O.dir_head[s], 1u);
     run = uni(run);
@@ -1991,6 +2078,7 @@ __device__ __forceinline__ void deep_templates(const SearchArgs &A, WaveScratchT
         run = uni(claimed);
     }
     if (D.ti != 0xffffffffu && Q.cost && lane == 0) atomicAdd(&Q.cost[D.ti], __builtin_amdgcn_s_memtime() - D.since);
+    slab_release(C);
 }
 
 // All three launch modes (kModeBlocks, kModeSingly, kModeDeep) stage the structure of their work item in LDS the same way.
@@ -2011,6 +2099,9 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
     uint32_t *s_kl = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(s_res) +
                                                   (kLds ? search_res_bytes(max_res) : 0));
     uint16_t *s_pool = reinterpret_cast<uint16_t *>(s_kl + (kLds ? search_kl_words(L.n_lead) : 0));
+    // k_deep on a structure that is not in LDS: the residue cache takes the place of the structure's copy
+    ResCache *cache = (!kLds && kMode == kModeDeep) ? reinterpret_cast<ResCache *>(s_rec) : nullptr;
+    (void)cache;
     __shared__ uint32_t s_next;
 
     // Workgroups b and b + 8 share an XCD.  The template selection of a work item is cut into
@@ -2074,8 +2165,8 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
     __syncthreads();
 #endif
     if constexpr (kMode == kModeDeep) {
-        if (pool_in_lds) deep_templates<kLds, kIgnoreChain, true>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, s, a0, r0, n_listed);
-        else deep_templates<kLds, kIgnoreChain, false>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, s, a0, r0, n_listed);
+        if (pool_in_lds) deep_templates<kLds, kIgnoreChain, true>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, s, a0, r0, n_listed, cache);
+        else deep_templates<kLds, kIgnoreChain, false>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, s, a0, r0, n_listed, cache);
     } else {
         if (pool_in_lds)
             search_templates<kLds, kIgnoreChain, true, kSingly>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, &s_next, s, a0, r0, chunk, n_chunks);
@@ -2106,6 +2197,7 @@ TM_INSTANTIATE(kModeSingly)
 TM_INSTANTIATE(kModeDeep)
 #undef TM_INSTANTIATE
 
+size_t search_cache_bytes() { return sizeof(ResCache) * kSearchWaves; }
 size_t search_scratch_bytes(int mode) {
     return (mode == kModeBlocks ? sizeof(WaveScratchT<kModeBlocks>) : mode == kModeSingly ? sizeof(WaveScratchT<kModeSingly>)
                                                                                          : sizeof(WaveScratchT<kModeDeep>)) * kSearchWaves;
@@ -2231,6 +2323,7 @@ __global__ __launch_bounds__(256) void k_superpose(LibView L, BatchView B, Query
     for (unsigned long long c = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += stride) {
         double R[9], T[3];
         const Cand &cand = O.cands[c];
+        if (cand.s == 0xffffffffu) continue;  // a reserved slot no candidate was written to
         const double r = superpose_candidate(L, B, Q, cand, R, T);
         O.cand_rmsd[c] = r;
         // the pair's minimum within the threshold (non-negative doubles order like their bit patterns)
@@ -2247,6 +2340,7 @@ __global__ __launch_bounds__(256) void k_ties(QueryView Q, OutView O) {
     const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
     for (unsigned long long c = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += stride) {
         Cand &cand = O.cands[c];
+        if (cand.s == 0xffffffffu) continue;
         const double r = O.cand_rmsd[c];
         const size_t pair = (size_t)cand.s * Q.n_sel + Q.order[cand.ti];
         const unsigned long long low = O.pair_min[pair];
