@@ -1593,8 +1593,22 @@ static int build_tables(const tm_library *lib, tm_batch *b, const StagedSelectio
     const bool mostly_large = (size_t)b->n_atoms > (size_t)3800 * ns;
     // (such a batch still reserves 4096 records = 64 KB, two workgroups per CU: the staging area for list B of the
     // big tables its workgroups build together)
-    const uint32_t lr_cap = mostly_large ? 4096u : (uint32_t)std::min<size_t>(9600, std::max<size_t>(1024, 3 * (size_t)b->max_atoms));
-    const size_t lds_bytes = (size_t)lr_cap * sizeof(float4) + ((size_t)lib->n_lead + 2) * sizeof(uint32_t);  // s_lr + s_kl
+    uint32_t lr_cap = mostly_large ? 4096u : (uint32_t)std::min<size_t>(9600, std::max<size_t>(1024, 3 * (size_t)b->max_atoms));
+    size_t lds_bytes = (size_t)lr_cap * sizeof(float4) + ((size_t)lib->n_lead + 2) * sizeof(uint32_t);  // s_lr + s_kl
+    // Compact layout -- atom records once (16 B per atom) and the kind lists as positions (2 B each) instead of a record
+    // per position: when the batch's largest structure then leaves room for TWO workgroups per CU (80 KB each), the
+    // build runs at eight waves per SIMD instead of four, which is worth the second LDS read per operand.
+    uint32_t atom_cap = 0;
+    {
+        static const bool off = std::getenv("ENZYMM_AMD_TAB_COMPACT") && std::atoi(std::getenv("ENZYMM_AMD_TAB_COMPACT")) == 0;
+        const size_t budget = 80 * 1024 - 512;  // static LDS of the kernel and allocation granularity
+        const size_t fixed = (size_t)b->max_atoms * sizeof(float4) + ((size_t)lib->n_lead + 2) * sizeof(uint32_t);
+        if (!off && !mostly_large && fixed + 2 * 2 * (size_t)b->max_atoms + 16 <= budget) {  // room for two positions per atom at least
+            atom_cap = b->max_atoms;
+            lr_cap = (uint32_t)std::min<size_t>(65528, ((budget - fixed) / sizeof(uint16_t)) & ~size_t(7));
+            lds_bytes = (size_t)atom_cap * sizeof(float4) + (size_t)lr_cap * sizeof(uint16_t) + ((size_t)lib->n_lead + 2) * sizeof(uint32_t);
+        }
+    }
     unsigned long long shared_limit = kTabShared;
     if (const char *env = std::getenv("ENZYMM_AMD_TAB_SHARED"))  // test hook: smaller tables take the shared build too
         shared_limit = std::max<unsigned long long>(1, std::strtoull(env, nullptr, 10));
@@ -1607,7 +1621,7 @@ static int build_tables(const tm_library *lib, tm_batch *b, const StagedSelectio
                        b->d_tab_cursors.p, rows, b->d_tab_overflow.p, b->d_tab_ok.p);
     hipLaunchKernelGGL(k_tab_build, dim3(b->tab_work_items), dim3(kTabBlock), lds_bytes, stream, lib->n_lead, B,
                        S->d_tables.p, b->d_tab_work.p, b->d_tab_ok.p, b->d_tab_rows.p, b->d_tab_ent.p, b->d_tab_seg.p,
-                       b->d_tab_cursors.p, ents, b->d_tab_overflow.p, lr_arg, shared_limit);
+                       b->d_tab_cursors.p, ents, b->d_tab_overflow.p, lr_arg, shared_limit, atom_cap);
     {
         const uint32_t n_sel = (uint32_t)S->sel.size();
         hipLaunchKernelGGL(k_tab_refs, dim3(ns, (n_sel + 255) / 256), dim3(256), 0, stream, B, lib->n_lead, n_sel, S->d_pair_table.p,

@@ -520,7 +520,11 @@ __host__ __device__ inline uint32_t tab_chunk(uint32_t n_atoms) {
     while (c < 8192 && c < 2 * n_atoms) c <<= 1;
     return c;
 }
-template <bool kLds>
+// kSrc: where the atom record of kind-list position p comes from -- 0: rec[pool[p]] in global memory; 1: s_lr[p], a copy
+// of the record per POSITION in LDS (one read per operand, 16 B per position: about 100 KB for a 300-residue structure,
+// one workgroup per CU); 2: the structure's atom records and its kind lists in LDS (two dependent reads per operand,
+// 16 B per atom + 2 B per position: about 50 KB, two workgroups per CU).
+template <int kSrc>
 __device__ __forceinline__ void tab_build_tables(const BatchView &B, const TableDesc *__restrict__ tables,
                                                  const TabWork w, const float4 *rec, const uint16_t *pool,
                                                  const float4 *s_lr, const uint32_t *kl,
@@ -532,7 +536,14 @@ __device__ __forceinline__ void tab_build_tables(const BatchView &B, const Table
                                                  uint32_t stage_cap, unsigned long long shared_limit, bool rows_ok) {
     const uint32_t nt = B.n_tables;
     const uint32_t wave = uni(threadIdx.x >> 6), n_waves = blockDim.x >> 6, lane = threadIdx.x & 63;
-    auto lead = [&](uint32_t p) -> float4 { return kLds ? s_lr[p] : rec[pool[p]]; };
+    auto lead = [&](uint32_t p) -> float4 {
+        if constexpr (kSrc == 1) return s_lr[p];
+        else if constexpr (kSrc == 2) {
+            const uint32_t atom = ((const __attribute__((address_space(3))) uint16_t *)pool)[p];
+            const auto *r = (const __attribute__((address_space(3))) float *)rec + 4u * atom;
+            return make_float4(r[0], r[1], r[2], r[3]);
+        } else return rec[pool[p]];
+    };
     // entries [first, first + n) of the pool, or ~0 when the pool is exhausted (the query then reports the overflow)
     auto allocate = [&](unsigned long long n) -> unsigned long long {
         unsigned long long first = 0;
@@ -608,7 +619,7 @@ __device__ __forceinline__ void tab_build_tables(const BatchView &B, const Table
         const uint32_t i0 = min(n_a, wave * block), i1 = min(n_a, i0 + block);
         // a structure too large for the LDS copy of all its lead records reads them through L2 (two dependent loads
         // per operand): list B of a big table, which every row block sweeps in full, is staged in that unused LDS
-        const bool staged = !kLds && n_b <= stage_cap;
+        const bool staged = kSrc == 0 && n_b <= stage_cap;
         if (staged) {
             for (uint32_t j = threadIdx.x; j < n_b; j += blockDim.x) s_stage[j] = rec[pool[b_lo + j]];
             __syncthreads();
@@ -653,7 +664,8 @@ __global__ __launch_bounds__(kTabBlock) void k_tab_build(uint32_t n_lead, BatchV
                                                           uint2 *__restrict__ tab_seg,
                                                           unsigned long long *__restrict__ cursors,
                                                           unsigned long long ent_capacity, uint32_t *__restrict__ overflow,
-                                                          uint32_t lr_cap, unsigned long long shared_limit) {
+                                                          uint32_t lr_cap, unsigned long long shared_limit,
+                                                          uint32_t atom_cap) {
     extern __shared__ __align__(16) unsigned char tab_smem[];
     __shared__ uint32_t s_count[kTabBlock / 64];
     __shared__ unsigned long long s_first;
@@ -672,16 +684,36 @@ __global__ __launch_bounds__(kTabBlock) void k_tab_build(uint32_t n_lead, BatchV
     const uint32_t *kl = B.kl_off + (size_t)w.s * (n_lead + 1);
     const float4 *rec = B.q_rec + B.s_off[w.s];
     const uint32_t p0 = kl[0], plen = kl[n_lead] - p0;
+    if (atom_cap != 0u) {
+        // compact layout (host: the batch's largest structure leaves room for two workgroups per CU):
+        // [float4 x atom_cap] atom records, [u16 x lr_cap] kind lists, [u32 x (n_lead + 1)] their offsets
+        const uint32_t n = B.s_off[w.s + 1] - B.s_off[w.s];
+        float4 *s_atoms = reinterpret_cast<float4 *>(tab_smem);
+        uint16_t *s_pool = reinterpret_cast<uint16_t *>(s_atoms + atom_cap);
+        uint32_t *s_kl2 = reinterpret_cast<uint32_t *>(s_pool + ((lr_cap + 7u) & ~7u));
+        if (plen <= lr_cap && n <= atom_cap) {
+            for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) s_atoms[i] = rec[i];
+            for (uint32_t i = threadIdx.x; i < plen; i += blockDim.x) s_pool[i] = B.kl_pool[p0 + i];
+            for (uint32_t i = threadIdx.x; i <= n_lead; i += blockDim.x) s_kl2[i] = kl[i] - p0;
+            __syncthreads();
+            tab_build_tables<2>(B, tables, w, s_atoms, s_pool, nullptr, s_kl2, tab_rows, tab_ent, tab_seg, cursors,
+                                ent_capacity, overflow, tab_ok, dbg_mode, s_count, &s_first, n_lead, nullptr, 0u, shared_limit, rows_ok);
+        } else {
+            tab_build_tables<0>(B, tables, w, rec, B.kl_pool, nullptr, kl, tab_rows, tab_ent, tab_seg, cursors,
+                                ent_capacity, overflow, tab_ok, dbg_mode, s_count, &s_first, n_lead, s_atoms, atom_cap, shared_limit, rows_ok);
+        }
+        return;
+    }
     float4 *s_lr = reinterpret_cast<float4 *>(tab_smem);
     uint32_t *s_kl = reinterpret_cast<uint32_t *>(s_lr + lr_cap);
     if (plen <= lr_cap) {
         for (uint32_t i = threadIdx.x; i < plen; i += blockDim.x) s_lr[i] = rec[B.kl_pool[p0 + i]];
         for (uint32_t i = threadIdx.x; i <= n_lead; i += blockDim.x) s_kl[i] = kl[i] - p0;
         __syncthreads();
-        tab_build_tables<true>(B, tables, w, rec, B.kl_pool, s_lr, s_kl, tab_rows, tab_ent, tab_seg, cursors,
+        tab_build_tables<1>(B, tables, w, rec, B.kl_pool, s_lr, s_kl, tab_rows, tab_ent, tab_seg, cursors,
                                ent_capacity, overflow, tab_ok, dbg_mode, s_count, &s_first, n_lead, nullptr, 0u, shared_limit, rows_ok);
     } else {
-        tab_build_tables<false>(B, tables, w, rec, B.kl_pool, nullptr, kl, tab_rows, tab_ent, tab_seg, cursors,
+        tab_build_tables<0>(B, tables, w, rec, B.kl_pool, nullptr, kl, tab_rows, tab_ent, tab_seg, cursors,
                                 ent_capacity, overflow, tab_ok, dbg_mode, s_count, &s_first, n_lead, s_lr, lr_cap, shared_limit, rows_ok);
     }
 }
