@@ -1673,6 +1673,10 @@ __device__ __forceinline__ void block_look(Ctx &C, const SearchArgs &A, SlotRegs
         TM_STAT(69, n_empty);
     }
 #endif
+    // (consecutive triples mostly belong to one template and so share the kind list of their fourth lead: its first 64
+    // records stay in registers from one triple to the next)
+    uint32_t held_lo = 0xffffffffu, held_cnt = 0u;
+    float4 held = make_float4(0.f, 0.f, 0.f, 0.f);
     for (unsigned long long todo = ballot64(lead3 && n_c != 0u); todo; todo &= todo - 1ull) {
         const int q = __ffsll((long long)todo) - 1;
         const float ax = RLf(q0.x, q), ay = RLf(q0.y, q), az = RLf(q0.z, q);
@@ -1681,10 +1685,16 @@ __device__ __forceinline__ void block_look(Ctx &C, const SearchArgs &A, SlotRegs
         const float2 wa = make_float2(RLf(H.w30.x, q), RLf(H.w30.y, q)), wb = make_float2(RLf(H.w31.x, q), RLf(H.w31.y, q)),
                      wc = make_float2(RLf(H.w32.x, q), RLf(H.w32.y, q));
         const uint32_t lo = RL(first, q), cnt = RL(n_c, q);
+        if (lo != held_lo || cnt != held_cnt) {
+            held = C.rec[C.pool_at(lo + min(lane, cnt - 1u))];
+            held_lo = lo;
+            held_cnt = cnt;
+        }
         for (uint32_t base = 0; base < cnt; base += 64u) {
             TM_STAT(61, 1);
             const uint32_t idx = base + lane;
-            const float4 r = C.rec[C.pool_at(lo + min(idx, cnt - 1u))];
+            float4 r = held;
+            if (base != 0u) r = C.rec[C.pool_at(lo + min(idx, cnt - 1u))];
             float dx = r.x - ax, dy = r.y - ay, dz = r.z - az;
             const float da = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
             dx = r.x - bx; dy = r.y - by; dz = r.z - bz;
