@@ -954,6 +954,84 @@ import atexit  # noqa: E402
 atexit.register(_shutdown)
 
 
+class _QueryCombiner:
+    """Single-molecule queries with identical templates and thresholds, issued from several threads at once, merged
+    into batches.  No timer: the first call launches at once; calls arriving while it runs queue up, and when it is done
+    one of the waiting threads takes everything queued as ONE query_batch call and hands the others their hits."""
+
+    class _Request:
+        __slots__ = ("molecule", "event", "hits", "error", "promoted")
+
+        def __init__(self, molecule):
+            self.molecule, self.event = molecule, threading.Event()
+            self.hits, self.error, self.promoted = None, None, False
+
+    MAX_BATCH = 64
+
+    def __init__(self, templates):
+        self._templates = templates  # kept alive: the combiner is found by id(templates), which must not be reused
+        self._lock = threading.Lock()
+        self._queue: list = []
+        self._busy = False
+
+    def run(self, jess, molecule, thresholds, options):
+        req = self._Request(molecule)
+        with self._lock:
+            self._queue.append(req)
+            lead = not self._busy
+            if lead:
+                self._busy = True
+        if not lead:
+            req.event.wait()
+            lead = req.promoted  # the thread that just finished a batch handed the GPU to this one
+        while lead:
+            with self._lock:
+                batch, self._queue = self._queue[:self.MAX_BATCH], self._queue[self.MAX_BATCH:]
+            if batch:
+                try:
+                    per_molecule = jess.query_batch([r.molecule for r in batch], *thresholds, stream=_OWN_STREAM, **options)
+                    for r, hits in zip(batch, per_molecule):
+                        r.hits = hits
+                except BaseException as exc:  # every caller of the batch sees the failure
+                    for r in batch:
+                        r.error = exc
+                for r in batch:
+                    if r is not req:
+                        r.event.set()
+            with self._lock:
+                if req.hits is None and req.error is None:
+                    continue  # (own request not served yet: cannot happen with FIFO batches, kept for safety)
+                if self._queue:  # someone is waiting: it becomes the next leader, this thread returns
+                    nxt = self._queue[0]
+                    nxt.promoted = True
+                    nxt.event.set()
+                else:
+                    self._busy = False
+                lead = False
+        if req.error is not None:
+            raise req.error
+        return req.hits
+
+
+_combiners: "collections.OrderedDict[tuple, _QueryCombiner]" = collections.OrderedDict()
+_combiners_lock = threading.Lock()
+
+
+def _combiner(key, templates) -> _QueryCombiner:
+    with _combiners_lock:
+        c = _combiners.get(key)
+        if c is None:
+            c = _combiners[key] = _QueryCombiner(templates)
+            while len(_combiners) > 64:
+                old_key, old = next(iter(_combiners.items()))
+                if old._busy or old._queue:
+                    break
+                _combiners.pop(old_key)
+        else:
+            _combiners.move_to_end(key)
+        return c
+
+
 class Jess:
     query_batch_accepts_async = True  # Matcher pipelines batches through query_batch(_async=True)
 
@@ -1100,11 +1178,13 @@ class Jess:
     def query(self, molecule: Molecule, rmsd_threshold: float, distance_cutoff: float,
               max_dynamic_distance: float, *, max_candidates: Optional[int] = None, ignore_chain: bool = False,
               best_match: bool = False) -> Query:
-        # enzymm maps this call over molecules from a thread pool (jess_run.py:919-921, 977-981): every calling thread
-        # gets a stream of its own, so the small kernels of concurrent single-molecule queries overlap on the GPU
-        # instead of queueing on the null stream
-        hits = self.query_batch([molecule], rmsd_threshold, distance_cutoff, max_dynamic_distance,
-                                max_candidates=max_candidates, ignore_chain=ignore_chain, best_match=best_match,
-                                stream=_OWN_STREAM)
+        # enzymm maps this call over molecules from a thread pool (jess_run.py:919-921, 977-981).  Calls that arrive
+        # while another call with the same templates and thresholds is on the GPU are searched TOGETHER, as one batch, by
+        # whichever of the waiting threads goes next (_QueryCombiner): sixteen threads then cost a launch chain per
+        # sixteen molecules, not per molecule.  A lone call goes straight through (on the calling thread's own stream).
+        key = (id(self._templates), self._device, float(rmsd_threshold), float(distance_cutoff), float(max_dynamic_distance),
+               max_candidates, bool(ignore_chain), bool(best_match))
+        hits = _combiner(key, self._templates).run(self, molecule, (rmsd_threshold, distance_cutoff, max_dynamic_distance),
+                                  dict(max_candidates=max_candidates, ignore_chain=ignore_chain, best_match=best_match))
         return Query(self, molecule, rmsd_threshold, distance_cutoff, max_dynamic_distance, max_candidates,
-                     ignore_chain, best_match, hits[0])
+                     ignore_chain, best_match, hits)

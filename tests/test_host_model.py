@@ -552,3 +552,49 @@ def test_header_is_plain_c():
     out = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-fsyntax-only", "-x", "c", str(header)],
                          capture_output=True, text=True)
     assert out.returncode == 0 and "warning" not in out.stderr, out.stderr
+
+
+def test_concurrent_single_molecule_queries_are_merged():
+    """The reference maps Jess(templates).query(molecule) over molecules from a thread pool
+    (/root/reference/enzymm/jess_run.py:919-921, 977-981).  pyjess._QueryCombiner merges the calls that arrive while one
+    is running into batches; every caller gets its own molecule's hits, errors reach every caller of the failed batch,
+    and a lone call is a batch of one.  (Engine replaced by a recorder: no GPU here.)"""
+    import threading
+    import time
+    from multiprocessing.pool import ThreadPool
+
+    calls = []
+
+    class Recorder:
+        def query_batch(self, molecules, *thresholds, stream=None, **options):
+            calls.append(len(molecules))
+            time.sleep(0.02)  # the "GPU" is busy: other callers queue up meanwhile
+            if any(m == "bad" for m in molecules):
+                raise ValueError("bad molecule in the batch")
+            return [[("hit of", m)] for m in molecules]
+
+    comb = pyjess._QueryCombiner(templates=())
+    jess = Recorder()
+    with ThreadPool(8) as pool:
+        out = pool.map(lambda m: comb.run(jess, m, (2.0, 1.0, 1.0), {}), [f"m{i}" for i in range(40)])
+    assert out == [[("hit of", f"m{i}")] for i in range(40)]
+    assert sum(calls) == 40 and len(calls) < 40 and max(calls) > 1  # merged, nobody served twice or dropped
+    assert comb.run(jess, "alone", (2.0, 1.0, 1.0), {}) == [("hit of", "alone")] and calls[-1] == 1
+    assert not comb._busy and not comb._queue
+    # a failing batch: its callers see the error, later callers are unaffected
+    calls.clear()
+    results, errors = [], []
+
+    def one(m):
+        try:
+            results.append(comb.run(jess, m, (2.0, 1.0, 1.0), {}))
+        except ValueError as exc:
+            errors.append(str(exc))
+
+    threads = [threading.Thread(target=one, args=(m,)) for m in ["bad", "x", "y", "z"]]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert errors and len(errors) + len(results) == 4
+    assert comb.run(jess, "after", (2.0, 1.0, 1.0), {}) == [("hit of", "after")]
