@@ -175,10 +175,15 @@ def test_page_directory_overflow_takes_one_retry(monkeypatch):
     assert _same_as_oracle(got, r, lib) > 5
 
 
-def test_templates_of_one_atom_per_residue(amy):
+@pytest.mark.parametrize("target", ["1AMY", "complex"])
+def test_templates_of_one_atom_per_residue(amy, target):
     """Templates whose residues contribute a single atom each (k == number of residues; legal for Jess, absent from
     the shipped library): 1 to 5 atoms, every atom a "lead" for the search -- the level-3 look and the depth-first
-    search below the tables have nothing left to place for k <= 3."""
+    search below the tables have nothing left to place for k <= 3.  The one- and two-atom templates go through the
+    template-at-a-time launch; "complex" (25 k atoms) is searched with its records outside LDS, every launch mode in
+    its `global` variant."""
+    if target == "complex":
+        amy = synthetic.complex_structure(0, 6000).conserved(70)
     src = template.Template.load(TPL / "5_residues" / "results" / "csa3d_0285" /
                                  "csa3d_0285.cluster_1_1_1.1uh3_A396-A262-A356-A471-A472.template.pdb")
     atoms = list(src)
