@@ -1729,7 +1729,7 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
                         const double lim = kTableClassLimit[c];
                         const float d2 = c + 1 == kTableClasses ? 3.0e38f : (float)(lim * lim) * (1.0f + 4e-6f);
                         it = ids.emplace(std::make_tuple(a, b, c), (uint16_t)S->tables.size()).first;
-                        S->tables.push_back(TableDesc{a, b, d2});
+                        S->tables.push_back(TableDesc{a, b, d2, (uint16_t)S->tables.size(), (uint16_t)0xffffu});
                     }
                     return it->second;
                 };
@@ -1773,6 +1773,26 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
                     for (int c = 0; c < kTableClasses; ++c) std::fprintf(stderr, " %d", per_class[c]);
                     std::fprintf(stderr, "\n");
                 }
+                // groups of tables over the same two kind lists: the one with the largest limit leads, the others are
+                // derived from it (ids is ordered by (a, b, class): a group's members are consecutive, the leader last)
+                for (auto it = ids.begin(); it != ids.end();) {
+                    auto last = it;
+                    std::vector<uint16_t> members;
+                    for (; it != ids.end() && std::get<0>(it->first) == std::get<0>(last->first) &&
+                           std::get<1>(it->first) == std::get<1>(last->first); ++it)
+                        members.push_back(it->second);
+                    const uint16_t leader = members.back();
+                    uint16_t chain = 0xffffu;
+                    for (size_t m = 0; m + 1 < members.size(); ++m) {
+                        S->tables[members[m]].src = leader;
+                        S->tables[members[m]].next = chain;
+                        chain = members[m];
+                    }
+                    S->tables[leader].src = leader;
+                    S->tables[leader].next = chain;
+                }
+                if (std::getenv("ENZYMM_AMD_TAB_DERIVE") && std::atoi(std::getenv("ENZYMM_AMD_TAB_DERIVE")) == 0)  // experiments: every table swept
+                    for (size_t t = 0; t < S->tables.size(); ++t) { S->tables[t].src = (uint16_t)t; S->tables[t].next = 0xffffu; }
                 for (uint32_t i = 0; i < n_sel; ++i)
                     if (tt[i] == 0xffffu) S->small.push_back(i);
                 {

@@ -22,7 +22,13 @@ constexpr int kTripleQueue = 128;  // triple survivors waiting for their subtree
 struct TableDesc {
     uint16_t li_a, li_b;  // lead-kind indices
     float dmax2;          // squared distance limit (already holds the prefilter slack); +inf: every pair
+    // Tables of the same two kind lists differ in their distance limit only: the one with the largest limit (the group's
+    // LEADER, src == its own index) is built by testing the lists' cross product; the others hold a subset of its
+    // entries in the same order and are DERIVED from it by filtering (k_tab_build), which costs its entries, not the
+    // cross product.  next: the next table derived from the same leader (0xffff: none); a leader's next starts the chain.
+    uint16_t src, next;
 };
+static_assert(sizeof(TableDesc) == 12, "TableDesc layout");
 constexpr int kTableClasses = 5;
 constexpr double kTableClassLimit[kTableClasses] = {8.0, 12.0, 16.0, 24.0, 1e30};  // upper window edge (A) per class
 

@@ -426,6 +426,7 @@ __global__ __launch_bounds__(256) void k_tab_layout(uint32_t n_lead, BatchView B
 // a table with more than this many (position A, position B) pairs is built by all waves of its workgroup together
 // (k_tab_build's shared_limit; ENZYMM_AMD_TAB_SHARED overrides it -- tests send ordinary structures down that path)
 constexpr unsigned long long kTabShared = 256ull * 1024ull;
+constexpr unsigned long long kDeriveMin = 16384;  // cross product above which a group's smaller-limit tables are derived from its leader
 constexpr int kTabBlock = 1024;  // threads of a k_tab_build workgroup: 16 waves share one LDS copy of the lead records
 
 // One sweep over the tiles of one table.  A tile lays TI rows x TJ columns over the 64 lanes, row-major (TJ = the
@@ -508,6 +509,47 @@ __device__ __forceinline__ uint32_t tab_sweep(Lead lead, LeadB lead_b, uint32_t 
     return running - row_base;
 }
 
+// A table derived from its group's leader (same kind lists, smaller distance limit): the leader's entries that lie
+// within the limit, in the leader's order -- exactly what a sweep of the cross product with that limit writes.  One
+// streaming pass, lane = entry of the leader: survivors are compacted into ent_c (ballot + rank), and the first entry the
+// leader holds of a row fixes that row's offset (an entry carries its row: the low 16 bits of its first word).  Rows the
+// leader has no entry of take the offset of the next row that has one (a second, short pass over the rows, back to
+// front).  Returns the number of entries written.
+__device__ __forceinline__ uint32_t tab_derive(const uint32_t *rows_l, const uint2 *ent_l, uint32_t total_l, uint32_t n_a,
+                                               float dmax2, uint32_t *rows_c, uint2 *ent_c, uint32_t lane) {
+    uint32_t running = 0, prev_row = 0xffffffffu;
+    for (uint32_t e0 = 0; e0 < total_l; e0 += 64u) {
+        const uint32_t e = e0 + lane;
+        uint2 ent = make_uint2(0xffffffffu, 0x7f800000u);  // past the end: row 0xffff, distance +inf
+        if (e < total_l) ent = ent_l[e];
+        const bool ok = e < total_l && __uint_as_float(ent.y) <= dmax2;
+        const unsigned long long mask = ballot64(ok);
+        const uint32_t before = running + rank_in(mask);
+        const uint32_t row = ent.x & 0xffffu;
+        uint32_t left = lane_get(row, (lane + 63u) & 63u);  // the row of the entry before this one
+        if (lane == 0u) left = prev_row;
+        if (e < total_l && row != left) rows_c[row] = before;
+        if (ok) ent_c[before] = ent;
+        running += (uint32_t)__popcll(mask);
+        prev_row = (uint32_t)__builtin_amdgcn_readlane((int)row, 63);
+    }
+    // rows without an entry in the leader: the offset of the next row that has one (offsets never decrease with the row,
+    // so walking the rows back to front, "the nearest row with an entry behind me" is the smallest offset seen so far)
+    wave_sync();  // (the offsets written above are read by other lanes of this wave: its stores are done, none of those
+                  // lines was read before, so nothing stale sits in this CU's L1; a device-scope fence would write L2 back)
+    uint32_t carry = running;
+    for (uint32_t base = (n_a + 63u) & ~63u; base != 0u; base -= 64u) {
+        const uint32_t i = base - 1u - lane;  // lane 0 takes the last row of the chunk
+        uint32_t v = 0xffffffffu;
+        if (i < n_a && rows_l[i + 1u] != rows_l[i]) v = rows_c[i];
+        // running minimum over the lanes = bitwise complement of the running maximum of the complements
+        const uint32_t m = min(~wave_scan_max(~v), carry);
+        if (i < n_a && v == 0xffffffffu) rows_c[i] = m;
+        carry = (uint32_t)__builtin_amdgcn_readlane((int)m, 63);
+    }
+    return running;
+}
+
 // All tables of one work item (structure, part), one wave per table.  Entries are bump-allocated per WAVE in chunks of
 // tab_chunk() entries (one atomic per chunk; one per table would serialise a million atomics on one address): a table whose
 // cross product fits the rest of the wave's chunk is swept ONCE -- rows and entries written as they are found, the
@@ -568,6 +610,11 @@ __device__ __forceinline__ void tab_build_tables(const BatchView &B, const Table
         uint32_t *rows = tab_rows + B.tab_dir[(size_t)w.s * nt + t];
         const unsigned long long bound = (unsigned long long)n_a * n_b;
         if (bound > shared_limit) continue;  // a big table: all waves build it together, below
+        // Tables of one group (same two lists, different limits): when the cross product is large, only the leader is
+        // swept and the others are derived from its entries by the wave that builds it (below); a small cross product
+        // -- a few dozen tiles out of LDS -- is cheaper to sweep per table than to read a leader back from L2.
+        const bool derive = bound > kDeriveMin;
+        if (derive && T.src != t) continue;
         unsigned long long first = 0;
         uint32_t total = 0;
         if (dbg_mode == 2u) {
@@ -596,6 +643,37 @@ __device__ __forceinline__ void tab_build_tables(const BatchView &B, const Table
         if (lane == 0 && rows_ok) {
             tab_seg[(size_t)w.s * nt + t] = first == ~0ull ? make_uint2(0u, 0u) : make_uint2((uint32_t)first, (uint32_t)first + total);
             rows[n_a] = total;
+        }
+        // ---- the tables derived from this one (same lists, smaller limits): its entries within their limit
+        if (derive && T.next != 0xffffu && dbg_mode != 2u) {
+            const bool have = first != ~0ull && rows_ok && dbg_mode == 0u;
+            if (have) wave_sync();  // the leader's rows and entries are read back below (by this wave, which wrote them)
+            for (uint32_t d = T.next; d != 0xffffu;) {
+                const TableDesc Td = tables[d];
+                uint32_t *rows_d = tab_rows + B.tab_dir[(size_t)w.s * nt + d];
+                unsigned long long first_d = ~0ull;
+                uint32_t total_d = 0;
+                // room for as many entries as the leader has (an upper bound), from the wave's chunk like a small table;
+                // a build that only counts (no room, no row slots) moves the cursors exactly as one with room does
+                if (total <= kTabChunk) {
+                    if (used + total > kTabChunk) {
+                        chunk = allocate(kTabChunk);
+                        used = 0;
+                    }
+                    if (have && chunk != ~0ull) first_d = chunk + used;
+                } else {
+                    first_d = allocate(total);
+                    if (!have) first_d = ~0ull;
+                }
+                if (first_d != ~0ull) total_d = tab_derive(rows, tab_ent + first, total, n_a, Td.dmax2, rows_d, tab_ent + first_d, lane);
+                else total_d = tab_sweep<false>(lead, lead, a_lo, n_a, b_lo, n_b, Td.dmax2, nullptr, nullptr);
+                if (total <= kTabChunk) used += total_d;
+                if (lane == 0 && rows_ok) {
+                    tab_seg[(size_t)w.s * nt + d] = first_d == ~0ull ? make_uint2(0u, 0u) : make_uint2((uint32_t)first_d, (uint32_t)first_d + total_d);
+                    rows_d[n_a] = total_d;
+                }
+                d = Td.next;
+            }
         }
     }
     // ---- big tables of this part (kind lists of several hundred atoms: large complexes): the rows are cut into one
