@@ -1762,15 +1762,23 @@ __device__ __forceinline__ void block_look(Ctx &C, const SearchArgs &A, SlotRegs
         float2 wa, wb, wc;
         uint32_t lo, cnt;
     };
+    // (a v_readlane per wave-uniform value is what a triple costs here: the windows and the list belong to the template,
+    // which most consecutive triples share, so those eight values are fetched again only when the slot changes)
+    uint32_t seen_slot = 0xffffffffu;
+    Uniform tpl = {};
     auto uniform_of = [&](int q) {
-        Uniform u;
+        const uint32_t sl = RL(slot, q);
+        if (sl != seen_slot) {
+            tpl.wa = make_float2(RLf(H.w30.x, q), RLf(H.w30.y, q));
+            tpl.wb = make_float2(RLf(H.w31.x, q), RLf(H.w31.y, q));
+            tpl.wc = make_float2(RLf(H.w32.x, q), RLf(H.w32.y, q));
+            tpl.lo = RL(first, q); tpl.cnt = RL(n_c, q);
+            seen_slot = sl;
+        }
+        Uniform u = tpl;
         u.ax = RLf(q0.x, q); u.ay = RLf(q0.y, q); u.az = RLf(q0.z, q);
         u.bx = RLf(q1.x, q); u.by = RLf(q1.y, q); u.bz = RLf(q1.z, q);
         u.cx = RLf(q2.x, q); u.cy = RLf(q2.y, q); u.cz = RLf(q2.z, q);
-        u.wa = make_float2(RLf(H.w30.x, q), RLf(H.w30.y, q));
-        u.wb = make_float2(RLf(H.w31.x, q), RLf(H.w31.y, q));
-        u.wc = make_float2(RLf(H.w32.x, q), RLf(H.w32.y, q));
-        u.lo = RL(first, q); u.cnt = RL(n_c, q);
         return u;
     };
     auto fits = [&](const Uniform &u, const float4 &r, uint32_t idx) {
