@@ -901,7 +901,7 @@ def register_vocabulary(templates) -> None:
                 pass
 
 
-_jess_cache: "dict[tuple, tuple]" = {}  # (id(template list), device) -> (tuple of its templates, _PackedLibrary or None)
+_jess_cache: "dict[tuple, tuple]" = {}  # (id(template list), device) -> (tuple of its templates, _PackedLibrary or None, the list)
 _thread_streams = threading.local()
 _OWN_STREAM = -1  # query_batch(stream=...): "the calling thread's own stream" (resolved only when something is launched)
 
@@ -1048,9 +1048,11 @@ class Jess:
         # enzymm builds Jess(templates) anew for every (molecule, size) call with the SAME list object
         # (jess_run.py:800, templates_by_effective_size[size]): a list seen before, holding the same objects (tuple
         # comparison stops at identity, at C speed), needs neither the type checks nor a new device library
+        # (the entry keeps the list object itself: while it is cached no other list can take its id, and `is` says it is
+        # that very list; the tuple comparison then only has to notice a list that was changed in place)
         self._cache_key = (id(templates), self._device) if isinstance(templates, (list, tuple)) else None
         known = _jess_cache.get(self._cache_key) if self._cache_key is not None else None
-        if known is not None and known[0] == self._templates:
+        if known is not None and known[2] is templates and known[0] == self._templates:
             self._templates = known[0]
             if known[1] is not None and known[1].vocab_version == VOCAB.version:
                 self._packed_ref = known[1]
@@ -1060,7 +1062,7 @@ class Jess:
                 raise TypeError(f"expected Template, found {type(t).__name__}")
         register_vocabulary(self._templates)
         if self._cache_key is not None and self._templates:
-            _jess_cache[self._cache_key] = (self._templates, None)
+            _jess_cache[self._cache_key] = (self._templates, None, templates)
             while len(_jess_cache) > _PACK_CACHE_SIZE:
                 _jess_cache.pop(next(iter(_jess_cache)))
 
@@ -1102,7 +1104,7 @@ class Jess:
             packed = self._packed_ref = _packed(self._templates, self._device)
             key = getattr(self, "_cache_key", None)
             if key is not None and key in _jess_cache and _jess_cache[key][0] is self._templates:
-                _jess_cache[key] = (self._templates, packed)
+                _jess_cache[key] = (self._templates, packed, _jess_cache[key][2])
         own_batch = batch is None
         release = None
         if own_batch and len(molecules) == 1:

@@ -598,3 +598,23 @@ def test_concurrent_single_molecule_queries_are_merged():
         t.join()
     assert errors and len(errors) + len(results) == 4
     assert comb.run(jess, "after", (2.0, 1.0, 1.0), {}) == [("hit of", "after")]
+
+
+def test_jess_construction_cache_is_by_identity():
+    """Jess(templates) of a list seen before reuses what it built for THAT list.  Two lists of equal-content but
+    distinct Template objects must never share an entry -- Hit.template would be an object the caller does not hold
+    (Matcher looks templates up by identity); regression for a recycled id(list) meeting Template.__eq__."""
+    text = (helpers.GOLDEN / "templates" / "3_residues" / "results" / "csa3d_0415" /
+            "csa3d_0415.cluster_1_1_2.1be0_A125-A175-A289.template.pdb")
+    if not text.exists():  # the exact file name is not what matters here
+        text = next((helpers.GOLDEN / "templates").rglob("*.template.pdb"))
+    src = text.read_text()
+    for _ in range(200):  # many short-lived lists: their ids get recycled
+        lst = [pyjess.Template.loads(src, id="x")]
+        j = pyjess.Jess(lst)
+        assert j[0] is lst[0]
+    keep = [pyjess.Template.loads(src, id="x")]
+    a, b = pyjess.Jess(keep), pyjess.Jess(keep)
+    assert a[0] is keep[0] and b[0] is keep[0] and a._templates is b._templates  # the same list: one entry, reused
+    keep[0] = pyjess.Template.loads(src, id="x")  # changed in place (equal content, another object)
+    assert keep[0] == a[0] and keep[0] is not a[0]
