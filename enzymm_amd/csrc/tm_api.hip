@@ -2045,7 +2045,7 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
             const size_t scratch = search_scratch_bytes(mode);
             const size_t base = scratch + (size_t)b->max_atoms * sizeof(float4) + search_res_bytes(b->max_res) +
                                 search_kl_words(lib->view().n_lead) * sizeof(uint32_t);
-            const size_t lds_limit = 160 * 1024 - 64;
+            const size_t lds_limit = 160 * 1024 - 64 - search_static_bytes(mode);
             const bool lds_path = base <= lds_limit;
             args.pool_cap = lds_path ? (uint32_t)((lds_limit - base) / sizeof(uint16_t)) : 0u;
             const size_t lds_bytes = lds_path ? lds_limit : scratch + (mode == kModeDeep ? search_cache_bytes() : 0);

@@ -156,9 +156,12 @@ struct DeepEntry {
 };
 constexpr uint32_t kPageTriples = 64;
 #ifndef TM_DEEP_RUN
-#define TM_DEEP_RUN 4
+#define TM_DEEP_RUN 2
 #endif
-constexpr uint32_t kDeepRun = TM_DEEP_RUN;  // triples a wave of k_deep claims at a time
+// triples a wave of k_deep claims at a time (a power of two).  Measured with the run list and two claims in flight: 2 beats
+// 4 (bench batch 2.36-2.39 vs 2.42 ms, ten 25 k-atom complexes at loose cutoffs 28.5 vs 33 ms of k_deep: the last runs of a
+// structure are what its workgroups wait for) and 8 loses 10 %.
+constexpr uint32_t kDeepRun = TM_DEEP_RUN;
 
 struct QueryView {
     uint32_t n_sel;

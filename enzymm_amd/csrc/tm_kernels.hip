@@ -890,6 +890,15 @@ __device__ __forceinline__ void WLf(float &v, int lane, float x) { v = lane_id()
 // keeps those residues in LDS (per wave: one slot per template residue, filled when a non-lead level of that residue
 // is first prepared and valid for as long as the residue's lead stays the same atom).
 constexpr uint32_t kResCacheAtoms = 32;
+#ifndef TM_RUN_LDS
+#define TM_RUN_LDS 4096
+#endif
+#ifndef TM_DEEP_SHARE
+#define TM_DEEP_SHARE 8
+#endif
+constexpr uint32_t kDeepShare = TM_DEEP_SHARE;  // k_deep: triples per wave a structure must have for one more of its workgroups to take part
+constexpr uint32_t kRunLds = TM_RUN_LDS;  // k_deep: runs of triples a workgroup's run list holds (a structure with more is claimed by page position)
+static_assert((kDeepRun & (kDeepRun - 1u)) == 0u && kPageTriples % kDeepRun == 0u, "a run-list entry keeps its triple count in the low bits of an entry position");
 struct __align__(16) ResCache {
     float4 rec[kMaxG][kResCacheAtoms];
     uint32_t tag[kMaxG];    // lead atom whose residue sits in the slot (0xffffffff: none)
@@ -2152,7 +2161,7 @@ template <bool kLds, bool kIgnoreChain, bool kPoolLds>
 __device__ __forceinline__ void deep_templates(const SearchArgs &A, WaveScratchT<kModeDeep> *scratch, const float4 *s_rec,
                                                const uint16_t *s_res, const uint32_t *s_kl, const uint16_t *s_pool,
                                                const uint32_t *kl_off, uint32_t s, uint32_t a0, uint32_t r0, uint32_t n_listed,
-                                               ResCache *cache) {
+                                               ResCache *cache, const uint32_t *s_run, uint32_t n_compact) {
     const BatchView &B = A.B;
     const QueryView &Q = A.Q;
     SearchCtx<kIgnoreChain, kPoolLds, kModeDeep, !kLds> C;
@@ -2175,28 +2184,53 @@ __device__ __forceinline__ void deep_templates(const SearchArgs &A, WaveScratchT
     const uint32_t *kl = kLds ? s_kl : kl_off;
     const uint2 *dir = A.O.dir + A.O.dir_off[s];
     // Triples are claimed kDeepRun at a time: fewer claims on the structure's one counter, and the next template's
-    // constants load under the current triple's search.  (One at a time is slower even for a lone structure: the claims
-    // of a thousand waves on one address are what that case waits for.)
+    // constants load under the current triple's search.
+    // What a claim number means: with the workgroup's run list (k_search<..., kModeDeep> builds it in LDS when the
+    // structure's pages are few) the n-th run that HAS triples -- most pages are the partly filled last pages of the
+    // block search's waves, and a claim that lands on the empty part of one costs the round trips of a claim and gets
+    // no work behind which to hide the next --; without it run n of the listed pages, kRunsPerPage to a page.
     constexpr uint32_t run_len = kDeepRun;
     constexpr uint32_t kRunsPerPage = kPageTriples / run_len;
-    const uint32_t n_runs = n_listed * kRunsPerPage;
+    const bool compact = n_compact != 0xffffffffu;
+    const uint32_t n_runs = compact ? n_compact : n_listed * kRunsPerPage;
+    const DeepEntry *pages = A.O.pages;
+    // the entries of run r (lane q < nt holds triple q) -- a load that is left in flight: callers use it a run later
+    auto fetch = [&](uint32_t r, DeepEntry &t) -> uint32_t {
+        t.a01 = 0u; t.c = 0u; t.ti = 0xffffffffu;
+        if (r >= n_runs) return 0u;
+        size_t first;
+        uint32_t nt;
+        if (compact) {
+            const uint32_t e = uni(s_run[r]);
+            first = (size_t)(e & ~(run_len - 1u));
+            nt = (e & (run_len - 1u)) + 1u;
+        } else {
+            const uint2 pg = dir[r / kRunsPerPage];  // {page, triples in it}
+            const uint32_t e0 = (r % kRunsPerPage) * run_len;
+            nt = uni(pg.y) > e0 ? min(run_len, uni(pg.y) - e0) : 0u;
+            first = (size_t)uni(pg.x) * kPageTriples + e0;
+        }
+        if (lane < nt) t = pages[first + lane];
+        return nt;
+    };
     WaveRegs W = {};
     DeepState D;
     D.ti = 0xffffffffu; D.next_ti = 0xffffffffu; D.feasible = false; D.since = 0ull;
     D.P.s = s; D.P.ti = 0; D.P.truncated = false;
     slab_init(C);
+    // two runs are claimed ahead: while run n is searched, the entries of run n + 1 are on their way (and, towards the
+    // end of run n, the constants of its first template), and the claim of run n + 2 is
     uint32_t run = 0;
-    if (lane == 0) run = atomicAdd(&A.O.dir_head[s], 1u);
+    if (lane == 0) run = atomicAdd(&A.O.dir_head[s], 2u);
     run = uni(run);
+    uint32_t run1 = run + 1u;
+    DeepEntry t;
+    uint32_t nt = fetch(run, t);
     while (run < n_runs) {
-        uint32_t claimed = 0;  // the next run is claimed now: the atomic's round trip runs under this run's searches
+        uint32_t claimed = 0;
         if (lane == 0) claimed = atomicAdd(&A.O.dir_head[s], 1u);
-        const uint2 pg = dir[run / kRunsPerPage];  // {page, triples in it}
-        const uint32_t e0 = (run % kRunsPerPage) * run_len;
-        const uint32_t nt = uni(pg.y) > e0 ? min(run_len, uni(pg.y) - e0) : 0u;
-        DeepEntry t;
-        t.a01 = 0u; t.c = 0u; t.ti = 0xffffffffu;
-        if (lane < nt) t = A.O.pages[(size_t)uni(pg.x) * kPageTriples + e0 + lane];
+        DeepEntry tn;
+        const uint32_t nn = fetch(run1, tn);
         for (uint32_t q = 0; q < nt; ++q) {
             const uint32_t a01 = RL(t.a01, (int)q), c = RL(t.c, (int)q), ti = RL(t.ti, (int)q);
             const uint32_t x0 = a01 & 0xffffu, x1 = a01 >> 16;
@@ -2215,12 +2249,18 @@ __device__ __forceinline__ void deep_templates(const SearchArgs &A, WaveScratchT
                 // loads from HBM per triple; a wave learns it with its own first completion, on_complete)
                 D.P.truncated = false;
                 D.since = Q.cost ? __builtin_amdgcn_s_memtime() : 0ull;
-                // the next template of the run starts loading now
+                // the next template starts loading now: the one of a later triple of this run, or else of the next run
                 const unsigned long long later = ballot64(lane > q && lane < nt && t.ti != ti);
                 D.next_ti = 0xffffffffu;
                 if (later) {
                     D.next_ti = RL(t.ti, __ffsll((long long)later) - 1);
                     load_template(Q, D.next_ti, (int)lane, D.next);
+                } else {
+                    const unsigned long long beyond = ballot64(lane < nn && tn.ti != ti);
+                    if (beyond) {
+                        D.next_ti = RL(tn.ti, __ffsll((long long)beyond) - 1);
+                        load_template(Q, D.next_ti, (int)lane, D.next);
+                    }
                 }
             }
             if (D.P.truncated || !D.feasible) continue;
@@ -2239,7 +2279,10 @@ __device__ __forceinline__ void deep_templates(const SearchArgs &A, WaveScratchT
             }
             dfs(C, W, D.P, 3);  // false: cut short by max_candidates (D.P.truncated is set)
         }
-        run = uni(claimed);
+        run = run1;
+        run1 = uni(claimed);
+        t = tn;
+        nt = nn;
     }
     if (D.ti != 0xffffffffu && Q.cost && lane == 0) atomicAdd(&Q.cost[D.ti], __builtin_amdgcn_s_memtime() - D.since);
     slab_release(C);
@@ -2296,7 +2339,7 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
         if (n_listed == 0u) return;
         // a structure with few triples is not worth all its workgroups (each stages the structure in LDS and queues at the
         // structure's counter): as many take part as there are 8 triples per wave for
-        if ((unsigned long long)chunk * (8u * kSearchWaves) >= A.O.dir_triples[s]) return;
+        if ((unsigned long long)chunk * (kDeepShare * kSearchWaves) >= A.O.dir_triples[s]) return;
     }
     const uint32_t a0 = B.s_off[s], n = B.s_off[s + 1] - a0;
     const uint32_t r0 = B.s_roff[s], nres1 = B.s_roff[s + 1] - r0;  // n_res + 1 entries
@@ -2329,8 +2372,39 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
     __syncthreads();
 #endif
     if constexpr (kMode == kModeDeep) {
-        if (pool_in_lds) deep_templates<kLds, kIgnoreChain, true>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, s, a0, r0, n_listed, cache);
-        else deep_templates<kLds, kIgnoreChain, false>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, s, a0, r0, n_listed, cache);
+        // The workgroup's run list: entry n = where the n-th run of triples of this structure sits (first entry among all
+        // pages | triples in it - 1), over the runs that have triples.  Built when the structure lists at most one page
+        // per thread and kRunLds runs; a structure beyond that (a large complex: its pages are full) is claimed by
+        // page position (deep_templates).
+        __shared__ uint32_t s_run[kRunLds];
+        __shared__ uint32_t s_wtot[kSearchWaves], s_wide[kSearchWaves];
+        uint32_t n_compact = 0xffffffffu;
+        if (n_listed <= kSearchBlock) {
+            uint2 d = make_uint2(0u, 0u);
+            if (threadIdx.x < n_listed) d = A.O.dir[A.O.dir_off[s] + threadIdx.x];
+            const uint32_t mine = (d.y + kDeepRun - 1u) / kDeepRun;
+            const uint32_t incl = wave_scan_add(mine);
+            const uint32_t wave = threadIdx.x >> 6;
+            const bool wave_wide = ballot64(d.x >= (1u << 26)) != 0ull;  // (an entry position must fit 32 bits)
+            if ((threadIdx.x & 63u) == 63u) { s_wtot[wave] = incl; s_wide[wave] = wave_wide ? 1u : 0u; }
+            __syncthreads();
+            uint32_t before = 0, total = 0, wide = 0;
+            for (uint32_t w = 0; w < kSearchWaves; ++w) {
+                const uint32_t v = s_wtot[w];
+                total += v;
+                before += w < wave ? v : 0u;
+                wide |= s_wide[w];
+            }
+            if (total <= kRunLds && !wide) {
+                const uint32_t at = before + incl - mine;
+                for (uint32_t j = 0; j < mine; ++j)
+                    s_run[at + j] = (d.x * kPageTriples + j * kDeepRun) | (min(kDeepRun, d.y - j * kDeepRun) - 1u);
+                n_compact = total;
+            }
+            __syncthreads();
+        }
+        if (pool_in_lds) deep_templates<kLds, kIgnoreChain, true>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, s, a0, r0, n_listed, cache, s_run, n_compact);
+        else deep_templates<kLds, kIgnoreChain, false>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, s, a0, r0, n_listed, cache, s_run, n_compact);
     } else {
         if (pool_in_lds)
             search_templates<kLds, kIgnoreChain, true, kSingly>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, &s_next, s, a0, r0, chunk, n_chunks);
@@ -2362,6 +2436,8 @@ TM_INSTANTIATE(kModeDeep)
 #undef TM_INSTANTIATE
 
 size_t search_cache_bytes() { return sizeof(ResCache) * kSearchWaves; }
+// LDS a launch mode declares statically, beyond the few words every mode has (k_deep's run list)
+size_t search_static_bytes(int mode) { return mode == kModeDeep ? (kRunLds + 2 * kSearchWaves) * sizeof(uint32_t) : 0; }
 size_t search_scratch_bytes(int mode) {
     return (mode == kModeBlocks ? sizeof(WaveScratchT<kModeBlocks>) : mode == kModeSingly ? sizeof(WaveScratchT<kModeSingly>)
                                                                                          : sizeof(WaveScratchT<kModeDeep>)) * kSearchWaves;
