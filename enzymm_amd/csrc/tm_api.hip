@@ -1466,9 +1466,9 @@ static int build_index(const tm_library *lib, tm_batch *b, tm_result *r, hipStre
     if (wanted > cap) cap = wanted + wanted / 8 + 1024;
     if (cap > 0xffffffffull)
         return fail(TM_E_UNSUPPORTED, "candidate index needs more than 2^32 entries: split the batch");
-    if (b->d_kl_pool.n != cap) {
+    if (b->d_kl_pool.n != cap + 8) {  // (+8: k_search copies a structure's lists in 16-byte words, the last one in full)
         if (b->queried) HIP_TRY(hipStreamSynchronize(b->last_stream));  // an earlier query may still read the old pool
-        HIP_TRY(b->d_kl_pool.alloc(cap));
+        HIP_TRY(b->d_kl_pool.alloc(cap + 8));
     }
     b->pool_capacity = cap;
     {
@@ -2047,7 +2047,7 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
                                 search_kl_words(lib->view().n_lead) * sizeof(uint32_t);
             const size_t lds_limit = 160 * 1024 - 64 - search_static_bytes(mode);
             const bool lds_path = base <= lds_limit;
-            args.pool_cap = lds_path ? (uint32_t)((lds_limit - base) / sizeof(uint16_t)) : 0u;
+            args.pool_cap = lds_path ? (uint32_t)((lds_limit - base) / sizeof(uint16_t)) & ~7u : 0u;  // (copied in 16-byte words)
             const size_t lds_bytes = lds_path ? lds_limit : scratch + (mode == kModeDeep ? search_cache_bytes() : 0);
             void (*kernel)(SearchArgs) = nullptr;
 #define TM_PICK(m) (lds_path ? (ic ? k_search<true, true, m> : k_search<true, false, m>) : (ic ? k_search<false, true, m> : k_search<false, false, m>))

@@ -769,10 +769,30 @@ __global__ __launch_bounds__(kTabBlock) void k_tab_build(uint32_t n_lead, BatchV
         float4 *s_atoms = reinterpret_cast<float4 *>(tab_smem);
         uint16_t *s_pool = reinterpret_cast<uint16_t *>(s_atoms + atom_cap);
         uint32_t *s_kl2 = reinterpret_cast<uint32_t *>(s_pool + ((lr_cap + 7u) & ~7u));
-        if (plen <= lr_cap && n <= atom_cap) {
-            for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) s_atoms[i] = rec[i];
-            for (uint32_t i = threadIdx.x; i < plen; i += blockDim.x) s_pool[i] = B.kl_pool[p0 + i];
-            for (uint32_t i = threadIdx.x; i <= n_lead; i += blockDim.x) s_kl2[i] = kl[i] - p0;
+        if (plen + 7u <= lr_cap && n <= atom_cap) {
+            // all loads of the first pass before the first LDS store (one trip to L2, not one per array and iteration); the
+            // kind lists in 16-byte words from the 16-byte boundary below their first entry, the offsets rebased to that
+            const uint32_t rebase = p0 & ~7u, n_pool = (p0 - rebase + plen + 7u) / 8u;
+            const uint32_t tid = threadIdx.x, step = blockDim.x;
+            const uint4 *g_rec = reinterpret_cast<const uint4 *>(rec);
+            const uint4 *g_pool = reinterpret_cast<const uint4 *>(B.kl_pool + rebase);
+            uint4 *l_rec = reinterpret_cast<uint4 *>(s_atoms), *l_pool = reinterpret_cast<uint4 *>(s_pool);
+            constexpr int kRecPer = 3;
+            uint4 v_rec[kRecPer], v_pool;
+            uint32_t v_kl = 0;
+#pragma unroll
+            for (int k = 0; k < kRecPer; ++k)
+                if (tid + k * step < n) v_rec[k] = g_rec[tid + k * step];
+            if (tid < n_pool) v_pool = g_pool[tid];
+            if (tid <= n_lead) v_kl = kl[tid];
+#pragma unroll
+            for (int k = 0; k < kRecPer; ++k)
+                if (tid + k * step < n) l_rec[tid + k * step] = v_rec[k];
+            if (tid < n_pool) l_pool[tid] = v_pool;
+            if (tid <= n_lead) s_kl2[tid] = v_kl - rebase;
+            for (uint32_t i = tid + kRecPer * step; i < n; i += step) l_rec[i] = g_rec[i];
+            for (uint32_t i = tid + step; i < n_pool; i += step) l_pool[i] = g_pool[i];
+            for (uint32_t i = tid + step; i <= n_lead; i += step) s_kl2[i] = kl[i] - rebase;
             __syncthreads();
             tab_build_tables<2>(B, tables, w, s_atoms, s_pool, nullptr, s_kl2, tab_rows, tab_ent, tab_seg, cursors,
                                 ent_capacity, overflow, tab_ok, dbg_mode, s_count, &s_first, n_lead, nullptr, 0u, shared_limit, rows_ok);
@@ -974,6 +994,7 @@ __device__ __forceinline__ unsigned long long eval_chunk(const Ctx &C, WaveRegs 
         mychain = lvl_tchain(RL(W.pk, level));
     }
     TM_STAT(level, 1);
+    TM_STAT(lead ? 82 : 83, 1);
     unsigned long long alive;
     if (lead) {
         const uint32_t cres = meta_res(m);
@@ -2277,6 +2298,7 @@ __device__ __forceinline__ void deep_templates(const SearchArgs &A, WaveScratchT
                     if (!C.ignore_chain) W.achain = (uint32_t)C.qchain[mine];
                 }
             }
+            TM_STAT(84 + min(C.n_groups, 8), 1);  // [87..92]: paged triples by residue count of their template
             dfs(C, W, D.P, 3);  // false: cut short by max_candidates (D.P.truncated is set)
         }
         run = run1;
@@ -2348,14 +2370,42 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
     if (kLds) {
         // the structure's atom records, residue starts, kind-list offsets and (when it fits) the
         // kind lists themselves: after this the search reads global memory only for template data
+        // Every load of the first pass is issued before the first LDS store -- one trip to L2 for the four arrays together,
+        // where a loop per array waits once per iteration (the kind lists, 2 bytes per lane, took seven) --; the kind
+        // lists travel 16 bytes per lane: from the 16-byte boundary below their first entry, the offsets rebased to that.
         const uint32_t p0 = kl_off[0], plen = kl_off[L.n_lead] - p0;
-        pool_in_lds = plen <= pool_cap;
-        const uint32_t rebase = pool_in_lds ? p0 : 0u;
-        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) s_rec[i] = B.q_rec[a0 + i];
-        for (uint32_t i = threadIdx.x; i < nres1; i += blockDim.x) s_res[i] = B.res_start[r0 + i];
-        for (uint32_t i = threadIdx.x; i <= L.n_lead; i += blockDim.x) s_kl[i] = kl_off[i] - rebase;
-        if (pool_in_lds)
-            for (uint32_t i = threadIdx.x; i < plen; i += blockDim.x) s_pool[i] = B.kl_pool[p0 + i];
+        pool_in_lds = plen + 7u <= pool_cap;
+        const uint32_t rebase = pool_in_lds ? p0 & ~7u : 0u;
+        const uint32_t tid = threadIdx.x, step = blockDim.x;
+        const uint4 *g_rec = reinterpret_cast<const uint4 *>(B.q_rec + a0);
+        const uint4 *g_pool = reinterpret_cast<const uint4 *>(B.kl_pool + rebase);
+        uint4 *l_rec = reinterpret_cast<uint4 *>(s_rec), *l_pool = reinterpret_cast<uint4 *>(s_pool);
+        const uint32_t n_pool = pool_in_lds ? (p0 - rebase + plen + 7u) / 8u : 0u;  // 16-byte words of kind lists
+        constexpr int kRecPer = 3, kPoolPer = 1;
+        uint4 v_rec[kRecPer], v_pool[kPoolPer];
+        uint16_t v_res = 0;
+        uint32_t v_kl = 0;
+#pragma unroll
+        for (int k = 0; k < kRecPer; ++k)
+            if (tid + k * step < n) v_rec[k] = g_rec[tid + k * step];
+#pragma unroll
+        for (int k = 0; k < kPoolPer; ++k)
+            if (tid + k * step < n_pool) v_pool[k] = g_pool[tid + k * step];
+        if (tid < nres1) v_res = B.res_start[r0 + tid];
+        if (tid <= L.n_lead) v_kl = kl_off[tid];
+#pragma unroll
+        for (int k = 0; k < kRecPer; ++k)
+            if (tid + k * step < n) l_rec[tid + k * step] = v_rec[k];
+#pragma unroll
+        for (int k = 0; k < kPoolPer; ++k)
+            if (tid + k * step < n_pool) l_pool[tid + k * step] = v_pool[k];
+        if (tid < nres1) s_res[tid] = v_res;
+        if (tid <= L.n_lead) s_kl[tid] = v_kl - rebase;
+        // what a structure has beyond the first pass
+        for (uint32_t i = tid + kRecPer * step; i < n; i += step) l_rec[i] = g_rec[i];
+        for (uint32_t i = tid + kPoolPer * step; i < n_pool; i += step) l_pool[i] = g_pool[i];
+        for (uint32_t i = tid + step; i < nres1; i += step) s_res[i] = B.res_start[r0 + i];
+        for (uint32_t i = tid + step; i <= L.n_lead; i += step) s_kl[i] = kl_off[i] - rebase;
     }
     if (threadIdx.x == 0) s_next = 0u;
     TM_STAT(55, threadIdx.x == 0 ? 1 : 0);

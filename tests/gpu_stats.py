@@ -41,6 +41,8 @@ paged = max(s[65], 1)
 print("k_deep chunk evaluations per level (per paged triple)", np.round(s[3:24] / paged, 2))
 print("k_deep survivors per level (per paged triple)        ", np.round(s[27:48] / paged, 2))
 print("pair tests (j-loop trips) per paged triple", s[50] / paged)
+print("chunk evaluations per paged triple: lead levels %.2f, other levels %.2f" % (s[82] / paged, s[83] / paged))
+print("paged triples by residue count of their template (3..8):", np.round(s[87:93] / paged, 3))
 for mode, name in ((0, "k_search blocks"), (2, "k_deep")):
     busy, held, staging = s[70 + 4 * mode], s[71 + 4 * mode], s[72 + 4 * mode]
     print("%s: waves working %.1f %% of the time their workgroup holds its CU after staging; staging %.1f %% of that time" %
