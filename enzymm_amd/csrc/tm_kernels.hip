@@ -2429,7 +2429,7 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
         __shared__ uint32_t s_run[kRunLds];
         __shared__ uint32_t s_wtot[kSearchWaves], s_wide[kSearchWaves];
         uint32_t n_compact = 0xffffffffu;
-        if (n_listed <= kSearchBlock) {
+        if (n_listed <= kSearchBlock && !(Q.flags & 0x4000u)) {  // (flag: test hook ENZYMM_AMD_RUN_LIST=0)
             uint2 d = make_uint2(0u, 0u);
             if (threadIdx.x < n_listed) d = A.O.dir[A.O.dir_off[s] + threadIdx.x];
             const uint32_t mine = (d.y + kDeepRun - 1u) / kDeepRun;

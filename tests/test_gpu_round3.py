@@ -175,6 +175,27 @@ def test_page_directory_overflow_takes_one_retry(monkeypatch):
     assert _same_as_oracle(got, r, lib) > 5
 
 
+def test_deep_claims_with_and_without_the_run_list(monkeypatch):
+    """k_deep hands out a structure's triples through the workgroup's run list (LDS) when its pages are few, and by page
+    position otherwise (large complexes).  ENZYMM_AMD_RUN_LIST=0 sends ordinary structures down the second path: the hit
+    table must not change, and is the oracle's."""
+    idx, cut = helpers.default_selection()
+    mols = [pyjess.Molecule.load(helpers.GOLDEN / "1AMY.pdb")] + synthetic.structures(30, start=900)
+    jess = pyjess.Jess(helpers.product_library_templates())
+    tables = []
+    for hook in (None, "0"):
+        if hook is not None:
+            monkeypatch.setenv("ENZYMM_AMD_RUN_LIST", hook)
+        tables.append(distributed.sort_rows(jess.query_batch(mols, 2.0, cut, cut, max_candidates=10000, ignore_chain=True,
+                                                             template_index=idx, return_raw=True)))
+    monkeypatch.delenv("ENZYMM_AMD_RUN_LIST")
+    assert len(tables[0]) > 30 and tables[0].tobytes() == tables[1].tobytes()
+    otpl = helpers.oracle_library_templates()
+    lib = oracle.OracleLibrary([otpl[i] for i in idx])
+    r = oracle.query_library(helpers.to_oracle_molecule(mols[0]), lib, 2.0, cut, cut, max_candidates=10000, ignore_chain=True)
+    assert _same_as_oracle(tables[1], r, lib) > 5
+
+
 @pytest.mark.parametrize("target", ["1AMY", "complex"])
 def test_templates_of_one_atom_per_residue(amy, target):
     """Templates whose residues contribute a single atom each (k == number of residues; legal for Jess, absent from
