@@ -1481,8 +1481,9 @@ static int build_index(const tm_library *lib, tm_batch *b, tm_result *r, hipStre
     if (b->n_structs && lib->n_lead) {
         // LDS for the per-name atom buckets (4 B per atom of the largest structure): structures above the cap scan all
         // their atoms for every lead kind -- 3.5 ms per batch of 25 k-atom complexes when the cap was 12 288 atoms
-        const uint32_t bucket_cap = 38912;  // 152 KB
-        const size_t lds = ((size_t)lib->n_lead + 1 + std::min<uint32_t>(b->max_atoms, bucket_cap)) * sizeof(uint32_t);
+        const uint32_t bucket_cap = 38912;  // 152 KB at 4 bytes per atom
+        const size_t lds = ((size_t)lib->n_lead + 1) * sizeof(uint32_t) +
+                           (size_t)std::min<uint32_t>(b->max_atoms, bucket_cap) * 2 * sizeof(uint16_t) + 16;
         HIP_TRY(allow_dynamic_lds(reinterpret_cast<const void *>(k_kind_lists), lds));
         hipLaunchKernelGGL(k_kind_lists, dim3(b->n_structs), dim3(512), lds, stream,
                            lib->view(), b->view(), b->d_kl_off.p, b->d_kl_pool.p, b->d_cursor.p, cap,

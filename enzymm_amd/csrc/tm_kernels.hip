@@ -208,9 +208,13 @@ __global__ __launch_bounds__(64) void k_stage_templates(LibView L, uint32_t n_se
 // that bucket for its residue types instead of the whole structure.  Pass A counts the admissible
 // atoms of every lead kind, a bump allocation reserves the structure's slice of the pool, pass B
 // writes the lists (ascending atom index).
+// The thousand workgroups of a batch are resident together, so the launch takes as long as one workgroup does: nothing
+// in it waits on global memory inside a loop -- the atoms' name and residue-type ids are read once (into LDS, 2 bytes
+// per atom), a wave holds the constants of the lead kinds it handles in its lanes (kind j of the wave in lane j), and
+// the two prefix sums (name buckets, list offsets) are wave scans, not one thread's loop.
 //
-// Dynamic LDS: [n_lead + 1] counts/offsets, then (when n <= bucket_cap) one u32 per atom:
-// atom index | residue-type id << 16, grouped by name id.
+// Dynamic LDS: [n_lead + 1] counts/offsets, then (when n <= bucket_cap) one u16 per atom: name id | residue-type id << 8,
+// then one u16 per atom: the atom indices grouped by name id.
 __global__ __launch_bounds__(512) void k_kind_lists(LibView L, BatchView B, uint32_t *__restrict__ kl_off,
                                                      uint16_t *__restrict__ kl_pool,
                                                      unsigned long long *__restrict__ cursor,
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(512) void k_kind_lists(LibView L, BatchView B, uint
                                                      uint32_t bucket_cap) {
     extern __shared__ uint32_t s_dyn[];
     uint32_t *s_cnt = s_dyn;                      // [n_lead + 1]
-    uint32_t *s_bucket = s_dyn + L.n_lead + 1;    // [n] when bucketed
+    uint16_t *s_meta = reinterpret_cast<uint16_t *>(s_dyn + L.n_lead + 1);  // [n] when bucketed
     __shared__ unsigned long long s_base;
     __shared__ uint32_t s_noff[65];               // bucket of name id i: [s_noff[i], s_noff[i + 1])
     const uint32_t s = blockIdx.x;
@@ -226,17 +230,31 @@ __global__ __launch_bounds__(512) void k_kind_lists(LibView L, BatchView B, uint
     const int lane = lane_id(), wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const float4 *rec = B.q_rec + a0;
     const bool bucketed = n <= bucket_cap;
+    uint16_t *s_bucket = s_meta + (bucketed ? n : 0u);                         // [n] when bucketed
+
+    // the lead kinds this wave handles: kind number j of the wave (li = wave + nwaves j) sits in lane j
+    uint32_t my_rm = 0, my_nm_lo = 0, my_nm_hi = 0, my_any = 0;
+    {
+        const uint32_t li = (uint32_t)wave + (uint32_t)nwaves * (uint32_t)lane;
+        if (li < L.n_lead) {
+            const uint32_t kind = L.lead_kind[li];
+            const uint64_t nm = L.k_namemask[kind];
+            my_rm = L.k_resmask[kind];
+            my_nm_lo = (uint32_t)nm; my_nm_hi = (uint32_t)(nm >> 32);
+            my_any = L.k_any[kind] != 0 ? 1u : 0u;
+        }
+    }
 
     if (bucketed) {
         if (threadIdx.x < 65) s_noff[threadIdx.x] = 0;
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x)
-            atomicAdd(&s_noff[meta_name(__float_as_uint(rec[i].w)) + 1], 1u);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t run = 0;
-            for (int i = 1; i <= 64; ++i) { run += s_noff[i]; s_noff[i] = run; }
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+            const uint32_t m = __float_as_uint(rec[i].w);
+            s_meta[i] = (uint16_t)(meta_name(m) | (meta_rtype(m) << 8));
+            atomicAdd(&s_noff[meta_name(m) + 1], 1u);
         }
+        __syncthreads();
+        if (wave == 0) s_noff[lane + 1] = wave_scan_add(s_noff[lane + 1]);  // (64 name ids: one per lane)
         __syncthreads();
         // every wave takes the names w, w + nwaves, ...: ordered compaction of the atoms carrying that name
         for (uint32_t name = wave; name < 64; name += nwaves) {
@@ -247,23 +265,30 @@ __global__ __launch_bounds__(512) void k_kind_lists(LibView L, BatchView B, uint
                 uint32_t m = 0;
                 bool ok = false;
                 if (i < n) {
-                    m = __float_as_uint(rec[i].w);
-                    ok = meta_name(m) == name;
+                    m = s_meta[i];
+                    ok = (m & 0xffu) == name;
                 }
                 const unsigned long long mask = ballot64(ok);
-                if (ok) s_bucket[w + rank_in(mask)] = i | (meta_rtype(m) << 16);
+                if (ok) s_bucket[w + rank_in(mask)] = (uint16_t)i;
                 w += __popcll(mask);
             }
         }
         __syncthreads();
     }
 
-    // admissible atoms of lead kind li, in ascending order, handed to `emit(mask, ok, atom)` 64 at a time
-    auto scan_kind = [&](uint32_t li, auto emit) {
-        const uint32_t kind = L.lead_kind[li];
-        const uint32_t rm = L.k_resmask[kind];
-        const uint64_t nm = L.k_namemask[kind];
-        const bool any = L.k_any[kind] != 0;
+    // admissible atoms of the wave's lead kind number j, in ascending order, handed to `emit(mask, ok, atom)` 64 at a time
+    auto scan_kind = [&](uint32_t j, auto emit) {
+        uint32_t rm, nm_lo, nm_hi, any_u;
+        if (j < 64u) {
+            rm = __builtin_amdgcn_readlane(my_rm, (int)j); nm_lo = __builtin_amdgcn_readlane(my_nm_lo, (int)j);
+            nm_hi = __builtin_amdgcn_readlane(my_nm_hi, (int)j); any_u = __builtin_amdgcn_readlane(my_any, (int)j);
+        } else {  // (more lead kinds than 64 per wave: read where they are)
+            const uint32_t kind = L.lead_kind[(uint32_t)wave + (uint32_t)nwaves * j];
+            const uint64_t nm64 = L.k_namemask[kind];
+            rm = L.k_resmask[kind]; nm_lo = (uint32_t)nm64; nm_hi = (uint32_t)(nm64 >> 32); any_u = L.k_any[kind] != 0 ? 1u : 0u;
+        }
+        const uint64_t nm = ((uint64_t)nm_hi << 32) | nm_lo;
+        const bool any = any_u != 0u;
         if (bucketed && (nm & (nm - 1)) == 0ull && nm != 0ull) {
             const uint32_t name = (uint32_t)__ffsll((long long)nm) - 1u;
             const uint32_t e1 = s_noff[name + 1];
@@ -273,9 +298,19 @@ __global__ __launch_bounds__(512) void k_kind_lists(LibView L, BatchView B, uint
                 bool ok = false;
                 if (e < e1) {
                     v = s_bucket[e];
-                    ok = any || ((rm >> (v >> 16)) & 1u);
+                    ok = any || ((rm >> (s_meta[v] >> 8)) & 1u);
                 }
-                emit(ballot64(ok), ok, v & 0xffffu);
+                emit(ballot64(ok), ok, v);
+            }
+        } else if (bucketed) {
+            for (uint32_t b0 = 0; b0 < n; b0 += 64) {
+                const uint32_t i = b0 + lane;
+                bool ok = false;
+                if (i < n) {
+                    const uint32_t m = s_meta[i];
+                    ok = ((nm >> (m & 0xffu)) & 1ull) && (any || ((rm >> (m >> 8)) & 1u));
+                }
+                emit(ballot64(ok), ok, i);
             }
         } else {
             for (uint32_t b0 = 0; b0 < n; b0 += 64) {
@@ -290,26 +325,30 @@ __global__ __launch_bounds__(512) void k_kind_lists(LibView L, BatchView B, uint
         }
     };
 
-    for (uint32_t li = wave; li < L.n_lead; li += nwaves) {
+    for (uint32_t j = 0, li = wave; li < L.n_lead; ++j, li += nwaves) {
         uint32_t c = 0;
-        scan_kind(li, [&](unsigned long long mask, bool, uint32_t) { c += __popcll(mask); });
+        scan_kind(j, [&](unsigned long long mask, bool, uint32_t) { c += __popcll(mask); });
         if (lane == 0) s_cnt[li] = c;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {  // exclusive scan (n_lead is a few hundred)
+    if (wave == 0) {  // exclusive scan of the counts, 64 at a time
         uint32_t run = 0;
-        for (uint32_t li = 0; li < L.n_lead; ++li) {
-            const uint32_t c = s_cnt[li];
-            s_cnt[li] = run;
-            run += c;
+        for (uint32_t l0 = 0; l0 < L.n_lead; l0 += 64u) {
+            const uint32_t li = l0 + (uint32_t)lane;
+            const uint32_t c = li < L.n_lead ? s_cnt[li] : 0u;
+            const uint32_t incl = wave_scan_add(c);
+            if (li < L.n_lead) s_cnt[li] = run + incl - c;
+            run += __builtin_amdgcn_readlane(incl, 63);
         }
-        s_cnt[L.n_lead] = run;
-        unsigned long long base = atomicAdd(cursor, (unsigned long long)run);
-        if (base + run > capacity) {
-            *overflow = 1u;
-            base = ~0ull;
+        if (lane == 0) {
+            s_cnt[L.n_lead] = run;
+            unsigned long long base = atomicAdd(cursor, (unsigned long long)run);
+            if (base + run > capacity) {
+                *overflow = 1u;
+                base = ~0ull;
+            }
+            s_base = base;
         }
-        s_base = base;
     }
     __syncthreads();
     const unsigned long long base = s_base;
@@ -318,9 +357,9 @@ __global__ __launch_bounds__(512) void k_kind_lists(LibView L, BatchView B, uint
         off_out[li] = base == ~0ull ? 0u : (uint32_t)(base + s_cnt[li]);
     if (base == ~0ull) return;
 
-    for (uint32_t li = wave; li < L.n_lead; li += nwaves) {
+    for (uint32_t j = 0, li = wave; li < L.n_lead; ++j, li += nwaves) {
         unsigned long long w = base + s_cnt[li];
-        scan_kind(li, [&](unsigned long long mask, bool ok, uint32_t atom) {
+        scan_kind(j, [&](unsigned long long mask, bool ok, uint32_t atom) {
             if (ok) kl_pool[w + rank_in(mask)] = (uint16_t)atom;
             w += __popcll(mask);
         });
