@@ -816,17 +816,18 @@ __global__ __launch_bounds__(kTabBlock) void k_tab_build(uint32_t n_lead, BatchV
             const uint4 *g_rec = reinterpret_cast<const uint4 *>(rec);
             const uint4 *g_pool = reinterpret_cast<const uint4 *>(B.kl_pool + rebase);
             uint4 *l_rec = reinterpret_cast<uint4 *>(s_atoms), *l_pool = reinterpret_cast<uint4 *>(s_pool);
-            constexpr int kRecPer = 3;
-            uint4 v_rec[kRecPer], v_pool;
+            constexpr uint32_t kRecPer = 3;
+            const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);  // (named registers, initialised: see k_search)
+            uint4 v_rec0 = zero4, v_rec1 = zero4, v_rec2 = zero4, v_pool = zero4;
             uint32_t v_kl = 0;
-#pragma unroll
-            for (int k = 0; k < kRecPer; ++k)
-                if (tid + k * step < n) v_rec[k] = g_rec[tid + k * step];
+            if (tid < n) v_rec0 = g_rec[tid];
+            if (tid + step < n) v_rec1 = g_rec[tid + step];
+            if (tid + 2u * step < n) v_rec2 = g_rec[tid + 2u * step];
             if (tid < n_pool) v_pool = g_pool[tid];
             if (tid <= n_lead) v_kl = kl[tid];
-#pragma unroll
-            for (int k = 0; k < kRecPer; ++k)
-                if (tid + k * step < n) l_rec[tid + k * step] = v_rec[k];
+            if (tid < n) l_rec[tid] = v_rec0;
+            if (tid + step < n) l_rec[tid + step] = v_rec1;
+            if (tid + 2u * step < n) l_rec[tid + 2u * step] = v_rec2;
             if (tid < n_pool) l_pool[tid] = v_pool;
             if (tid <= n_lead) s_kl2[tid] = v_kl - rebase;
             for (uint32_t i = tid + kRecPer * step; i < n; i += step) l_rec[i] = g_rec[i];
@@ -2420,24 +2421,23 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
         const uint4 *g_pool = reinterpret_cast<const uint4 *>(B.kl_pool + rebase);
         uint4 *l_rec = reinterpret_cast<uint4 *>(s_rec), *l_pool = reinterpret_cast<uint4 *>(s_pool);
         const uint32_t n_pool = pool_in_lds ? (p0 - rebase + plen + 7u) / 8u : 0u;  // 16-byte words of kind lists
-        constexpr int kRecPer = 3, kPoolPer = 1;
-        uint4 v_rec[kRecPer], v_pool[kPoolPer];
+        constexpr uint32_t kRecPer = 3, kPoolPer = 1;
+        // (named registers, every one initialised: an array indexed in a loop went to scratch memory -- 64 bytes per
+        // lane through L2, +75 MB of writes per launch)
+        const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+        uint4 v_rec0 = zero4, v_rec1 = zero4, v_rec2 = zero4, v_pool0 = zero4;
         uint16_t v_res = 0;
         uint32_t v_kl = 0;
-#pragma unroll
-        for (int k = 0; k < kRecPer; ++k)
-            if (tid + k * step < n) v_rec[k] = g_rec[tid + k * step];
-#pragma unroll
-        for (int k = 0; k < kPoolPer; ++k)
-            if (tid + k * step < n_pool) v_pool[k] = g_pool[tid + k * step];
+        if (tid < n) v_rec0 = g_rec[tid];
+        if (tid + step < n) v_rec1 = g_rec[tid + step];
+        if (tid + 2u * step < n) v_rec2 = g_rec[tid + 2u * step];
+        if (tid < n_pool) v_pool0 = g_pool[tid];
         if (tid < nres1) v_res = B.res_start[r0 + tid];
         if (tid <= L.n_lead) v_kl = kl_off[tid];
-#pragma unroll
-        for (int k = 0; k < kRecPer; ++k)
-            if (tid + k * step < n) l_rec[tid + k * step] = v_rec[k];
-#pragma unroll
-        for (int k = 0; k < kPoolPer; ++k)
-            if (tid + k * step < n_pool) l_pool[tid + k * step] = v_pool[k];
+        if (tid < n) l_rec[tid] = v_rec0;
+        if (tid + step < n) l_rec[tid + step] = v_rec1;
+        if (tid + 2u * step < n) l_rec[tid + 2u * step] = v_rec2;
+        if (tid < n_pool) l_pool[tid] = v_pool0;
         if (tid < nres1) s_res[tid] = v_res;
         if (tid <= L.n_lead) s_kl[tid] = v_kl - rebase;
         // what a structure has beyond the first pass
