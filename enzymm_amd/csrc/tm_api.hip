@@ -1625,7 +1625,7 @@ static int build_tables(const tm_library *lib, tm_batch *b, const StagedSelectio
                        b->d_tab_cursors.p, ents, b->d_tab_overflow.p, lr_arg, shared_limit, atom_cap);
     {
         const uint32_t n_sel = (uint32_t)S->sel.size();
-        hipLaunchKernelGGL(k_tab_refs, dim3(ns, (n_sel + 255) / 256), dim3(256), 0, stream, B, lib->n_lead, n_sel, S->d_pair_table.p,
+        hipLaunchKernelGGL(k_tab_refs, dim3(ns, (n_sel + 255) / 256), dim3(256), ((size_t)lib->n_lead + 15) & ~size_t(15), stream, B, lib->n_lead, n_sel, S->d_pair_table.p,
                            S->d_triple_table.p, S->d_lead8.p, b->d_tab_ref.p);
     }
     HIP_TRY(hipGetLastError());

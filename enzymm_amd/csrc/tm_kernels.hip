@@ -868,16 +868,25 @@ __global__ __launch_bounds__(256) void k_tab_refs(BatchView B, uint32_t n_lead, 
                                                    const uint16_t *__restrict__ pair_table,
                                                    const uint16_t *__restrict__ triple_table,
                                                    const uint16_t *__restrict__ lead8, uint4 *__restrict__ tab_ref) {
+    // dynamic LDS: one byte per lead kind -- does this structure have an atom of it? (sixteen dependent loads per thread
+    // from the structure's offsets otherwise)
+    extern __shared__ unsigned char s_has[];
     const uint32_t s = blockIdx.x;
     const uint32_t ti = blockIdx.y * blockDim.x + threadIdx.x;
+    const uint32_t *kl = B.kl_off + (size_t)s * (n_lead + 1);
+    for (uint32_t li = threadIdx.x; li < n_lead; li += blockDim.x) s_has[li] = kl[li + 1] != kl[li] ? 1 : 0;
+    __syncthreads();
     if (ti >= n_sel) return;
     const size_t base = (size_t)s * B.n_tables;
     const uint32_t tp = pair_table[ti], tt = triple_table[ti];
-    const uint32_t *kl = B.kl_off + (size_t)s * (n_lead + 1);
+    static_assert(kMaxG == 8, "a template's lead kinds are read as one 16-byte word");
+    const uint4 leads = reinterpret_cast<const uint4 *>(lead8)[ti];
+    const uint32_t lw[4] = {leads.x, leads.y, leads.z, leads.w};
     bool feasible = true;
+#pragma unroll
     for (int g = 0; g < kMaxG; ++g) {
-        const uint32_t li = lead8[(size_t)ti * kMaxG + g];
-        if (li != 0xffffu && kl[li + 1] == kl[li]) feasible = false;
+        const uint32_t li = (lw[g >> 1] >> ((g & 1) * 16)) & 0xffffu;
+        if (li != 0xffffu && s_has[li] == 0) feasible = false;
     }
     uint4 r = make_uint4(0u, 0u, 0u, 0u);
     if (B.tab_ok[s] == 1u && feasible) {
