@@ -65,3 +65,19 @@ for label, c in (("default cutoffs", cut), ("-j 2 2.5 2.5", np.full(len(idx), 2.
           f"{timing[0]:.1f} ms, search {timing[1]:.1f} ms, finish {timing[2]:.1f} ms per batch of {n}), {n_hits} hits, "
           f"{n_cand} candidates, {n_trunc} truncated pairs", flush=True)
 batch.close()
+# one complex alone (latency of the largest single query the path sees)
+single = pyjess.make_batch(mols[:1], jess._device)
+loose = np.full(len(idx), 2.5)
+best = None
+for rep in range(4):
+    t0 = time.perf_counter()
+    res = _native.query(packed.native, single, idx, 2.0, loose, loose, 10000, base)
+    n_hits = res.hit_count()
+    wall = time.perf_counter() - t0
+    if best is None or wall < best[0]:
+        best = (wall, res.timing(), res.search_split(), n_hits)
+    res.close()
+single.close()
+print(f"configs[4] one complex alone, -j 2 2.5 2.5: {1e3 * best[0]:.1f} ms wall (index+tables {best[1][0]:.1f} ms, search "
+      f"{best[1][1]:.1f} ms = block {best[2][0]:.1f} + depth-first {best[2][1]:.1f}, finish {best[1][2]:.1f} ms), {best[3]} hits",
+      flush=True)
