@@ -311,7 +311,6 @@ struct StagedSelection {
     DevBuf<Staged> d_staged;
     DevBuf<BlockHdr> d_hdr;      // per staged template: the record of the table-driven stages (k_search reads 64 at a time)
     DevBuf<LookHdr> d_look;      // per staged template: the record of the look at search level 3
-    DevBuf<uint4> d_levels;      // per staged template and search level: the record the lane-parallel depth-first search reads
     // Directory of the pages of triples waiting for k_deep: a structure of n atoms owns one entry per wave that works on
     // it (the partly filled last page of each) + dir_milli * n^2 / 1e7 entries for its full pages.  Starts at 0.1 page
     // per 1e4 atoms^2 (a 300-residue structure under the default thresholds fills about twenty pages); raised to what a
@@ -1810,13 +1809,12 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
             HIP_TRY(S->d_staged.alloc(n_sel));
             HIP_TRY(S->d_hdr.alloc(n_sel));
             HIP_TRY(S->d_look.alloc(n_sel));
-            HIP_TRY(S->d_levels.alloc((size_t)n_sel * kMaxK));
             HIP_TRY(S->d_lead8.alloc((size_t)n_sel * kMaxG));
             HIP_TRY(hipEventCreateWithFlags(&S->ready, hipEventDisableTiming));
             if (n_sel) {
                 hipLaunchKernelGGL(k_stage_templates, dim3(n_sel), dim3(64), 0, stream, lib->view(), n_sel, S->d_sel.p,
                                    S->d_cut.p, S->d_maxdyn.p, S->d_pair_table.p, S->d_triple_table.p, S->d_triple_key.p,
-                                   S->d_staged.p, S->d_bounds.p, S->d_hdr.p, S->d_look.p, S->d_lead8.p, S->d_levels.p, S->slack);
+                                   S->d_staged.p, S->d_bounds.p, S->d_hdr.p, S->d_look.p, S->d_lead8.p, S->slack);
                 HIP_TRY(hipGetLastError());
             }
             HIP_TRY(hipEventRecord(S->ready, stream));
@@ -1910,7 +1908,7 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
 
     QueryView Q;
     Q.n_sel = n_sel; Q.sel = S->d_sel.p; Q.rmsd_thr = S->d_rmsd.p; Q.cutoff = S->d_cut.p; Q.maxdyn = S->d_maxdyn.p;
-    Q.staged = S->d_staged.p; Q.hdr = S->d_hdr.p; Q.look = S->d_look.p; Q.levels = S->d_levels.p; Q.bounds = S->d_bounds.p; Q.order = S->d_order.p; Q.max_candidates = p->max_candidates; Q.flags = p->flags;
+    Q.staged = S->d_staged.p; Q.hdr = S->d_hdr.p; Q.look = S->d_look.p; Q.bounds = S->d_bounds.p; Q.order = S->d_order.p; Q.max_candidates = p->max_candidates; Q.flags = p->flags;
     if (const char *env = std::getenv("ENZYMM_AMD_RUN_LIST"))  // test hook: k_deep claims by page position, as for a large complex
         if (std::atoi(env) == 0) Q.flags |= 0x4000u;
     Q.n_tables = (uint32_t)S->tables.size(); Q.tables = S->d_tables.p;
@@ -2057,10 +2055,10 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
             const size_t lds_bytes = lds_path ? lds_limit : scratch + (mode == kModeDeep ? search_cache_bytes() : 0);
             void (*kernel)(SearchArgs) = nullptr;
 #define TM_PICK(m) (lds_path ? (ic ? k_search<true, true, m> : k_search<true, false, m>) : (ic ? k_search<false, true, m> : k_search<false, false, m>))
-            kernel = mode == kModeBlocks ? TM_PICK(kModeBlocks) : mode == kModeSingly ? TM_PICK(kModeSingly) : mode == kModeDeep ? TM_PICK(kModeDeep) : TM_PICK(kModeLanes);
+            kernel = mode == kModeBlocks ? TM_PICK(kModeBlocks) : mode == kModeSingly ? TM_PICK(kModeSingly) : TM_PICK(kModeDeep);
 #undef TM_PICK
             HIP_TRY(allow_dynamic_lds(reinterpret_cast<const void *>(kernel), lds_bytes));
-            hipLaunchKernelGGL(kernel, dim3(grid), dim3(search_threads(mode)), lds_bytes, stream, args);
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(kSearchBlock), lds_bytes, stream, args);
             HIP_TRY(hipGetLastError());
             return TM_OK;
         };
@@ -2077,9 +2075,7 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
         HIP_TRY(hipEventRecord(r->ev[4], stream));
         // the depth-first search below the triples the block search paged out: the same work items (every workgroup
         // of a structure takes triples of that structure until none are left)
-        // (lane = triple unless ENZYMM_AMD_DEEP=wave asks for the wave-cooperative search of round 3: A/B experiments)
-        static const bool deep_wave = std::getenv("ENZYMM_AMD_DEEP") && std::string(std::getenv("ENZYMM_AMD_DEEP")) == "wave";
-        rc = launch(deep_wave ? kModeDeep : kModeLanes);
+        rc = launch(kModeDeep);
         if (rc != TM_OK) return rc;
     }
     HIP_TRY(hipEventRecord(r->ev[2], stream));

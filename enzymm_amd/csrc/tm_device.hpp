@@ -11,6 +11,7 @@ constexpr int kMaxK = TM_MAX_TEMPLATE_ATOMS;        // template atoms per templa
 constexpr int kMaxG = TM_MAX_TEMPLATE_GROUPS;       // template residues
 constexpr int kMaxPairs = kMaxK * (kMaxK - 1) / 2;  // 276 pair constraints
 constexpr int kWave = 64;
+// (experiment knobs: make variant NAME=occ EXTRA="-DTM_SEARCH_WAVES=12 -DTM_SEARCH_MIN_WAVES=6", tests/gpu_occ_exp.sh)
 #ifndef TM_SEARCH_WAVES
 #define TM_SEARCH_WAVES 16
 #endif
@@ -155,9 +156,8 @@ static_assert(sizeof(LookHdr) == 48, "LookHdr layout");
 struct DeepEntry {
     uint32_t a01;  // target atoms of leads 0 and 1 (device order), 16 bits each
     uint32_t c;    // ... of lead 2
-    uint32_t ti;   // staged template | its residues << 23 | its atoms << 27
+    uint32_t ti;   // staged template
 };
-constexpr uint32_t kTiGroupsShift = 23, kTiAtomsShift = 27, kTiMask = (1u << kTiGroupsShift) - 1u;
 constexpr uint32_t kPageTriples = 64;
 #ifndef TM_DEEP_RUN
 #define TM_DEEP_RUN 2
@@ -176,7 +176,6 @@ struct QueryView {
     const Staged *staged;       // [n_sel]
     const BlockHdr *hdr;        // [n_sel]
     const LookHdr *look;        // [n_sel]
-    const uint4 *levels;        // [n_sel*kMaxK] per search level: see k_stage_templates (the lane-parallel depth-first search)
     const float2 *bounds;       // [n_sel*kMaxPairs] (lo^2, hi^2) fp32 prefilter bounds, search order
     const uint32_t *order;      // [n_sel] every per-selection array above is sorted by descending estimated cost;
                                 // order[pos] = the caller's selection index (reported in tm_hit / candidate counts)

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(64) void k_stage_templates(LibView L, uint32_t n_se
                                                          const uint8_t *__restrict__ triple_key,
                                                          Staged *__restrict__ staged, float2 *__restrict__ bounds,
                                                          BlockHdr *__restrict__ hdr, LookHdr *__restrict__ look,
-                                                         uint16_t *__restrict__ lead8, uint4 *__restrict__ levels, double slack) {
+                                                         uint16_t *__restrict__ lead8, double slack) {
     const uint32_t ti = blockIdx.x;
     if (ti >= n_sel) return;
     const uint32_t t = sel[ti];
@@ -137,15 +137,8 @@ __global__ __launch_bounds__(64) void k_stage_templates(LibView L, uint32_t n_se
             S.resmask[lane] = L.k_resmask[kind];
             S.lead_li[lane] = ref == lane ? (uint16_t)L.k_lead[kind] : (uint16_t)0xffffu;
             S.orig[lane] = L.a_orig[off + lane];
-            const uint32_t pk = lvl_pack(L.a_group[off + lane], ref, L.k_any[kind], L.a_orig[off + lane], L.a_chain[off + lane]);
-            S.packed[lane] = pk;
-            // one 16-byte record per level for the lane-parallel depth-first search (a lane reads the record of ITS template's
-            // level): a lead level {lead-kind index, -, -, packed word}, any other {name mask, residue-type mask, packed word}
-            const uint64_t nm = L.k_namemask[kind];
-            levels[(size_t)ti * kMaxK + lane] = ref == lane ? make_uint4((uint32_t)L.k_lead[kind], 0u, 0u, pk)
-                                                            : make_uint4((uint32_t)nm, (uint32_t)(nm >> 32), L.k_resmask[kind], pk);
+            S.packed[lane] = lvl_pack(L.a_group[off + lane], ref, L.k_any[kind], L.a_orig[off + lane], L.a_chain[off + lane]);
         } else {
-            levels[(size_t)ti * kMaxK + lane] = make_uint4(0u, 0u, 0u, lvl_pack(0xff, 0, 0, 0, 0));
             S.namemask[lane] = 0; S.resmask[lane] = 0; S.lead_li[lane] = 0xffffu;
             S.orig[lane] = 0;
             S.packed[lane] = lvl_pack(0xff, 0, 0, 0, 0);
@@ -915,29 +908,19 @@ __global__ __launch_bounds__(256) void k_tab_refs(BatchView B, uint32_t n_lead, 
 
 // kMode of k_search: 0 the block search (stages A - D1, surviving triples to pages); 1 the template-at-a-time search of
 // the templates the block search leaves out; 2 the depth-first search below the paged triples (k_deep).
-// 3: the same part searched lane = triple (deep_lanes): what the launch runs unless ENZYMM_AMD_DEEP=wave asks for mode 2.
-constexpr int kModeBlocks = 0, kModeSingly = 1, kModeDeep = 2, kModeLanes = 3;
+constexpr int kModeBlocks = 0, kModeSingly = 1, kModeDeep = 2;
 
 // Per-wave LDS: only what lanes exchange.  All search state lives in registers (see WaveRegs).  What a launch mode
 // does not use is not reserved: the block search has no template constants in LDS, the depth-first part no queues.
 template <int kMode>
 struct __align__(16) WaveScratchT {
-    static constexpr bool kSearches = kMode == kModeSingly || kMode == kModeDeep;  // runs the wave-cooperative per-level search (dfs, eval_chunk)
-    static constexpr bool kQueues = kMode == kModeBlocks || kMode == kModeSingly;  // runs the table stages
-    static constexpr bool kLanes = kMode == kModeLanes;                            // runs the lane-parallel search (lane_search)
+    static constexpr bool kSearches = kMode != kModeBlocks;  // runs the per-level search (dfs, eval_chunk, completion)
+    static constexpr bool kQueues = kMode != kModeDeep;      // runs the table stages
     float2 bnd[kSearches ? kMaxPairs : 1];           // every pair bound of the current template (pair (i, j < i) at tri(i) + j)
     uint16_t surv[kSearches ? kMaxG : 1][64];        // per template residue: one 64-entry chunk of its lead list
     uint2 pairs[kQueues ? kPairQueue : 1];           // pair-table survivors {position in list 0 | position in list 1 << 16, slot}
     uint2 triples[kQueues ? kTripleQueue : 1];       // triple survivors {a0 | a1 << 16, a2 | slot << 16} waiting for the look at level 3
-    uint32_t owner[kLanes ? 1 : 64];                 // item-parallel stages: who owns the item at which its segment / row starts
-    // lane-parallel search: the search stack of lane l is column l -- the atom assigned to level L >= 3 and, for the lead
-    // levels among them (levels 3 .. residues - 1), which 64-entry chunk of the kind list comes next and the candidates
-    // of the chunk before it that fit every placed lead and have not been tried
-    uint16_t atom[kLanes ? kMaxK - 3 : 1][64];
-    uint16_t lchunk[kLanes ? kMaxG - 3 : 1][64];
-    uint2 lmask[kLanes ? kMaxG - 3 : 1][64];
-    DeepEntry pool[kLanes ? 64 : 1];   // triples of the pages the wave has claimed, handed to lanes as they run out of work
-    uint16_t give[kLanes ? 64 : 1];    // candidates of a lead level handed from the lane that found them to lanes without work
+    uint32_t owner[64];                              // item-parallel stages: who owns the item at which its segment / row starts
     // candidate slots this wave has reserved: {next, end, size of the next reservation} (on_complete, slab_release)
     uint32_t slab[4];
 };
@@ -1989,10 +1972,7 @@ __device__ __forceinline__ void block_look(Ctx &C, const SearchArgs &A, SlotRegs
 #if defined(TM_STATS) || defined(TM_ABLATE)
     if (A.Q.flags & 0x800u) keep = 0ull;  // phase timing: the look at level 3, nothing below it
 #endif
-    if (keep) {  // (the entry carries its template's residue and atom counts: BlockHdr::flags bits 4-7 and 8-12)
-        const uint32_t fl = lane_get(R.flags, slot);
-        page_append(PW, s, lane, keep, t.x, c, ti | (((fl >> 4) & 0xfu) << kTiGroupsShift) | (((fl >> 8) & 0x1fu) << kTiAtomsShift));
-    }
+    if (keep) page_append(PW, s, lane, keep, t.x, c, ti);
 }
 
 // Moves queue entries [from, from + n) to the front (n < 64).
@@ -2300,7 +2280,7 @@ __device__ __forceinline__ void deep_templates(const SearchArgs &A, WaveScratchT
             nt = uni(pg.y) > e0 ? min(run_len, uni(pg.y) - e0) : 0u;
             first = (size_t)uni(pg.x) * kPageTriples + e0;
         }
-        if (lane < nt) { t = pages[first + lane]; t.ti &= kTiMask; }
+        if (lane < nt) t = pages[first + lane];
         return nt;
     };
     WaveRegs W = {};
@@ -2379,393 +2359,6 @@ __device__ __forceinline__ void deep_templates(const SearchArgs &A, WaveScratchT
     slab_release(C);
 }
 
-// ------------------------------------------------------------------ depth-first part, lane = triple (k_deep, mode kModeLanes)
-//
-// The wave-cooperative search above spends a whole wave on ONE triple: below the lead atoms a level's candidates are the
-// atoms of one target residue, of which the masks leave one or two, so a level evaluation -- two hundred instructions
-// that depend on each other -- keeps one or two lanes busy (970 instructions and 16 k cycles per triple, 3.1 evaluations).
-// Here every lane searches its own triple: the nested loops (levels, candidates of a level, assigned levels a candidate
-// is tested against) become one loop in which a lane makes ONE step of its own search per trip -- enter a level, fetch
-// the next candidate, or test the candidate against one assigned level -- so the lanes stay busy whatever the shape of
-// their searches.  The stack of a lane (assigned atom per level) is a column of the wave's LDS scratch; what belongs to a
-// lane's TEMPLATE (a 16-byte record per level, an 8-byte window per pair) is read from the staged selection in L2 by the
-// lane that needs it.  A complete assignment is rare: it is handed to the whole wave (on_complete: the fp64 re-check with
-// lane = pair constraint), one completion at a time.
-//
-// Search order (plan_template): the leads of all residues first (levels 0 .. G - 1), then the other atoms residue by
-// residue.  So at a lead level every assigned level is a lead of another residue (the candidate's residue must differ
-// from each), and at any other level the candidate comes from the residue of its own lead, which differs from the other
-// leads' residues by construction: only "no atom twice" is left to test there.
-
-// The record of (template ti, level L): x: lead-kind index (lead level) or name mask low word; y: name mask high word;
-// z: residue-type mask; w: packed word (lvl_*).
-template <class Ctx>
-__device__ __forceinline__ bool lane_complete(Ctx &C, const SearchArgs &A, uint32_t s, int b, uint32_t ti, uint32_t a01,
-                                              uint32_t a2, uint32_t k) {
-    const uint32_t lane = (uint32_t)C.lane;
-    const uint32_t ti_b = RL(ti, b), k_b = RL(k, b), a01_b = RL(a01, b), a2_b = RL(a2, b);
-    {  // another lane (or wave) has met the pair's max_candidates limit: nothing this search finds would be kept
-        ColdArgsPtr cold = cold_args();
-        const uint32_t seen = __hip_atomic_load(&cold->O.pair_count[(size_t)s * cold->Q.n_sel + cold->Q.order[ti_b]], __ATOMIC_RELAXED,
-                                                __HIP_MEMORY_SCOPE_AGENT);
-        if (seen >> 31) return false;
-    }
-    WaveRegs W = {};  // (on_complete reads the assignment and the packed words by lane = level)
-    W.pk = A.Q.staged[ti_b].packed[min(lane, (uint32_t)kMaxK - 1u)];
-    uint32_t at = lane == 0u ? a01_b & 0xffffu : lane == 1u ? a01_b >> 16 : a2_b;
-    if (lane >= 3u && lane < k_b) at = C.S->atom[lane - 3u][b];
-    W.aidx = at;
-    C.k = (int)k_b;
-    PairState P;
-    P.s = s; P.ti = ti_b; P.truncated = false;
-    return on_complete(C, W, P);
-}
-
-// waves of a workgroup that searches lane = triple
-constexpr int kLaneWaves = 12;
-template <int kMode> constexpr int waves_of() { return kMode == kModeLanes ? kLaneWaves : kSearchWaves; }
-
-// One wave of the lane-parallel search: lanes take triples from the wave's pool (the pages it has claimed) whenever they
-// run out of work, so a long search below one triple does not hold 63 lanes idle; a lane whose lead level yields several
-// candidates at once hands all but one to lanes that have nothing to do (each takes a copy of the stack down to that level
-// and searches only below it: `floor`).
-template <bool kLds, bool kIgnoreChain, bool kPoolLds>
-__device__ __forceinline__ void deep_lanes(const SearchArgs &A, WaveScratchT<kModeLanes> *scratch, const float4 *s_rec,
-                                           const uint16_t *s_res, const uint32_t *s_kl, const uint16_t *s_pool,
-                                           const uint32_t *kl_off, uint32_t s, uint32_t a0, uint32_t r0, uint32_t n_listed) {
-    const BatchView &B = A.B;
-    const QueryView &Q = A.Q;
-    SearchCtx<kIgnoreChain, kPoolLds, kModeLanes> C;
-    C.rc = nullptr;
-    C.rec = kLds ? s_rec : B.q_rec + a0;
-    C.res_start = kLds ? s_res : B.res_start + r0;
-    C.pool_lds = (const __attribute__((address_space(3))) uint16_t *)s_pool;
-    C.pool_glb = B.kl_pool;
-    C.qchain = B.q_chain + a0;
-    C.tab_rows = B.tab_rows;
-    C.tab_ent = B.tab_ent;
-    C.S = scratch + (threadIdx.x >> 6);
-    C.lane = lane_id();
-    C.k = 0; C.n_groups = 0; C.bnd = Q.bounds;
-    auto &S = *C.S;
-    const uint32_t lane = (uint32_t)C.lane;
-    const uint32_t *kl = kLds ? s_kl : kl_off;
-    const uint2 *dir = A.O.dir + A.O.dir_off[s];
-    const DeepEntry *pages = A.O.pages;
-    slab_init(C);
-
-    // ---- the wave's pool of triples: pages are claimed in pairs (most are the partly filled last pages of the block
-    // search's waves); the next claim and its directory entries are fetched while the current pool is searched
-    auto claim = [&]() -> uint32_t {
-        uint32_t n = 0;
-        if (lane == 0u) n = atomicAdd(&A.O.dir_head[s], 2u);
-        return n;  // (lane 0's value; made uniform where it is used)
-    };
-    auto entries = [&](uint32_t n, uint2 &p0, uint2 &p1) {
-        p0 = make_uint2(0u, 0u); p1 = p0;
-        if (n < n_listed) p0 = dir[n];
-        if (n + 1u < n_listed) p1 = dir[n + 1u];
-    };
-    uint32_t n_claim = uni(claim());
-    uint2 e0, e1;
-    entries(n_claim, e0, e1);
-    uint32_t n_ahead = claim();   // in flight
-    uint32_t pend_page = 0, pend_count = 0;  // the second page of a pair that did not fit the pool with the first
-    uint32_t pool_next = 0, pool_count = 0;
-    bool exhausted = false;
-    auto load_pool = [&]() {  // wave-uniform; the pool is empty
-        wave_sync();
-        pool_next = 0u;
-        if (pend_count != 0u) {
-            if (lane < pend_count) S.pool[lane] = pages[(size_t)pend_page * kPageTriples + lane];
-            pool_count = pend_count;
-            pend_count = 0u;
-        } else if (n_claim >= n_listed) {
-            pool_count = 0u;
-            exhausted = true;
-        } else {
-            const uint32_t page0 = uni(e0.x), c0 = uni(e0.y), page1 = uni(e1.x), c1 = uni(e1.y);
-            if (lane < c0) S.pool[lane] = pages[(size_t)page0 * kPageTriples + lane];
-            pool_count = c0;
-            if (c0 + c1 <= kPageTriples) {
-                if (lane >= c0 && lane < c0 + c1) S.pool[lane] = pages[(size_t)page1 * kPageTriples + (lane - c0)];
-                pool_count = c0 + c1;
-            } else {
-                pend_page = page1;
-                pend_count = c1;
-            }
-            n_claim = uni(n_ahead);
-            entries(n_claim, e0, e1);
-            n_ahead = n_claim < n_listed ? claim() : n_claim;
-        }
-        wave_sync();
-    };
-
-    // ---- lane state
-    enum : uint32_t { kEnter = 0, kNext = 1, kTest = 2, kEval = 3, kComplete = 4, kDone = 5 };
-    uint32_t ti = 0, a01 = 0, a2 = 0, k = 0, G = 0;
-    float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;  // records of the triple's three leads
-    uint32_t phase = kDone;
-    uint32_t L = 3, floor = 3;  // the level this lane is working on; it never returns above `floor`
-    bool resume = false;        // kEnter: the level was left for a deeper one and is taken up again behind its candidate
-    // candidates of the level.  A lead level: the kind list [lo, lo + end) in the pool, cur = first position (relative) of
-    // the chunk the wave evaluates next, mask = untried survivors of the chunk at mbase.  Any other level: the atoms
-    // [cur, end) of a target residue.
-    uint32_t cur = 0, end = 0, lo = 0, mbase = 0;
-    unsigned long long mask = 0ull;
-    uint32_t cand = 0, j = 0;   // the candidate under test and the assigned level it meets next
-    float4 rc = make_float4(0.f, 0.f, 0.f, 0.f);
-    uint4 lv = make_uint4(0u, 0u, 0u, 0u);
-    float2 b0 = make_float2(0.f, 0.f), b1 = b0, b2 = b0;  // windows of the level against the three leads of the triple
-    uint32_t tc0 = 0, tc1 = 0, tc2 = 0, qc0 = 0, qc1 = 0, qc2 = 0;  // !ignore_chain: template and target chains of the three leads
-    auto assigned = [&](uint32_t level) -> uint32_t {
-        uint32_t a = level == 0u ? a01 & 0xffffu : level == 1u ? a01 >> 16 : a2;
-        if (level >= 3u) a = S.atom[level - 3u][lane];
-        return a;
-    };
-    auto placed = [&]() {  // level L holds `cand`: one level down, or a complete assignment
-        S.atom[L - 3u][lane] = (uint16_t)cand;
-        if (L + 1u == k) phase = kComplete;
-        else {
-            if (L < G) {  // (what is left of the lead level stays in the lane's column)
-                S.lchunk[L - 3u][lane] = (uint16_t)(cur >> 6);  // (a multiple of 64)
-                S.lmask[L - 3u][lane] = make_uint2((uint32_t)mask, (uint32_t)(mask >> 32));
-            }
-            ++L;
-            phase = kEnter;
-        }
-    };
-    auto leave = [&]() {  // the level is exhausted: back to the one above, behind the candidate it holds
-        if (L <= floor) phase = kDone;
-        else { --L; resume = true; phase = kEnter; }
-    };
-#ifdef TM_STATS
-    uint32_t my_steps = 0;  // [93] trips of the loop, [94] lanes at work in them, [95] chunk evaluations; [3 + b]: triples that took [2^(b-1), 2^b) trips
-#endif
-    for (;;) {
-        // ---- lanes without work take the next triples of the pool
-        const unsigned long long idle = ballot64(phase == kDone);
-        if (idle != 0ull) {
-            if (pool_next == pool_count && !exhausted && (idle == ~0ull || __popcll(idle) >= 24)) load_pool();
-            if (pool_next < pool_count) {
-                const uint32_t at = pool_next + rank_in(idle);
-                if (phase == kDone && at < pool_count) {
-#ifdef TM_STATS
-                    if (my_steps) atomicAdd(&g_stats[3 + min(20, 32 - __clz((int)my_steps))], 1ull);
-                    my_steps = 0;
-#endif
-                    const DeepEntry t = S.pool[at];
-                    ti = t.ti & kTiMask;
-                    G = (t.ti >> kTiGroupsShift) & 0xfu;
-                    k = t.ti >> kTiAtomsShift;
-                    a01 = t.a01; a2 = t.c;
-                    q0 = C.rec[a01 & 0xffffu]; q1 = C.rec[a01 >> 16]; q2 = C.rec[a2];
-                    if (!C.ignore_chain) {
-                        const uint4 *lvs = Q.levels + (size_t)ti * kMaxK;
-                        tc0 = lvl_tchain(lvs[0].w); tc1 = lvl_tchain(lvs[1].w); tc2 = lvl_tchain(lvs[2].w);
-                        qc0 = C.qchain[a01 & 0xffffu]; qc1 = C.qchain[a01 >> 16]; qc2 = C.qchain[a2];
-                    }
-                    L = 3u; floor = 3u; resume = false;
-                    phase = k > 3u ? (uint32_t)kEnter : (uint32_t)kComplete;
-                }
-                pool_next = min(pool_count, pool_next + (uint32_t)__popcll(idle));
-            } else if (idle == ~0ull && exhausted) break;
-        }
-#ifdef TM_STATS
-        {
-            const uint32_t n_busy = (uint32_t)__popcll(ballot64(phase != kDone));
-            TM_STAT(93, 1);
-            TM_STAT(94, n_busy);
-            if (phase != kDone) ++my_steps;
-        }
-#endif
-        const uint4 *levels = Q.levels + (size_t)ti * kMaxK;
-        const float2 *bounds = Q.bounds + (size_t)ti * kMaxPairs;
-        if (phase == kEnter) {
-            lv = levels[L];
-            if (L < G) {  // the lead of a further residue: its kind list, evaluated 64 entries at a time by the wave
-                lo = kl[lv.x];
-                end = kl[lv.x + 1u] - lo;
-                cur = 0u;
-                mask = 0ull;
-                if (resume) {
-                    cur = (uint32_t)S.lchunk[L - 3u][lane] << 6;
-                    const uint2 m = S.lmask[L - 3u][lane];
-                    mask = ((unsigned long long)m.y << 32) | m.x;
-                    mbase = cur - 64u;
-                }
-            } else {      // another atom of a residue whose lead is placed: the atoms of that target residue
-                const float2 *row = bounds + tri((int)L);
-                b0 = row[0]; b1 = row[1]; b2 = row[2];
-                const uint32_t ref = lvl_ref(lv.w);
-                const uint32_t rmeta = __float_as_uint(ref == 0u ? q0.w : ref == 1u ? q1.w : ref == 2u ? q2.w : C.rec[assigned(ref)].w);
-                const uint32_t res = meta_res(rmeta);
-                cur = C.res_start[res];
-                end = C.res_start[res + 1u];
-                if (resume) cur = (uint32_t)S.atom[L - 3u][lane] + 1u;
-            }
-            resume = false;
-            phase = kNext;
-        }
-        if (phase == kNext) {
-            if (L < G) {
-                if (mask != 0ull) {  // the next survivor of the evaluated chunk: it fits every placed lead already
-                    const uint32_t bit = (uint32_t)__ffsll((long long)mask) - 1u;
-                    mask &= mask - 1ull;
-                    cand = (uint32_t)C.pool_at(lo + mbase + bit);
-                    placed();
-                } else if (cur < end) phase = kEval;
-                else leave();
-            } else {
-                // the next atom of the residue that carries an admissible name and residue type and fits the triple's leads
-                const unsigned long long nm = ((unsigned long long)lv.y << 32) | lv.x;
-                const bool any = lvl_any(lv.w) != 0u;
-                bool found = false;
-                while (cur < end) {
-                    const uint32_t m = __float_as_uint(C.rec[cur].w);
-                    found = (((nm >> meta_name(m)) & 1ull) != 0ull) & (any | (((lv.z >> meta_rtype(m)) & 1u) != 0u));
-                    if (found) break;
-                    ++cur;
-                }
-                if (!found) leave();
-                else {
-                    cand = cur;
-                    rc = C.rec[cand];
-                    bool ok = in_window(rc, q0, b0) & in_window(rc, q1, b1) & in_window(rc, q2, b2) & (cand != (a01 & 0xffffu)) &
-                              (cand != (a01 >> 16)) & (cand != a2);
-                    if (!C.ignore_chain) {
-                        const uint32_t tcl = lvl_tchain(lv.w), qcc = C.qchain[cand];
-                        ok = ok & ((tc0 == tcl) == (qc0 == qcc)) & ((tc1 == tcl) == (qc1 == qcc)) & ((tc2 == tcl) == (qc2 == qcc));
-                    }
-                    if (!ok) ++cur;           // (stays in kNext)
-                    else if (L == 3u) placed();
-                    else { j = 3u; phase = kTest; }
-                }
-            }
-        }
-        if (phase == kTest) {  // the candidate against assigned level j >= 3
-            const uint32_t aj = S.atom[j - 3u][lane];
-            const float4 rj = C.rec[aj];
-            const float2 b = bounds[tri((int)L) + (int)j];
-            bool ok = in_window(rc, rj, b) & (cand != aj);
-            if (!C.ignore_chain) {
-                const bool tc = lvl_tchain(levels[j].w) == lvl_tchain(lv.w);
-                ok = ok & (tc == (C.qchain[aj] == C.qchain[cand]));
-            }
-            if (!ok) { ++cur; phase = kNext; }
-            else if (++j == L) placed();  // it fits every assigned level
-        }
-        // ---- a chunk of a lead level's kind list: lanes = candidates, tested against every assigned level (all of them
-        // leads of other residues), one requesting lane at a time
-        unsigned long long todo = ballot64(phase == kEval);
-        if (todo) {
-            wave_sync();  // (the stacks are read across lanes)
-            do {
-                const int b = __ffsll((long long)todo) - 1;
-                todo &= todo - 1ull;
-                TM_STAT(95, 1);
-                const uint32_t ti_b = RL(ti, b), L_b = RL(L, b), lo_b = RL(lo, b), chunk_b = RL(cur, b), cnt_b = RL(end, b),
-                               a01_b = RL(a01, b), a2_b = RL(a2, b);
-                // lane j < L: the atom assigned to level j, its record and the window (L, j)
-                uint32_t aj = lane == 0u ? a01_b & 0xffffu : lane == 1u ? a01_b >> 16 : a2_b;
-                if (lane >= 3u && lane < L_b) aj = S.atom[lane - 3u][b];
-                const float4 rj = C.rec[aj];
-                float2 brow = make_float2(0.f, 0.f);
-                if (lane < L_b) brow = Q.bounds[(size_t)ti_b * kMaxPairs + tri((int)L_b) + lane];
-                uint32_t tcj = 0, qcj = 0, mychain = 0;
-                if (!C.ignore_chain) {
-                    tcj = lvl_tchain(Q.levels[(size_t)ti_b * kMaxK + min(lane, (uint32_t)kMaxK - 1u)].w);
-                    qcj = C.qchain[aj];
-                    mychain = RL(tcj, (int)L_b);
-                }
-                const uint32_t idx = chunk_b + lane;
-                bool ok = idx < cnt_b;
-                const uint32_t cnd = (uint32_t)C.pool_at(lo_b + min(idx, cnt_b - 1u));
-                const float4 r = C.rec[cnd];
-                const uint32_t cres = meta_res(__float_as_uint(r.w));
-                uint32_t cchain = 0;
-                if (!C.ignore_chain) cchain = C.qchain[cnd];
-                unsigned long long alive = ballot64(ok);
-                for (uint32_t jj = 0; jj < L_b && alive; ++jj) {
-                    const float dx = r.x - RLf(rj.x, (int)jj), dy = r.y - RLf(rj.y, (int)jj), dz = r.z - RLf(rj.z, (int)jj);
-                    const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-                    ok = ok & (d2 >= RLf(brow.x, (int)jj)) & (d2 <= RLf(brow.y, (int)jj)) &
-                         (meta_res(RL(__float_as_uint(rj.w), (int)jj)) != cres) & (cnd != RL(aj, (int)jj));
-                    if (!C.ignore_chain) ok = ok & ((RL(tcj, (int)jj) == mychain) == (RL(qcj, (int)jj) == cchain));
-                    alive = ballot64(ok);
-                }
-                // Several candidates and lanes with nothing to do (and nothing left in the pool): all candidates but the
-                // first go to such lanes, one each.  A receiver copies the stack of lane b down to level L - 1, places its
-                // candidate at level L and searches below it only.
-                const unsigned long long free_lanes = pool_next == pool_count ? ballot64(phase == kDone) : 0ull;
-                const uint32_t n_alive = (uint32_t)__popcll(alive);
-                if (n_alive > 1u && free_lanes != 0ull && L_b + 1u < RL(k, b)) {
-                    const uint32_t n_give = min(n_alive - 1u, (uint32_t)__popcll(free_lanes));
-                    const uint32_t ord = rank_in(alive);  // (of a candidate lane)
-                    const bool given = ok && ord >= 1u && ord <= n_give;
-                    if (given) S.give[ord - 1u] = (uint16_t)cnd;
-                    alive &= ~ballot64(given);
-                    wave_sync();
-                    const bool takes = phase == kDone && ((free_lanes >> lane) & 1ull) != 0ull && rank_in(free_lanes) < n_give;
-                    const uint32_t k_b = RL(k, b), G_b = RL(G, b);
-                    const float4 q0_b = make_float4(RLf(q0.x, b), RLf(q0.y, b), RLf(q0.z, b), RLf(q0.w, b)),
-                                 q1_b = make_float4(RLf(q1.x, b), RLf(q1.y, b), RLf(q1.z, b), RLf(q1.w, b)),
-                                 q2_b = make_float4(RLf(q2.x, b), RLf(q2.y, b), RLf(q2.z, b), RLf(q2.w, b));
-                    const uint32_t tc0_b = RL(tc0, b), tc1_b = RL(tc1, b), tc2_b = RL(tc2, b), qc0_b = RL(qc0, b), qc1_b = RL(qc1, b), qc2_b = RL(qc2, b);
-                    for (uint32_t lvl = 3u; lvl < L_b; ++lvl) {
-                        const uint16_t v = S.atom[lvl - 3u][b];
-                        if (takes) S.atom[lvl - 3u][lane] = v;
-                    }
-                    if (takes) {
-#ifdef TM_STATS
-                        if (my_steps) atomicAdd(&g_stats[3 + min(20, 32 - __clz((int)my_steps))], 1ull);
-                        my_steps = 0;
-#endif
-                        ti = ti_b; a01 = a01_b; a2 = a2_b; k = k_b; G = G_b;
-                        q0 = q0_b; q1 = q1_b; q2 = q2_b;
-                        tc0 = tc0_b; tc1 = tc1_b; tc2 = tc2_b; qc0 = qc0_b; qc1 = qc1_b; qc2 = qc2_b;
-                        L = L_b; floor = L_b + 1u; resume = false;
-                        mask = 0ull; cur = 0u; end = 0u;
-                        cand = S.give[rank_in(free_lanes)];
-                        S.atom[L - 3u][lane] = (uint16_t)cand;
-                        ++L;             // (L_b + 1 < k: there is a level below)
-                        phase = kEnter;
-                    }
-                    wave_sync();
-                }
-                if (lane == (uint32_t)b) {
-                    mask = alive;
-                    mbase = cur;
-                    cur += 64u;
-                    phase = kNext;
-                }
-            } while (todo);
-        }
-        // ---- complete assignments: one at a time, by the whole wave
-        todo = ballot64(phase == kComplete);
-        if (todo) {
-            wave_sync();
-            do {
-                const int b = __ffsll((long long)todo) - 1;
-                todo &= todo - 1ull;
-                const bool more = lane_complete(C, A, s, b, ti, a01, a2, k);
-                if (lane == (uint32_t)b) {
-                    // cut short by max_candidates, or nothing left to vary below the lane's floor: done
-                    if (!more || k <= 3u || L < floor) phase = kDone;
-                    else {
-                        if (L >= G) ++cur;  // (a lead level goes on with what is left of its mask)
-                        phase = kNext;
-                    }
-                }
-            } while (todo);
-        }
-    }
-#ifdef TM_STATS
-    if (my_steps) atomicAdd(&g_stats[3 + min(20, 32 - __clz((int)my_steps))], 1ull);
-#endif
-    slab_release(C);
-}
-
 // All three launch modes (kModeBlocks, kModeSingly, kModeDeep) stage the structure of their work item in LDS the same way.
 template <bool kLds, bool kIgnoreChain, int kMode>
 #ifdef TM_SEARCH_MIN_WAVES
@@ -2783,7 +2376,7 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
     // [WaveScratchT<kMode> x kSearchWaves][rec float4 x max_atoms][res_start u16 x (max_res+1)]
     // [kind-list offsets u32 x (n_lead+1)][kind-list pool u16 x pool_cap]
     WaveScratchT<kMode> *scratch = reinterpret_cast<WaveScratchT<kMode> *>(smem);
-    float4 *s_rec = reinterpret_cast<float4 *>(smem + sizeof(WaveScratchT<kMode>) * waves_of<kMode>());
+    float4 *s_rec = reinterpret_cast<float4 *>(smem + sizeof(WaveScratchT<kMode>) * kSearchWaves);
     uint16_t *s_res = reinterpret_cast<uint16_t *>(s_rec + (kLds ? max_atoms : 0));
     uint32_t *s_kl = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(s_res) +
                                                   (kLds ? search_res_bytes(max_res) : 0));
@@ -2816,13 +2409,12 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
 
     if (B.tab_ok[s] != 1u) return;  // pair tables incomplete (pool overflow, reported with the result): nothing to search
     uint32_t n_listed = 0;
-    if (kMode == kModeDeep || kMode == kModeLanes) {  // pages of triples the block search left for this structure (its share of the directory)
+    if (kMode == kModeDeep) {  // pages of triples the block search left for this structure (its share of the directory)
         n_listed = min(A.O.dir_n[s], A.O.dir_off[s + 1] - A.O.dir_off[s]);
         if (n_listed == 0u) return;
         // a structure with few triples is not worth all its workgroups (each stages the structure in LDS and queues at the
-        // structure's counter): as many take part as there are 8 triples per wave for -- or, lane = triple, a page per wave
-        if (kMode == kModeDeep && (unsigned long long)chunk * (kDeepShare * kSearchWaves) >= A.O.dir_triples[s]) return;
-        if (kMode == kModeLanes && chunk * (uint32_t)(2 * kLaneWaves) >= n_listed) return;
+        // structure's counter): as many take part as there are 8 triples per wave for
+        if ((unsigned long long)chunk * (kDeepShare * kSearchWaves) >= A.O.dir_triples[s]) return;
     }
     const uint32_t a0 = B.s_off[s], n = B.s_off[s + 1] - a0;
     const uint32_t r0 = B.s_roff[s], nres1 = B.s_roff[s + 1] - r0;  // n_res + 1 entries
@@ -2915,9 +2507,6 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
         }
         if (pool_in_lds) deep_templates<kLds, kIgnoreChain, true>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, s, a0, r0, n_listed, cache, s_run, n_compact);
         else deep_templates<kLds, kIgnoreChain, false>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, s, a0, r0, n_listed, cache, s_run, n_compact);
-    } else if constexpr (kMode == kModeLanes) {
-        if (pool_in_lds) deep_lanes<kLds, kIgnoreChain, true>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, s, a0, r0, n_listed);
-        else deep_lanes<kLds, kIgnoreChain, false>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, s, a0, r0, n_listed);
     } else {
         if (pool_in_lds)
             search_templates<kLds, kIgnoreChain, true, kSingly>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, &s_next, s, a0, r0, chunk, n_chunks);
@@ -2946,16 +2535,14 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
 TM_INSTANTIATE(kModeBlocks)
 TM_INSTANTIATE(kModeSingly)
 TM_INSTANTIATE(kModeDeep)
-TM_INSTANTIATE(kModeLanes)
 #undef TM_INSTANTIATE
 
-uint32_t search_threads(int mode) { return 64u * (uint32_t)(mode == kModeLanes ? kLaneWaves : kSearchWaves); }
 size_t search_cache_bytes() { return sizeof(ResCache) * kSearchWaves; }
 // LDS a launch mode declares statically, beyond the few words every mode has (k_deep's run list)
 size_t search_static_bytes(int mode) { return mode == kModeDeep ? (kRunLds + 2 * kSearchWaves) * sizeof(uint32_t) : 0; }
 size_t search_scratch_bytes(int mode) {
-    return (mode == kModeBlocks ? sizeof(WaveScratchT<kModeBlocks>) * kSearchWaves : mode == kModeSingly ? sizeof(WaveScratchT<kModeSingly>) * kSearchWaves
-            : mode == kModeDeep ? sizeof(WaveScratchT<kModeDeep>) * kSearchWaves : sizeof(WaveScratchT<kModeLanes>) * kLaneWaves);
+    return (mode == kModeBlocks ? sizeof(WaveScratchT<kModeBlocks>) : mode == kModeSingly ? sizeof(WaveScratchT<kModeSingly>)
+                                                                                         : sizeof(WaveScratchT<kModeDeep>)) * kSearchWaves;
 }
 
 // ------------------------------------------------------------------ superposition (fp64)

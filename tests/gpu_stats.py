@@ -59,7 +59,3 @@ for label, extra in (("full", 0), ("no k_deep work", 0x800), ("stage A only", 0x
         times.append(res.timing()[1])
         res.close()
     print("k_search ms (%s): %.3f" % (label, min(times)))
-if s[93]:
-    print("lane search: %d trips, %.1f lanes at work per trip, %d chunk evaluations, %.1f trips per paged triple (mean over lanes)" %
-          (s[93], s[94] / s[93], s[95], s[94] / paged))
-    print("triples by trips taken (<1, <2, <4, ...):", [int(v) for v in s[3:24]])
