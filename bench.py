@@ -262,7 +262,11 @@ def untimed_extras(args, device, templates, idx, cut, molecules, search, flags):
                     found.setdefault(mi, []).extend(hits)
         return found
 
-    reference_pattern(mols[:threads])  # warm: libraries of the six buckets built, selections staged
+    # warm: the libraries of the six buckets packed and their selections staged (first sweep), the library over all six the
+    # sweep planner searches once the buckets are known (pyjess._Sweeps) built and staged (second sweep, other molecules)
+    spare = molecules[len(mols):]
+    for warm in (spare[:threads], spare[threads:2 * threads]) if len(spare) >= 2 * threads else (mols[:threads], mols[:threads]):
+        reference_pattern(warm)
     t0 = time.perf_counter()
     found = reference_pattern(mols)
     dt = time.perf_counter() - t0

@@ -54,6 +54,19 @@ struct PhaseTrace {
 // Host threads one native call may use: ENZYMM_AMD_HOST_THREADS, else the smallest of the hardware threads, the
 // affinity mask, the container's CPU quota (cgroup v2 cpu.max; a box that shows 256 CPUs may grant 16) and 16.
 // More threads than the quota grants are throttled in bursts, which shows as run-to-run variance.
+// Atoms a host thread of a batch-creation team takes at least (ENZYMM_AMD_HOST_GRAIN; 4 Ki, 8 Ki and 64 Ki measured alike on
+// batches of sixteen molecules: a thread costs as much to start as its share saves).
+uint32_t host_grain() {
+    static const uint32_t grain = [] {
+        if (const char *e = std::getenv("ENZYMM_AMD_HOST_GRAIN")) {
+            const long v = std::strtol(e, nullptr, 10);
+            if (v >= 256) return (uint32_t)v;
+        }
+        return 65536u;
+    }();
+    return grain;
+}
+
 uint32_t host_team() {
     static const uint32_t team = [] {
         if (const char *e = std::getenv("ENZYMM_AMD_HOST_THREADS")) {
@@ -815,7 +828,7 @@ int batch_from_encoded(int device, const tm_batch_desc *d, const double *const *
         while (seen < bits && !extent_bits.compare_exchange_weak(seen, bits)) {}
     };
     {
-        const uint32_t team = std::min<uint32_t>(host_team(), std::max(1u, na / 65536u));  // ~64 k atoms per thread at least
+        const uint32_t team = std::min<uint32_t>(host_team(), std::max(1u, na / host_grain()));
         if (team <= 1) {
             flatten(0, ns);
         } else {
@@ -984,7 +997,7 @@ int batch_from_structures(int device, uint32_t ns, const tm_structure_columns *s
         }
     };
     {
-        const uint32_t team = std::min<uint32_t>(host_team(), std::max(1u, na / 65536u));
+        const uint32_t team = std::min<uint32_t>(host_team(), std::max(1u, na / host_grain()));
         if (team <= 1) {
             encode(0, ns);
         } else {

@@ -31,6 +31,7 @@ import io
 import math
 import os
 import threading
+import time
 from typing import Iterable, Iterator, List, Optional, Sequence
 
 import numpy as np
@@ -45,9 +46,15 @@ __all__ = ["Atom", "Molecule", "TemplateAtom", "Template", "Jess", "Query", "Hit
 _UNLIMITED = 0xFFFFFFFF
 
 
+_default_device = None  # (read once: Jess objects are built per query in the reference's loop)
+
+
 def default_device() -> int:
-    """GPU ordinal used by this process: $ENZYMM_AMD_DEVICE, else $LOCAL_RANK, else 0."""
-    return int(os.environ.get("ENZYMM_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    """GPU ordinal used by this process: $ENZYMM_AMD_DEVICE, else $LOCAL_RANK, else 0 (as they stand at the first use)."""
+    global _default_device
+    if _default_device is None:
+        _default_device = int(os.environ.get("ENZYMM_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    return _default_device
 
 
 # ---------------------------------------------------------------------------------- Atom
@@ -584,6 +591,7 @@ class _PackedLibrary:
             tables = templates.device_tables(VOCAB)
             self.vocab_version = VOCAB.version
             self.offsets = np.ascontiguousarray(tables[0], dtype=np.uint32)
+            self.tables = tuple(tables[:9])
             self.native = _native.Library(device, *tables[:8], orientation=tables[8])
             self.device = device
             return
@@ -620,9 +628,44 @@ class _PackedLibrary:
                 chain[i] = chains.setdefault(a.chain_id, len(chains))
                 i += 1
             self.offsets[ti + 1] = i
+        orientation = self._orientation_table(templates)
+        # (the host tables are kept: a library over several template lists is put together from theirs, `concat`)
+        self.tables = (self.offsets, xyz, weight, res_mask, name_mask, any_res, group, chain, orientation)
         self.native = _native.Library(device, self.offsets, xyz, weight, res_mask, name_mask, any_res, group, chain,
-                                      orientation=self._orientation_table(templates))
+                                      orientation=orientation)
         self.device = device
+
+    @classmethod
+    def concat(cls, parts: Sequence["_PackedLibrary"], device: int) -> "_PackedLibrary":
+        """One device library holding the templates of several packed lists, one list after the other: the per-atom
+        tables are concatenated (no walk over Template objects).  The parts must have been packed under the current
+        vocabulary and agree on whether they carry residue-orientation tables."""
+        self = cls.__new__(cls)
+        self.vocab_version = VOCAB.version
+        if any(p.vocab_version != VOCAB.version for p in parts):
+            raise ValueError("parts packed under another state of the vocabulary")
+        with_orientation = [p.tables[8] is not None for p in parts]
+        if any(with_orientation) and not all(with_orientation):
+            raise ValueError("only some of the parts carry orientation tables")
+        offs, shift = [np.zeros(1, dtype=np.uint32)], 0
+        for p in parts:
+            o = np.asarray(p.tables[0], dtype=np.uint32)
+            offs.append(o[1:] + np.uint32(shift))
+            shift += int(o[-1])
+        self.offsets = np.concatenate(offs)
+        cols = [np.concatenate([np.asarray(p.tables[c]) for p in parts]) for c in range(1, 8)]
+        orientation = None
+        if all(with_orientation) and parts:
+            ro, rshift = [np.zeros(1, dtype=np.uint32)], 0
+            for p in parts:
+                o = np.asarray(p.tables[8][0], dtype=np.uint32)
+                ro.append(o[1:] + np.uint32(rshift))
+                rshift += int(o[-1])
+            orientation = (np.concatenate(ro),) + tuple(np.concatenate([np.asarray(p.tables[8][c]) for p in parts]) for c in (1, 2, 3))
+        self.tables = (self.offsets, *cols, orientation)
+        self.native = _native.Library(device, self.offsets, *cols, orientation=orientation)
+        self.device = device
+        return self
 
 
     @staticmethod
@@ -708,7 +751,7 @@ class _SingleBatches:
                     return None, None  # on loan
                 e[2] = True
                 self._entries.move_to_end(key)
-                return e[1], lambda: self._give_back(key)
+                return e[1], lambda e=e: self._give_back(e)
         batch = make_batch([molecule], device)
         with self._lock:
             if key in self._entries:  # another thread was faster: this one stays private
@@ -717,25 +760,28 @@ class _SingleBatches:
                 ref = weakref.ref(molecule)
             except TypeError:
                 return batch, None
-            self._entries[key] = [ref, batch, True, len(molecule)]
+            e = self._entries[key] = [ref, batch, True, len(molecule), False]
             self._atoms += len(molecule)
             while self._atoms > self.BUDGET_ATOMS and len(self._entries) > 1:
                 oldest = next(iter(self._entries))
                 if self._entries[oldest][2]:
                     break
                 self._drop(oldest)
-        return batch, lambda: self._give_back(key)
+        return batch, lambda e=e: self._give_back(e)
 
-    def _give_back(self, key):
+    def _give_back(self, e):
+        """The borrower of entry ``e`` (that very list, not whatever sits under its key by now) is done with it."""
         with self._lock:
-            e = self._entries.get(key)
-            if e is not None:
-                e[2] = False
+            e[2] = False
+            if e[4]:  # dropped while on loan: closed now
+                e[1].close()
 
     def _drop(self, key):
         e = self._entries.pop(key)
         self._atoms -= e[3]
-        if not e[2]:
+        if e[2]:
+            e[4] = True  # on loan: its borrower closes it when it hands it back
+        else:
             e[1].close()
 
 
@@ -901,7 +947,8 @@ def register_vocabulary(templates) -> None:
                 pass
 
 
-_jess_cache: "dict[tuple, tuple]" = {}  # (id(template list), device) -> (tuple of its templates, _PackedLibrary or None, the list)
+_jess_cache: "dict[tuple, tuple]" = {}  # (id(template list), device) -> (tuple of its templates, _PackedLibrary or None, the list, a copy of the list)
+_jess_cache_lock = threading.Lock()
 _thread_streams = threading.local()
 _OWN_STREAM = -1  # query_batch(stream=...): "the calling thread's own stream" (resolved only when something is launched)
 
@@ -928,7 +975,10 @@ def _shutdown():
     with _single_batches._lock:
         for e in _single_batches._entries.values():
             try:
-                e[1].close()
+                if e[2]:
+                    e[4] = True  # a query is still using it: closed when it is handed back
+                else:
+                    e[1].close()
             except Exception:
                 pass
         _single_batches._entries.clear()
@@ -947,6 +997,7 @@ def _shutdown():
                 pass
         _pack_cache.clear()
     _jess_cache.clear()
+    _sweeps.clear()
 
 
 import atexit  # noqa: E402
@@ -960,38 +1011,86 @@ class _QueryCombiner:
     one of the waiting threads takes everything queued as ONE query_batch call and hands the others their hits."""
 
     class _Request:
-        __slots__ = ("molecule", "event", "hits", "error", "promoted")
+        __slots__ = ("molecule", "event", "hits", "error", "promoted", "rows", "leading")
 
         def __init__(self, molecule):
             self.molecule, self.event = molecule, threading.Event()
-            self.hits, self.error, self.promoted = None, None, False
+            self.hits, self.error, self.promoted, self.rows, self.leading = None, None, False, None, False
 
     MAX_BATCH = 64
+    MAX_LEADERS = int(os.environ.get("ENZYMM_AMD_LEADERS", "1"))  # launches of one key in flight at a time
+    PEER_WINDOW_S = 0.05   # a thread that called this recently is expected to call again (a pool mapping over molecules)
+    FILL_WAIT_S = 1e-6 * float(os.environ.get("ENZYMM_AMD_FILL_WAIT_US", "400"))  # how long a leader waits for those threads to queue up
 
     def __init__(self, templates):
         self._templates = templates  # kept alive: the combiner is found by id(templates), which must not be reused
         self._lock = threading.Lock()
+        self._filled = threading.Condition(self._lock)
         self._queue: list = []
-        self._busy = False
+        self._leaders = 0
+        self._peers: dict = {}  # thread ident -> when it last called
 
-    def run(self, jess, molecule, thresholds, options):
+    def _pass_on(self):
+        """(under the lock) A leader is done: whoever waits first in the queue takes its place, else the place is free."""
+        for nxt in self._queue:
+            if not nxt.promoted and not nxt.leading:  # (a leader's own request waits in the queue, too)
+                nxt.promoted = True
+                nxt.event.set()
+                return
+        self._leaders -= 1
+
+    def run(self, jess, molecule, thresholds, options, execute=None):
+        """``execute(batch)`` serves a list of requests (sets ``hits`` on each); the default searches their molecules as
+        one ``jess.query_batch`` call."""
         req = self._Request(molecule)
         with self._lock:
+            self._peers[threading.get_ident()] = time.monotonic()
             self._queue.append(req)
-            lead = not self._busy
+            lead = req.leading = self._leaders < self.MAX_LEADERS
             if lead:
-                self._busy = True
-        if not lead:
-            req.event.wait()
-            lead = req.promoted  # the thread that just finished a batch handed the GPU to this one
-        while lead:
+                self._leaders += 1
+            else:
+                self._filled.notify_all()
+        while True:
+            if not lead:
+                req.event.wait()
+                with self._lock:
+                    served = req.hits is not None or req.error is not None
+                    req.event.clear()
+                    if req.promoted:  # a thread that finished a batch handed its place as a leader to this one
+                        req.promoted = False
+                        if served:    # ... which the other leader has served meanwhile: the place goes on
+                            self._pass_on()
+                            break
+                        lead = req.leading = True
+                    elif served:
+                        break
+                    else:
+                        continue
             with self._lock:
+                # The threads of a pool come back for their next molecule within a few hundred microseconds of each other:
+                # a leader that launched at once would search ONE molecule while the others queue up behind it.  It waits --
+                # bounded -- until its share of the threads that have been calling lately is queued (two leaders: while one
+                # batch is on the GPU the other is being put together and uploaded).
+                now = time.monotonic()
+                if len(self._peers) > 1:
+                    for ident in [i for i, t in self._peers.items() if now - t > self.PEER_WINDOW_S]:
+                        del self._peers[ident]
+                    target = min(self.MAX_BATCH, -(-len(self._peers) // self.MAX_LEADERS))
+                    deadline = now + self.FILL_WAIT_S
+                    while len(self._queue) < target:
+                        left = deadline - time.monotonic()
+                        if left <= 0 or not self._filled.wait(left):
+                            break
                 batch, self._queue = self._queue[:self.MAX_BATCH], self._queue[self.MAX_BATCH:]
             if batch:
                 try:
-                    per_molecule = jess.query_batch([r.molecule for r in batch], *thresholds, stream=_OWN_STREAM, **options)
-                    for r, hits in zip(batch, per_molecule):
-                        r.hits = hits
+                    if execute is not None:
+                        execute(batch)
+                    else:
+                        per_molecule = jess.query_batch([r.molecule for r in batch], *thresholds, stream=_OWN_STREAM, **options)
+                        for r, hits in zip(batch, per_molecule):
+                            r.hits = hits
                 except BaseException as exc:  # every caller of the batch sees the failure
                     for r in batch:
                         r.error = exc
@@ -999,15 +1098,12 @@ class _QueryCombiner:
                     if r is not req:
                         r.event.set()
             with self._lock:
-                if req.hits is None and req.error is None:
-                    continue  # (own request not served yet: cannot happen with FIFO batches, kept for safety)
-                if self._queue:  # someone is waiting: it becomes the next leader, this thread returns
-                    nxt = self._queue[0]
-                    nxt.promoted = True
-                    nxt.event.set()
-                else:
-                    self._busy = False
+                req.leading = False
+                self._pass_on()
                 lead = False
+                if req.hits is not None or req.error is not None:
+                    break
+            # (the request went into the other leader's batch: wait for that one)
         if req.error is not None:
             raise req.error
         return req.hits
@@ -1024,12 +1120,325 @@ def _combiner(key, templates) -> _QueryCombiner:
             c = _combiners[key] = _QueryCombiner(templates)
             while len(_combiners) > 64:
                 old_key, old = next(iter(_combiners.items()))
-                if old._busy or old._queue:
+                if old._leaders or old._queue:
                     break
                 _combiners.pop(old_key)
         else:
             _combiners.move_to_end(key)
         return c
+
+
+def _search_raw(jess, molecules, thresholds, options, trace=None):
+    """The raw hit table of ``molecules`` against ``jess``'s templates: the one place where the sweep planner meets the
+    engine (tests put a recorder here)."""
+    t0 = time.perf_counter()
+    batch = make_batch(molecules, jess._device) if len(molecules) > 1 else None  # (one molecule: its kept device copy)
+    t1 = time.perf_counter()
+    try:
+        pending = jess.query_batch(molecules, *thresholds, return_raw=True, stream=_OWN_STREAM, batch=batch, _async=True, **options)
+        t2 = time.perf_counter()
+        table = pending.result()
+    finally:
+        if batch is not None:
+            batch.close()
+    if trace is not None:
+        trace[:] = [(t1 - t0) * 1e3, (t2 - t1) * 1e3, (time.perf_counter() - t2) * 1e3]
+    return table
+
+
+class _Sweeps:
+    """enzymm's ``Matcher.run`` asks ``Jess(templates of size k).query(molecule)`` for every molecule, one size bucket after
+    the other, from a thread pool (/root/reference/enzymm/jess_run.py:896-988 around :785-843): 6 x N small queries, each
+    a launch chain of its own however the concurrent ones are merged.  A query is a pure function of (templates,
+    thresholds, options, molecule) and all four are immutable, so the answer may be computed BEFORE it is asked for.
+    This planner sits between ``Jess.query`` and the launch and recognises the sweep:
+
+    * molecules ahead: once a (templates, thresholds, options) combination -- a *key* -- has been asked for two
+      molecules, a launch for that key also searches every recently queried molecule the key has not been asked for
+      yet (the molecules of the previous bucket, in the reference's loop);
+    * buckets ahead: a launch also searches, for its molecules, the other keys seen recently with the same options
+      that those molecules have not been asked with -- through ONE device library put together from the keys' packed
+      tables (``_PackedLibrary.concat``), so a molecule's candidate index and pair tables are built once for all
+      buckets instead of once per bucket.
+
+    Results that were not asked for wait in a table keyed by (key, molecule) and are handed out -- as the same ``Hit``
+    lists a direct query builds -- when the call arrives; they expire after ``WINDOW_S``.  What is computed ahead is
+    bounded per launch (``MAX_MOLECULES``, ``MAX_ATOMS``); a lone query stays a lone query.  ``ENZYMM_AMD_SWEEP=0``
+    switches the planner off (every call is then searched when it is made, merged only with concurrent calls)."""
+
+    WINDOW_S = 120.0
+    MAX_MOLECULES = 1024
+    MAX_ATOMS = 8_000_000
+    MAX_RESULTS = 1 << 17
+    MAX_UNIONS = 4
+
+    class _Key:
+        __slots__ = ("key", "jess", "templates", "thresholds", "options", "device", "last_seen", "asked", "planned", "sel", "requests", "_pack")
+
+        def pack(self):
+            """The packed tables of the key's templates (looked up once: the key of that cache is a tuple of 6780 ids)."""
+            p = self._pack
+            if p is None or p.vocab_version != VOCAB.version:
+                p = self._pack = _packed(self.templates, self.device)
+            return p
+
+        def hits(self, rows, molecule):
+            if len(rows) == 0:
+                return []
+            return self.jess._hits_from_table(rows, self.sel, [molecule])[0]
+
+    def __init__(self):
+        self.enabled = os.environ.get("ENZYMM_AMD_SWEEP", "1") != "0"
+        self._lock = threading.Lock()
+        self._keys: "collections.OrderedDict[tuple, _Sweeps._Key]" = collections.OrderedDict()
+        self._molecules: "collections.OrderedDict[int, list]" = collections.OrderedDict()  # id -> [weakref, device, last seen]
+        self._results: "collections.OrderedDict[tuple, tuple]" = collections.OrderedDict()  # (key, id) -> (weakref, rows, when)
+        self._unions: "collections.OrderedDict[tuple, tuple]" = collections.OrderedDict()
+        self._inflight: dict = {}  # (key, id(molecule)) -> Event set when the launch computing it ahead has stored its results
+        self.launches = []  # (molecules, keys) of the last launches: what tests and traces look at
+
+    # -- bookkeeping (under the lock) -----------------------------------------------------------------------------
+    def _touch_key(self, jess, key, thresholds, options, now):
+        info = self._keys.get(key)
+        if info is None:
+            info = self._keys[key] = self._Key()
+            info.key, info.jess, info.templates = key, jess, jess._templates
+            info.thresholds, info.options, info.device = thresholds, options, jess._device
+            info.asked, info.planned, info.requests, info._pack = {}, {}, 0, None
+            info.sel = np.arange(len(jess._templates), dtype=np.uint32)
+            while len(self._keys) > 64:
+                self._keys.popitem(last=False)
+        info.last_seen = now
+        return info
+
+    def _touch_molecule(self, molecule, device, now):
+        import weakref
+        mid = id(molecule)
+        ent = self._molecules.get(mid)
+        if ent is not None:
+            if ent[0]() is molecule:
+                ent[2] = now
+                return
+            for k in self._keys.values():  # another object at that address now: what was noted for the old one is void
+                k.asked.pop(mid, None)
+                k.planned.pop(mid, None)
+                self._results.pop((k.key, mid), None)
+        try:
+            self._molecules[mid] = [weakref.ref(molecule), device, now]
+        except TypeError:
+            return
+        while len(self._molecules) > 4 * self.MAX_MOLECULES:
+            self._molecules.popitem(last=False)
+
+    def _expire(self, now):
+        while self._results:
+            k, ent = next(iter(self._results.items()))
+            if now - ent[2] <= self.WINDOW_S and len(self._results) <= self.MAX_RESULTS:
+                break
+            self._results.popitem(last=False)
+
+    def _take(self, key, molecule):
+        ent = self._results.pop((key, id(molecule)), None)
+        if ent is None or ent[0]() is not molecule:
+            return None
+        return ent[1]
+
+    # -- the two entry points ---------------------------------------------------------------------------------------
+    def lookup(self, jess, key, thresholds, options, molecule):
+        """The hits of a query whose answer was computed ahead, or None."""
+        now = time.monotonic()
+        with self._lock:
+            rows = self._take(key, molecule)
+            if rows is None:
+                return None
+            info = self._touch_key(jess, key, thresholds, options, now)
+            info.asked[id(molecule)] = now
+            info.requests += 1
+            self._touch_molecule(molecule, info.device, now)
+        return info.hits(rows, molecule)
+
+    def execute(self, jess, key, thresholds, options, requests):
+        """Serves the requests (objects with ``molecule`` and ``hits``) of one key: from the table of results computed
+        ahead where it can -- waiting for those a launch of another thread is computing right now --, by ONE launch
+        otherwise, which also computes ahead what the sweep will ask next."""
+        pending, first = list(requests), True
+        while pending:
+            now = time.monotonic()
+            todo, waiting = [], []
+            with self._lock:
+                info = self._touch_key(jess, key, thresholds, options, now)
+                if first:
+                    self._expire(now)
+                for r in pending:
+                    mid = id(r.molecule)
+                    if first:
+                        self._touch_molecule(r.molecule, info.device, now)
+                    rows = self._take(key, r.molecule)
+                    if rows is not None:
+                        r.hits = info.hits(rows, r.molecule)
+                    elif (key, mid) in self._inflight:
+                        waiting.append((r, self._inflight[(key, mid)]))
+                    else:
+                        todo.append(r)
+                    info.asked[mid] = now
+                if first:
+                    info.requests += len(pending)
+                    if len(info.asked) + len(info.planned) > 1 << 16:
+                        info.asked = {m: t for m, t in info.asked.items() if now - t <= self.WINDOW_S}
+                        info.planned = {m: t for m, t in info.planned.items() if now - t <= self.WINDOW_S}
+                extra, parts, flight = [], [info], None
+                if todo and self.enabled:
+                    extra, parts, flight = self._plan(info, todo, now)
+            if todo:
+                molecules = [r.molecule for r in todo] + extra
+                try:
+                    try:
+                        self._launch(jess, info, thresholds, todo, molecules, parts)
+                    except (_native.NativeError, ValueError):
+                        if len(parts) == 1:
+                            raise
+                        self._launch(jess, info, thresholds, todo, molecules, [info])  # (a library over all the keys the engine refuses)
+                finally:
+                    if flight is not None:
+                        self._landed(flight)
+            for _, event in waiting:
+                event.wait(120.0)
+            pending, first = [r for r, _ in waiting], False
+
+    def _landed(self, flight):
+        """The launch that was computing the pairs of ``flight`` ahead has stored them (or failed): whoever waits may look."""
+        with self._lock:
+            for pair in flight[1]:
+                self._inflight.pop(pair, None)
+        flight[0].set()
+
+    def _launch(self, jess, info, thresholds, todo, molecules, parts):
+        """One search of ``molecules`` with the keys ``parts`` (one library over all of them when there are several); the
+        first ``len(todo)`` molecules are the ones asked for with ``info``'s key, everything else is kept for later."""
+        t_launch = time.perf_counter()
+        trace = [0.0, 0.0, 0.0]  # ms: device copy of the molecules, launch, wait + hit table
+        table = offsets = None
+        options = parts[0].options
+        if len(parts) > 1:
+            ujess, offsets, thr = self._union(parts)
+            table = _search_raw(ujess, molecules, thr, options, trace)
+        else:
+            table = _search_raw(parts[0].jess if jess is None else jess, molecules, parts[0].thresholds if thresholds is None else thresholds,
+                                options, trace)
+        self.launches.append((len(molecules), len(todo), tuple(k.key for k in parts), time.perf_counter() - t_launch, tuple(trace)))
+        del self.launches[:-64]
+        # rows of (molecule, key), as tables of that key's own query of that one molecule
+        nk, nm = len(parts), len(molecules)
+        tsel = table["template_sel"].astype(np.int64)
+        kidx = np.searchsorted(offsets[1:], tsel, side="right") if offsets is not None else np.zeros(len(table), dtype=np.int64)
+        group = table["structure"].astype(np.int64) * nk + kidx
+        if len(group) > 1 and np.any(group[1:] < group[:-1]):  # (the engine sorts by structure, template)
+            order = np.argsort(group, kind="stable")
+            table, group, tsel, kidx = table[order], group[order], tsel[order], kidx[order]
+        table["template_sel"] = tsel - (offsets[kidx] if offsets is not None else 0)
+        table["structure"] = 0
+        bounds = np.searchsorted(group, np.arange(nm * nk + 1)).tolist()
+        own = parts.index(info) if info is not None else -1
+        import weakref
+        now = time.monotonic()
+        with self._lock:
+            for mi, m in enumerate(molecules):
+                mid = id(m)
+                for ki, kinfo in enumerate(parts):
+                    rows = table[bounds[mi * nk + ki]:bounds[mi * nk + ki + 1]]
+                    if ki == own and mi < len(todo):
+                        todo[mi].rows = rows
+                    elif (kinfo.key, mid) not in self._results:  # (kept until asked for, or until it expires)
+                        self._results[(kinfo.key, mid)] = (weakref.ref(m), rows, now)
+        for r in todo:
+            r.hits = info.hits(r.rows, r.molecule)
+
+    def drain(self, timeout=60.0):
+        """Waits until nothing computed ahead is in flight any more (tests)."""
+        deadline = time.monotonic() + timeout
+        while time.monotonic() < deadline:
+            with self._lock:
+                if not self._inflight:
+                    return True
+            time.sleep(0.0005)
+        return False
+
+    def _plan(self, info, todo, now):
+        """(molecules to search ahead with info's key, keys to search in the launch: info and those worth searching ahead)"""
+        extra = []
+        if info.requests >= 2:
+            have = {id(r.molecule) for r in todo}
+            n_atoms = sum(len(r.molecule) for r in todo)
+            ahead = self._molecules.keys() - info.asked.keys() - info.planned.keys() - have
+            for mid, ent in (self._molecules.items() if ahead else ()):  # (in the order they were first seen)
+                if len(todo) + len(extra) >= self.MAX_MOLECULES or n_atoms >= self.MAX_ATOMS:
+                    break
+                if mid not in ahead:
+                    continue
+                m = ent[0]()
+                if m is None or ent[1] != info.device or now - ent[2] > self.WINDOW_S or (info.key, mid) in self._results:
+                    continue
+                extra.append(m)
+                info.planned[mid] = now  # (a launch of another leader must not compute it ahead as well)
+                n_atoms += len(m)
+        wanted = [id(r.molecule) for r in todo] + [id(m) for m in extra]
+        parts = []
+        for k in self._keys.values():
+            if k is info:
+                parts.append(k)
+            elif (k.options == info.options and k.device == info.device and k.requests >= 2 and now - k.last_seen <= self.WINDOW_S
+                  and any(mid not in k.asked and mid not in k.planned and (k.key, mid) not in self._results for mid in wanted)):
+                parts.append(k)
+        if len(parts) > 1:  # (orientation tables: all or none, see _PackedLibrary.concat)
+            try:
+                packs = [k.pack() for k in parts]
+                if len({p.tables[8] is not None for p in packs}) != 1:
+                    parts = [info]
+            except Exception:
+                parts = [info]
+        # what this launch computes ahead is IN FLIGHT until its results are stored: a request for it waits instead of
+        # launching the same search again
+        flight = (threading.Event(), [(info.key, id(m)) for m in extra])
+        for k in parts:
+            if k is not info:
+                for mid in wanted:
+                    if mid not in k.asked and mid not in k.planned and (k.key, mid) not in self._results:
+                        k.planned[mid] = now
+                        flight[1].append((k.key, mid))
+        for pair in flight[1]:
+            self._inflight[pair] = flight[0]
+        return extra, parts, flight
+
+    def _union(self, parts):
+        ukey = tuple(k.key for k in parts)
+        with self._lock:
+            hit = self._unions.get(ukey)
+            if hit is not None and hit[0]._packed_ref.vocab_version == VOCAB.version:
+                self._unions.move_to_end(ukey)
+                return hit
+        device = parts[0].device
+        packs = [k.pack() for k in parts]
+        union = _PackedLibrary.concat(packs, device)
+        ujess = Jess.__new__(Jess)
+        ujess._device, ujess._cache_key = device, None
+        ujess._templates = tuple(t for k in parts for t in k.templates)
+        ujess._packed_ref = union
+        offsets = np.concatenate([[0], np.cumsum([len(k.templates) for k in parts])]).astype(np.int64)
+        thr = tuple(np.concatenate([np.full(len(k.templates), k.thresholds[i], dtype=np.float64) for k in parts]) for i in range(3))
+        with self._lock:
+            self._unions[ukey] = (ujess, offsets, thr)
+            while len(self._unions) > self.MAX_UNIONS:
+                self._unions.popitem(last=False)  # (its device library goes when the last query using it is done)
+        return ujess, offsets, thr
+
+    def clear(self):
+        self.drain(5.0)
+        with self._lock:
+            self._keys.clear(); self._molecules.clear(); self._results.clear(); self._unions.clear(); self._inflight.clear()
+            del self.launches[:]
+
+
+_sweeps = _Sweeps()
 
 
 class Jess:
@@ -1044,27 +1453,33 @@ class Jess:
             self._templates = templates
             _packed(templates, self._device)  # registers the library's vocabulary
             return
-        self._templates = tuple(templates)
         # enzymm builds Jess(templates) anew for every (molecule, size) call with the SAME list object
-        # (jess_run.py:800, templates_by_effective_size[size]): a list seen before, holding the same objects (tuple
-        # comparison stops at identity, at C speed), needs neither the type checks nor a new device library
-        # (the entry keeps the list object itself: while it is cached no other list can take its id, and `is` says it is
-        # that very list; the tuple comparison then only has to notice a list that was changed in place)
+        # (jess_run.py:800, templates_by_effective_size[size]): a list seen before, holding the same objects, needs
+        # neither a new tuple of its members nor the type checks nor a new device library.  The entry keeps the list
+        # object itself (while it is cached no other list can take its id, and `is` says it is that very list) and a copy
+        # of it: comparing the two lists -- at C speed, element comparison stops at identity -- notices a list that was
+        # changed in place.
         self._cache_key = (id(templates), self._device) if isinstance(templates, (list, tuple)) else None
         known = _jess_cache.get(self._cache_key) if self._cache_key is not None else None
-        if known is not None and known[2] is templates and known[0] == self._templates:
+        if known is not None and known[2] is templates and known[3] == templates:
             self._templates = known[0]
             if known[1] is not None and known[1].vocab_version == VOCAB.version:
                 self._packed_ref = known[1]
             return
+        self._templates = tuple(templates)
         for t in self._templates:
             if not isinstance(t, Template):
                 raise TypeError(f"expected Template, found {type(t).__name__}")
         register_vocabulary(self._templates)
         if self._cache_key is not None and self._templates:
-            _jess_cache[self._cache_key] = (self._templates, None, templates)
-            while len(_jess_cache) > _PACK_CACHE_SIZE:
-                _jess_cache.pop(next(iter(_jess_cache)))
+            with _jess_cache_lock:  # (Jess objects are built from pool threads)
+                known = _jess_cache.get(self._cache_key)
+                if known is not None and known[2] is templates and known[3] == templates:
+                    self._templates = known[0]  # another thread was faster: one tuple per list (queries are keyed by it)
+                else:
+                    _jess_cache[self._cache_key] = (self._templates, None, templates, type(templates)(templates))
+                    while len(_jess_cache) > _PACK_CACHE_SIZE:
+                        _jess_cache.pop(next(iter(_jess_cache)), None)
 
     def __len__(self):
         return len(self._templates)
@@ -1103,8 +1518,10 @@ class Jess:
         if packed is None or packed.vocab_version != VOCAB.version:
             packed = self._packed_ref = _packed(self._templates, self._device)
             key = getattr(self, "_cache_key", None)
-            if key is not None and key in _jess_cache and _jess_cache[key][0] is self._templates:
-                _jess_cache[key] = (self._templates, packed, _jess_cache[key][2])
+            with _jess_cache_lock:
+                known = _jess_cache.get(key) if key is not None else None
+                if known is not None and known[0] is self._templates:
+                    _jess_cache[key] = (self._templates, packed, known[2], known[3])
         own_batch = batch is None
         release = None
         if own_batch and len(molecules) == 1:
@@ -1184,9 +1601,16 @@ class Jess:
         # while another call with the same templates and thresholds is on the GPU are searched TOGETHER, as one batch, by
         # whichever of the waiting threads goes next (_QueryCombiner): sixteen threads then cost a launch chain per
         # sixteen molecules, not per molecule.  A lone call goes straight through (on the calling thread's own stream).
+        # The reference repeats the sweep for every size bucket: _Sweeps computes ahead what it can (the molecules of the
+        # previous bucket, the buckets still to come) and hands those answers out here without a launch.
         key = (id(self._templates), self._device, float(rmsd_threshold), float(distance_cutoff), float(max_dynamic_distance),
                max_candidates, bool(ignore_chain), bool(best_match))
-        hits = _combiner(key, self._templates).run(self, molecule, (rmsd_threshold, distance_cutoff, max_dynamic_distance),
-                                  dict(max_candidates=max_candidates, ignore_chain=ignore_chain, best_match=best_match))
+        thresholds = (rmsd_threshold, distance_cutoff, max_dynamic_distance)
+        options = dict(max_candidates=max_candidates, ignore_chain=ignore_chain, best_match=best_match)
+        hits = _sweeps.lookup(self, key, thresholds, options, molecule) if _sweeps.enabled else None
+        if hits is None:
+            hits = _combiner(key, self._templates).run(
+                self, molecule, thresholds, options,
+                execute=lambda batch: _sweeps.execute(self, key, thresholds, options, batch))
         return Query(self, molecule, rmsd_threshold, distance_cutoff, max_dynamic_distance, max_candidates,
                      ignore_chain, best_match, hits)

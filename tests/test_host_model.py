@@ -580,7 +580,7 @@ def test_concurrent_single_molecule_queries_are_merged():
     assert out == [[("hit of", f"m{i}")] for i in range(40)]
     assert sum(calls) == 40 and len(calls) < 40 and max(calls) > 1  # merged, nobody served twice or dropped
     assert comb.run(jess, "alone", (2.0, 1.0, 1.0), {}) == [("hit of", "alone")] and calls[-1] == 1
-    assert not comb._busy and not comb._queue
+    assert not comb._leaders and not comb._queue
     # a failing batch: its callers see the error, later callers are unaffected
     calls.clear()
     results, errors = [], []
@@ -618,3 +618,119 @@ def test_jess_construction_cache_is_by_identity():
     assert a[0] is keep[0] and b[0] is keep[0] and a._templates is b._templates  # the same list: one entry, reused
     keep[0] = pyjess.Template.loads(src, id="x")  # changed in place (equal content, another object)
     assert keep[0] == a[0] and keep[0] is not a[0]
+
+
+def test_reference_sweep_is_computed_ahead(monkeypatch):
+    """The reference's loop -- for every size bucket, a thread pool maps Jess(bucket).query(molecule) over the molecules
+    (/root/reference/enzymm/jess_run.py:896-988 around :785-843) -- through pyjess._Sweeps, with the engine replaced by a
+    recorder (no GPU here): every call gets exactly the hits a direct query gives; in a first sweep the buckets after
+    the first are searched in one launch over all the molecules of the bucket before; in a second sweep over new
+    molecules every molecule is searched ONCE, with all buckets in one library (one candidate index and one set of pair
+    tables per molecule instead of one per bucket), and the later buckets need no launch at all."""
+    from multiprocessing.pool import ThreadPool
+    from enzymm_amd import _native
+
+    class FakeLibrary:
+        def __init__(self, device, offsets, *tables, orientation=None):
+            self.n_templates = len(offsets) - 1
+
+        def close(self):
+            pass
+
+    monkeypatch.setattr(_native, "Library", FakeLibrary)
+    calls = []
+
+    def expected(template, molecule):  # the "search": a pure function of the two objects
+        v = (sum(template.id.encode()) * 31 + len(molecule) * 7) % 5
+        return None if v > 1 else (0.1 + 0.01 * v + 0.001 * (len(molecule) % 9), [(len(molecule) * (i + 1)) % len(molecule) for i in range(len(list(template)))])
+
+    def recorder(self, molecules, thresholds, options, trace=None):
+        rmsd_threshold, distance_cutoff, max_dynamic_distance = thresholds
+        calls.append((tuple(id(m) for m in molecules), len(self._templates)))
+        cut = np.broadcast_to(np.asarray(distance_cutoff, dtype=np.float64), (len(self._templates),))
+        rows = []
+        for si, m in enumerate(molecules):
+            for ti, t in enumerate(self._templates):
+                e = expected(t, m)
+                if e is not None:
+                    row = np.zeros(1, dtype=_native.HIT_DTYPE)
+                    row["structure"], row["template_sel"], row["rmsd"], row["n_atoms"] = si, ti, e[0] + cut[ti], len(e[1])
+                    row["atoms"][0, :len(e[1])] = e[1]
+                    row["rot"][0] = np.eye(3).ravel()
+                    rows.append(row)
+        return np.concatenate(rows) if rows else np.zeros(0, dtype=_native.HIT_DTYPE)
+
+    monkeypatch.setattr(pyjess, "_search_raw", recorder)
+    pyjess._sweeps.clear()
+    monkeypatch.setattr(pyjess._sweeps, "enabled", True)
+    files = sorted((helpers.GOLDEN / "templates").rglob("*.pdb"))[:9]
+    all_templates = [pyjess.Template.loads(f.read_text(), id=f"t{n}_{f.stem[:12]}") for n, f in enumerate(files)]
+    buckets = [all_templates[0:2], all_templates[2:5], all_templates[5:9]]  # lists the caller holds, like templates_by_effective_size
+    cuts = [1.5, 1.3, 1.1]
+
+    def molecules(start, count):
+        out = []
+        for i in range(start, start + count):
+            n = 20 + i
+            out.append(pyjess.Molecule.from_columns(f"m{i}", xyz=np.arange(3 * n, dtype=np.float64).reshape(n, 3),
+                                                    name=np.array([b" CA "] * n, dtype="S4"),
+                                                    residue_name=np.array([b"GLY"] * n, dtype="S3"),
+                                                    chain_id=np.array([b" A"] * n, dtype="S2"), residue_number=np.arange(1, n + 1)))
+        return out
+
+    def sweep(mols):
+        per_bucket_calls, found = [], {}
+        with ThreadPool(6) as pool:
+            for tpls, d in zip(buckets, cuts):
+                before = len(calls)
+
+                def one(mol, tpls=tpls, d=d):
+                    return list(pyjess.Jess(tpls).query(mol, 2.0, d, d, max_candidates=10000, best_match=True, ignore_chain=True))
+
+                for mi, hits in enumerate(pool.imap(one, mols)):
+                    found.setdefault(mi, []).extend(hits)
+                per_bucket_calls.append(calls[before:])
+        return found, per_bucket_calls
+
+    def check(found, mols):
+        for mi, m in enumerate(mols):
+            want = [(t, expected(t, m), d) for tpls, d in zip(buckets, cuts) for t in tpls]
+            want = [(t, e, d) for t, e, d in want if e is not None]
+            got = found.get(mi, [])
+            assert len(got) == len(want)
+            for h, (t, e, d) in zip(got, want):
+                assert h.template is t and h._molecule is m
+                assert h.rmsd == pytest.approx(e[0] + d) and list(h._atom_index) == e[1]
+
+    first = molecules(0, 40)
+    found, per_bucket = sweep(first)
+    check(found, first)
+    # bucket 1: concurrent calls merged; buckets 2 and 3: a lone first call, then ONE launch over everything else
+    assert sum(len(c[0]) for c in per_bucket[0]) == 40
+    for later in per_bucket[1:]:
+        assert len(later) <= 3 and sum(len(c[0]) for c in later) == 40, later
+        assert max(len(c[0]) for c in later) >= 30
+    # a second sweep over new molecules: the three buckets are known -- one library of all nine templates, every molecule
+    # in exactly one launch (one candidate index and one set of pair tables per molecule), nothing launched for buckets 2 and 3
+    second = molecules(100, 32)
+    calls.clear()
+    found, per_bucket = sweep(second)
+    check(found, second)
+    assert per_bucket[1] == [] and per_bucket[2] == []
+    assert all(n_templates == 9 for _, n_templates in per_bucket[0])
+    searched = [mid for ids, _ in per_bucket[0] for mid in ids]
+    assert sorted(searched) == sorted(id(m) for m in second)  # each molecule once
+    # the same molecules again (a second Matcher.run on them): asked before, so nothing is computed ahead for them, and
+    # the answers are the same
+    calls.clear()
+    found, per_bucket = sweep(second)
+    check(found, second)
+    # switched off: every bucket is searched when it is asked for
+    monkeypatch.setattr(pyjess._sweeps, "enabled", False)
+    third = molecules(200, 12)
+    calls.clear()
+    found, per_bucket = sweep(third)
+    check(found, third)
+    assert all(sum(len(c[0]) for c in b) == 12 for b in per_bucket)
+    assert all(n_templates == len(tpls) for b, tpls in zip(per_bucket, buckets) for _, n_templates in b)
+    pyjess._sweeps.clear()
