@@ -91,7 +91,7 @@ EXPORTS = (
     "tm_batch_create", "tm_batch_create_from_columns", "tm_batch_create_from_structures", "tm_batch_create_from_pdb", "tm_batch_atom_counts", "tm_batch_line_offsets",
     "tm_batch_residue_counts",
     "tm_batch_destroy", "tm_query", "tm_result_wait", "tm_result_needed", "tm_result_hit_count",
-    "tm_result_copy_hits", "tm_result_copy_candidates", "tm_result_timing", "tm_result_search_split", "tm_result_device_hits",
+    "tm_batch_refused", "tm_result_copy_hits", "tm_result_copy_candidates", "tm_result_timing", "tm_result_search_split", "tm_result_page_census", "tm_result_device_hits",
     "tm_result_append_hits", "tm_result_destroy", "tm_pdb_count_host", "tm_pdb_parse_host", "tm_pdb_count_host_many",
     "tm_pdb_parse_host_many", "tm_files_sizes", "tm_files_read", "tm_batch_create_from_files", "tm_batch_file_text",
     "tm_stream_create", "tm_stream_destroy", "tm_batch_text_layout",
@@ -465,6 +465,18 @@ class Batch:
         _check(lib.tm_batch_atom_counts(self._h, _ptr(self.atom_offsets)))
         return self
 
+    def refused(self):
+        """``[(structure index, atoms it came with)]``: structures beyond TM_MAX_STRUCTURE_ATOMS.  They stay in the batch
+        as empty structures (no hits); the others are searched as usual."""
+        lib = load()
+        count = C.c_uint32(0)
+        _check(lib.tm_batch_refused(self._h, None, None, C.c_uint32(0), C.byref(count)))
+        if count.value == 0:
+            return []
+        idx, atoms = np.zeros(count.value, dtype=np.uint32), np.zeros(count.value, dtype=np.uint32)
+        _check(lib.tm_batch_refused(self._h, _ptr(idx), _ptr(atoms), C.c_uint32(count.value), C.byref(count)))
+        return list(zip(idx.tolist(), atoms.tolist()))
+
     def file_text(self, index: int) -> bytes:
         """A private copy of file ``index``'s bytes (batches made by ``from_files``, while open)."""
         text, length = C.c_char_p(), C.c_uint64()
@@ -540,6 +552,12 @@ class Result:
         depth-first part below the surviving triples."""
         a, b = C.c_float(0), C.c_float(0)
         _check(load().tm_result_search_split(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def page_census(self):
+        """(most pages of triples one structure listed, triples in all pages) between the two search kernels."""
+        a, b = C.c_uint32(0), C.c_uint64(0)
+        _check(load().tm_result_page_census(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
     def needed(self):

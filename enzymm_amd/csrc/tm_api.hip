@@ -428,6 +428,9 @@ struct IndexShared {
 struct tm_batch {
     int device = 0;
     uint32_t n_structs = 0, n_atoms = 0, max_atoms = 0, max_res = 0;
+    // structures beyond TM_MAX_STRUCTURE_ATOMS: kept in the batch as EMPTY structures (no hits), listed here with the
+    // atom counts they came with (tm_batch_refused) -- one oversized file does not fail the batch it arrives in
+    std::vector<uint32_t> refused, refused_atoms;
     float extent = 0.f;  // largest |centred coordinate| of any atom (A): sizes the fp32 prefilter slack of its queries
     std::vector<uint32_t> s_off;
     DevBuf<uint32_t> d_s_off, d_s_roff, d_orig, d_kl_off;
@@ -511,6 +514,7 @@ struct tm_result {
     bool waited = false;
     uint32_t overflow = 0;
     unsigned long long n_hits = 0, n_cands = 0, n_pairs = 0;
+    bool split_recorded = false;  // ev[4] (between the block search and the depth-first part) was recorded
     ~tm_result() {
         for (auto &e : ev)
             if (e) (void)hipEventDestroy(e);
@@ -880,10 +884,43 @@ extern "C" {
 
 int tm_batch_create(int device, const tm_batch_desc *d, tm_batch **out) {
     if (!d || !out || !d->atom_offsets) return fail(TM_E_INVALID, "tm_batch_create: NULL argument");
-    std::vector<const double *> xyz_of(d->n_structures, nullptr);
+    const uint32_t ns = d->n_structures;
+    std::vector<const double *> xyz_of(ns, nullptr);
     if (d->xyz)
-        for (uint32_t s = 0; s < d->n_structures; ++s) xyz_of[s] = d->xyz + 3 * (size_t)d->atom_offsets[s];
-    return batch_from_encoded(device, d, d->xyz ? xyz_of.data() : nullptr, nullptr, out);
+        for (uint32_t s = 0; s < ns; ++s) xyz_of[s] = d->xyz + 3 * (size_t)d->atom_offsets[s];
+    // a structure beyond TM_MAX_STRUCTURE_ATOMS stays in the batch as an empty one (tm_batch_refused): the per-atom
+    // columns are copied without its atoms
+    std::vector<uint32_t> refused, refused_atoms;
+    for (uint32_t s = 0; s < ns; ++s)
+        if (d->atom_offsets[s + 1] >= d->atom_offsets[s] && d->atom_offsets[s + 1] - d->atom_offsets[s] > TM_MAX_STRUCTURE_ATOMS) {
+            refused.push_back(s);
+            refused_atoms.push_back(d->atom_offsets[s + 1] - d->atom_offsets[s]);
+        }
+    if (refused.empty()) return batch_from_encoded(device, d, d->xyz ? xyz_of.data() : nullptr, nullptr, out);
+    if (d->atom_offsets[ns] && (!d->res_type || !d->name_id || !d->residue)) return fail(TM_E_INVALID, "tm_batch_create: NULL argument");
+    std::vector<uint32_t> off(ns + 1, 0), residue;
+    std::vector<uint8_t> res_type, name_id, chain;
+    size_t next = 0;
+    for (uint32_t s = 0; s < ns; ++s) {
+        const uint32_t o = d->atom_offsets[s], n = d->atom_offsets[s + 1] - o;
+        const bool drop = next < refused.size() && refused[next] == s;
+        if (drop) ++next;
+        else {
+            res_type.insert(res_type.end(), d->res_type + o, d->res_type + o + n);
+            name_id.insert(name_id.end(), d->name_id + o, d->name_id + o + n);
+            residue.insert(residue.end(), d->residue + o, d->residue + o + n);
+            if (d->chain) chain.insert(chain.end(), d->chain + o, d->chain + o + n);
+        }
+        off[s + 1] = (uint32_t)res_type.size();
+    }
+    tm_batch_desc kept = *d;
+    kept.atom_offsets = off.data();
+    kept.xyz = nullptr;
+    kept.res_type = res_type.data(); kept.name_id = name_id.data(); kept.residue = residue.data();
+    kept.chain = d->chain ? chain.data() : nullptr;
+    const int rc = batch_from_encoded(device, &kept, d->xyz ? xyz_of.data() : nullptr, nullptr, out);
+    if (rc == TM_OK) { (*out)->refused = std::move(refused); (*out)->refused_atoms = std::move(refused_atoms); }
+    return rc;
 }
 
 }  // extern "C"
@@ -896,11 +933,18 @@ namespace {
 int batch_from_structures(int device, uint32_t ns, const tm_structure_columns *src, const tm_vocab *vocab, tm_batch **out) {
     PhaseTrace trace("tm_batch_create_from_structures");
     std::vector<uint32_t> atom_offsets(ns + 1, 0);
+    std::vector<uint32_t> refused, refused_atoms;
+    std::vector<tm_structure_columns> kept;  // (a copy of the descriptors only when one has to be emptied)
+    for (uint32_t s = 0; s < ns; ++s)
+        if (src[s].n_atoms > TM_MAX_STRUCTURE_ATOMS) {
+            if (kept.empty()) kept.assign(src, src + ns);
+            refused.push_back(s);
+            refused_atoms.push_back((uint32_t)std::min<uint64_t>(src[s].n_atoms, 0xffffffffull));
+            kept[s].n_atoms = 0;
+        }
+    if (!kept.empty()) src = kept.data();
     for (uint32_t s = 0; s < ns; ++s) {
         const uint64_t n = src[s].n_atoms;
-        if (n > TM_MAX_STRUCTURE_ATOMS)
-            return fail(TM_E_UNSUPPORTED, "structure " + std::to_string(s) + " has " + std::to_string(n) +
-                                              " atoms; limit " + std::to_string(TM_MAX_STRUCTURE_ATOMS));
         if (n && (!src[s].xyz || !src[s].name || !src[s].residue_name || !src[s].chain_id || !src[s].residue_number ||
                   !src[s].insertion_code))
             return fail(TM_E_INVALID, "structure " + std::to_string(s) + ": NULL column");
@@ -1024,7 +1068,9 @@ int batch_from_structures(int device, uint32_t ns, const tm_structure_columns *s
     enc.name_id = name_id.data();
     enc.residue = residue.data();
     enc.chain = chain.data();
-    return batch_from_encoded(device, &enc, xyz_of.data(), nres_of.data(), out);
+    const int rc = batch_from_encoded(device, &enc, xyz_of.data(), nres_of.data(), out);
+    if (rc == TM_OK) { (*out)->refused = std::move(refused); (*out)->refused_atoms = std::move(refused_atoms); }
+    return rc;
 }
 
 }  // namespace
@@ -1222,9 +1268,29 @@ static int flatten_pdb_on_host(const char *text, uint64_t length, uint32_t flags
 
 extern "C" {
 
+static int batch_from_pdb_text(int device, uint32_t n_files, const char *const *text, const uint64_t *length,
+                               const tm_vocab *vocab, uint32_t flags, double min_bfactor, tm_batch **out,
+                               std::vector<uint32_t> *oversized, std::vector<uint32_t> *oversized_atoms);
+
+// A file with more than TM_MAX_STRUCTURE_ATOMS kept atoms is found out only after the device has classified its lines:
+// the batch is then laid out once more with that file's text left out -- it stays in the batch as an empty structure,
+// listed by tm_batch_refused -- instead of failing the other files with it.
 int tm_batch_create_from_pdb(int device, uint32_t n_files, const char *const *text, const uint64_t *length,
                              const tm_vocab *vocab, uint32_t flags, double min_bfactor, tm_batch **out) {
     if (!out || !vocab || (n_files && (!text || !length))) return fail(TM_E_INVALID, "tm_batch_create_from_pdb: NULL argument");
+    std::vector<uint32_t> oversized, oversized_atoms;
+    int rc = batch_from_pdb_text(device, n_files, text, length, vocab, flags, min_bfactor, out, &oversized, &oversized_atoms);
+    if (rc != TM_OK || oversized.empty()) return rc;
+    std::vector<uint64_t> kept(length, length + n_files);
+    for (uint32_t f : oversized) kept[f] = 0;
+    rc = batch_from_pdb_text(device, n_files, text, kept.data(), vocab, flags, min_bfactor, out, nullptr, nullptr);
+    if (rc == TM_OK) { (*out)->refused = std::move(oversized); (*out)->refused_atoms = std::move(oversized_atoms); }
+    return rc;
+}
+
+static int batch_from_pdb_text(int device, uint32_t n_files, const char *const *text, const uint64_t *length,
+                               const tm_vocab *vocab, uint32_t flags, double min_bfactor, tm_batch **out,
+                               std::vector<uint32_t> *oversized, std::vector<uint32_t> *oversized_atoms) {
     *out = nullptr;
     HIP_TRY(hipSetDevice(device));
     hipStream_t stream = nullptr;
@@ -1367,9 +1433,15 @@ int tm_batch_create_from_pdb(int device, uint32_t n_files, const char *const *te
     std::vector<HostFlattened> host_files;
     for (uint32_t f = 0; f < n_files; ++f) {
         const uint32_t n = s_off[f + 1] - s_off[f];
-        if (n > TM_MAX_STRUCTURE_ATOMS)
-            return fail(TM_E_UNSUPPORTED, "structure " + std::to_string(f) + " has " + std::to_string(n) + " atoms; limit " +
-                                              std::to_string(TM_MAX_STRUCTURE_ATOMS));
+        if (n > TM_MAX_STRUCTURE_ATOMS) {
+            if (!oversized)
+                return fail(TM_E_UNSUPPORTED, "structure " + std::to_string(f) + " has " + std::to_string(n) + " atoms; limit " +
+                                                  std::to_string(TM_MAX_STRUCTURE_ATOMS));
+            oversized->push_back(f);
+            oversized_atoms->push_back(n);
+            continue;
+        }
+        if (oversized && !oversized->empty()) continue;  // (this layout is abandoned: the caller starts over)
         if (needs_host[f]) {
             host_files.emplace_back();
             HostFlattened &h = host_files.back();
@@ -1383,6 +1455,7 @@ int tm_batch_create_from_pdb(int device, uint32_t n_files, const char *const *te
         max_atoms = std::max(max_atoms, n);
         max_res = std::max(max_res, runs[f]);
     }
+    if (oversized && !oversized->empty()) return TM_OK;  // (*out is still NULL: tm_batch_create_from_pdb lays the batch out again)
     b->max_atoms = max_atoms; b->max_res = max_res; b->s_off = s_off;
     HIP_TRY(b->d_s_off.upload(s_off, stream)); HIP_TRY(b->d_s_roff.upload(s_roff, stream));
     HIP_TRY(b->d_rec.alloc(n_atoms)); HIP_TRY(b->d_chain.alloc(n_atoms)); HIP_TRY(b->d_orig.alloc(n_atoms));
@@ -1424,6 +1497,16 @@ int tm_batch_create_from_pdb(int device, uint32_t n_files, const char *const *te
     trace.mark("sync3");
     guard.b = nullptr;
     *out = b;
+    return TM_OK;
+}
+
+int tm_batch_refused(const tm_batch *b, uint32_t *structures, uint32_t *atoms, uint32_t capacity, uint32_t *count) {
+    if (!b || !count) return fail(TM_E_INVALID, "NULL argument");
+    *count = (uint32_t)b->refused.size();
+    for (uint32_t i = 0; i < capacity && i < b->refused.size(); ++i) {
+        if (structures) structures[i] = b->refused[i];
+        if (atoms) atoms[i] = b->refused_atoms[i];
+    }
     return TM_OK;
 }
 
@@ -2086,6 +2169,7 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
             if (rc != TM_OK) return rc;
         }
         HIP_TRY(hipEventRecord(r->ev[4], stream));
+        r->split_recorded = true;
         // the depth-first search below the triples the block search paged out: the same work items (every workgroup
         // of a structure takes triples of that structure until none are left)
         rc = launch(kModeDeep);
@@ -2255,12 +2339,32 @@ int tm_result_search_split(tm_result *r, float *front_ms, float *deep_ms) {
     HIP_TRY(hipSetDevice(r->device));
     HIP_TRY(hipEventSynchronize(r->ev[3]));
     float a = 0, d = 0;
-    if (hipEventQuery(r->ev[4]) == hipSuccess) {  // recorded (a query with templates and structures)
+    if (r->split_recorded) {  // (a query with templates and structures; hipEventQuery also succeeds on an event never recorded)
         HIP_TRY(hipEventElapsedTime(&a, r->ev[1], r->ev[4]));
         HIP_TRY(hipEventElapsedTime(&d, r->ev[4], r->ev[2]));
     }
     if (front_ms) *front_ms = a;
     if (deep_ms) *deep_ms = d;
+    return TM_OK;
+}
+
+int tm_result_page_census(tm_result *r, uint32_t *max_pages, uint64_t *triples) {
+    if (!r) return fail(TM_E_INVALID, "result is NULL");
+    int rc = tm_result_wait(r);
+    if (rc != TM_OK && rc != TM_E_OVERFLOW) return rc;
+    HIP_TRY(hipSetDevice(r->device));
+    std::vector<uint32_t> listed(r->n_structs, 0), held(r->n_structs, 0);
+    if (r->n_structs && r->d_dir_n.p && r->d_dir_triples.p) {
+        HIP_TRY(hipMemcpyAsync(listed.data(), r->d_dir_n.p, listed.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
+        HIP_TRY(hipMemcpyAsync(held.data(), r->d_dir_triples.p, held.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
+        HIP_TRY(hipStreamSynchronize(r->stream));
+    }
+    uint32_t most = 0;
+    uint64_t total = 0;
+    for (uint32_t v : listed) most = std::max(most, v);
+    for (uint32_t v : held) total += v;
+    if (max_pages) *max_pages = most;
+    if (triples) *triples = total;
     return TM_OK;
 }
 

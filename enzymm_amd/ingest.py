@@ -137,6 +137,9 @@ class PdbBatch:
         self.native.vocab_version = self.vocab_version
         counts = np.diff(self.native.atom_offsets).tolist()
         paths = list(paths) if paths is not None else [None] * len(counts)
+        # files beyond the engine's atom limit: empty structures in this batch (no hits), reported, the rest searched
+        self.refused = self.native.refused()
+        pyjess.warn_refused([(paths[k] if paths[k] is not None else ids[k], n) for k, n in self.refused])
         self.molecules: List[LazyMolecule] = [
             LazyMolecule(texts[k], ids[k], counts[k], conservation_cutoff, ignore_endmdl, paths[k])
             for k in range(len(counts))]

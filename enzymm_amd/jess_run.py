@@ -431,6 +431,9 @@ class Matcher:
         self.cpus = _default_cpus() if cpus is None else cpus
         self.conservation_cutoff = conservation_cutoff
         self.warn, self.verbose = warn, verbose
+        #: (molecule, atoms) of the molecules this matcher could not search: more atoms than the engine indexes
+        #: (65 535, include/enzymm_amd.h); they have no entry in the results of run / run_files
+        self.refused: List = []
         self.skip_smaller_hits = skip_smaller_hits
         self.match_small_templates = match_small_templates
         self.filter_matches = filter_matches
@@ -522,6 +525,12 @@ class Matcher:
         device_batch = None
         if hasattr(molecules, "native") and hasattr(molecules, "molecules"):  # an ingest.PdbBatch
             device_batch, molecules = molecules, molecules.molecules
+            for k, n in getattr(device_batch, "refused", ()):
+                self.refused.append((molecules[k], n))
+        else:
+            # (beyond the engine's atom limit: the molecule is kept in the batch as an empty structure -- no matches -- and
+            # listed here; pyjess.make_batch warns)
+            self.refused.extend((m, len(m)) for m in molecules if len(m) > pyjess._native.TM_MAX_STRUCTURE_ATOMS)
         plan = self._plan()
         sizes, searched, rmsd, dist, dyn, size_of, pairwise, models, jess = plan
         pending = None

@@ -722,7 +722,18 @@ def make_batch(molecules: Sequence[Molecule], device: int) -> "_native.Batch":
         rows[i] = m._pointer_row()
     batch = _native.Batch.from_structures(device, rows, tables)
     batch.vocab_version = tables[-1]  # ids are only meaningful against this state of the vocabulary
+    if any(len(m) > _native.TM_MAX_STRUCTURE_ATOMS for m in molecules):
+        warn_refused([(molecules[i].id, n) for i, n in batch.refused()])
     return batch
+
+
+def warn_refused(refused) -> None:
+    """Structures beyond the engine's atom limit are kept in their batch as empty structures: they get no hits, the
+    rest of the batch is searched as usual (``tm_batch_refused``).  ``refused``: ``[(id or path, atoms)]``."""
+    if refused:
+        import warnings
+        listed = ", ".join(f"{ident} ({atoms} atoms)" for ident, atoms in refused[:8]) + (" ..." if len(refused) > 8 else "")
+        warnings.warn(f"{len(refused)} structure(s) with more than {_native.TM_MAX_STRUCTURE_ATOMS} atoms are not searched: {listed}")
 
 
 class _SingleBatches:

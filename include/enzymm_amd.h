@@ -218,6 +218,11 @@ int tm_batch_create_from_files(int device, uint32_t n_files, const char *const *
 int tm_batch_file_text(tm_batch *batch, uint32_t file, const char **text, uint64_t *length);
 /* the whole text buffer: file f occupies [offsets[f], offsets[f + 1] - 1) of it; offsets has n_structures + 1 entries */
 int tm_batch_text_layout(tm_batch *batch, const char **base, uint64_t *offsets);
+/* Structures that came with more than TM_MAX_STRUCTURE_ATOMS atoms (pyjess.Molecule.load takes any PDB file,
+ * /root/reference/enzymm/jess_run.py:538; this build indexes a structure's atoms with 16 bits): they are kept in the batch
+ * as EMPTY structures -- no hits, the other structures of the batch unaffected -- and listed here with the atom counts
+ * they came with.  *count receives how many there are; up to `capacity` of them are written. */
+int tm_batch_refused(const tm_batch *batch, uint32_t *structures, uint32_t *atoms, uint32_t capacity, uint32_t *count);
 int tm_batch_atom_counts(tm_batch *batch, uint32_t *atom_offsets);            /* [n_structures + 1] */
 int tm_batch_line_offsets(tm_batch *batch, uint32_t *out, uint64_t n);        /* byte offset of each kept record in its file */
 int tm_batch_residue_counts(tm_batch *batch, uint32_t *out);                  /* [n_structures]; TM_E_UNSUPPORTED without tm_vocab.counted_residue_names */
@@ -236,6 +241,9 @@ int tm_result_timing(tm_result *res, float *index_ms, float *search_ms, float *f
 /* search_ms split into its two launches: the block search over the pair tables (k_search; with the template-at-a-time
  * launch, when the selection needs one) and the depth-first part below the surviving triples (k_deep) */
 int tm_result_search_split(tm_result *res, float *front_ms, float *deep_ms);
+/* Diagnostic: the most pages of surviving triples any structure of the query listed between the block search and the
+ * depth-first part (64 triples to a page), and the triples in all pages.  Waits for the result. */
+int tm_result_page_census(tm_result *res, uint32_t *max_pages, uint64_t *triples);
 const void *tm_result_device_hits(tm_result *res);           /* device pointer to the unsorted tm_hit table */
 /* Appends this query's hit rows to a caller-owned DEVICE table (rows: tm_hit[capacity], *count: rows in use, both in
  * device memory), adding structure_offset to tm_hit.structure -- enqueued on the query's stream behind its kernels,

@@ -301,11 +301,13 @@ def test_structure_near_the_atom_limit(af, default_library):
                                  ignore_chain=True)
         n = compare(table, cands, s, r, sub)
     assert n >= 1
-    with pytest.raises(_native.NativeError):  # one atom too many is refused, not truncated
-        extra = {k: np.concatenate([v, v[: 65536 - len(big)]]) for k, v in cols.items()}
-        over = pyjess.Molecule.__new__(pyjess.Molecule)
-        over._init_columns(extra, np.concatenate([xyz, xyz[: 65536 - len(big)]]), "too_big")
-        jess.query_batch([over], 2.0, cut[sel], cut[sel], template_index=idx[sel])
+    # one atom too many: the structure is refused (a warning, no hits), not truncated -- and not its batch
+    # (tests/test_gpu_round4.py::test_oversized_structure_is_refused_not_its_batch)
+    extra = {k: np.concatenate([v, v[: 65536 - len(big)]]) for k, v in cols.items()}
+    over = pyjess.Molecule.__new__(pyjess.Molecule)
+    over._init_columns(extra, np.concatenate([xyz, xyz[: 65536 - len(big)]]), "too_big")
+    with pytest.warns(UserWarning, match="too_big"):
+        assert len(jess.query_batch([over], 2.0, cut[sel], cut[sel], template_index=idx[sel], return_raw=True)) == 0
 
 
 def test_index_pool_overflow_is_reported_and_retried(amy, af, monkeypatch):

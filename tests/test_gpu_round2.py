@@ -438,8 +438,12 @@ def test_rccl_gather_world_size_1():
     a child process -- a process group must not outlive the test in the pytest process."""
     import subprocess
     import sys
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
-    out = subprocess.run([sys.executable, str(helpers.ROOT / "tests" / "gpu_rccl_world1.py")], env=env, timeout=200,
+    import socket
+    with socket.socket() as sock:  # (a port nobody holds: a fixed one may still be in TIME_WAIT from an earlier run)
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    out = subprocess.run([sys.executable, str(helpers.ROOT / "tests" / "gpu_rccl_world1.py")], env=env, timeout=300,
                          capture_output=True, text=True)
     assert out.returncode == 0 and "RCCL world-size-1 gather ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
