@@ -301,6 +301,8 @@ def main():
     ap.add_argument("--generator", default="v2", choices=["v2", "v1", "real"],
                     help="v2: natively packed synthetic globules (default); v1: the round-1 generator (under-dense, "
                          "kept for side-by-side rates); real: rigid-transform copies of 1AMY / AF-P0DUB6 (density reference)")
+    ap.add_argument("--sustained-seconds", type=float, default=5.0,
+                    help="after the timed region, the same loop for at least this long (config.sustained_structures_per_s; 0: skip)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
@@ -337,11 +339,22 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     os.environ["ENZYMM_AMD_DEVICE"] = str(local_rank)
-    if world > 1:
+    # ENZYMM_AMD_BENCH_FORCE_SHARDED=1 (tests): --gpus 1 through the N > 1 branch -- the device hit table, its gather over
+    # a world-size-1 "nccl" group (RCCL), the error exchange -- so that the loop the driver runs at N = 2, 4, 8 is
+    # exercised over RCCL on the one GPU a test box has
+    force_sharded = world == 1 and os.environ.get("ENZYMM_AMD_BENCH_FORCE_SHARDED") == "1"
+    if world > 1 or force_sharded:
+        if force_sharded:
+            import socket
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:
+                with socket.socket() as sock:
+                    sock.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
         if one_gpu:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     gather_device = "cpu" if one_gpu else f"cuda:{local_rank}"
 
     from enzymm_amd import _native, pyjess
@@ -382,7 +395,7 @@ def main():
 
     # N > 1: the rank's rows of one pass collect in HBM and leave in one gather (two tables: pass j + 1 fills one while
     # pass j's is gathered).  Sized for 4x the rows a pass of this workload has been seen to produce.
-    sharded = world > 1
+    sharded = world > 1 or force_sharded
     pass_tables = None
     if sharded:
         rows_per_pass = max(16384, 16 * args.structures)
@@ -425,10 +438,26 @@ def main():
 
         def finish_pass(results, table):
             nonlocal hit_total, last_hits
+            # each result is waited for by its OWN events (the counters' copy behind its last kernel, the append behind
+            # that), not by its stream, on which the next pass's searches are already queued: they run during the gather.
+            # A failure on one rank (an overflowed table) is exchanged before the collective, so that every rank raises
+            # instead of one raising and the others waiting in the gather.
+            failure = None
             for res in results:
-                res.wait()  # the search's stream has drained (its append with it); raises on an overflowed table
+                try:
+                    res.wait()
+                    res.wait_appended()
+                except _native.NativeError as exc:
+                    failure = failure or exc
+            if dist.is_available() and dist.is_initialized():
+                flag = torch.tensor([1 if failure is not None else 0], dtype=torch.int32, device="cpu" if one_gpu else f"cuda:{local_rank}")
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                if int(flag.item()) and failure is None:
+                    failure = _native.NativeError(_native.TM_E_OVERFLOW, "a search of this pass failed on another rank")
+            if failure is not None:
+                raise failure
             g0 = time.perf_counter()
-            gathered = table.gather(sort=False)  # the pass's ONE exchange; rank 0 sorts after the timed region
+            gathered = table.gather(sort=False, force_collective=force_sharded)  # the pass's ONE exchange; rank 0 sorts after the timed region
             gather_ms.append(1e3 * (time.perf_counter() - g0))
             if record:
                 for res in results:
@@ -499,6 +528,30 @@ def main():
         if world > 1:
             dist.all_reduce(rt, op=dist.ReduceOp.MAX)
         repeats.append(args.structures * world * args.steps / float(rt.item()))
+
+    # ---- not part of `value`: the same loop for at least --sustained-seconds (the contract's timed region is a tenth
+    # of a second: this is the figure that outlives a clock ramp or a cold cache)
+    sustained = None
+    if args.sustained_seconds > 0:
+        fence()
+        s0 = time.perf_counter()
+        done = 0
+        while True:
+            run_steps(args.steps, False)
+            done += args.steps
+            stop = torch.tensor([1 if time.perf_counter() - s0 >= args.sustained_seconds else 0], dtype=torch.int32,
+                                device="cpu" if one_gpu else "cuda")
+            if dist.is_available() and dist.is_initialized():
+                dist.all_reduce(stop, op=dist.ReduceOp.MAX)  # (every rank runs the same number of passes)
+            if int(stop.item()):
+                break
+        fence()
+        st = torch.tensor([time.perf_counter() - s0], dtype=torch.float64, device="cpu" if one_gpu else "cuda")
+        if world > 1:
+            dist.all_reduce(st, op=dist.ReduceOp.MAX)
+        sustained = {"structures_per_s": args.structures * world * done / float(st.item()), "seconds": float(st.item()), "steps": done}
+    free_b, total_b = torch.cuda.mem_get_info()
+    hbm_in_use = int(total_b - free_b)  # (this rank's GPU, after the timed loops: resident batches, tables, result pools)
 
     # ---- not part of `value`: the kernels' durations with ONE search in flight (nothing else on the GPU), for
     # roofline.exclusive -- with two in flight the HIP events of a search also span what the other search's kernels ran
@@ -608,9 +661,12 @@ def main():
                 "generator": args.generator,
                 "structures_per_gpu": args.structures, "batch": args.batch, "templates": int(len(idx)),
                 "repeats_structures_per_s": repeats,  # the same K steps timed three more times (not `value`)
+                "sustained_structures_per_s": None if sustained is None else sustained["structures_per_s"],
+                "sustained": sustained,  # the same loop for >= --sustained-seconds (not `value`)
+                "hbm_bytes_in_use_rank0": hbm_in_use,
                 "streamed_structures_per_s": streamed,  # upload-inclusive (host atom tables -> HBM overlapped with the search)
                 "atoms_per_structure": n_atoms / max(1, len(molecules)),
-                "parallelism": f"structures sharded over {world} GPU(s), hit-table gather to rank 0",
+                "parallelism": f"structures sharded over {world} GPU(s), hit-table gather to rank 0" + (" (N > 1 loop forced on one GPU over RCCL)" if force_sharded else ""),
                 "hits_rank0": int(hit_total), "hits_total": int(len(last_hits)),
                 # fingerprint of (structure, template, atoms) of the whole job's hit table: a sharded run and the
                 # unsharded run of the same structures print the same value (tests/test_gpu_round3.py)
@@ -667,7 +723,7 @@ def main():
                         mism += 1
             out["parity_sample"] = {"structures": len(oracle_results), "mismatches": mism}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_sharded:
         dist.destroy_process_group()
 
 

@@ -91,7 +91,7 @@ EXPORTS = (
     "tm_batch_create", "tm_batch_create_from_columns", "tm_batch_create_from_structures", "tm_batch_create_from_pdb", "tm_batch_atom_counts", "tm_batch_line_offsets",
     "tm_batch_residue_counts",
     "tm_batch_destroy", "tm_query", "tm_result_wait", "tm_result_needed", "tm_result_hit_count",
-    "tm_batch_refused", "tm_result_copy_hits", "tm_result_copy_candidates", "tm_result_timing", "tm_result_search_split", "tm_result_page_census", "tm_result_device_hits",
+    "tm_batch_refused", "tm_result_copy_hits", "tm_result_copy_candidates", "tm_result_timing", "tm_result_search_split", "tm_result_page_census", "tm_result_wait_appended", "tm_result_device_hits",
     "tm_result_append_hits", "tm_result_destroy", "tm_pdb_count_host", "tm_pdb_parse_host", "tm_pdb_count_host_many",
     "tm_pdb_parse_host_many", "tm_files_sizes", "tm_files_read", "tm_batch_create_from_files", "tm_batch_file_text",
     "tm_stream_create", "tm_stream_destroy", "tm_batch_text_layout",
@@ -574,6 +574,10 @@ class Result:
         table: ``rows_ptr`` tm_hit[capacity], ``count_ptr`` a uint64 row counter, both device addresses."""
         _check(load().tm_result_append_hits(self._h, C.c_void_p(rows_ptr), C.c_uint64(capacity), C.c_void_p(count_ptr),
                                             C.c_uint32(structure_offset)))
+
+    def wait_appended(self):
+        """Waits for the rows of the last ``append_hits`` to be in the table (not for later work on the stream)."""
+        _check(load().tm_result_wait_appended(self._h))
 
     def close(self):
         if getattr(self, "_h", None) and not _finalizing():

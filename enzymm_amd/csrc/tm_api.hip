@@ -515,9 +515,18 @@ struct tm_result {
     uint32_t overflow = 0;
     unsigned long long n_hits = 0, n_cands = 0, n_pairs = 0;
     bool split_recorded = false;  // ev[4] (between the block search and the depth-first part) was recorded
+    // The query's counters and flags travel to page-locked host memory behind its last kernel, and an event marks their
+    // arrival: tm_result_wait waits for THAT, not for the whole stream -- searches of the next pass may already be queued
+    // on it (bench.py's N > 1 loop finishes pass j while pass j + 1 runs).  [0..3] counters, [4] overflow word,
+    // [5] kind-list entries the index needed, [6..7] pair-table row slots / entries.
+    PinnedBuf<unsigned long long> h_outcome;
+    hipEvent_t ev_done = nullptr, ev_appended = nullptr;
+    bool outcome_queued = false, appended = false;
     ~tm_result() {
         for (auto &e : ev)
             if (e) (void)hipEventDestroy(e);
+        if (ev_done) (void)hipEventDestroy(ev_done);
+        if (ev_appended) (void)hipEventDestroy(ev_appended);
     }
 };
 
@@ -2189,6 +2198,17 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(r->ev[3], stream));
+    {
+        HIP_TRY(r->h_outcome.alloc(8));
+        for (int i = 0; i < 8; ++i) r->h_outcome[i] = 0ull;
+        HIP_TRY(hipMemcpyAsync(r->h_outcome.p, r->d_counters.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(r->h_outcome.p + 4, r->d_overflow.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(r->h_outcome.p + 5, r->d_pool_used.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(r->h_outcome.p + 6, r->d_tab_used.p, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipEventCreateWithFlags(&r->ev_done, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(r->ev_done, stream));
+        r->outcome_queued = true;
+    }
     trace.mark("finish launch");
     guard.r = nullptr;
     *out = r;
@@ -2200,12 +2220,20 @@ int tm_result_wait(tm_result *r) {
     if (!r->waited) {
         HIP_TRY(hipSetDevice(r->device));
         unsigned long long counters[4] = {0, 0, 0, 0};
-        HIP_TRY(hipMemcpyAsync(counters, r->d_counters.p, sizeof counters, hipMemcpyDeviceToHost, r->stream));
         unsigned long long pool_used = 0, tab_used[2] = {0, 0};
-        HIP_TRY(hipMemcpyAsync(&r->overflow, r->d_overflow.p, sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
-        HIP_TRY(hipMemcpyAsync(&pool_used, r->d_pool_used.p, sizeof pool_used, hipMemcpyDeviceToHost, r->stream));
-        HIP_TRY(hipMemcpyAsync(tab_used, r->d_tab_used.p, sizeof tab_used, hipMemcpyDeviceToHost, r->stream));
-        HIP_TRY(hipStreamSynchronize(r->stream));
+        if (r->outcome_queued) {  // (copied behind the query's last kernel: wait for that copy, not for the stream)
+            HIP_TRY(hipEventSynchronize(r->ev_done));
+            for (int i = 0; i < 4; ++i) counters[i] = r->h_outcome[i];
+            r->overflow = (uint32_t)r->h_outcome[4];
+            pool_used = r->h_outcome[5];
+            tab_used[0] = r->h_outcome[6]; tab_used[1] = r->h_outcome[7];
+        } else {
+            HIP_TRY(hipMemcpyAsync(counters, r->d_counters.p, sizeof counters, hipMemcpyDeviceToHost, r->stream));
+            HIP_TRY(hipMemcpyAsync(&r->overflow, r->d_overflow.p, sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
+            HIP_TRY(hipMemcpyAsync(&pool_used, r->d_pool_used.p, sizeof pool_used, hipMemcpyDeviceToHost, r->stream));
+            HIP_TRY(hipMemcpyAsync(tab_used, r->d_tab_used.p, sizeof tab_used, hipMemcpyDeviceToHost, r->stream));
+            HIP_TRY(hipStreamSynchronize(r->stream));
+        }
         if ((r->overflow & 16u) && r->index_shared) {  // a pair-table pool ran out: remember what the build needed
             auto raise = [](std::atomic<unsigned long long> &a, unsigned long long v) {
                 unsigned long long seen = a.load();
@@ -2368,6 +2396,14 @@ int tm_result_page_census(tm_result *r, uint32_t *max_pages, uint64_t *triples) 
     return TM_OK;
 }
 
+int tm_result_wait_appended(tm_result *r) {
+    if (!r) return fail(TM_E_INVALID, "result is NULL");
+    if (!r->appended) return TM_OK;
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipEventSynchronize(r->ev_appended));
+    return TM_OK;
+}
+
 const void *tm_result_device_hits(tm_result *r) { return r ? r->d_hits.p : nullptr; }
 
 int tm_result_append_hits(tm_result *r, void *rows, uint64_t capacity, uint64_t *count, uint32_t structure_offset) {
@@ -2377,6 +2413,9 @@ int tm_result_append_hits(tm_result *r, void *rows, uint64_t capacity, uint64_t 
                        reinterpret_cast<tm_hit *>(rows), (unsigned long long)capacity,
                        reinterpret_cast<unsigned long long *>(count), structure_offset);
     HIP_TRY(hipGetLastError());
+    if (!r->ev_appended) HIP_TRY(hipEventCreateWithFlags(&r->ev_appended, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(r->ev_appended, r->stream));
+    r->appended = true;
     return TM_OK;
 }
 

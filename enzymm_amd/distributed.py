@@ -228,21 +228,31 @@ class DeviceHitTable:
         import torch.distributed as dist
 
         n_local = int(self.count.item())  # the pass's one read-back of a count
-        if n_local > self.capacity:
-            raise _native.NativeError(_native.TM_E_OVERFLOW, f"device hit table holds {self.capacity} rows, the pass produced {n_local}")
+        overflow = _native.NativeError(_native.TM_E_OVERFLOW,
+                                       f"device hit table holds {self.capacity} rows, the pass produced {n_local}")
         active = dist.is_available() and dist.is_initialized()
         if not active or (dist.get_world_size(group) == 1 and not force_collective):
+            if n_local > self.capacity:
+                raise overflow
             table = self.rows[: n_local * self.width].cpu().numpy().view(_native.HIT_DTYPE).copy()
             return sort_rows(table) if sort else table
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         on_device = dist.get_backend(group) != "gloo"
         comm = self.device if on_device else torch.device("cpu")
-        mine = torch.tensor([n_local], dtype=torch.int64, device=comm)
-        counts = torch.zeros(world, dtype=torch.int64, device=comm)
+        # every rank takes part in the exchange of the counts -- an overflowed rank included (it sends its count and its
+        # capacity) -- and all of them raise together: a rank that raised BEFORE the collective would leave the others
+        # waiting in it until the watchdog fires
+        mine = torch.tensor([n_local, self.capacity], dtype=torch.int64, device=comm)
+        counts = torch.zeros(2 * world, dtype=torch.int64, device=comm)
         dist.all_gather_into_tensor(counts, mine, group=group)
         counts = counts.cpu().tolist()
+        counts, capacities = counts[0::2], counts[1::2]
+        full = [r for r in range(world) if counts[r] > capacities[r]]
+        if full:
+            raise _native.NativeError(_native.TM_E_OVERFLOW, "device hit table too small on rank(s) " +
+                                      ", ".join(f"{r} ({counts[r]} rows, room for {capacities[r]})" for r in full))
         pad = max(counts + [1]) * self.width
-        if pad > self.rows.numel():
+        if pad > self.rows.numel():  # (equal capacities on every rank rule this out; unequal ones: every rank sees the same counts)
             raise _native.NativeError(_native.TM_E_OVERFLOW, "a rank's hit table is larger than this rank's capacity")
         send = self.rows[:pad] if on_device else self.rows[:pad].cpu()  # a view of the table itself: no staging copy
         out = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None

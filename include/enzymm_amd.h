@@ -244,6 +244,9 @@ int tm_result_search_split(tm_result *res, float *front_ms, float *deep_ms);
 /* Diagnostic: the most pages of surviving triples any structure of the query listed between the block search and the
  * depth-first part (64 triples to a page), and the triples in all pages.  Waits for the result. */
 int tm_result_page_census(tm_result *res, uint32_t *max_pages, uint64_t *triples);
+/* Waits until the rows of the last tm_result_append_hits of this result are in the table (an event behind that copy,
+ * not the stream: later queries queued on the same stream keep running). */
+int tm_result_wait_appended(tm_result *res);
 const void *tm_result_device_hits(tm_result *res);           /* device pointer to the unsorted tm_hit table */
 /* Appends this query's hit rows to a caller-owned DEVICE table (rows: tm_hit[capacity], *count: rows in use, both in
  * device memory), adding structure_offset to tm_hit.structure -- enqueued on the query's stream behind its kernels,

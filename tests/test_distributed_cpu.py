@@ -203,3 +203,34 @@ def test_pass_table_without_process_group_and_overflow():
     small.append_rows(rows)
     with pytest.raises(_native.NativeError):
         small.gather()
+
+
+def _overflow_worker(rank, world, port, out_path):
+    """Rank 1's table overflows, rank 0's does not: BOTH must raise TM_E_OVERFLOW from gather() -- rank 1 takes part in
+    the exchange of the counts before it raises, so rank 0 is not left waiting in a collective."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=60))
+    try:
+        rows = np.zeros(6, dtype=_native.HIT_DTYPE)
+        rows["structure"] = np.arange(6)
+        table = distributed.DeviceHitTable(4, device="cpu")
+        table.append_rows(rows[:2] if rank == 0 else rows, 100 * rank)  # 2 rows fit, 6 do not
+        try:
+            table.gather()
+            outcome = "no error"
+        except _native.NativeError as exc:
+            outcome = f"{exc.code}: {exc}"
+        with open(f"{out_path}.{rank}", "w") as handle:
+            handle.write(outcome)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overflowed_rank_does_not_hang_the_gather(tmp_path):
+    import torch.multiprocessing as mp
+    out = tmp_path / "outcome"
+    mp.spawn(_overflow_worker, args=(2, _free_port(), str(out)), nprocs=2, join=True)
+    for rank in (0, 1):
+        text = (tmp_path / f"outcome.{rank}").read_text()
+        assert text.startswith(f"{_native.TM_E_OVERFLOW}:") and "rank(s) 1 (6 rows, room for 4)" in text, text

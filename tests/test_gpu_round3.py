@@ -301,7 +301,7 @@ def test_bench_two_ranks_as_the_driver_launches_it():
     """bench.py --gpus 2 under torch.distributed.run in a FRESH child process (both ranks on this box's one GPU, gloo
     for the collective: ENZYMM_AMD_BENCH_ONE_GPU=1): one JSON line, n_gpus 2, and the gathered hit table of the two
     shards equals the table of the unsharded run over the same 128 structures."""
-    common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--streamed-passes", "0"]
+    common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--streamed-passes", "0", "--sustained-seconds", "0"]
     two = _bench_line(["--gpus", "2", "--structures", "64"] + common, {"ENZYMM_AMD_BENCH_ONE_GPU": "1"}, nproc=2)
     one = _bench_line(["--gpus", "1", "--structures", "128"] + common, {})
     assert two["n_gpus"] == 2 and one["n_gpus"] == 1 and two["scaling"] == "weak"

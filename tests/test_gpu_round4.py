@@ -268,3 +268,24 @@ def test_reference_call_pattern_through_the_sweep_planner(amy, af):
             launched = [l for l in pyjess._sweeps.launches]
             assert sum(l[0] for l in launched) == len(mols) and all(len(l[2]) == len(sizes) for l in launched)
     pyjess._sweeps.clear()
+
+
+# ------------------------------------------------------------------------------------------- bench.py's N > 1 loop over RCCL
+
+
+def test_bench_sharded_loop_over_rccl_on_one_gpu():
+    """ENZYMM_AMD_BENCH_FORCE_SHARDED=1 sends `bench.py --gpus 1` through the N > 1 branch in a fresh child process: a
+    world-size-1 "nccl" group with device_id set, the rows of every search appended to the device hit table behind its
+    kernels, per-result event waits, the error exchange (all_reduce) and ONE all_gather_into_tensor + gather per pass
+    over RCCL -- the loop the driver runs at N = 2, 4, 8.  Its hit table equals the plain run's (digest and count), with
+    two resident batches per pass (the next pass's searches are queued while a pass is finished)."""
+    from tests.test_gpu_round3 import _bench_line
+    common = ["--gpus", "1", "--structures", "192", "--batch", "96", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+              "--no-extras", "--streamed-passes", "0", "--sustained-seconds", "0.5"]
+    plain = _bench_line(common, {})
+    forced = _bench_line(common, {"ENZYMM_AMD_BENCH_FORCE_SHARDED": "1"})
+    assert forced["n_gpus"] == 1 and "forced" in forced["config"]["parallelism"]
+    assert forced["config"]["hits_total"] == plain["config"]["hits_total"] > 100
+    assert forced["config"]["hit_table_digest"] == plain["config"]["hit_table_digest"]
+    assert forced["config"]["gather_ms_per_pass"] is not None and plain["config"]["gather_ms_per_pass"] is None
+    assert forced["config"]["sustained_structures_per_s"] > 0 and forced["value"] > 0
