@@ -722,6 +722,14 @@ def main():
                             abs(mine[ti]["rmsd"] - r["rmsd"][ti]) > 1e-5:
                         mism += 1
             out["parity_sample"] = {"structures": len(oracle_results), "mismatches": mism}
+        # (RCCL keeps a version banner in the C library's stdout buffer until the process ends: out with it first, so that
+        # the JSON line is the last thing this process prints)
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
         print(json.dumps(out), flush=True)
     if world > 1 or force_sharded:
         dist.destroy_process_group()
