@@ -146,9 +146,25 @@ struct __align__(16) LookHdr {
     uint16_t li3;           // lead-kind index when level 3 is the lead of a fourth residue, else 0xffff
     uint8_t ref;            // else: which of leads 0, 1, 2 shares its residue
     uint8_t flags;          // bit 0: any residue type; bit 1: the template has no level 3 (three atoms)
-    uint32_t pad[2];
+    uint32_t n_rescheck;    // ResCheck records of the template (stage D0)
+    uint32_t pad;
 };
 static_assert(sizeof(LookHdr) == 48, "LookHdr layout");
+
+// Stage D0 of the block search: what it takes to ask, for a triple of placed leads, whether ONE OTHER atom of one of their
+// three residues can exist at all -- a search level that is not a lead and belongs to template residue 0, 1 or 2: the
+// names and residue types it admits and its windows against the three leads.  Such a level depends on nothing but the
+// triple, so a triple for which any of them has no candidate cannot be completed, whatever the other leads will be.
+// One record per such level, kResChecks slots per staged template.
+struct __align__(16) ResCheck {
+    uint32_t nm_lo, nm_hi;  // admissible atom names
+    uint32_t resmask;       // ... and residue types
+    uint32_t ref_any;       // which of leads 0, 1, 2 shares its residue | any residue type << 8
+    float2 w0, w1, w2;      // fp32 windows (lo^2, hi^2) against leads 0, 1, 2
+    uint32_t pad[2];
+};
+static_assert(sizeof(ResCheck) == 48, "ResCheck layout");
+constexpr int kResChecks = kMaxK - 3;
 
 // A triple (lead atoms of the first three template residues) that survived the tables and the look at level 3, waiting
 // for the depth-first search below it (k_deep).  k_search writes them in pages of kPageTriples; a structure's pages
@@ -176,6 +192,7 @@ struct QueryView {
     const Staged *staged;       // [n_sel]
     const BlockHdr *hdr;        // [n_sel]
     const LookHdr *look;        // [n_sel]
+    const ResCheck *rescheck;   // [n_sel * kResChecks]
     const float2 *bounds;       // [n_sel*kMaxPairs] (lo^2, hi^2) fp32 prefilter bounds, search order
     const uint32_t *order;      // [n_sel] every per-selection array above is sorted by descending estimated cost;
                                 // order[pos] = the caller's selection index (reported in tm_hit / candidate counts)

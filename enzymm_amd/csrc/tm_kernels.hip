@@ -119,7 +119,8 @@ __global__ __launch_bounds__(64) void k_stage_templates(LibView L, uint32_t n_se
                                                          const uint8_t *__restrict__ triple_key,
                                                          Staged *__restrict__ staged, float2 *__restrict__ bounds,
                                                          BlockHdr *__restrict__ hdr, LookHdr *__restrict__ look,
-                                                         uint16_t *__restrict__ lead8, double slack) {
+                                                         uint16_t *__restrict__ lead8, ResCheck *__restrict__ rescheck,
+                                                         double slack) {
     const uint32_t ti = blockIdx.x;
     if (ti >= n_sel) return;
     const uint32_t t = sel[ti];
@@ -167,6 +168,22 @@ __global__ __launch_bounds__(64) void k_stage_templates(LibView L, uint32_t n_se
         pair_of(p, i, j);
         bounds[(size_t)ti * kMaxPairs + p] = window(i, j);
     }
+    // stage D0's records: the levels that are not leads and belong to template residues 0, 1, 2, in search order
+    unsigned long long rc_mask = 0ull;
+    {
+        const bool qual = lane < k && L.a_ref[off + min(lane, k - 1)] != lane && L.a_ref[off + min(lane, k - 1)] < 3 && k > 3;
+        rc_mask = ballot64(qual);
+        if (qual) {
+            const uint32_t kind = L.a_kind[off + lane];
+            const uint64_t nm = L.k_namemask[kind];
+            ResCheck r = {};
+            r.nm_lo = (uint32_t)nm; r.nm_hi = (uint32_t)(nm >> 32);
+            r.resmask = L.k_resmask[kind];
+            r.ref_any = (uint32_t)L.a_ref[off + lane] | (L.k_any[kind] ? 256u : 0u);
+            r.w0 = window(lane, 0); r.w1 = window(lane, 1); r.w2 = window(lane, 2);
+            rescheck[(size_t)ti * kResChecks + rank_in(rc_mask)] = r;
+        }
+    }
     if (lane == 0) {
         // the compact record of the table-driven stages (leads 0, 1, 2 are search positions 0, 1, 2)
         int g = 0;
@@ -196,6 +213,7 @@ __global__ __launch_bounds__(64) void k_stage_templates(LibView L, uint32_t n_se
             q.li3 = 0xffffu;
             q.flags = 2u;
         }
+        q.n_rescheck = (uint32_t)__popcll(rc_mask);
         look[ti] = q;
         for (int i = 0; i < kMaxG; ++i) lead8[(size_t)ti * kMaxG + i] = i < g ? (uint16_t)L.k_lead[L.a_kind[off + i]] : (uint16_t)0xffffu;
     }
@@ -1787,7 +1805,16 @@ __device__ __forceinline__ void page_append(PageWriter &PW, uint32_t s, uint32_t
     }
 }
 
-// Stage D1 over the first `nt` queued triples: those with a candidate for level 3 go to the wave's page.
+// Stages D0 and D1 over the first `nt` queued triples: those that pass both go to the wave's page.
+//
+//   D0  Can the OTHER atoms of the three placed residues exist?  The search levels that are not leads and belong to
+//       template residues 0, 1, 2 depend on nothing but the triple: lane = (triple, such level) -- laid end to end like the
+//       table stages -- walks the atoms of the target residue its lead sits in and asks for one that carries an admissible
+//       name and residue type and fits the windows against the three leads.  A triple with a level that has no candidate
+//       cannot be completed whatever the remaining leads will be: it ends here (round 3 looked at search level 3 only,
+//       and the depth-first part found the same out one level evaluation -- two hundred dependent instructions -- at a time).
+//   D1  the lead of a FOURTH residue (search level 3 of templates with more than three residues): is there any candidate
+//       in its kind list that fits the three leads?  Only for the triples D0 left.
 template <class Ctx>
 __device__ __forceinline__ void block_look(Ctx &C, const SearchArgs &A, SlotRegs &R, PageWriter &PW, uint32_t s,
                                            const uint32_t *kl, uint32_t nt) {
@@ -1798,42 +1825,89 @@ __device__ __forceinline__ void block_look(Ctx &C, const SearchArgs &A, SlotRegs
     if (vt) t = S.triples[lane];
     const uint32_t slot = t.y >> 16, c = t.y & 0xffffu, x0 = t.x & 0xffffu, x1 = t.x >> 16;
     const uint32_t ti = lane_get(R.ti, slot);
+
+    // ---- D0: lane = (triple, level of residues 0-2 that is not a lead)
+    bool fail = false;
+    {
+        const uint32_t n_rl = vt ? A.Q.look[ti].n_rescheck : 0u;
+        const uint32_t incl = wave_scan_add(n_rl), excl = incl - n_rl;
+        const uint32_t total = RL(incl, 63);
+        TM_STAT(62, total);
+        for (uint32_t w0 = 0; w0 < total; w0 += 64u) {
+            S.owner[lane] = 0u;
+            {
+                const uint32_t start = max(excl, w0);
+                if (n_rl != 0u && start < w0 + 64u && incl > w0) S.owner[start - w0] = lane;
+            }
+            wave_sync();
+            const uint32_t p = wave_scan_max(S.owner[lane]);
+            wave_sync();
+            const bool item = w0 + lane < total;
+            const uint32_t w = min(w0 + lane, total - 1u);
+            const uint32_t j = w - lane_get(excl, p);  // which of the triple's records
+            const uint32_t pti = lane_get(ti, p);
+            const uint4 *rec4 = reinterpret_cast<const uint4 *>(A.Q.rescheck + (size_t)pti * kResChecks + j);
+            const uint4 ra = rec4[0], rb = rec4[1];
+            const uint2 rw2 = *reinterpret_cast<const uint2 *>(rec4 + 2);
+            const uint2 pt = S.triples[p];  // (the owner's queue entry: its three atoms)
+            const uint32_t px0 = pt.x & 0xffffu, px1 = pt.x >> 16, pc = pt.y & 0xffffu;
+            const float4 l0 = C.rec[px0], l1 = C.rec[px1], l2 = C.rec[pc];
+            const uint32_t ref = ra.w & 0xffu;
+            const uint32_t res = meta_res(__float_as_uint(ref == 0u ? l0.w : ref == 1u ? l1.w : l2.w));
+            uint32_t a = C.res_start[res];
+            const uint32_t a_end = C.res_start[res + 1u];
+            const unsigned long long nm = ((unsigned long long)ra.y << 32) | ra.x;
+            const bool any = (ra.w & 256u) != 0u;
+            const float2 w0b = make_float2(__uint_as_float(rb.x), __uint_as_float(rb.y)), w1b = make_float2(__uint_as_float(rb.z), __uint_as_float(rb.w)),
+                         w2b = make_float2(__uint_as_float(rw2.x), __uint_as_float(rw2.y));
+            bool found = false;
+            for (; a < a_end && !found; ++a) {  // (a dozen atoms at most; the name leaves one of them, usually)
+                const uint32_t m = __float_as_uint(C.rec[a].w);
+                if ((((nm >> meta_name(m)) & 1ull) != 0ull) & (any | (((ra.z >> meta_rtype(m)) & 1u) != 0u)) & (a != px0) & (a != px1) & (a != pc)) {
+                    const float4 r = C.rec[a];
+                    found = in_window(r, l0, w0b) & in_window(r, l1, w1b) & in_window(r, l2, w2b);
+                }
+            }
+            const unsigned long long missing = ballot64(item && !found);
+            TM_STAT(63, 1);
+            // does any of MY triple's levels of this pass lack a candidate?  (items [max(excl, w0), min(incl, w0 + 64)) - w0)
+            if (n_rl != 0u && incl > w0 && excl < w0 + 64u) {
+                const uint32_t lo = max(excl, w0) - w0, hi = min(incl, w0 + 64u) - w0;  // 0 <= lo < hi <= 64
+                const unsigned long long span = (hi == 64u ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
+                fail = fail | ((missing & span) != 0ull);
+            }
+        }
+    }
+    const bool alive = vt && !fail;
+    {
+        const uint32_t n_failed = (uint32_t)__popcll(ballot64(vt && fail));
+        (void)n_failed;
+        TM_STAT(69, n_failed);
+    }
+
+    // ---- D1: the lead of a fourth residue.  Its kind list is long (a hundred atoms is common), so these triples go one at
+    // a time with their atoms and windows as wave-uniform values and the LANES over the candidates -- a candidate then
+    // costs its record and nine multiply-adds, nothing is exchanged between lanes.
     const LookHdr H = A.Q.look[ti];
     const float4 q0 = C.rec[x0], q1 = C.rec[x1], q2 = C.rec[c];
     const bool lead3 = H.li3 != 0xffffu;
-    const bool nolook = (H.flags & 2u) != 0u;
-    // where the candidates come from: a kind list (pool positions) or the atoms of an assigned residue (atom indices)
-    uint32_t first, n_c, own;
-    if (lead3) {
+    uint32_t first = 0, n_c = 0;
+    if (lead3 && alive) {
         first = kl[H.li3];
         n_c = kl[H.li3 + 1u] - first;
-        own = 0xffffffffu;
-    } else {
-        const uint32_t res = meta_res(__float_as_uint(H.ref == 0u ? q0.w : H.ref == 1u ? q1.w : q2.w));
-        first = C.res_start[res];
-        n_c = C.res_start[res + 1u] - first;
-        own = H.ref == 0u ? x0 : H.ref == 1u ? x1 : c;
     }
-    if (!vt || nolook) n_c = 0u;
-    bool pass = vt && nolook;
-
-    // ---- the lead of a fourth residue: its kind list is long (a hundred atoms is common), so the triples of this sort
-    // go one at a time with their atoms and windows as wave-uniform values and the LANES over the candidates -- a
-    // candidate then costs its record and nine multiply-adds, nothing is exchanged between lanes.
+    // (no level 3 at all, or level 3 is another atom of a placed residue, which D0 has looked at: nothing left to ask here)
+    bool pass = alive && !lead3;
     unsigned long long found_lead = 0ull;
 #ifdef TM_STATS
     {
-        const uint32_t n_lead3 = (uint32_t)__popcll(ballot64(lead3 && n_c != 0u)), n_res3 = (uint32_t)__popcll(ballot64(!lead3 && n_c != 0u));
-        const uint32_t n_empty = (uint32_t)__popcll(ballot64(vt && !nolook && n_c == 0u));
+        const uint32_t n_lead3 = (uint32_t)__popcll(ballot64(lead3 && n_c != 0u));
         TM_STAT(60, n_lead3);
-        TM_STAT(62, n_res3);
-        TM_STAT(69, n_empty);
     }
 #endif
     // Consecutive triples mostly belong to one template and so share the kind list of their fourth lead: a list's first
     // 64 records stay in registers from one triple to the next, and the first chunk -- the only one for nine lists in ten --
-    // is tested without a loop around it.  (kTurn triples per turn, their chains of list -> record -> nine multiply-adds ->
-    // vote interleaved: 4.52 / 4.52 / 4.55 / 4.47 ms per search for 1 / 2 / 3 / 4, at 0 / 27 / 60 / 109 spilled SGPRs; 1.)
+    // is tested without a loop around it.
     uint32_t held_lo = 0xffffffffu, held_cnt = 0u;
     float4 held = make_float4(0.f, 0.f, 0.f, 0.f);
     struct Uniform {
@@ -1869,98 +1943,23 @@ __device__ __forceinline__ void block_look(Ctx &C, const SearchArgs &A, SlotRegs
         const float dc = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
         return (idx < u.cnt) & (da >= u.wa.x) & (da <= u.wa.y) & (db >= u.wb.x) & (db <= u.wb.y) & (dc >= u.wc.x) & (dc <= u.wc.y);
     };
-#ifndef TM_LOOK_ILP
-#define TM_LOOK_ILP 1
-#endif
-    constexpr int kTurn = TM_LOOK_ILP;  // triples per turn
     for (unsigned long long todo = ballot64(lead3 && n_c != 0u); todo;) {
-        int q[kTurn];
-        Uniform u[kTurn];
-        float4 r[kTurn];
-        bool f[kTurn];
-#pragma unroll
-        for (int n = 0; n < kTurn; ++n) {  // (turns with fewer triples left repeat the last one: harmless)
-            q[n] = todo ? __ffsll((long long)todo) - 1 : q[n > 0 ? n - 1 : 0];
-            if (todo) todo &= todo - 1ull;
-            u[n] = uniform_of(q[n]);
+        const int q = __ffsll((long long)todo) - 1;
+        todo &= todo - 1ull;
+        const Uniform u = uniform_of(q);
+        if (u.lo != held_lo || u.cnt != held_cnt) {
+            held = C.rec[C.pool_at(u.lo + min(lane, u.cnt - 1u))];
+            held_lo = u.lo;
+            held_cnt = u.cnt;
         }
-        if (u[0].lo != held_lo || u[0].cnt != held_cnt) {
-            held = C.rec[C.pool_at(u[0].lo + min(lane, u[0].cnt - 1u))];
-            held_lo = u[0].lo;
-            held_cnt = u[0].cnt;
-        }
-        r[0] = held;
-#pragma unroll
-        for (int n = 1; n < kTurn; ++n) {  // the same list as the triple before, usually
-            r[n] = r[n - 1];
-            if (u[n].lo != u[n - 1].lo || u[n].cnt != u[n - 1].cnt) r[n] = C.rec[C.pool_at(u[n].lo + min(lane, u[n].cnt - 1u))];
-        }
-#pragma unroll
-        for (int n = 0; n < kTurn; ++n) f[n] = ballot64(fits(u[n], r[n], lane)) != 0ull;
-        TM_STAT(61, kTurn);
-        // lists of more than 64 atoms: the chunks beyond the first, one triple at a time
-#pragma unroll
-        for (int n = 0; n < kTurn; ++n) {
-            for (uint32_t base = 64u; base < u[n].cnt && !f[n]; base += 64u)
-                f[n] = ballot64(fits(u[n], C.rec[C.pool_at(u[n].lo + min(base + lane, u[n].cnt - 1u))], base + lane)) != 0ull;
-            if (f[n]) found_lead |= 1ull << q[n];
-        }
-        held = r[kTurn - 1];  // the list the next turn most likely starts with
-        held_lo = u[kTurn - 1].lo;
-        held_cnt = u[kTurn - 1].cnt;
+        bool f = ballot64(fits(u, held, lane)) != 0ull;
+        TM_STAT(61, 1);
+        // lists of more than 64 atoms: the chunks beyond the first
+        for (uint32_t base = 64u; base < u.cnt && !f; base += 64u)
+            f = ballot64(fits(u, C.rec[C.pool_at(u.lo + min(base + lane, u.cnt - 1u))], base + lane)) != 0ull;
+        if (f) found_lead |= 1ull << q;
     }
     pass = pass | (((found_lead >> lane) & 1ull) != 0ull);
-
-    // ---- another atom of an assigned residue: a dozen atoms at most, of which the masks leave one or two.  These go
-    // lane = (triple, atom), laid end to end like the table stages.
-    if (lead3) n_c = 0u;
-    const uint32_t anyres = H.flags & 1u;
-    const uint32_t incl = wave_scan_add(n_c), excl = incl - n_c;
-    const uint32_t total = RL(incl, 63);
-    const uint32_t cbase = first - excl;  // candidate atom of item w of this triple: cbase + w
-    TM_STAT(63, total);
-    for (uint32_t w0 = 0; w0 < total; w0 += 64u) {
-        S.owner[lane] = 0u;
-        {
-            const uint32_t start = max(excl, w0);
-            if (n_c != 0u && start < w0 + 64u && incl > w0) S.owner[start - w0] = lane;
-        }
-        wave_sync();
-        const uint32_t p = wave_scan_max(S.owner[lane]);
-        wave_sync();
-        const uint32_t w = min(w0 + lane, total - 1u);
-        const uint32_t atom = lane_get(cbase, p) + w;
-        const float4 r = C.rec[atom];
-        const uint32_t m = __float_as_uint(r.w);
-        bool ok = w0 + lane < total;
-        {
-            const float dx = r.x - lane_getf(q0.x, p), dy = r.y - lane_getf(q0.y, p), dz = r.z - lane_getf(q0.z, p);
-            const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-            ok = ok & (d2 >= lane_getf(H.w30.x, p)) & (d2 <= lane_getf(H.w30.y, p));
-        }
-        {
-            const float dx = r.x - lane_getf(q1.x, p), dy = r.y - lane_getf(q1.y, p), dz = r.z - lane_getf(q1.z, p);
-            const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-            ok = ok & (d2 >= lane_getf(H.w31.x, p)) & (d2 <= lane_getf(H.w31.y, p));
-        }
-        {
-            const float dx = r.x - lane_getf(q2.x, p), dy = r.y - lane_getf(q2.y, p), dz = r.z - lane_getf(q2.z, p);
-            const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-            ok = ok & (d2 >= lane_getf(H.w32.x, p)) & (d2 <= lane_getf(H.w32.y, p));
-        }
-        // it must also carry an admissible name and residue type and not be the lead itself (a superset is all a filter
-        // needs: the search proper repeats every test)
-        const unsigned long long nm = ((unsigned long long)lane_get(H.nm_hi, p) << 32) | lane_get(H.nm_lo, p);
-        const uint32_t rm = lane_get(H.resmask, p), pown = lane_get(own, p), pany = lane_get(anyres, p);
-        ok = ok & (((nm >> meta_name(m)) & 1ull) != 0ull) & ((pany != 0u) | (((rm >> meta_rtype(m)) & 1u) != 0u)) & (atom != pown);
-        const unsigned long long found = ballot64(ok);
-        // does any of MY triple's items of this pass carry a vote?  (items [max(excl, w0), min(incl, w0 + 64)) - w0)
-        if (n_c != 0u && incl > w0 && excl < w0 + 64u) {
-            const uint32_t lo = max(excl, w0) - w0, hi = min(incl, w0 + 64u) - w0;  // 0 <= lo < hi <= 64
-            const unsigned long long span = (hi == 64u ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
-            pass = pass | ((found & span) != 0ull);
-        }
-    }
     unsigned long long keep = ballot64(pass);
     {
         const uint32_t n_keep = (uint32_t)__popcll(keep);

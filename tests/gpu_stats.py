@@ -34,9 +34,9 @@ searches = s[49]
 print("searches", int(searches), "completes", int(s[48]), "fp64 rejects", int(s[51]))
 print("per search: pair passes %.3f  pair survivors %.3f  triple passes %.3f  triple survivors %.3f" %
       (s[52] / searches, s[53] / searches, s[67] / searches, s[68] / searches))
-print("per search: look flushes %.4f  triples with a lead at level 3 %.3f (chunks each %.2f)  with a residue atom %.3f (items each %.2f)  paged out %.3f" %
-      (s[64] / searches, s[60] / searches, s[61] / max(s[60], 1), s[62] / searches, s[63] / max(s[62], 1), s[65] / searches))
-print("triples looked at per search %.3f, of them with an empty candidate source %.3f" % (s[66] / searches, s[69] / searches))
+print("per search: look flushes %.4f  triples looked at %.3f  ended by the residue check (D0) %.3f  asked for a fourth lead (D1) %.3f (chunks each %.2f)  paged out %.3f" %
+      (s[64] / searches, s[66] / searches, s[69] / searches, s[60] / searches, s[61] / max(s[60], 1), s[65] / searches))
+print("residue-check items per triple looked at %.2f, passes of 64 items per search %.4f" % (s[62] / max(s[66], 1), s[63] / searches))
 paged = max(s[65], 1)
 print("k_deep chunk evaluations per level (per paged triple)", np.round(s[3:24] / paged, 2))
 print("k_deep survivors per level (per paged triple)        ", np.round(s[27:48] / paged, 2))
