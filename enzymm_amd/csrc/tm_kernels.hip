@@ -1278,7 +1278,9 @@ __device__ __forceinline__ bool on_complete(const Ctx &C, WaveRegs &W, PairState
         if (lane == 0) base = atomicAdd(A->O.n_cands, (unsigned long long)want);
         base = uni64(base);
         if (base + want > A->O.cand_capacity) {
-            if (lane == 0) atomicOr(A->O.overflow, 1u);  // (the query is run again with room: tm_result_needed)
+            // (the query is run again with room: tm_result_needed.  From here on the wave asks for ONE slot per candidate, so
+            // that the counter ends on what the query needs, not on up to 64 times that)
+            if (lane == 0) { atomicOr(A->O.overflow, 1u); S.slab[2] = 1u; }
             return true;
         }
         next = (uint32_t)base;

@@ -186,7 +186,7 @@ def test_one_pair_beyond_100000_candidates_and_a_thousand_pages_in_lds(amy):
     idx, _ = helpers.default_selection()
     jess = pyjess.Jess(lib)
     packed = pyjess._packed(jess._templates, jess._device)
-    sel = idx[::3].astype(np.uint32)
+    sel = idx.astype(np.uint32)  # (all 6780: since stage D0 of the block search, a third of them lists 667 pages)
     batch = pyjess.make_batch([amy], jess._device)
     flags = _native.TM_FLAG_BEST_MATCH | _native.TM_FLAG_IGNORE_CHAIN | _native.TM_FLAG_COUNT_CANDIDATES
     res = _native.query(packed.native, batch, sel, 3.0, 4.0, 4.0, 0xFFFFFFFF, flags)
@@ -199,7 +199,7 @@ def test_one_pair_beyond_100000_candidates_and_a_thousand_pages_in_lds(amy):
     assert counts.max() > 100_000, counts.max()
     assert pages > 1024 and triples > 65536, (pages, triples)
     heavy = np.argsort(counts)[-3:]
-    sample = np.unique(np.concatenate([heavy, np.arange(0, len(sel), 97)]))
+    sample = np.unique(np.concatenate([heavy, np.arange(0, len(sel), 293)]))
     otpl = helpers.oracle_library_templates()
     olib = oracle.OracleLibrary([otpl[int(sel[i])] for i in sample])
     r = oracle.query_library(helpers.to_oracle_molecule(amy), olib, 3.0, 4.0, 4.0, max_candidates=2_000_000_000, ignore_chain=True)
