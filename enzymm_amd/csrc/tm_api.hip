@@ -2018,6 +2018,8 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
     Q.staged = S->d_staged.p; Q.hdr = S->d_hdr.p; Q.look = S->d_look.p; Q.rescheck = S->d_rescheck.p; Q.bounds = S->d_bounds.p; Q.order = S->d_order.p; Q.max_candidates = p->max_candidates; Q.flags = p->flags;
     if (const char *env = std::getenv("ENZYMM_AMD_RUN_LIST"))  // test hook: k_deep claims by page position, as for a large complex
         if (std::atoi(env) == 0) Q.flags |= 0x4000u;
+    if (const char *env = std::getenv("ENZYMM_AMD_LOCAL_DEEP"))  // test hook / A-B: every surviving triple is paged out to k_deep (round 3's flow)
+        if (std::atoi(env) == 0) Q.flags |= 0x8000u;
     Q.n_tables = (uint32_t)S->tables.size(); Q.tables = S->d_tables.p;
     Q.cost = nullptr;
     {

@@ -943,6 +943,34 @@ struct __align__(16) WaveScratchT {
     uint32_t slab[4];
 };
 
+// The block search also runs the depth-first search below the (few) triples its stage D0/D1 lets through, at the end of
+// each block: by then the stage queues are empty, so the template's pair bounds and the lead-list chunks of that search
+// use the same LDS.
+constexpr uint32_t kSharedTriples = 256;
+template <>
+struct __align__(16) WaveScratchT<kModeBlocks> {
+    union {
+        struct {
+            uint2 pairs[kPairQueue];
+            uint2 triples[kTripleQueue];
+        };
+        struct {
+            float2 bnd[kMaxPairs];
+            uint16_t surv[kMaxG][64];
+        };
+    };
+    uint32_t owner[64];
+    uint32_t slab[4];
+};
+
+// The workgroup's queue of triples that passed D0/D1 (in LDS, filled once: no wrap-around): any wave that comes to the end
+// of a block takes triples from it and searches below them, so a block with many survivors is not its wave's burden
+// alone.  What does not fit goes to the structure's pages in global memory (k_deep).
+struct SharedTriples {
+    DeepEntry entry[kSharedTriples];  // .ti == 0xffffffff: reserved, not written yet
+    uint32_t head, tail;              // next to take; next to reserve (may run past kSharedTriples: those went to pages)
+};
+
 // Search state of one wave, held in VGPRs and indexed BY LANE: lane L holds the entry of search
 // level L.  Uniform reads are v_readlane (SGPR result), uniform writes v_writelane: the DFS state
 // machine touches no memory at all.
@@ -1759,6 +1787,7 @@ struct SlotRegs {  // lane = template slot of the block
 struct PageWriter {
     uint32_t page;   // 0xffffffff: none yet
     uint32_t fill;
+    SharedTriples *shared;  // the workgroup's queue (NULL: every surviving triple is paged out)
 };
 
 constexpr uint32_t kNoPage = 0xffffffffu, kVirtualPage = 0xfffffffeu;
@@ -1973,7 +2002,27 @@ __device__ __forceinline__ void block_look(Ctx &C, const SearchArgs &A, SlotRegs
 #if defined(TM_STATS) || defined(TM_ABLATE)
     if (A.Q.flags & 0x800u) keep = 0ull;  // phase timing: the look at level 3, nothing below it
 #endif
-    if (keep) page_append(PW, s, lane, keep, t.x, c, ti);
+    if (keep) {
+        // into the workgroup's queue (searched by whichever wave comes to the end of a block next: drain_shared); what does
+        // not fit goes to the structure's pages, where every wave working on the structure takes a share (k_deep)
+        if (PW.shared != nullptr) {
+            SharedTriples &Q2 = *PW.shared;
+            const uint32_t r = rank_in(keep), n_keep = (uint32_t)__popcll(keep);
+            uint32_t base = 0;
+            if (lane == 0u) base = atomicAdd(&Q2.tail, n_keep);
+            base = uni(base);
+            const bool mine = ((keep >> lane) & 1ull) != 0ull;
+            const bool here = mine && base + r < kSharedTriples;
+            if (here) {
+                DeepEntry &e = Q2.entry[base + r];
+                e.a01 = t.x; e.c = c;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __hip_atomic_store(&e.ti, ti, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            keep &= ~ballot64(here);
+        }
+        if (keep) page_append(PW, s, lane, keep, t.x, c, ti);
+    }
 }
 
 // Moves queue entries [from, from + n) to the front (n < 64).
@@ -2064,6 +2113,67 @@ __device__ __forceinline__ void block_pairs(Ctx &C, const SearchArgs &A, SlotReg
     }
 }
 
+// The depth-first search below triples of the workgroup's queue (wave-cooperative: dfs), one triple at a time until the
+// queue is empty.  Called when the wave's stage queues are empty: the template's pair bounds and lead-list chunks take
+// their place in LDS.
+template <class Ctx>
+__device__ __forceinline__ void drain_shared(Ctx &C, const SearchArgs &A, PageWriter &PW, uint32_t s, const uint32_t *kl) {
+    if (PW.shared == nullptr) return;
+    SharedTriples &Q2 = *PW.shared;
+    const QueryView &Q = A.Q;
+    const uint32_t lane = (uint32_t)C.lane;
+    WaveRegs W = {};
+    uint32_t cur_ti = 0xffffffffu;
+    bool feasible = false;
+    PairState P;
+    P.s = s; P.ti = 0; P.truncated = false;
+    for (;;) {
+        // take the next entry, if there is one (a compare-and-swap: the head never runs past what has been reserved)
+        uint32_t idx = 0xffffffffu;
+        if (lane == 0u) {
+            uint32_t head = __hip_atomic_load(&Q2.head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (;;) {
+                const uint32_t tail = min(__hip_atomic_load(&Q2.tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), kSharedTriples);
+                if (head >= tail) break;
+                if (__hip_atomic_compare_exchange_strong(&Q2.head, &head, head + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                    idx = head;
+                    break;
+                }
+            }
+        }
+        idx = uni(idx);
+        if (idx == 0xffffffffu) break;
+        uint32_t ti;  // (reserved before it is written: wait for the writer, a wave of this workgroup a few instructions behind)
+        do {
+            ti = uni(__hip_atomic_load(&Q2.entry[idx].ti, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        } while (ti == 0xffffffffu);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const uint32_t a01 = uni(Q2.entry[idx].a01), c = uni(Q2.entry[idx].c);
+        if (ti != cur_ti) {
+            TemplateRegs T;
+            load_template(Q, ti, (int)lane, T);
+            feasible = setup_template(C, W, T, kl, Q, ti);
+            cur_ti = ti;
+            P.ti = ti;
+            P.truncated = false;
+        }
+        if (P.truncated || !feasible) continue;
+        {  // the three placed leads: lane L < 3 fetches and keeps the entry of level L (lane = level)
+            const uint32_t mine = lane == 0u ? a01 & 0xffffu : lane == 1u ? a01 >> 16 : c;
+            const float4 r = C.rec[mine];
+            if (lane < 3u) {
+                W.aidx = mine;
+                W.ax = r.x; W.ay = r.y; W.az = r.z;
+                W.ameta = __float_as_uint(r.w);
+                if (!C.ignore_chain) W.achain = (uint32_t)C.qchain[mine];
+            }
+        }
+        TM_STAT(84 + min(C.n_groups, 8), 1);
+        dfs(C, W, P, 3);
+    }
+    wave_sync();  // (the next block's stages write the queues again)
+}
+
 // One block: templates chunk + n_chunks * (m0 .. m0 + count - 1) of the staged selection against structure s.
 template <class Ctx>
 __device__ __forceinline__ void search_block(Ctx &C, const SearchArgs &A, PageWriter &PW, uint32_t s, uint32_t m0, uint32_t count,
@@ -2145,6 +2255,7 @@ __device__ __forceinline__ void search_block(Ctx &C, const SearchArgs &A, PageWr
         wave_sync();
         block_look(C, A, R, PW, s, kl, nq3);
     }
+    drain_shared(C, A, PW, s, kl);
     if (Q.cost && valid) {  // calibration query: the table-driven stages are shared out evenly over the block's templates
         const unsigned long long spent = __builtin_amdgcn_s_memtime() - t_block;
         atomicAdd(&Q.cost[R.ti], spent / (64ull * count));
@@ -2160,7 +2271,7 @@ template <bool kLds, bool kIgnoreChain, bool kPoolLds, bool kSingly>
 __device__ __forceinline__ void search_templates(const SearchArgs &A, WaveScratchT<kSingly ? kModeSingly : kModeBlocks> *scratch, const float4 *s_rec,
                                                  const uint16_t *s_res, const uint32_t *s_kl, const uint16_t *s_pool,
                                                  const uint32_t *kl_off, uint32_t *s_next_p, uint32_t s, uint32_t a0,
-                                                 uint32_t r0, uint32_t chunk, uint32_t n_chunks) {
+                                                 uint32_t r0, uint32_t chunk, uint32_t n_chunks, SharedTriples *shared = nullptr) {
     const BatchView &B = A.B;
     const QueryView &Q = A.Q;
     SearchCtx<kIgnoreChain, kPoolLds, kSingly ? kModeSingly : kModeBlocks> C;
@@ -2197,6 +2308,9 @@ __device__ __forceinline__ void search_templates(const SearchArgs &A, WaveScratc
     const uint32_t n_mine = (Q.n_sel - chunk + n_chunks - 1u) / n_chunks;  // templates chunk, chunk + n_chunks, ...
     PageWriter PW;
     PW.page = kNoPage; PW.fill = 0u;
+    // (a structure that is not in LDS is searched below its triples by k_deep only, which keeps the residues it touches in LDS)
+    PW.shared = kLds && !(Q.flags & 0x8000u) ? shared : nullptr;  // (flag: test hook ENZYMM_AMD_LOCAL_DEEP=0)
+    slab_init(C);
     for (;;) {
         uint32_t m0 = 0, count = 0;
         if (lane == 0) {
@@ -2210,7 +2324,9 @@ __device__ __forceinline__ void search_templates(const SearchArgs &A, WaveScratc
         if (m0 >= n_mine) break;
         search_block(C, A, PW, s, m0, min(count, n_mine - m0), chunk, n_chunks, kl, tab_ref);
     }
+    drain_shared(C, A, PW, s, kl);  // (what other waves queued since this wave's last block)
     page_publish(PW, s, (uint32_t)lane);
+    slab_release(C);
     }
 }
 
@@ -2461,6 +2577,14 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
         for (uint32_t i = tid + step; i <= L.n_lead; i += step) s_kl[i] = kl_off[i] - rebase;
     }
     if (threadIdx.x == 0) s_next = 0u;
+    // the block search's queue of triples for the depth-first search (static LDS of that mode only)
+    SharedTriples *shared = nullptr;
+    if constexpr (kMode == kModeBlocks) {
+        __shared__ SharedTriples s_shared;
+        shared = &s_shared;
+        for (uint32_t i = threadIdx.x; i < kSharedTriples; i += blockDim.x) s_shared.entry[i].ti = 0xffffffffu;
+        if (threadIdx.x == 0) { s_shared.head = 0u; s_shared.tail = 0u; }
+    }
     TM_STAT(55, threadIdx.x == 0 ? 1 : 0);
     TM_STAT(56, threadIdx.x == 0 && pool_in_lds ? 1 : 0);
     TM_STAT(57, threadIdx.x == 0 ? kl_off[L.n_lead] - kl_off[0] : 0);
@@ -2510,9 +2634,9 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
         else deep_templates<kLds, kIgnoreChain, false>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, s, a0, r0, n_listed, cache, s_run, n_compact);
     } else {
         if (pool_in_lds)
-            search_templates<kLds, kIgnoreChain, true, kSingly>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, &s_next, s, a0, r0, chunk, n_chunks);
+            search_templates<kLds, kIgnoreChain, true, kSingly>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, &s_next, s, a0, r0, chunk, n_chunks, shared);
         else
-            search_templates<kLds, kIgnoreChain, false, kSingly>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, &s_next, s, a0, r0, chunk, n_chunks);
+            search_templates<kLds, kIgnoreChain, false, kSingly>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, &s_next, s, a0, r0, chunk, n_chunks, shared);
     }
 #ifdef TM_STATS
     {
@@ -2540,7 +2664,9 @@ TM_INSTANTIATE(kModeDeep)
 
 size_t search_cache_bytes() { return sizeof(ResCache) * kSearchWaves; }
 // LDS a launch mode declares statically, beyond the few words every mode has (k_deep's run list)
-size_t search_static_bytes(int mode) { return mode == kModeDeep ? (kRunLds + 2 * kSearchWaves) * sizeof(uint32_t) : 0; }
+size_t search_static_bytes(int mode) {
+    return mode == kModeDeep ? (kRunLds + 2 * kSearchWaves) * sizeof(uint32_t) : mode == kModeBlocks ? sizeof(SharedTriples) + 16 : 0;
+}
 size_t search_scratch_bytes(int mode) {
     return (mode == kModeBlocks ? sizeof(WaveScratchT<kModeBlocks>) : mode == kModeSingly ? sizeof(WaveScratchT<kModeSingly>)
                                                                                          : sizeof(WaveScratchT<kModeDeep>)) * kSearchWaves;

@@ -163,11 +163,16 @@ def test_page_directory_overflow_takes_one_retry(monkeypatch):
         res.close(); batch.close()
         return table
 
+    # (round 4: the block search keeps the triples that pass its stages in the workgroup's own queue and searches below
+    # them itself; ENZYMM_AMD_LOCAL_DEEP=0 sends every one of them through the pages and k_deep, as large complexes do)
+    monkeypatch.setenv("ENZYMM_AMD_LOCAL_DEEP", "0")
     monkeypatch.setenv("ENZYMM_AMD_DIR_MILLI", "0")  # (the hook also drops the per-wave part of a structure's share)
     got = run(True)     # stages the selection with an empty directory, overflows, learns, succeeds
     again = run(False)  # the selection remembers what it needed
     monkeypatch.delenv("ENZYMM_AMD_DIR_MILLI")
+    monkeypatch.delenv("ENZYMM_AMD_LOCAL_DEEP")
     assert len(got) > 20 and got.tobytes() == again.tobytes()
+    assert got.tobytes() == run(False).tobytes()  # and the workgroup-queue path gives the same table
     # and the same hits as the oracle's for the first structure
     otpl = helpers.oracle_library_templates()
     lib = oracle.OracleLibrary([otpl[i] for i in idx])
@@ -183,13 +188,17 @@ def test_deep_claims_with_and_without_the_run_list(monkeypatch):
     mols = [pyjess.Molecule.load(helpers.GOLDEN / "1AMY.pdb")] + synthetic.structures(30, start=900)
     jess = pyjess.Jess(helpers.product_library_templates())
     tables = []
+    monkeypatch.setenv("ENZYMM_AMD_LOCAL_DEEP", "0")  # every surviving triple through the pages and k_deep
     for hook in (None, "0"):
         if hook is not None:
             monkeypatch.setenv("ENZYMM_AMD_RUN_LIST", hook)
         tables.append(distributed.sort_rows(jess.query_batch(mols, 2.0, cut, cut, max_candidates=10000, ignore_chain=True,
                                                              template_index=idx, return_raw=True)))
     monkeypatch.delenv("ENZYMM_AMD_RUN_LIST")
-    assert len(tables[0]) > 30 and tables[0].tobytes() == tables[1].tobytes()
+    monkeypatch.delenv("ENZYMM_AMD_LOCAL_DEEP")
+    tables.append(distributed.sort_rows(jess.query_batch(mols, 2.0, cut, cut, max_candidates=10000, ignore_chain=True,
+                                                         template_index=idx, return_raw=True)))  # the workgroup-queue path
+    assert len(tables[0]) > 30 and tables[0].tobytes() == tables[1].tobytes() == tables[2].tobytes()
     otpl = helpers.oracle_library_templates()
     lib = oracle.OracleLibrary([otpl[i] for i in idx])
     r = oracle.query_library(helpers.to_oracle_molecule(mols[0]), lib, 2.0, cut, cut, max_candidates=10000, ignore_chain=True)

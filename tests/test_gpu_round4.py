@@ -176,12 +176,13 @@ def test_candidate_and_hit_table_overflow_take_one_retry(amy, af):
     batch.close()
 
 
-def test_one_pair_beyond_100000_candidates_and_a_thousand_pages_in_lds(amy):
+def test_one_pair_beyond_100000_candidates_and_a_thousand_pages_in_lds(amy, monkeypatch):
     """Loose thresholds on 1AMY (a structure k_search / k_deep hold in LDS), max_candidates unlimited: (a) at least one
     (template, structure) pair has more than 10^5 complete assignments, every one of them verified and counted, and the
-    counts equal the oracle's for a sample of templates around the heaviest; (b) the structure lists more than 1024
-    pages of triples, so k_deep's workgroups claim by page position in the LDS variant (a run list holds at most
-    1024 pages) -- the hit table equals the one ENZYMM_AMD_RUN_LIST=0 gives and the oracle's."""
+    counts equal the oracle's for a sample of templates around the heaviest; (b) with every surviving triple sent through
+    the pages (ENZYMM_AMD_LOCAL_DEEP=0) the structure lists more than 1024 of them, so k_deep's workgroups claim by page
+    position in the LDS variant (a run list holds at most 1024 pages); (c) the default flow -- the workgroups' own queues
+    first, pages for what does not fit them -- gives the same hit table and the same counts."""
     lib = helpers.product_library_templates()
     idx, _ = helpers.default_selection()
     jess = pyjess.Jess(lib)
@@ -190,10 +191,16 @@ def test_one_pair_beyond_100000_candidates_and_a_thousand_pages_in_lds(amy):
     batch = pyjess.make_batch([amy], jess._device)
     flags = _native.TM_FLAG_BEST_MATCH | _native.TM_FLAG_IGNORE_CHAIN | _native.TM_FLAG_COUNT_CANDIDATES
     res = _native.query(packed.native, batch, sel, 3.0, 4.0, 4.0, 0xFFFFFFFF, flags)
+    default_table, default_cands = res.hits(), res.candidates()[0]
+    res.close()
+    monkeypatch.setenv("ENZYMM_AMD_LOCAL_DEEP", "0")
+    res = _native.query(packed.native, batch, sel, 3.0, 4.0, 4.0, 0xFFFFFFFF, flags)
     table, cands = res.hits(), res.candidates()[0]
     pages, triples = res.page_census()
     res.close()
+    monkeypatch.delenv("ENZYMM_AMD_LOCAL_DEEP")
     batch.close()
+    assert np.array_equal(cands, default_cands) and table.tobytes() == default_table.tobytes()
     counts = cands & 0x7FFFFFFF
     assert not np.any(cands >> 31)
     assert counts.max() > 100_000, counts.max()
