@@ -4,6 +4,8 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -17,6 +19,7 @@
 #include <thread>
 
 #include <fcntl.h>
+#include <pthread.h>
 #include <sched.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -54,15 +57,15 @@ struct PhaseTrace {
 // Host threads one native call may use: ENZYMM_AMD_HOST_THREADS, else the smallest of the hardware threads, the
 // affinity mask, the container's CPU quota (cgroup v2 cpu.max; a box that shows 256 CPUs may grant 16) and 16.
 // More threads than the quota grants are throttled in bursts, which shows as run-to-run variance.
-// Atoms a host thread of a batch-creation team takes at least (ENZYMM_AMD_HOST_GRAIN; 4 Ki, 8 Ki and 64 Ki measured alike on
-// batches of sixteen molecules: a thread costs as much to start as its share saves).
+// Atoms a slice of a batch-creation loop holds at least (ENZYMM_AMD_HOST_GRAIN): the loops run on a persistent team
+// (HostPool), so a slice of a few thousand atoms -- 50 microseconds of work -- is worth handing out.
 uint32_t host_grain() {
     static const uint32_t grain = [] {
         if (const char *e = std::getenv("ENZYMM_AMD_HOST_GRAIN")) {
             const long v = std::strtol(e, nullptr, 10);
             if (v >= 256) return (uint32_t)v;
         }
-        return 65536u;
+        return 4096u;
     }();
     return grain;
 }
@@ -100,6 +103,88 @@ uint32_t host_team() {
     }();
     return team;
 }
+
+// A persistent team of host threads for the short parallel loops of batch creation (encode, flatten, file reads): a
+// std::thread per slice costs about as much to start as a slice of a sixteen-molecule batch takes to run.  One loop at
+// a time: a caller that finds the team busy (another Python thread creating a batch) runs its loop inline.  After a
+// fork() the child starts its own team on first use (the parent's threads do not exist there).
+class HostPool {
+public:
+    static HostPool &get() {
+        static std::once_flag once;
+        std::call_once(once, [] { pthread_atfork(nullptr, nullptr, [] { instance().store(nullptr); }); });
+        HostPool *p = instance().load();
+        if (!p) {
+            static std::mutex create;
+            std::lock_guard<std::mutex> lock(create);
+            p = instance().load();
+            if (!p) { p = new HostPool(host_team() > 1 ? host_team() - 1 : 0); instance().store(p); }
+        }
+        return *p;
+    }
+    // f(i) for i in [0, n): on the team and the calling thread
+    void run(uint32_t n, const std::function<void(uint32_t)> &f) {
+        std::unique_lock<std::mutex> one(run_mu_, std::try_to_lock);
+        if (n <= 1 || workers_.empty() || !one.owns_lock()) {
+            for (uint32_t i = 0; i < n; ++i) f(i);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            job_ = &f; n_ = n; next_.store(0); left_ = n; ++generation_;
+        }
+        work_.notify_all();
+        pull();
+        std::unique_lock<std::mutex> lock(mu_);
+        done_.wait(lock, [&] { return left_ == 0 && active_ == 0; });  // (no worker is still looking at this job)
+        job_ = nullptr;
+    }
+
+private:
+    explicit HostPool(uint32_t n_threads) {
+        for (uint32_t t = 0; t < n_threads; ++t) workers_.emplace_back([this] { loop(); }).detach();
+    }
+    static std::atomic<HostPool *> &instance() { static std::atomic<HostPool *> p{nullptr}; return p; }
+    void pull() {
+        uint32_t mine = 0;
+        for (;;) {
+            const uint32_t i = next_.fetch_add(1);
+            if (i >= n_) break;
+            (*job_)(i);
+            ++mine;
+        }
+        if (mine) {
+            std::lock_guard<std::mutex> lock(mu_);
+            left_ -= mine;
+            if (left_ == 0 && active_ == 0) done_.notify_all();
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lock(mu_);
+                work_.wait(lock, [&] { return generation_ != seen; });
+                seen = generation_;
+                if (!job_) continue;
+                ++active_;
+            }
+            pull();
+            {
+                std::lock_guard<std::mutex> lock(mu_);
+                --active_;
+                if (left_ == 0 && active_ == 0) done_.notify_all();
+            }
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex mu_, run_mu_;
+    std::condition_variable work_, done_;
+    const std::function<void(uint32_t)> *job_ = nullptr;
+    uint32_t n_ = 0, left_ = 0, active_ = 0;
+    std::atomic<uint32_t> next_{0};
+    uint64_t generation_ = 0;
+};
 
 int fail(int code, const std::string &msg) {
     g_err = msg;
@@ -847,16 +932,16 @@ int batch_from_encoded(int device, const tm_batch_desc *d, const double *const *
             flatten(0, ns);
         } else {
             // contiguous slices of structures with about the same number of atoms each
-            std::vector<std::thread> workers;
+            std::vector<std::pair<uint32_t, uint32_t>> slices;
             uint32_t s0 = 0;
             for (uint32_t t = 0; t < team; ++t) {
                 const uint64_t target = (uint64_t)na * (t + 1) / team;
                 uint32_t s1 = s0;
                 while (s1 < ns && (t + 1 == team || d->atom_offsets[s1 + 1] <= target)) ++s1;
-                if (s1 > s0) workers.emplace_back(flatten, s0, s1);
+                if (s1 > s0) slices.emplace_back(s0, s1);
                 s0 = s1;
             }
-            for (auto &w : workers) w.join();
+            HostPool::get().run((uint32_t)slices.size(), [&](uint32_t t) { flatten(slices[t].first, slices[t].second); });
         }
     }
 
@@ -1055,16 +1140,16 @@ int batch_from_structures(int device, uint32_t ns, const tm_structure_columns *s
         if (team <= 1) {
             encode(0, ns);
         } else {
-            std::vector<std::thread> workers;
+            std::vector<std::pair<uint32_t, uint32_t>> slices;
             uint32_t s0 = 0;
             for (uint32_t t = 0; t < team; ++t) {
                 const uint64_t target = (uint64_t)na * (t + 1) / team;
                 uint32_t s1 = s0;
                 while (s1 < ns && (t + 1 == team || atom_offsets[s1 + 1] <= target)) ++s1;
-                if (s1 > s0) workers.emplace_back(encode, s0, s1);
+                if (s1 > s0) slices.emplace_back(s0, s1);
                 s0 = s1;
             }
-            for (auto &w : workers) w.join();
+            HostPool::get().run((uint32_t)slices.size(), [&](uint32_t t) { encode(slices[t].first, slices[t].second); });
         }
     }
     trace.mark("encode");
@@ -2609,12 +2694,10 @@ void parallel_for(uint32_t n, uint32_t grain, F &&f) {
         for (uint32_t i = 0; i < n; ++i) f(i);
         return;
     }
-    std::vector<std::thread> workers;
-    for (uint32_t t = 0; t < team; ++t) {
+    HostPool::get().run(team, [&](uint32_t t) {
         const uint32_t lo = (uint32_t)((uint64_t)n * t / team), hi = (uint32_t)((uint64_t)n * (t + 1) / team);
-        workers.emplace_back([&f, lo, hi] { for (uint32_t i = lo; i < hi; ++i) f(i); });
-    }
-    for (auto &w : workers) w.join();
+        for (uint32_t i = lo; i < hi; ++i) f(i);
+    });
 }
 
 tm_pdb_columns columns_at(const tm_pdb_columns &c, uint64_t o) {

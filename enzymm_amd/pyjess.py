@@ -1620,6 +1620,9 @@ class Jess:
         options = dict(max_candidates=max_candidates, ignore_chain=ignore_chain, best_match=best_match)
         hits = _sweeps.lookup(self, key, thresholds, options, molecule) if _sweeps.enabled else None
         if hits is None:
+            # (the molecule's column record, built once per molecule, by the thread that asks -- not by the leader of the
+            # launch, whose work is on the critical path of everyone waiting for that launch)
+            molecule._pointer_row()
             hits = _combiner(key, self._templates).run(
                 self, molecule, thresholds, options,
                 execute=lambda batch: _sweeps.execute(self, key, thresholds, options, batch))
