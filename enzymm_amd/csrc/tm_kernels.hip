@@ -947,6 +947,10 @@ struct __align__(16) WaveScratchT {
 // each block: by then the stage queues are empty, so the template's pair bounds and the lead-list chunks of that search
 // use the same LDS.
 constexpr uint32_t kSharedTriples = 256;
+#ifndef TM_RES_FIRST
+#define TM_RES_FIRST 2
+#endif
+constexpr uint32_t kResFirst = TM_RES_FIRST;  // stage D0: levels looked at in its first round
 template <>
 struct __align__(16) WaveScratchT<kModeBlocks> {
     union {
@@ -1857,55 +1861,60 @@ __device__ __forceinline__ void block_look(Ctx &C, const SearchArgs &A, SlotRegs
     const uint32_t slot = t.y >> 16, c = t.y & 0xffffu, x0 = t.x & 0xffffu, x1 = t.x >> 16;
     const uint32_t ti = lane_get(R.ti, slot);
 
-    // ---- D0: lane = (triple, level of residues 0-2 that is not a lead)
+    // ---- D0: lane = (triple, level of residues 0-2 that is not a lead), in two rounds: the first two such levels of
+    // every triple, then the others of the triples that are left (most are not: 42 M items per launch become 25 M)
     bool fail = false;
     {
-        const uint32_t n_rl = vt ? A.Q.look[ti].n_rescheck : 0u;
-        const uint32_t incl = wave_scan_add(n_rl), excl = incl - n_rl;
-        const uint32_t total = RL(incl, 63);
-        TM_STAT(62, total);
-        for (uint32_t w0 = 0; w0 < total; w0 += 64u) {
-            S.owner[lane] = 0u;
-            {
-                const uint32_t start = max(excl, w0);
-                if (n_rl != 0u && start < w0 + 64u && incl > w0) S.owner[start - w0] = lane;
-            }
-            wave_sync();
-            const uint32_t p = wave_scan_max(S.owner[lane]);
-            wave_sync();
-            const bool item = w0 + lane < total;
-            const uint32_t w = min(w0 + lane, total - 1u);
-            const uint32_t j = w - lane_get(excl, p);  // which of the triple's records
-            const uint32_t pti = lane_get(ti, p);
-            const uint4 *rec4 = reinterpret_cast<const uint4 *>(A.Q.rescheck + (size_t)pti * kResChecks + j);
-            const uint4 ra = rec4[0], rb = rec4[1];
-            const uint2 rw2 = *reinterpret_cast<const uint2 *>(rec4 + 2);
-            const uint2 pt = S.triples[p];  // (the owner's queue entry: its three atoms)
-            const uint32_t px0 = pt.x & 0xffffu, px1 = pt.x >> 16, pc = pt.y & 0xffffu;
-            const float4 l0 = C.rec[px0], l1 = C.rec[px1], l2 = C.rec[pc];
-            const uint32_t ref = ra.w & 0xffu;
-            const uint32_t res = meta_res(__float_as_uint(ref == 0u ? l0.w : ref == 1u ? l1.w : l2.w));
-            uint32_t a = C.res_start[res];
-            const uint32_t a_end = C.res_start[res + 1u];
-            const unsigned long long nm = ((unsigned long long)ra.y << 32) | ra.x;
-            const bool any = (ra.w & 256u) != 0u;
-            const float2 w0b = make_float2(__uint_as_float(rb.x), __uint_as_float(rb.y)), w1b = make_float2(__uint_as_float(rb.z), __uint_as_float(rb.w)),
-                         w2b = make_float2(__uint_as_float(rw2.x), __uint_as_float(rw2.y));
-            bool found = false;
-            for (; a < a_end && !found; ++a) {  // (a dozen atoms at most; the name leaves one of them, usually)
-                const uint32_t m = __float_as_uint(C.rec[a].w);
-                if ((((nm >> meta_name(m)) & 1ull) != 0ull) & (any | (((ra.z >> meta_rtype(m)) & 1u) != 0u)) & (a != px0) & (a != px1) & (a != pc)) {
-                    const float4 r = C.rec[a];
-                    found = in_window(r, l0, w0b) & in_window(r, l1, w1b) & in_window(r, l2, w2b);
+        const uint32_t n_all = vt ? A.Q.look[ti].n_rescheck : 0u;
+        for (uint32_t round = 0; round < 2u; ++round) {
+            const uint32_t j_first = round == 0u ? 0u : min(n_all, kResFirst);
+            const uint32_t n_rl = fail ? 0u : (round == 0u ? min(n_all, kResFirst) : n_all - j_first);
+            const uint32_t incl = wave_scan_add(n_rl), excl = incl - n_rl;
+            const uint32_t total = RL(incl, 63);
+            TM_STAT(62, total);
+            for (uint32_t w0 = 0; w0 < total; w0 += 64u) {
+                S.owner[lane] = 0u;
+                {
+                    const uint32_t start = max(excl, w0);
+                    if (n_rl != 0u && start < w0 + 64u && incl > w0) S.owner[start - w0] = lane;
                 }
-            }
-            const unsigned long long missing = ballot64(item && !found);
-            TM_STAT(63, 1);
-            // does any of MY triple's levels of this pass lack a candidate?  (items [max(excl, w0), min(incl, w0 + 64)) - w0)
-            if (n_rl != 0u && incl > w0 && excl < w0 + 64u) {
-                const uint32_t lo = max(excl, w0) - w0, hi = min(incl, w0 + 64u) - w0;  // 0 <= lo < hi <= 64
-                const unsigned long long span = (hi == 64u ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
-                fail = fail | ((missing & span) != 0ull);
+                wave_sync();
+                const uint32_t p = wave_scan_max(S.owner[lane]);
+                wave_sync();
+                const bool item = w0 + lane < total;
+                const uint32_t w = min(w0 + lane, total - 1u);
+                const uint32_t j = w - lane_get(excl, p) + lane_get(j_first, p);  // which of the triple's records
+                const uint32_t pti = lane_get(ti, p);
+                const uint4 *rec4 = reinterpret_cast<const uint4 *>(A.Q.rescheck + (size_t)pti * kResChecks + j);
+                const uint4 ra = rec4[0], rb = rec4[1];
+                const uint2 rw2 = *reinterpret_cast<const uint2 *>(rec4 + 2);
+                const uint2 pt = S.triples[p];  // (the owner's queue entry: its three atoms)
+                const uint32_t px0 = pt.x & 0xffffu, px1 = pt.x >> 16, pc = pt.y & 0xffffu;
+                const float4 l0 = C.rec[px0], l1 = C.rec[px1], l2 = C.rec[pc];
+                const uint32_t ref = ra.w & 0xffu;
+                const uint32_t res = meta_res(__float_as_uint(ref == 0u ? l0.w : ref == 1u ? l1.w : l2.w));
+                uint32_t a = C.res_start[res];
+                const uint32_t a_end = C.res_start[res + 1u];
+                const unsigned long long nm = ((unsigned long long)ra.y << 32) | ra.x;
+                const bool any = (ra.w & 256u) != 0u;
+                const float2 w0b = make_float2(__uint_as_float(rb.x), __uint_as_float(rb.y)), w1b = make_float2(__uint_as_float(rb.z), __uint_as_float(rb.w)),
+                             w2b = make_float2(__uint_as_float(rw2.x), __uint_as_float(rw2.y));
+                bool found = false;
+                for (; a < a_end && !found; ++a) {  // (a dozen atoms at most; the name leaves one of them, usually)
+                    const uint32_t m = __float_as_uint(C.rec[a].w);
+                    if ((((nm >> meta_name(m)) & 1ull) != 0ull) & (any | (((ra.z >> meta_rtype(m)) & 1u) != 0u)) & (a != px0) & (a != px1) & (a != pc)) {
+                        const float4 r = C.rec[a];
+                        found = in_window(r, l0, w0b) & in_window(r, l1, w1b) & in_window(r, l2, w2b);
+                    }
+                }
+                const unsigned long long missing = ballot64(item && !found);
+                TM_STAT(63, 1);
+                // does any of MY triple's levels of this pass lack a candidate?  (items [max(excl, w0), min(incl, w0 + 64)) - w0)
+                if (n_rl != 0u && incl > w0 && excl < w0 + 64u) {
+                    const uint32_t lo = max(excl, w0) - w0, hi = min(incl, w0 + 64u) - w0;  // 0 <= lo < hi <= 64
+                    const unsigned long long span = (hi == 64u ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
+                    fail = fail | ((missing & span) != 0ull);
+                }
             }
         }
     }
