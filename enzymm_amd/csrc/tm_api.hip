@@ -410,6 +410,7 @@ struct StagedSelection {
     DevBuf<BlockHdr> d_hdr;      // per staged template: the record of the table-driven stages (k_search reads 64 at a time)
     DevBuf<LookHdr> d_look;      // per staged template: the record of the look at search level 3
     DevBuf<ResCheck> d_rescheck; // per staged template: the records of stage D0 (kResChecks slots each)
+    DevBuf<double2> d_exact;     // per staged template and pair: fp64 (template distance, threshold) for the re-check
     // Directory of the pages of triples waiting for k_deep: a structure of n atoms owns one entry per wave that works on
     // it (the partly filled last page of each) + dir_milli * n^2 / 1e7 entries for its full pages.  Starts at 0.1 page
     // per 1e4 atoms^2 (a 300-residue structure under the default thresholds fills about twenty pages); raised to what a
@@ -2001,12 +2002,13 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
             HIP_TRY(S->d_hdr.alloc(n_sel));
             HIP_TRY(S->d_look.alloc(n_sel));
             HIP_TRY(S->d_rescheck.alloc((size_t)n_sel * kResChecks));
+            HIP_TRY(S->d_exact.alloc((size_t)n_sel * kMaxPairs));
             HIP_TRY(S->d_lead8.alloc((size_t)n_sel * kMaxG));
             HIP_TRY(hipEventCreateWithFlags(&S->ready, hipEventDisableTiming));
             if (n_sel) {
                 hipLaunchKernelGGL(k_stage_templates, dim3(n_sel), dim3(64), 0, stream, lib->view(), n_sel, S->d_sel.p,
                                    S->d_cut.p, S->d_maxdyn.p, S->d_pair_table.p, S->d_triple_table.p, S->d_triple_key.p,
-                                   S->d_staged.p, S->d_bounds.p, S->d_hdr.p, S->d_look.p, S->d_lead8.p, S->d_rescheck.p, S->slack);
+                                   S->d_staged.p, S->d_bounds.p, S->d_hdr.p, S->d_look.p, S->d_lead8.p, S->d_rescheck.p, S->d_exact.p, S->slack);
                 HIP_TRY(hipGetLastError());
             }
             HIP_TRY(hipEventRecord(S->ready, stream));
@@ -2100,7 +2102,7 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
 
     QueryView Q;
     Q.n_sel = n_sel; Q.sel = S->d_sel.p; Q.rmsd_thr = S->d_rmsd.p; Q.cutoff = S->d_cut.p; Q.maxdyn = S->d_maxdyn.p;
-    Q.staged = S->d_staged.p; Q.hdr = S->d_hdr.p; Q.look = S->d_look.p; Q.rescheck = S->d_rescheck.p; Q.bounds = S->d_bounds.p; Q.order = S->d_order.p; Q.max_candidates = p->max_candidates; Q.flags = p->flags;
+    Q.staged = S->d_staged.p; Q.hdr = S->d_hdr.p; Q.look = S->d_look.p; Q.rescheck = S->d_rescheck.p; Q.exact = S->d_exact.p; Q.bounds = S->d_bounds.p; Q.order = S->d_order.p; Q.max_candidates = p->max_candidates; Q.flags = p->flags;
     if (const char *env = std::getenv("ENZYMM_AMD_RUN_LIST"))  // test hook: k_deep claims by page position, as for a large complex
         if (std::atoi(env) == 0) Q.flags |= 0x4000u;
     if (const char *env = std::getenv("ENZYMM_AMD_LOCAL_DEEP"))  // test hook / A-B: every surviving triple is paged out to k_deep (round 3's flow)

@@ -194,6 +194,7 @@ struct QueryView {
     const LookHdr *look;        // [n_sel]
     const ResCheck *rescheck;   // [n_sel * kResChecks]
     const float2 *bounds;       // [n_sel*kMaxPairs] (lo^2, hi^2) fp32 prefilter bounds, search order
+    const double2 *exact;       // [n_sel*kMaxPairs] fp64 (template distance, threshold) of every pair, search order: the re-check of a complete assignment
     const uint32_t *order;      // [n_sel] every per-selection array above is sorted by descending estimated cost;
                                 // order[pos] = the caller's selection index (reported in tm_hit / candidate counts)
     uint32_t n_tables;

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(64) void k_stage_templates(LibView L, uint32_t n_se
                                                          Staged *__restrict__ staged, float2 *__restrict__ bounds,
                                                          BlockHdr *__restrict__ hdr, LookHdr *__restrict__ look,
                                                          uint16_t *__restrict__ lead8, ResCheck *__restrict__ rescheck,
-                                                         double slack) {
+                                                         double2 *__restrict__ exact, double slack) {
     const uint32_t ti = blockIdx.x;
     if (ti >= n_sel) return;
     const uint32_t t = sel[ti];
@@ -167,6 +167,14 @@ __global__ __launch_bounds__(64) void k_stage_templates(LibView L, uint32_t n_se
         int i, j;
         pair_of(p, i, j);
         bounds[(size_t)ti * kMaxPairs + p] = window(i, j);
+        // what the fp64 re-check of a complete assignment compares against (on_complete), in the very arithmetic it used to
+        // redo per completion: template distance and threshold of the pair
+        const double *a = L.a_xyz + 3 * (size_t)(off + i), *b = L.a_xyz + 3 * (size_t)(off + j);
+        const double dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+        const double dt = sqrt(dx * dx + dy * dy + dz * dz);
+        double thr = cut + L.a_w[off + i] + L.a_w[off + j];
+        thr = thr < mx ? thr : mx;
+        exact[(size_t)ti * kMaxPairs + p] = make_double2(dt, thr);
     }
     // stage D0's records: the levels that are not leads and belong to template residues 0, 1, 2, in search order
     unsigned long long rc_mask = 0ull;
@@ -1246,9 +1254,7 @@ __device__ __forceinline__ bool on_complete(const Ctx &C, WaveRegs &W, PairState
     // completions are rare: everything but the assignment itself is fetched here, not per search
     ColdArgsPtr A = cold_args();
     const uint32_t max_candidates = A->Q.max_candidates;
-    const uint32_t off = A->L.t_off[A->Q.sel[P.ti]];
-    const double *a_xyz = A->L.a_xyz, *a_w = A->L.a_w;
-    const double cut = A->Q.cutoff[P.ti], mx = A->Q.maxdyn[P.ti];
+    const double2 *exact = A->Q.exact + (size_t)P.ti * kMaxPairs;  // (template distance, threshold) per pair, staged once
     const double *qx = A->B.q_xyz + 3 * (size_t)A->B.s_off[P.s];
     bool bad = false;
     for (int p0 = 0; p0 < npairs; p0 += 64) {  // uniform trip count: the shuffles below need every lane
@@ -1258,14 +1264,10 @@ __device__ __forceinline__ bool on_complete(const Ctx &C, WaveRegs &W, PairState
         const uint32_t ai = (uint32_t)__shfl((int)W.aidx, i), aj = (uint32_t)__shfl((int)W.aidx, j);
         if (p < npairs) {
             const double *qa = qx + 3 * (size_t)ai, *qb = qx + 3 * (size_t)aj;
-            const double *ta = a_xyz + 3 * (size_t)(off + i), *tb = a_xyz + 3 * (size_t)(off + j);
-            double dx = qa[0] - qb[0], dy = qa[1] - qb[1], dz = qa[2] - qb[2];
+            const double dx = qa[0] - qb[0], dy = qa[1] - qb[1], dz = qa[2] - qb[2];
             const double dq = sqrt(dx * dx + dy * dy + dz * dz);
-            dx = ta[0] - tb[0]; dy = ta[1] - tb[1]; dz = ta[2] - tb[2];
-            const double dt = sqrt(dx * dx + dy * dy + dz * dz);
-            double thr = cut + a_w[off + i] + a_w[off + j];
-            thr = thr < mx ? thr : mx;
-            if (fabs(dq - dt) > thr) bad = true;
+            const double2 e = exact[p];
+            if (fabs(dq - e.x) > e.y) bad = true;
         }
     }
     TM_STAT(48, 1);
