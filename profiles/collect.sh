@@ -17,15 +17,15 @@ echo "$head" > "$out/${tag}_git_head.txt"
 python3 tests/gpu_valu_ceiling.py "$tag" > "$out/valu.log" 2>&1 && mv "gpurun_out/${tag}_valu_ceiling.json" "$out/"
 export TMPDIR=/tmp ENZYMM_AMD_SYNTH_CACHE=/tmp/synth
 timeout 600 python3 bench.py --steps 10 --warmup 2 > "$out/${tag}_bench1000.json" 2> "$out/bench.err"
-timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o run -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras --streamed-passes 0 > "$out/trace.log" 2>&1
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o run -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras --streamed-passes 0 --sustained-seconds 0 > "$out/trace.log" 2>&1
 stats=$(find "$out/trace" -name "*kernel_stats.csv" | head -1)
 [ -n "$stats" ] && cp "$stats" "$out/${tag}_bench1000_kernel_stats.csv"
 # the same with ONE search in flight: kernel durations with nothing else on the GPU (roofline.exclusive, and the
 # duration the per-search instruction figures of summarize_pmc.py are set against)
-timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace1" -o run -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras --streamed-passes 0 --pipeline 1 > "$out/trace1.log" 2>&1
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace1" -o run -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras --streamed-passes 0 --sustained-seconds 0 --pipeline 1 > "$out/trace1.log" 2>&1
 stats=$(find "$out/trace1" -name "*kernel_stats.csv" | head -1)
 [ -n "$stats" ] && cp "$stats" "$out/${tag}_bench1000_pipeline1_kernel_stats.csv"
-pass() { timeout 200 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$out/pmc_$1" -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --streamed-passes 0 --pipeline 1 > "$out/pmc_$1.log" 2>&1; }
+pass() { timeout 200 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$out/pmc_$1" -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --streamed-passes 0 --sustained-seconds 0 --pipeline 1 > "$out/pmc_$1.log" 2>&1; }
 pass SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES
 pass SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT
 pass SQ_INSTS_BRANCH SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU
@@ -50,5 +50,8 @@ PY
         --valu-ceiling "$out/${tag}_valu_ceiling.json" --head "$head" \
         "$out"/pmc_SQ_INSTS_VALU "$out"/pmc_SQ_ACTIVE_INST_ANY "$out"/pmc_SQ_INSTS_BRANCH "$out"/pmc_FETCH_SIZE "$out"/pmc_WRITE_SIZE "$out"/pmc_TCC_HIT_sum >> "$out/summary.log" 2>&1
 done
+# (the raw traces stay on the box: gpurun copies back 64 MiB at most)
+rm -rf "$out"/trace "$out"/trace1
+find "$out" -name "*.csv" -path "*pmc_*" -size +4M -delete
 cat "$out/${tag}_bench1000.json" "$out/summary.log"
 [ -f "$out/${tag}_bench1000_kernel_stats.csv" ] && head -8 "$out/${tag}_bench1000_kernel_stats.csv"
