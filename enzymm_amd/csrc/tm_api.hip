@@ -2011,6 +2011,20 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
                                    S->d_staged.p, S->d_bounds.p, S->d_hdr.p, S->d_look.p, S->d_lead8.p, S->d_rescheck.p, S->d_exact.p, S->slack);
                 HIP_TRY(hipGetLastError());
             }
+            if (std::getenv("ENZYMM_AMD_TRACE") && n_sel) {  // census: how many templates share the records of the table stages
+                HIP_TRY(hipStreamSynchronize(stream));
+                std::vector<BlockHdr> h(n_sel);
+                HIP_TRY(hipMemcpy(h.data(), S->d_hdr.p, n_sel * sizeof(BlockHdr), hipMemcpyDeviceToHost));
+                std::map<std::string, int> whole, pair_part;
+                for (const BlockHdr &b : h) {
+                    whole[std::string(reinterpret_cast<const char *>(&b), sizeof b)]++;
+                    std::string k(reinterpret_cast<const char *>(&b.w10), sizeof b.w10);
+                    k.append(reinterpret_cast<const char *>(b.li), 2 * sizeof(uint16_t));
+                    pair_part[k]++;
+                }
+                std::fprintf(stderr, "block headers: %u templates, %zu distinct (leads 0-2 and their three windows), %zu distinct pair stages (leads 0-1, window (1,0))\n",
+                             n_sel, whole.size(), pair_part.size());
+            }
             HIP_TRY(hipEventRecord(S->ready, stream));
             if (restage) {
                 // ... and the logistic model tables of the hit epilogue (model_set follows the new order)

@@ -18,6 +18,9 @@ jess = pyjess.Jess(helpers.product_library_templates())
 if len(sys.argv) > 2 and sys.argv[2] == "complexes":  # BASELINE.json configs[4]: large complexes, loosened thresholds
     mols = [synthetic.complex_structure(i, 6000).conserved(70) for i in range(n)]
     cut = np.full(len(idx), 2.5)
+elif len(sys.argv) > 2 and sys.argv[2] == "real":  # rigid copies of the two structures the reference's tests ship (bench.py's real_* figures)
+    real = [pyjess.Molecule.load(ROOT / "tests" / "golden" / f) for f in ("1AMY.pdb", "AF-P0DUB6-F1-model_v4.pdb")]
+    mols = synthetic.rigid_copies(real[0], (n + 1) // 2, seed=7) + synthetic.rigid_copies(real[1], n // 2, seed=8)
 else:
     mols = synthetic.structures(n)
 lib = _native.load()
@@ -27,7 +30,7 @@ print("stats0", lib.tm_debug_stats(buf), flush=True)
 t0 = time.time()
 table = jess.query_batch(mols, 2.0, cut, cut, max_candidates=10000, ignore_chain=True, template_index=idx,
                          return_raw=True)
-print("query s", time.time() - t0, "hits", len(table))
+print("query s", time.time() - t0, "hits", len(table), "atoms per structure", sum(len(m) for m in mols) / len(mols))
 lib.tm_debug_stats(buf)
 s = np.array(list(buf), dtype=np.float64)
 searches = s[49]
