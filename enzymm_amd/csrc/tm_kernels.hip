@@ -955,6 +955,10 @@ struct __align__(16) WaveScratchT {
 // each block: by then the stage queues are empty, so the template's pair bounds and the lead-list chunks of that search
 // use the same LDS.
 constexpr uint32_t kSharedTriples = 256;
+#ifndef TM_MIN_BLOCK
+#define TM_MIN_BLOCK 32
+#endif
+constexpr uint32_t kMinBlock = TM_MIN_BLOCK;  // templates a wave claims at least (guided block sizes: 64 while much of the chunk is left)
 #ifndef TM_RES_FIRST
 #define TM_RES_FIRST 2
 #endif
@@ -2327,7 +2331,7 @@ __device__ __forceinline__ void search_templates(const SearchArgs &A, WaveScratc
         if (lane == 0) {
             const uint32_t seen = __atomic_load_n(s_next_p, __ATOMIC_RELAXED);
             const uint32_t left = seen < n_mine ? n_mine - seen : 0u;
-            count = min(64u, max(8u, (left / (2u * kSearchWaves)) & ~7u));
+            count = min(64u, max(kMinBlock, (left / (2u * kSearchWaves)) & ~7u));
             m0 = atomicAdd(s_next_p, count);
         }
         m0 = uni(m0);
