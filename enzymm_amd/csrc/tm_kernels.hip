@@ -2969,7 +2969,9 @@ __global__ __launch_bounds__(1024) void k_append_hits(const tm_hit *__restrict__
         const uint32_t col = (uint32_t)(w % kWords);
         if (base + row >= dst_capacity) continue;
         unsigned long long v = reinterpret_cast<const unsigned long long *>(src + row)[col];
-        if (col == 0) v += structure_offset;  // tm_hit.structure: the low word of a row's first 8 bytes
+        // tm_hit.structure is the LOW word of a row's first 8 bytes: the offset is added to that word alone (a sum beyond
+        // 2^32 must not carry into template_sel, the high word)
+        if (col == 0) v = (v & 0xffffffff00000000ull) | (uint32_t)((uint32_t)v + structure_offset);
         reinterpret_cast<unsigned long long *>(dst + base + row)[col] = v;
     }
 }
