@@ -734,3 +734,93 @@ def test_reference_sweep_is_computed_ahead(monkeypatch):
     assert all(sum(len(c[0]) for c in b) == 12 for b in per_bucket)
     assert all(n_templates == len(tpls) for b, tpls in zip(per_bucket, buckets) for _, n_templates in b)
     pyjess._sweeps.clear()
+
+
+def test_sweep_planner_failures_and_identity(monkeypatch):
+    """pyjess._Sweeps around its edges, with a recorder for an engine: (a) a launch that fails raises in every caller of
+    that launch, leaves nothing in flight (nobody waits for it) and later calls work; (b) a library over several buckets
+    that the engine refuses falls back to the bucket that was asked for; (c) keys with different options are never searched
+    in one launch; (d) an answer computed ahead for a molecule that has died is not handed to a new object at its address."""
+    import gc
+    from enzymm_amd import _native
+
+    class FakeLibrary:
+        def __init__(self, device, offsets, *tables, orientation=None):
+            pass
+
+        def close(self):
+            pass
+
+    monkeypatch.setattr(_native, "Library", FakeLibrary)
+    state = {"fail": False, "refuse_unions": False, "calls": []}
+    files = sorted((helpers.GOLDEN / "templates").rglob("*.pdb"))[:6]
+    tpls = [pyjess.Template.loads(f.read_text(), id=f"t{n}") for n, f in enumerate(files)]
+    buckets = [tpls[0:2], tpls[2:4], tpls[4:6]]
+
+    def recorder(jess, molecules, thresholds, options, trace=None):
+        state["calls"].append((len(molecules), len(jess._templates), dict(options)))
+        if state["fail"]:
+            raise _native.NativeError(_native.TM_E_DEVICE, "the engine is down")
+        if state["refuse_unions"] and len(jess._templates) > 2:
+            raise _native.NativeError(_native.TM_E_UNSUPPORTED, "too many pair tables")
+        rows = np.zeros(len(molecules) * len(jess._templates), dtype=_native.HIT_DTYPE)
+        rows["structure"] = np.repeat(np.arange(len(molecules)), len(jess._templates))
+        rows["template_sel"] = np.tile(np.arange(len(jess._templates)), len(molecules))
+        rows["rmsd"] = [len(m) + 0.01 * tpls.index(t) for m in molecules for t in jess._templates]  # (a function of the two objects)
+        rows["n_atoms"] = 1
+        return rows
+
+    monkeypatch.setattr(pyjess, "_search_raw", recorder)
+    pyjess._sweeps.clear()
+    monkeypatch.setattr(pyjess._sweeps, "enabled", True)
+
+    def mol(n):
+        return pyjess.Molecule.from_columns(f"m{n}", xyz=np.zeros((n, 3)), name=np.array([b" CA "] * n, dtype="S4"),
+                                            residue_name=np.array([b"GLY"] * n, dtype="S3"),
+                                            chain_id=np.array([b" A"] * n, dtype="S2"), residue_number=np.arange(1, n + 1))
+
+    def ask(bucket, m, **kw):
+        opts = dict(max_candidates=10000, best_match=True, ignore_chain=True)
+        opts.update(kw)
+        return [(h.template, h.rmsd) for h in pyjess.Jess(bucket).query(m, 2.0, 1.5, 1.5, **opts)]
+
+    def want(bucket, m):
+        return [(t, len(m) + 0.01 * tpls.index(t)) for t in bucket]
+
+    first = [mol(10 + i) for i in range(4)]
+    for b in buckets:  # a first sweep: the keys become known
+        for m in first:
+            assert ask(b, m) == want(b, m)
+    # (a) the engine fails: the caller sees it, nothing stays in flight, the next call works
+    state["fail"] = True
+    m = mol(30)
+    with pytest.raises(_native.NativeError, match="engine is down"):
+        ask(buckets[0], m)
+    assert pyjess._sweeps.drain(1.0)
+    state["fail"] = False
+    assert ask(buckets[0], m) == want(buckets[0], m) and ask(buckets[1], m) == want(buckets[1], m)
+    # (b) a library over all buckets that the engine refuses: the bucket asked for is searched on its own
+    state["refuse_unions"] = True
+    state["calls"].clear()
+    m = mol(31)
+    assert ask(buckets[0], m) == want(buckets[0], m)
+    assert [c[1] for c in state["calls"]] == [6, 2]
+    state["refuse_unions"] = False
+    # (c) other options: another key, searched alone (its first request), never in one launch with the ignore_chain=True keys
+    state["calls"].clear()
+    m = mol(32)
+    assert ask(buckets[1], m, ignore_chain=False) == want(buckets[1], m)
+    assert [(c[1], c[2]["ignore_chain"]) for c in state["calls"]] == [(2, False)]
+    # (d) an answer computed ahead for a molecule that died must not reach another object at its address
+    m = mol(33)
+    assert ask(buckets[0], m) == want(buckets[0], m)  # computes buckets 1 and 2 ahead for m
+    key1 = next(k for k, info in pyjess._sweeps._keys.items() if info.templates[0] is buckets[1][0] and k[6])
+    assert (key1, id(m)) in pyjess._sweeps._results
+    stale = id(m)
+    del m
+    gc.collect()
+    others = [mol(40 + i) for i in range(64)]
+    twin = next((o for o in others if id(o) == stale), None)
+    if twin is not None:  # (the allocator handed the address out again: the cached rows belong to the dead molecule)
+        assert ask(buckets[1], twin) == want(buckets[1], twin)
+    pyjess._sweeps.clear()
