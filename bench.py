@@ -267,12 +267,22 @@ def untimed_extras(args, device, templates, idx, cut, molecules, search, flags):
     spare = molecules[len(mols):]
     for warm in (spare[:threads], spare[threads:2 * threads]) if len(spare) >= 2 * threads else (mols[:threads], mols[:threads]):
         reference_pattern(warm)
+    # the timed sweep runs over molecules made just now, the way enzymm loads its molecules right before it matches them
+    # (load_molecules -> Matcher.run): nothing about them can have been computed during the warm-up, every answer of the
+    # sweep comes from a launch inside the timed region (config.reference_call_pattern_launches)
+    mols = [m.copy() for m in mols]
+    del pyjess._sweeps.launches[:]
     t0 = time.perf_counter()
     found = reference_pattern(mols)
     dt = time.perf_counter() - t0
+    launches = list(pyjess._sweeps.launches)
     out["reference_call_pattern_structures_per_s"] = len(mols) / dt
+    out["reference_call_pattern_launches"] = {"launches": len(launches), "molecules_searched": int(sum(l[0] for l in launches)),
+                                              "ms_inside_launches": float(1e3 * sum(l[3] for l in launches))}
     out["reference_call_pattern"] = (f"{len(mols)} molecules x {len(sizes)} size buckets, Jess(templates).query(molecule) per "
-                                     f"(molecule, size) from a ThreadPool of {threads}: {len(mols) * len(sizes) / dt:.0f} queries/s")
+                                     f"(molecule, size) from a ThreadPool of {threads}: {len(mols) * len(sizes) / dt:.0f} queries/s; "
+                                     "the molecules are new objects (copies made right before the sweep), the sweep planner of "
+                                     "enzymm_amd.pyjess searches them ahead -- all six buckets in one library -- from the second call on")
     # parity of that path: hits as (template index in idx order -> atoms) against the oracle
     sample = min(len(mols), max(2, cores))
     position = {id(templates[int(i)]): n for n, i in enumerate(idx)}

@@ -2119,6 +2119,8 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
     Q.staged = S->d_staged.p; Q.hdr = S->d_hdr.p; Q.look = S->d_look.p; Q.rescheck = S->d_rescheck.p; Q.exact = S->d_exact.p; Q.bounds = S->d_bounds.p; Q.order = S->d_order.p; Q.max_candidates = p->max_candidates; Q.flags = p->flags;
     if (const char *env = std::getenv("ENZYMM_AMD_RUN_LIST"))  // test hook: k_deep claims by page position, as for a large complex
         if (std::atoi(env) == 0) Q.flags |= 0x4000u;
+    if (const char *env = std::getenv("ENZYMM_AMD_SAME_XCD"))  // experiment: a structure's template chunks on one XCD
+        if (std::atoi(env) == 1) Q.flags |= 0x10000u;
     if (const char *env = std::getenv("ENZYMM_AMD_LOCAL_DEEP"))  // test hook / A-B: every surviving triple is paged out to k_deep (round 3's flow)
         if (std::atoi(env) == 0) Q.flags |= 0x8000u;
     Q.n_tables = (uint32_t)S->tables.size(); Q.tables = S->d_tables.p;
@@ -2248,7 +2250,8 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
             O.dir = r->d_dir.p; O.dir_off = r->d_dir_off.p;
         }
         const uint32_t per_group = 8u >> cx;  // work items per group of 8 consecutive workgroups
-        const uint32_t grid = (b->work_items + per_group - 1) / per_group * 8u;
+        uint32_t grid = (b->work_items + per_group - 1) / per_group * 8u;
+        if (Q.flags & 0x10000u) grid = (b->work_items + 7u) / 8u * (8u << cx);  // (8 work items per group of 8 << cx workgroups)
         const bool ic = (p->flags & TM_FLAG_IGNORE_CHAIN) != 0;
         SearchArgs args{lib->view(), b->view(), Q, O, b->d_work.p, b->work_items, cx, b->max_atoms, b->max_res, 0u, nullptr, 0u};
         // One launch of k_search in `mode`: the structure of a workgroup goes to LDS when the mode's per-wave scratch

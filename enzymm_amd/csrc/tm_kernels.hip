@@ -2531,11 +2531,19 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
     const uint32_t bid = blockIdx.x;
     const uint32_t xcd = bid & 7u;
     const uint32_t cx = A.chunk_xcd_shift;
-    const uint32_t item_index = ((bid >> 3) << (3u - cx)) + (xcd >> cx);
+    uint32_t item_index = ((bid >> 3) << (3u - cx)) + (xcd >> cx);
+    uint32_t chunk_low = xcd & ((1u << cx) - 1u);
+    if (Q.flags & 0x10000u) {
+        // experiment (ENZYMM_AMD_SAME_XCD=1): the 2^cx chunks of a work item on ONE XCD (workgroups b, b + 8, ... of a group
+        // of 8 << cx), so that a structure's pair tables enter one L2 -- every XCD then touches all staged templates
+        const uint32_t group = bid >> (3u + cx), within = bid & ((8u << cx) - 1u);
+        item_index = group * 8u + (within & 7u);
+        chunk_low = within >> 3;
+    }
     if (item_index >= A.n_items) return;
     const WorkItem item = A.work[item_index];
     const uint32_t s = item.s;
-    const uint32_t chunk = ((uint32_t)item.round << cx) + (xcd & ((1u << cx) - 1u));
+    const uint32_t chunk = ((uint32_t)item.round << cx) + chunk_low;
     const uint32_t n_chunks = (uint32_t)item.rounds << cx;
     if (chunk >= (kSingly ? A.n_singly : Q.n_sel)) return;
 

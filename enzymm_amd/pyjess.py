@@ -57,6 +57,9 @@ def default_device() -> int:
     return _default_device
 
 
+_molecule_created = None  # set once _Sweeps exists (end of this module)
+
+
 # ---------------------------------------------------------------------------------- Atom
 
 
@@ -286,6 +289,8 @@ class Molecule:
         self._enc = None  # (vocabulary version, encoded arrays)
         self._row = None  # (tm_structure_columns record, the arrays it points into)
         self._lock = threading.Lock()
+        if _molecule_created is not None:
+            _molecule_created(self)  # (the sweep planner keeps a weak reference: a molecule that was just made is about to be asked for)
 
     _ROW_COLUMNS = (("name", "S4"), ("residue_name", "S3"), ("chain_id", "S2"), ("residue_number", np.int32),
                     ("insertion_code", "S1"))
@@ -594,6 +599,7 @@ class _PackedLibrary:
             self.tables = tuple(tables[:9])
             self.native = _native.Library(device, *tables[:8], orientation=tables[8])
             self.device = device
+            _settle_library_objects(len(self.offsets) - 1)
             return
         for t in templates:
             if len(t._atoms) == 0:
@@ -634,6 +640,7 @@ class _PackedLibrary:
         self.native = _native.Library(device, self.offsets, xyz, weight, res_mask, name_mask, any_res, group, chain,
                                       orientation=orientation)
         self.device = device
+        _settle_library_objects(len(templates))
 
     @classmethod
     def concat(cls, parts: Sequence["_PackedLibrary"], device: int) -> "_PackedLibrary":
@@ -688,6 +695,25 @@ class _PackedLibrary:
             offsets.append(len(first))
         return (np.array(offsets, dtype=np.uint32), np.array(first, dtype=np.uint8),
                 np.array(second, dtype=np.uint8), np.array(vec, dtype=np.float64).reshape(-1, 3))
+
+
+_settled = False
+
+
+def _settle_library_objects(n_templates: int) -> None:
+    """A template library is a quarter of a million small Python objects that live as long as the process.  Every full
+    collection of the cyclic garbage collector walks them -- 250-300 ms with the GIL held, measured in the middle of a
+    50 ms sweep of the reference's call pattern (and of Matcher.run_files, which pauses the collector for that reason).
+    Once a large library has been packed for the device, the objects alive at that moment are moved to the collector's
+    permanent generation (``gc.freeze``): they are still freed when their reference counts drop to zero, they are just
+    no longer walked.  ``ENZYMM_AMD_GC_FREEZE=0`` leaves the collector alone."""
+    global _settled
+    if _settled or n_templates < 512 or os.environ.get("ENZYMM_AMD_GC_FREEZE", "1") == "0":
+        return
+    import gc
+    _settled = True
+    gc.collect()
+    gc.freeze()
 
 
 _pack_lock = threading.Lock()
@@ -1206,6 +1232,10 @@ class _Sweeps:
         self._results: "collections.OrderedDict[tuple, tuple]" = collections.OrderedDict()  # (key, id) -> (weakref, rows, when)
         self._unions: "collections.OrderedDict[tuple, tuple]" = collections.OrderedDict()
         self._inflight: dict = {}  # (key, id(molecule)) -> Event set when the launch computing it ahead has stored its results
+        # molecules that were constructed lately (Molecule.load, .conserved(), ...), oldest first: enzymm loads its molecules
+        # and then asks for them in that order (jess_run.py:509-560, 896-988), so these are what a sweep will ask for next
+        self._loaded: "collections.OrderedDict[int, tuple]" = collections.OrderedDict()  # id -> (weak reference, serial number)
+        self._made = 0
         self.launches = []  # (molecules, keys) of the last launches: what tests and traces look at
 
     # -- bookkeeping (under the lock) -----------------------------------------------------------------------------
@@ -1253,6 +1283,31 @@ class _Sweeps:
         if ent is None or ent[0]() is not molecule:
             return None
         return ent[1]
+
+    MAX_LOADED = 8192
+
+    def loaded(self, molecule):
+        """A molecule was constructed (a weak reference is all that is kept)."""
+        import weakref
+        try:
+            ref = weakref.ref(molecule)
+        except TypeError:
+            return
+        with self._lock:
+            mid = id(molecule)
+            self._loaded.pop(mid, None)  # (a new object at an address seen before goes to the young end)
+            self._made += 1
+            self._loaded[mid] = (ref, self._made)
+            while len(self._loaded) > self.MAX_LOADED:
+                self._loaded.popitem(last=False)
+            old = self._molecules.get(mid)
+            if old is not None and old[0]() is not molecule:
+                del self._molecules[mid]
+            for k in self._keys.values():  # ... and what was noted for the old object at that address is void
+                if mid in k.asked or mid in k.planned:
+                    k.asked.pop(mid, None)
+                    k.planned.pop(mid, None)
+                    self._results.pop((k.key, mid), None)
 
     # -- the two entry points ---------------------------------------------------------------------------------------
     def lookup(self, jess, key, thresholds, options, molecule):
@@ -1380,16 +1435,33 @@ class _Sweeps:
         if info.requests >= 2:
             have = {id(r.molecule) for r in todo}
             n_atoms = sum(len(r.molecule) for r in todo)
-            ahead = self._molecules.keys() - info.asked.keys() - info.planned.keys() - have
-            for mid, ent in (self._molecules.items() if ahead else ()):  # (in the order they were first seen)
+            # candidates: (1) the molecules constructed AFTER the ones asked for now, in the order they were made -- enzymm
+            # loads its molecules and then asks for them in that order, so those are what the sweep asks next; molecules made
+            # before them are not touched (already handled, or none of this sweep's business) --, (2) the molecules other keys
+            # were asked for lately (the buckets after the first of a first sweep)
+            seen = set()
+            first_made = min((self._loaded[mid][1] for mid in have if mid in self._loaded), default=None)
+            younger = []
+            if first_made is not None:
+                for mid in reversed(self._loaded):
+                    ref, serial = self._loaded[mid]
+                    if serial <= first_made:
+                        break
+                    younger.append((mid, ref))
+                younger.reverse()
+            recent = [(mid, ent[0]) for mid, ent in self._molecules.items() if ent[1] == info.device and now - ent[2] <= self.WINDOW_S] \
+                if (self._molecules.keys() - info.asked.keys() - info.planned.keys() - have) else []
+            for mid, ref in younger + recent:
                 if len(todo) + len(extra) >= self.MAX_MOLECULES or n_atoms >= self.MAX_ATOMS:
                     break
-                if mid not in ahead:
+                if mid in have or mid in seen or mid in info.asked or mid in info.planned or (info.key, mid) in self._results:
                     continue
-                m = ent[0]()
-                if m is None or ent[1] != info.device or now - ent[2] > self.WINDOW_S or (info.key, mid) in self._results:
+                m = ref()
+                if m is None or not len(m):
                     continue
+                self._touch_molecule(m, info.device, now)  # (voids whatever an earlier object at that address left behind)
                 extra.append(m)
+                seen.add(mid)
                 info.planned[mid] = now  # (a launch of another leader must not compute it ahead as well)
                 n_atoms += len(m)
         wanted = [id(r.molecule) for r in todo] + [id(m) for m in extra]
@@ -1446,10 +1518,12 @@ class _Sweeps:
         self.drain(5.0)
         with self._lock:
             self._keys.clear(); self._molecules.clear(); self._results.clear(); self._unions.clear(); self._inflight.clear()
+            self._loaded.clear()
             del self.launches[:]
 
 
 _sweeps = _Sweeps()
+_molecule_created = _sweeps.loaded
 
 
 class Jess:

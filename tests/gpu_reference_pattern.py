@@ -43,9 +43,18 @@ def sweep(ms):
 
 
 sweep(mols[n:])  # warm: libraries packed, selections staged, the six keys known
+import gc  # noqa: E402
+import os  # noqa: E402
+if os.environ.get("GC_MODE") == "freeze":    # the library's quarter of a million objects out of the collector's sight
+    gc.collect(); gc.freeze()
+elif os.environ.get("GC_MODE") == "off":
+    gc.disable()
+gc_runs = []
+gc.callbacks.append(lambda phase, info: gc_runs.append((info["generation"], time.perf_counter())) if phase == "start" else None)
 for rep in range(3):
     ms = mols[:n] if rep == 0 else synthetic.structures(n, start=1000 * rep)
     del pyjess._sweeps.launches[:]
+    del gc_runs[:]
     t0 = time.perf_counter()
     per_bucket = sweep(ms)
     dt = time.perf_counter() - t0
@@ -53,6 +62,7 @@ for rep in range(3):
     print("%d molecules x %d buckets from %d threads: %.1f ms = %.0f structures/s; %d launches (%.1f ms inside them, %.1f molecules each)" %
           (n, len(sizes), threads, dt * 1e3, n / dt, len(launches), 1e3 * sum(l[3] for l in launches),
            sum(l[0] for l in launches) / max(1, len(launches))))
+    print("   garbage collections during the sweep, by generation:", [sum(1 for g, _ in gc_runs if g == k) for k in range(3)])
     print("   per bucket (size, ms, hits):", [(s, round(t * 1e3, 1), h) for s, t, h in per_bucket])
     print("   launch ms:", [round(l[3] * 1e3, 2) for l in launches][:24])
     print("   of a launch (device copy, enqueue, wait + table) ms:", np.round(np.mean([l[4] for l in launches[2:]], axis=0), 3))
