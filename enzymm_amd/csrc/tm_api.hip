@@ -110,24 +110,35 @@ uint32_t host_team() {
 // fork() the child starts its own team on first use (the parent's threads do not exist there).
 class HostPool {
 public:
-    static HostPool &get() {
+    // kTeams teams: a loop takes the first team that is free (the ingest workers of Matcher.run_files and the leaders of
+    // pyjess's launches create batches side by side); all busy: the caller runs its loop inline
+    static constexpr int kTeams = 3;
+    static HostPool &get(int team = 0) {
         static std::once_flag once;
-        std::call_once(once, [] { pthread_atfork(nullptr, nullptr, [] { instance().store(nullptr); }); });
-        HostPool *p = instance().load();
+        std::call_once(once, [] { pthread_atfork(nullptr, nullptr, [] { for (int t = 0; t < kTeams; ++t) instance(t).store(nullptr); }); });
+        HostPool *p = instance(team).load();
         if (!p) {
             static std::mutex create;
             std::lock_guard<std::mutex> lock(create);
-            p = instance().load();
-            if (!p) { p = new HostPool(host_team() > 1 ? host_team() - 1 : 0); instance().store(p); }
+            p = instance(team).load();
+            if (!p) { p = new HostPool(host_team() > 1 ? host_team() - 1 : 0); instance(team).store(p); }
         }
         return *p;
     }
-    // f(i) for i in [0, n): on the team and the calling thread
-    void run(uint32_t n, const std::function<void(uint32_t)> &f) {
+    // f(i) for i in [0, n): on a free team and the calling thread
+    static void run_anywhere(uint32_t n, const std::function<void(uint32_t)> &f) {
+        if (n > 1)
+            for (int t = 0; t < kTeams; ++t)
+                if (get(t).run(n, f, false)) return;
+        for (uint32_t i = 0; i < n; ++i) f(i);
+    }
+    // the same on THIS team; false (nothing done) when it is busy and `inline_if_busy` is not set
+    bool run(uint32_t n, const std::function<void(uint32_t)> &f, bool inline_if_busy = true) {
         std::unique_lock<std::mutex> one(run_mu_, std::try_to_lock);
         if (n <= 1 || workers_.empty() || !one.owns_lock()) {
+            if (!inline_if_busy && n > 1 && !workers_.empty()) return false;
             for (uint32_t i = 0; i < n; ++i) f(i);
-            return;
+            return true;
         }
         {
             std::lock_guard<std::mutex> lock(mu_);
@@ -138,13 +149,14 @@ public:
         std::unique_lock<std::mutex> lock(mu_);
         done_.wait(lock, [&] { return left_ == 0 && active_ == 0; });  // (no worker is still looking at this job)
         job_ = nullptr;
+        return true;
     }
 
 private:
     explicit HostPool(uint32_t n_threads) {
         for (uint32_t t = 0; t < n_threads; ++t) workers_.emplace_back([this] { loop(); }).detach();
     }
-    static std::atomic<HostPool *> &instance() { static std::atomic<HostPool *> p{nullptr}; return p; }
+    static std::atomic<HostPool *> &instance(int team) { static std::atomic<HostPool *> p[kTeams]; return p[team]; }
     void pull() {
         uint32_t mine = 0;
         for (;;) {
@@ -942,7 +954,7 @@ int batch_from_encoded(int device, const tm_batch_desc *d, const double *const *
                 if (s1 > s0) slices.emplace_back(s0, s1);
                 s0 = s1;
             }
-            HostPool::get().run((uint32_t)slices.size(), [&](uint32_t t) { flatten(slices[t].first, slices[t].second); });
+            HostPool::run_anywhere((uint32_t)slices.size(), [&](uint32_t t) { flatten(slices[t].first, slices[t].second); });
         }
     }
 
@@ -1150,7 +1162,7 @@ int batch_from_structures(int device, uint32_t ns, const tm_structure_columns *s
                 if (s1 > s0) slices.emplace_back(s0, s1);
                 s0 = s1;
             }
-            HostPool::get().run((uint32_t)slices.size(), [&](uint32_t t) { encode(slices[t].first, slices[t].second); });
+            HostPool::run_anywhere((uint32_t)slices.size(), [&](uint32_t t) { encode(slices[t].first, slices[t].second); });
         }
     }
     trace.mark("encode");
@@ -2713,7 +2725,7 @@ void parallel_for(uint32_t n, uint32_t grain, F &&f) {
         for (uint32_t i = 0; i < n; ++i) f(i);
         return;
     }
-    HostPool::get().run(team, [&](uint32_t t) {
+    HostPool::run_anywhere(team, [&](uint32_t t) {
         const uint32_t lo = (uint32_t)((uint64_t)n * t / team), hi = (uint32_t)((uint64_t)n * (t + 1) / team);
         for (uint32_t i = lo; i < hi; ++i) f(i);
     });
