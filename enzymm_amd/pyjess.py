@@ -1295,7 +1295,7 @@ class _Sweeps:
             return
         with self._lock:
             mid = id(molecule)
-            self._loaded.pop(mid, None)  # (a new object at an address seen before goes to the young end)
+            known = self._loaded.pop(mid, None) is not None  # (a new object at an address seen before goes to the young end)
             self._made += 1
             self._loaded[mid] = (ref, self._made)
             while len(self._loaded) > self.MAX_LOADED:
@@ -1303,11 +1303,13 @@ class _Sweeps:
             old = self._molecules.get(mid)
             if old is not None and old[0]() is not molecule:
                 del self._molecules[mid]
-            for k in self._keys.values():  # ... and what was noted for the old object at that address is void
-                if mid in k.asked or mid in k.planned:
-                    k.asked.pop(mid, None)
-                    k.planned.pop(mid, None)
-                    self._results.pop((k.key, mid), None)
+                known = True
+            if known:  # what was noted for the old object at that address is void
+                for k in self._keys.values():
+                    if mid in k.asked or mid in k.planned:
+                        k.asked.pop(mid, None)
+                        k.planned.pop(mid, None)
+                        self._results.pop((k.key, mid), None)
 
     # -- the two entry points ---------------------------------------------------------------------------------------
     def lookup(self, jess, key, thresholds, options, molecule):
