@@ -1821,10 +1821,11 @@ static int build_tables(const tm_library *lib, tm_batch *b, const StagedSelectio
 #ifdef TM_ABLATE
     if (const char *env = std::getenv("ENZYMM_AMD_TAB_DEBUG")) lr_arg |= (uint32_t)std::atoi(env) << 30;
 #endif
-    HIP_TRY(allow_dynamic_lds(reinterpret_cast<const void *>(k_tab_build), lds_bytes));
+    const auto tab_build = atom_cap != 0u ? k_tab_build<true> : k_tab_build<false>;
+    HIP_TRY(allow_dynamic_lds(reinterpret_cast<const void *>(tab_build), lds_bytes));
     hipLaunchKernelGGL(k_tab_layout, dim3(ns), dim3(256), 0, stream, lib->n_lead, B, S->d_tables.p, b->d_tab_dir.p,
                        b->d_tab_cursors.p, rows, b->d_tab_overflow.p, b->d_tab_ok.p);
-    hipLaunchKernelGGL(k_tab_build, dim3(b->tab_work_items), dim3(kTabBlock), lds_bytes, stream, lib->n_lead, B,
+    hipLaunchKernelGGL(tab_build, dim3(b->tab_work_items), dim3(kTabBlock), lds_bytes, stream, lib->n_lead, B,
                        S->d_tables.p, b->d_tab_work.p, b->d_tab_ok.p, b->d_tab_rows.p, b->d_tab_ent.p, b->d_tab_seg.p,
                        b->d_tab_cursors.p, ents, b->d_tab_overflow.p, lr_arg, shared_limit, atom_cap);
     {
@@ -2543,8 +2544,8 @@ int tm_result_append_hits(tm_result *r, void *rows, uint64_t capacity, uint64_t 
 // diagnostic build only (make stats): read and reset the search counters
 int tm_debug_stats(unsigned long long *out) {
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(tmx::g_stats), 96 * sizeof(unsigned long long)));
-    unsigned long long zero[96] = {0};
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(tmx::g_stats), 192 * sizeof(unsigned long long)));
+    unsigned long long zero[192] = {0};
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(tmx::g_stats), zero, sizeof zero));
     return TM_OK;
 }

@@ -26,7 +26,8 @@ namespace tmx {
 // [66] triples looked at, [65] triples paged out, [60] / [62] triples whose level 3 is a lead / a residue atom, [61] candidate chunks of the
 // former, [63] items of the latter, [55] workgroups, [56] workgroups with their kind lists in LDS,
 // [57] kind-list entries of their structures
-__device__ unsigned long long g_stats[96];
+// [96+b] / [120+b]: distance tests of swept leader / non-leader tables whose cross product has bit length b; [144+b] / [168+b]: their entries
+__device__ unsigned long long g_stats[192];
 #define TM_STAT(i, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_stats[i], (unsigned long long)(v)); } while (0)
 // Ablation (diagnostic and timing builds): query flag bit 8 (0x100) drops the pair-scan survivors, bit 9 (0x200)
 // skips the search after template staging, bit 10 (0x400) drops the triple-scan survivors.
@@ -491,7 +492,10 @@ __global__ __launch_bounds__(256) void k_tab_layout(uint32_t n_lead, BatchView B
 // a table with more than this many (position A, position B) pairs is built by all waves of its workgroup together
 // (k_tab_build's shared_limit; ENZYMM_AMD_TAB_SHARED overrides it -- tests send ordinary structures down that path)
 constexpr unsigned long long kTabShared = 256ull * 1024ull;
-constexpr unsigned long long kDeriveMin = 16384;  // cross product above which a group's smaller-limit tables are derived from its leader
+#ifndef TM_DERIVE_MIN
+#define TM_DERIVE_MIN 16384
+#endif
+constexpr unsigned long long kDeriveMin = TM_DERIVE_MIN;  // cross product above which a group's smaller-limit tables are derived from its leader
 constexpr int kTabBlock = 1024;  // threads of a k_tab_build workgroup: 16 waves share one LDS copy of the lead records
 
 // One sweep over the tiles of one table.  A tile lays TI rows x TJ columns over the 64 lanes, row-major (TJ = the
@@ -709,6 +713,13 @@ __device__ __forceinline__ void tab_build_tables(const BatchView &B, const Table
             tab_seg[(size_t)w.s * nt + t] = first == ~0ull ? make_uint2(0u, 0u) : make_uint2((uint32_t)first, (uint32_t)first + total);
             rows[n_a] = total;
         }
+#ifdef TM_STATS
+        {
+            const uint32_t bl = min(23u, 64u - (uint32_t)__clzll((long long)bound));
+            TM_STAT((T.src == t ? 96 : 120) + bl, bound);
+            TM_STAT((T.src == t ? 144 : 168) + bl, total);
+        }
+#endif
         // ---- the tables derived from this one (same lists, smaller limits): its entries within their limit
         if (derive && T.next != 0xffffu && dbg_mode != 2u) {
             const bool have = first != ~0ull && rows_ok && dbg_mode == 0u;
@@ -801,7 +812,13 @@ __device__ __forceinline__ void tab_build_tables(const BatchView &B, const Table
 
 // Dynamic LDS: [float4 x lr_cap] lead records (the record of the atom at every position of the structure's kind
 // lists), [u32 x (n_lead + 1)] kind-list offsets.  A structure whose kind lists exceed lr_cap reads through L2.
-__global__ __launch_bounds__(kTabBlock) void k_tab_build(uint32_t n_lead, BatchView B, const TableDesc *__restrict__ tables,
+// kCompact: the compact layout below (atom_cap != 0) -- 80 KB, TWO 16-wave workgroups per CU, which takes eight waves
+// per SIMD = at most 64 VGPRs (the attribute: left to itself the compiler settles on 67 and one workgroup per CU).
+#ifndef TM_TAB_EU
+#define TM_TAB_EU 8
+#endif
+template <bool kCompact>
+__global__ __launch_bounds__(kTabBlock) __attribute__((amdgpu_waves_per_eu(kCompact ? TM_TAB_EU : 4, kCompact ? TM_TAB_EU : 4))) void k_tab_build(uint32_t n_lead, BatchView B, const TableDesc *__restrict__ tables,
                                                           const TabWork *__restrict__ work, uint32_t *__restrict__ tab_ok,
                                                           uint32_t *__restrict__ tab_rows, uint2 *__restrict__ tab_ent,
                                                           uint2 *__restrict__ tab_seg,
@@ -813,6 +830,9 @@ __global__ __launch_bounds__(kTabBlock) void k_tab_build(uint32_t n_lead, BatchV
     __shared__ uint32_t s_count[kTabBlock / 64];
     __shared__ unsigned long long s_first;
     const TabWork w = work[blockIdx.x];
+#ifdef TM_STATS
+    const unsigned long long t_wg = __builtin_amdgcn_s_memtime();
+#endif
     // Bit 0 of tab_ok[s]: the structure's row slots fit (k_tab_layout; never changes while this kernel runs).  Bit 1 is
     // set by whichever workgroup of the structure runs out of entries -- at any moment, so nothing here branches on it:
     // a structure without row slots, or a wave whose entries do not fit, keeps sweeping in count-only mode, so that
@@ -827,7 +847,7 @@ __global__ __launch_bounds__(kTabBlock) void k_tab_build(uint32_t n_lead, BatchV
     const uint32_t *kl = B.kl_off + (size_t)w.s * (n_lead + 1);
     const float4 *rec = B.q_rec + B.s_off[w.s];
     const uint32_t p0 = kl[0], plen = kl[n_lead] - p0;
-    if (atom_cap != 0u) {
+    if constexpr (kCompact) {
         // compact layout (host: the batch's largest structure leaves room for two workgroups per CU):
         // [float4 x atom_cap] atom records, [u16 x lr_cap] kind lists, [u32 x (n_lead + 1)] their offsets
         const uint32_t n = B.s_off[w.s + 1] - B.s_off[w.s];
@@ -860,27 +880,50 @@ __global__ __launch_bounds__(kTabBlock) void k_tab_build(uint32_t n_lead, BatchV
             for (uint32_t i = tid + step; i < n_pool; i += step) l_pool[i] = g_pool[i];
             for (uint32_t i = tid + step; i <= n_lead; i += step) s_kl2[i] = kl[i] - rebase;
             __syncthreads();
+#ifdef TM_STATS
+            // [93] sum of the waves' working ticks, [94] (last wave's end - start of work) x waves, [95] staging ticks x waves
+            __shared__ unsigned long long s_end;
+            const unsigned long long t_work = __builtin_amdgcn_s_memtime();
+            if (threadIdx.x == 0) s_end = 0ull;
+            __syncthreads();
+#endif
             tab_build_tables<2>(B, tables, w, s_atoms, s_pool, nullptr, s_kl2, tab_rows, tab_ent, tab_seg, cursors,
                                 ent_capacity, overflow, tab_ok, dbg_mode, s_count, &s_first, n_lead, nullptr, 0u, shared_limit, rows_ok);
+#ifdef TM_STATS
+            {
+                const unsigned long long t_done = __builtin_amdgcn_s_memtime();
+                TM_STAT(93, t_done - t_work);
+                if ((threadIdx.x & 63) == 0) atomicMax(&s_end, t_done);
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    atomicAdd(&g_stats[94], (s_end - t_work) * (unsigned long long)(kTabBlock / 64));
+                    atomicAdd(&g_stats[95], (t_work - t_wg) * (unsigned long long)(kTabBlock / 64));
+                }
+            }
+#endif
         } else {
             tab_build_tables<0>(B, tables, w, rec, B.kl_pool, nullptr, kl, tab_rows, tab_ent, tab_seg, cursors,
                                 ent_capacity, overflow, tab_ok, dbg_mode, s_count, &s_first, n_lead, s_atoms, atom_cap, shared_limit, rows_ok);
         }
-        return;
-    }
-    float4 *s_lr = reinterpret_cast<float4 *>(tab_smem);
-    uint32_t *s_kl = reinterpret_cast<uint32_t *>(s_lr + lr_cap);
-    if (plen <= lr_cap) {
-        for (uint32_t i = threadIdx.x; i < plen; i += blockDim.x) s_lr[i] = rec[B.kl_pool[p0 + i]];
-        for (uint32_t i = threadIdx.x; i <= n_lead; i += blockDim.x) s_kl[i] = kl[i] - p0;
-        __syncthreads();
-        tab_build_tables<1>(B, tables, w, rec, B.kl_pool, s_lr, s_kl, tab_rows, tab_ent, tab_seg, cursors,
-                               ent_capacity, overflow, tab_ok, dbg_mode, s_count, &s_first, n_lead, nullptr, 0u, shared_limit, rows_ok);
     } else {
-        tab_build_tables<0>(B, tables, w, rec, B.kl_pool, nullptr, kl, tab_rows, tab_ent, tab_seg, cursors,
+        float4 *s_lr = reinterpret_cast<float4 *>(tab_smem);
+        uint32_t *s_kl = reinterpret_cast<uint32_t *>(s_lr + lr_cap);
+        if (plen <= lr_cap) {
+            for (uint32_t i = threadIdx.x; i < plen; i += blockDim.x) s_lr[i] = rec[B.kl_pool[p0 + i]];
+            for (uint32_t i = threadIdx.x; i <= n_lead; i += blockDim.x) s_kl[i] = kl[i] - p0;
+            __syncthreads();
+            tab_build_tables<1>(B, tables, w, rec, B.kl_pool, s_lr, s_kl, tab_rows, tab_ent, tab_seg, cursors,
+                                ent_capacity, overflow, tab_ok, dbg_mode, s_count, &s_first, n_lead, nullptr, 0u, shared_limit, rows_ok);
+        } else {
+            tab_build_tables<0>(B, tables, w, rec, B.kl_pool, nullptr, kl, tab_rows, tab_ent, tab_seg, cursors,
                                 ent_capacity, overflow, tab_ok, dbg_mode, s_count, &s_first, n_lead, s_lr, lr_cap, shared_limit, rows_ok);
+        }
     }
 }
+template __global__ void k_tab_build<true>(uint32_t, BatchView, const TableDesc *, const TabWork *, uint32_t *, uint32_t *, uint2 *, uint2 *,
+                                           unsigned long long *, unsigned long long, uint32_t *, uint32_t, unsigned long long, uint32_t);
+template __global__ void k_tab_build<false>(uint32_t, BatchView, const TableDesc *, const TabWork *, uint32_t *, uint32_t *, uint2 *, uint2 *,
+                                            unsigned long long *, unsigned long long, uint32_t *, uint32_t, unsigned long long, uint32_t);
 
 constexpr uint32_t kRefLenMask = (1u << 25) - 1u;
 constexpr uint32_t kRefSingly = 1u << 31;

@@ -25,7 +25,7 @@ else:
     mols = synthetic.structures(n)
 lib = _native.load()
 print("loaded", flush=True)
-buf = (C.c_ulonglong * 96)()
+buf = (C.c_ulonglong * 192)()
 print("stats0", lib.tm_debug_stats(buf), flush=True)
 t0 = time.time()
 table = jess.query_batch(mols, 2.0, cut, cut, max_candidates=10000, ignore_chain=True, template_index=idx,
@@ -50,6 +50,12 @@ for mode, name in ((0, "k_search blocks"), (2, "k_deep")):
     busy, held, staging = s[70 + 4 * mode], s[71 + 4 * mode], s[72 + 4 * mode]
     print("%s: waves working %.1f %% of the time their workgroup holds its CU after staging; staging %.1f %% of that time" %
           (name, 100.0 * busy / max(held, 1), 100.0 * staging / max(held, 1)))
+print("k_tab_build (compact layout): waves working %.1f %% of the time their workgroup holds its CU after staging; staging %.1f %% of that time" %
+      (100.0 * s[93] / max(s[94], 1), 100.0 * s[95] / max(s[94], 1)))
+print("table build, by bit length of the cross product: tests of swept leaders / non-leaders, entries of both (per structure)")
+for b in range(24):
+    if s[96 + b] or s[120 + b]:
+        print("  2^%-2d  %10.0f %10.0f   %9.0f %9.0f" % (b, s[96 + b] / len(mols), s[120 + b] / len(mols), s[144 + b] / len(mols), s[168 + b] / len(mols)))
 print("workgroups", int(s[55]), "with kind lists in LDS", int(s[56]), "mean kind-list pool entries", s[57] / max(s[55], 1))
 # ablation: k_search time with (a) everything, (b) no subtrees below the joint scan, (c) staging only
 packed = pyjess._packed(jess._templates, jess._device)
