@@ -1805,7 +1805,8 @@ static int build_tables(const tm_library *lib, tm_batch *b, const StagedSelectio
     // build runs at eight waves per SIMD instead of four, which is worth the second LDS read per operand.
     uint32_t atom_cap = 0;
     {
-        static const bool off = std::getenv("ENZYMM_AMD_TAB_COMPACT") && std::atoi(std::getenv("ENZYMM_AMD_TAB_COMPACT")) == 0;
+        const char *compact_env = std::getenv("ENZYMM_AMD_TAB_COMPACT");  // experiments and tests: 0 = a record per list position
+        const bool off = compact_env && std::atoi(compact_env) == 0;
         const size_t budget = 80 * 1024 - 512;  // static LDS of the kernel and allocation granularity
         const size_t fixed = (size_t)b->max_atoms * sizeof(float4) + ((size_t)lib->n_lead + 2) * sizeof(uint32_t);
         if (!off && !mostly_large && fixed + 2 * 2 * (size_t)b->max_atoms + 16 <= budget) {  // room for two positions per atom at least
@@ -1817,6 +1818,9 @@ static int build_tables(const tm_library *lib, tm_batch *b, const StagedSelectio
     unsigned long long shared_limit = kTabShared;
     if (const char *env = std::getenv("ENZYMM_AMD_TAB_SHARED"))  // test hook: smaller tables take the shared build too
         shared_limit = std::max<unsigned long long>(1, std::strtoull(env, nullptr, 10));
+    unsigned long long derive_min = kDeriveMin;
+    if (const char *env = std::getenv("ENZYMM_AMD_TAB_DERIVE_MIN"))  // test hook: 0 = every grouped table derived, huge = every table swept
+        derive_min = std::strtoull(env, nullptr, 10);
     uint32_t lr_arg = lr_cap;
 #ifdef TM_ABLATE
     if (const char *env = std::getenv("ENZYMM_AMD_TAB_DEBUG")) lr_arg |= (uint32_t)std::atoi(env) << 30;
@@ -1827,7 +1831,7 @@ static int build_tables(const tm_library *lib, tm_batch *b, const StagedSelectio
                        b->d_tab_cursors.p, rows, b->d_tab_overflow.p, b->d_tab_ok.p);
     hipLaunchKernelGGL(tab_build, dim3(b->tab_work_items), dim3(kTabBlock), lds_bytes, stream, lib->n_lead, B,
                        S->d_tables.p, b->d_tab_work.p, b->d_tab_ok.p, b->d_tab_rows.p, b->d_tab_ent.p, b->d_tab_seg.p,
-                       b->d_tab_cursors.p, ents, b->d_tab_overflow.p, lr_arg, shared_limit, atom_cap);
+                       b->d_tab_cursors.p, ents, b->d_tab_overflow.p, lr_arg, shared_limit, atom_cap, derive_min);
     {
         const uint32_t n_sel = (uint32_t)S->sel.size();
         hipLaunchKernelGGL(k_tab_refs, dim3(ns, (n_sel + 255) / 256), dim3(256), ((size_t)lib->n_lead + 15) & ~size_t(15), stream, B, lib->n_lead, n_sel, S->d_pair_table.p,

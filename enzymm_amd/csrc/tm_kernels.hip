@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256) void k_tab_layout(uint32_t n_lead, BatchView B
 // (k_tab_build's shared_limit; ENZYMM_AMD_TAB_SHARED overrides it -- tests send ordinary structures down that path)
 constexpr unsigned long long kTabShared = 256ull * 1024ull;
 #ifndef TM_DERIVE_MIN
-#define TM_DERIVE_MIN 16384
+#define TM_DERIVE_MIN 512
 #endif
 constexpr unsigned long long kDeriveMin = TM_DERIVE_MIN;  // cross product above which a group's smaller-limit tables are derived from its leader
 constexpr int kTabBlock = 1024;  // threads of a k_tab_build workgroup: 16 waves share one LDS copy of the lead records
@@ -511,6 +511,10 @@ constexpr int kTabBlock = 1024;  // threads of a k_tab_build workgroup: 16 waves
 // A sweep may cover a block of rows of a larger table (several waves share a big table): `rows` then points at the
 // block's first row slot, `i_base` is that row's number and `row_base` the number of passing pairs in the rows before
 // it -- entries and row offsets are written for the whole table's numbering.  The return value counts this block only.
+template <class T>
+__device__ __forceinline__ T *lane_at(T *uniform, uint32_t bytes) {
+    return reinterpret_cast<T *>(reinterpret_cast<char *>(uniform) + bytes);
+}
 template <bool kFill, class Lead, class LeadB>
 __device__ __forceinline__ uint32_t tab_sweep(Lead lead, LeadB lead_b, uint32_t a_lo, uint32_t n_a, uint32_t b_lo,
                                               uint32_t n_b, float dmax2, uint32_t *rows, uint2 *ent,
@@ -525,30 +529,36 @@ __device__ __forceinline__ uint32_t tab_sweep(Lead lead, LeadB lead_b, uint32_t 
     const uint32_t shift = n_b <= 1u ? 0u : min(6u, 32u - (uint32_t)__clz((int)(n_b - 1u)));
     const uint32_t TJ = 1u << shift, TI = 64u >> shift;
     const uint32_t li = lane >> shift, lj = lane & (TJ - 1u);
-    const unsigned long long below = li == 0u ? 0ull : ((1ull << (li * TJ)) - 1ull);  // lanes of the tile's earlier rows
+    // (the last step is ONE comparison -- of the distance, or of +inf for a lane that does not count: the vote is then the
+    // comparison's own lane mask; a conjunction of three is voted on through a select and a second comparison)
     auto test = [&](const float4 &ra, const float4 &rb, bool valid, float &d2) {
         const float dx = ra.x - rb.x, dy = ra.y - rb.y, dz = ra.z - rb.z;
         d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-        return valid & (d2 <= dmax2) & (meta_res(__float_as_uint(ra.w)) != meta_res(__float_as_uint(rb.w)));
+        const bool counts = valid & (meta_res(__float_as_uint(ra.w)) != meta_res(__float_as_uint(rb.w)));
+        return (counts ? d2 : __builtin_inff()) <= dmax2;
     };
     if (n_b <= TJ) {
         // ---- list B is one tile wide: the column operand never changes, rows go by 2 x TI
         const bool vj = lj < n_b;
-        const float4 rb = lead_b(b_lo + (vj ? lj : 0u));
+        const float4 rb = lead_b(b_lo, lj, vj);
         for (uint32_t i0 = 0; i0 < n_a; i0 += 2u * TI) {
             const uint32_t iA = i0 + li, iB = iA + TI;
             const bool vA = iA < n_a, vB = iB < n_a;
-            const float4 raA = lead(a_lo + (vA ? iA : 0u)), raB = lead(a_lo + (vB ? iB : 0u));
+            const float4 raA = lead(a_lo, iA, vA), raB = lead(a_lo, iB, vB);
             float dA, dB;
             const bool okA = test(raA, rb, vA & vj, dA), okB = test(raB, rb, vB & vj, dB);
             const unsigned long long allA = ballot64(okA), allB = ballot64(okB);
             const uint32_t nA = (uint32_t)__popcll(allA);
             if (kFill) {
-                if (okA) ent[running + rank_in(allA)] = make_uint2((iA + i_base) | (lj << 16), __float_as_uint(dA));
-                if (okB) ent[running + nA + rank_in(allB)] = make_uint2((iB + i_base) | (lj << 16), __float_as_uint(dB));
+                // (the votes below the first lane of a tile row are those of the tile's earlier rows: a row's offset)
+                // (addresses as a wave-uniform pointer plus a 32-bit byte offset per lane: the store takes the pointer from
+                // scalar registers, no 64-bit address arithmetic per lane)
+                const uint32_t rA = rank_in(allA), rB = nA + rank_in(allB);
+                if (okA) *lane_at(ent + running, rA << 3) = make_uint2((iA + i_base) | (lj << 16), __float_as_uint(dA));
+                if (okB) *lane_at(ent + running, rB << 3) = make_uint2((iB + i_base) | (lj << 16), __float_as_uint(dB));
                 if (lj == 0u) {
-                    if (vA) rows[iA] = running + (uint32_t)__popcll(allA & below);
-                    if (vB) rows[iB] = running + nA + (uint32_t)__popcll(allB & below);
+                    if (vA) *lane_at(rows + i0, li << 2) = running + rA;
+                    if (vB) *lane_at(rows + i0 + TI, li << 2) = running + rB;
                 }
             }
             running += nA + (uint32_t)__popcll(allB);
@@ -557,20 +567,20 @@ __device__ __forceinline__ uint32_t tab_sweep(Lead lead, LeadB lead_b, uint32_t 
     }
     // ---- list B is longer than 64: one row per tile (TI = 1), columns go by 2 x 64
     for (uint32_t i = 0; i < n_a; ++i) {
-        const float4 ra = lead(a_lo + i);
+        const float4 ra = lead(a_lo, i, true);
         if (kFill)
             if (lane == 0u) rows[i] = running;
         for (uint32_t j0 = 0; j0 < n_b; j0 += 128u) {
             const uint32_t jA = j0 + lane, jB = jA + 64u;
             const bool vA = jA < n_b, vB = jB < n_b;
-            const float4 rbA = lead_b(b_lo + (vA ? jA : 0u)), rbB = lead_b(b_lo + (vB ? jB : 0u));
+            const float4 rbA = lead_b(b_lo, jA, vA), rbB = lead_b(b_lo, jB, vB);
             float dA, dB;
             const bool okA = test(ra, rbA, vA, dA), okB = test(ra, rbB, vB, dB);
             const unsigned long long allA = ballot64(okA), allB = ballot64(okB);
             const uint32_t nA = (uint32_t)__popcll(allA);
             if (kFill) {
-                if (okA) ent[running + rank_in(allA)] = make_uint2((i + i_base) | (jA << 16), __float_as_uint(dA));
-                if (okB) ent[running + nA + rank_in(allB)] = make_uint2((i + i_base) | (jB << 16), __float_as_uint(dB));
+                if (okA) *lane_at(ent + running, rank_in(allA) << 3) = make_uint2((i + i_base) | (jA << 16), __float_as_uint(dA));
+                if (okB) *lane_at(ent + running, (nA + rank_in(allB)) << 3) = make_uint2((i + i_base) | (jB << 16), __float_as_uint(dB));
             }
             running += nA + (uint32_t)__popcll(allB);
         }
@@ -619,6 +629,41 @@ __device__ __forceinline__ uint32_t tab_derive(const uint32_t *rows_l, const uin
     return running;
 }
 
+// The same table from a leader of at most kDeriveVotes x 64 entries (most are: a few hundred entries), without the scattered
+// row stores, the exchange with the neighbouring lane and the second sweep over freshly written offsets: the vote of every
+// 64-entry chunk and the count before it stay in the wave (chunk k in lane k of three registers); a row's offset is then
+// the count before the chunk its first leader entry falls into plus the votes below that entry -- one load of the
+// leader's offset per row (asked for before the entries are streamed), three lane reads, a population count.
+constexpr uint32_t kDeriveVotes = 63;
+__device__ __forceinline__ uint32_t tab_derive_small(const uint32_t *rows_l, const uint2 *ent_l, uint32_t total_l, uint32_t n_a,
+                                                     float dmax2, uint32_t *rows_c, uint2 *ent_c, uint32_t lane) {
+    uint32_t first_row = 0;
+    if (lane < n_a) first_row = rows_l[lane];
+    uint32_t vote_lo = 0, vote_hi = 0, before = 0;  // lane k: chunk k; the lane after the last chunk: no votes, the total
+    uint32_t running = 0, k = 0;
+    for (uint32_t e0 = 0; e0 < total_l; e0 += 64u, ++k) {
+        const uint32_t e = e0 + lane;
+        uint2 ent = make_uint2(0u, 0x7f800000u);
+        if (e < total_l) ent = ent_l[e];
+        const bool ok = e < total_l && __uint_as_float(ent.y) <= dmax2;
+        const unsigned long long mask = ballot64(ok);
+        if (ok) ent_c[running + rank_in(mask)] = ent;
+        if (lane == k) { vote_lo = (uint32_t)mask; vote_hi = (uint32_t)(mask >> 32); before = running; }
+        running += (uint32_t)__popcll(mask);
+    }
+    if (lane == k) before = running;
+    for (uint32_t i0 = 0; i0 < n_a; i0 += 64u) {
+        const uint32_t i = i0 + lane;
+        uint32_t e = first_row;
+        if (i0 != 0u) e = i < n_a ? rows_l[i] : 0u;
+        const uint32_t c = e >> 6, bit = e & 63u;
+        const unsigned long long votes = ((unsigned long long)lane_get(vote_hi, c) << 32) | lane_get(vote_lo, c);
+        const uint32_t count = lane_get(before, c) + (uint32_t)__popcll(votes & ((1ull << bit) - 1ull));
+        if (i < n_a) rows_c[i] = count;
+    }
+    return running;
+}
+
 // All tables of one work item (structure, part), one wave per table.  Entries are bump-allocated per WAVE in chunks of
 // tab_chunk() entries (one atomic per chunk; one per table would serialise a million atomics on one address): a table whose
 // cross product fits the rest of the wave's chunk is swept ONCE -- rows and entries written as they are found, the
@@ -644,16 +689,20 @@ __device__ __forceinline__ void tab_build_tables(const BatchView &B, const Table
                                                  unsigned long long ent_capacity, uint32_t *__restrict__ overflow,
                                                  uint32_t *__restrict__ tab_ok, uint32_t dbg_mode, uint32_t *s_count,
                                                  unsigned long long *s_first, uint32_t n_lead, float4 *s_stage,
-                                                 uint32_t stage_cap, unsigned long long shared_limit, bool rows_ok) {
+                                                 uint32_t stage_cap, unsigned long long shared_limit, bool rows_ok,
+                                                 unsigned long long derive_min) {
     const uint32_t nt = B.n_tables;
     const uint32_t wave = uni(threadIdx.x >> 6), n_waves = blockDim.x >> 6, lane = threadIdx.x & 63;
-    auto lead = [&](uint32_t p) -> float4 {
-        if constexpr (kSrc == 1) return s_lr[p];
+    // the record at position `first + k` of a kind list; `valid`: k lies inside the list.  A lane beyond the list is
+    // masked out of the vote whatever it reads: only a read from GLOBAL memory has to stay inside the arrays (position
+    // `first` then) -- an LDS read past the list returns a neighbouring list's atom, past the allocation zero
+    auto lead = [&](uint32_t first, uint32_t k, bool valid) -> float4 {
+        if constexpr (kSrc == 1) return s_lr[first + k];
         else if constexpr (kSrc == 2) {
-            const uint32_t atom = ((const __attribute__((address_space(3))) uint16_t *)pool)[p];
+            const uint32_t atom = ((const __attribute__((address_space(3))) uint16_t *)pool)[first + k];
             const auto *r = (const __attribute__((address_space(3))) float *)rec + 4u * atom;
             return make_float4(r[0], r[1], r[2], r[3]);
-        } else return rec[pool[p]];
+        } else return rec[pool[first + (valid ? k : 0u)]];
     };
     // entries [first, first + n) of the pool, or ~0 when the pool is exhausted (the query then reports the overflow)
     auto allocate = [&](unsigned long long n) -> unsigned long long {
@@ -682,7 +731,7 @@ __device__ __forceinline__ void tab_build_tables(const BatchView &B, const Table
         // Tables of one group (same two lists, different limits): when the cross product is large, only the leader is
         // swept and the others are derived from its entries by the wave that builds it (below); a small cross product
         // -- a few dozen tiles out of LDS -- is cheaper to sweep per table than to read a leader back from L2.
-        const bool derive = bound > kDeriveMin;
+        const bool derive = bound > derive_min;
         if (derive && T.src != t) continue;
         unsigned long long first = 0;
         uint32_t total = 0;
@@ -741,7 +790,10 @@ __device__ __forceinline__ void tab_build_tables(const BatchView &B, const Table
                     first_d = allocate(total);
                     if (!have) first_d = ~0ull;
                 }
-                if (first_d != ~0ull) total_d = tab_derive(rows, tab_ent + first, total, n_a, Td.dmax2, rows_d, tab_ent + first_d, lane);
+                if (first_d != ~0ull)
+                    total_d = total <= kDeriveVotes * 64u
+                                  ? tab_derive_small(rows, tab_ent + first, total, n_a, Td.dmax2, rows_d, tab_ent + first_d, lane)
+                                  : tab_derive(rows, tab_ent + first, total, n_a, Td.dmax2, rows_d, tab_ent + first_d, lane);
                 else total_d = tab_sweep<false>(lead, lead, a_lo, n_a, b_lo, n_b, Td.dmax2, nullptr, nullptr);
                 if (total <= kTabChunk) used += total_d;
                 if (lane == 0 && rows_ok) {
@@ -804,7 +856,7 @@ __device__ __forceinline__ void tab_build_tables(const BatchView &B, const Table
             if (first != ~0ull && dbg_mode == 0u)
                 tab_sweep<true>(lead, lead_b, a_lo + i0, i1 - i0, b_lo, n_b, T.dmax2, rows + i0, tab_ent + first, s_count[wave], i0);
         };
-        if (staged) build([&](uint32_t p) -> float4 { return s_stage[p - b_lo]; });
+        if (staged) build([&](uint32_t first, uint32_t k, bool valid) -> float4 { return s_stage[k]; });
         else build(lead);
         __syncthreads();  // s_count, s_first and the staged list are reused by the next big table
     }
@@ -825,7 +877,7 @@ __global__ __launch_bounds__(kTabBlock) __attribute__((amdgpu_waves_per_eu(kComp
                                                           unsigned long long *__restrict__ cursors,
                                                           unsigned long long ent_capacity, uint32_t *__restrict__ overflow,
                                                           uint32_t lr_cap, unsigned long long shared_limit,
-                                                          uint32_t atom_cap) {
+                                                          uint32_t atom_cap, unsigned long long derive_min) {
     extern __shared__ __align__(16) unsigned char tab_smem[];
     __shared__ uint32_t s_count[kTabBlock / 64];
     __shared__ unsigned long long s_first;
@@ -888,7 +940,7 @@ __global__ __launch_bounds__(kTabBlock) __attribute__((amdgpu_waves_per_eu(kComp
             __syncthreads();
 #endif
             tab_build_tables<2>(B, tables, w, s_atoms, s_pool, nullptr, s_kl2, tab_rows, tab_ent, tab_seg, cursors,
-                                ent_capacity, overflow, tab_ok, dbg_mode, s_count, &s_first, n_lead, nullptr, 0u, shared_limit, rows_ok);
+                                ent_capacity, overflow, tab_ok, dbg_mode, s_count, &s_first, n_lead, nullptr, 0u, shared_limit, rows_ok, derive_min);
 #ifdef TM_STATS
             {
                 const unsigned long long t_done = __builtin_amdgcn_s_memtime();
@@ -903,7 +955,7 @@ __global__ __launch_bounds__(kTabBlock) __attribute__((amdgpu_waves_per_eu(kComp
 #endif
         } else {
             tab_build_tables<0>(B, tables, w, rec, B.kl_pool, nullptr, kl, tab_rows, tab_ent, tab_seg, cursors,
-                                ent_capacity, overflow, tab_ok, dbg_mode, s_count, &s_first, n_lead, s_atoms, atom_cap, shared_limit, rows_ok);
+                                ent_capacity, overflow, tab_ok, dbg_mode, s_count, &s_first, n_lead, s_atoms, atom_cap, shared_limit, rows_ok, derive_min);
         }
     } else {
         float4 *s_lr = reinterpret_cast<float4 *>(tab_smem);
@@ -913,17 +965,17 @@ __global__ __launch_bounds__(kTabBlock) __attribute__((amdgpu_waves_per_eu(kComp
             for (uint32_t i = threadIdx.x; i <= n_lead; i += blockDim.x) s_kl[i] = kl[i] - p0;
             __syncthreads();
             tab_build_tables<1>(B, tables, w, rec, B.kl_pool, s_lr, s_kl, tab_rows, tab_ent, tab_seg, cursors,
-                                ent_capacity, overflow, tab_ok, dbg_mode, s_count, &s_first, n_lead, nullptr, 0u, shared_limit, rows_ok);
+                                ent_capacity, overflow, tab_ok, dbg_mode, s_count, &s_first, n_lead, nullptr, 0u, shared_limit, rows_ok, derive_min);
         } else {
             tab_build_tables<0>(B, tables, w, rec, B.kl_pool, nullptr, kl, tab_rows, tab_ent, tab_seg, cursors,
-                                ent_capacity, overflow, tab_ok, dbg_mode, s_count, &s_first, n_lead, s_lr, lr_cap, shared_limit, rows_ok);
+                                ent_capacity, overflow, tab_ok, dbg_mode, s_count, &s_first, n_lead, s_lr, lr_cap, shared_limit, rows_ok, derive_min);
         }
     }
 }
 template __global__ void k_tab_build<true>(uint32_t, BatchView, const TableDesc *, const TabWork *, uint32_t *, uint32_t *, uint2 *, uint2 *,
-                                           unsigned long long *, unsigned long long, uint32_t *, uint32_t, unsigned long long, uint32_t);
+                                           unsigned long long *, unsigned long long, uint32_t *, uint32_t, unsigned long long, uint32_t, unsigned long long);
 template __global__ void k_tab_build<false>(uint32_t, BatchView, const TableDesc *, const TabWork *, uint32_t *, uint32_t *, uint2 *, uint2 *,
-                                            unsigned long long *, unsigned long long, uint32_t *, uint32_t, unsigned long long, uint32_t);
+                                            unsigned long long *, unsigned long long, uint32_t *, uint32_t, unsigned long long, uint32_t, unsigned long long);
 
 constexpr uint32_t kRefLenMask = (1u << 25) - 1u;
 constexpr uint32_t kRefSingly = 1u << 31;

@@ -223,6 +223,35 @@ def test_one_pair_beyond_100000_candidates_and_a_thousand_pages_in_lds(amy, monk
 # ------------------------------------------------------------------------------------------- the reference's call pattern
 
 
+def test_derived_tables_equal_swept_tables(amy, af, monkeypatch):
+    """Tables of one group (same two kind lists, smaller distance limit) are filtered out of the group's leader instead
+    of being swept when the cross product exceeds 512 pairs -- tab_derive_small (votes kept in the wave) for leaders of at
+    most 4032 entries, tab_derive beyond.  With the threshold moved (ENZYMM_AMD_TAB_DERIVE_MIN: 0 = every grouped table
+    derived, huge = every table swept, 60000 = only the large ones) the hit tables and candidate counts must not change;
+    the swept build is what the oracle parity tests of round 2 were written against."""
+    idx, cut = helpers.default_selection()
+    jess = pyjess.Jess(helpers.product_library_templates())
+    mols = [amy] + synthetic.structures(24, start=300) + [af]
+    q = lambda: jess.query_batch(mols, 2.0, cut, cut, max_candidates=10000, ignore_chain=True, template_index=idx,
+                                 count_candidates=True, return_raw=True)
+    monkeypatch.setenv("ENZYMM_AMD_TAB_DERIVE_MIN", str(1 << 60))
+    want, want_c = q()
+    assert len(want) > 30
+    for limit in ("0", "60000"):
+        monkeypatch.setenv("ENZYMM_AMD_TAB_DERIVE_MIN", limit)
+        got, got_c = q()
+        assert got.tobytes() == want.tobytes() and np.array_equal(got_c, want_c), limit
+    monkeypatch.delenv("ENZYMM_AMD_TAB_DERIVE_MIN")
+    got, got_c = q()
+    assert got.tobytes() == want.tobytes() and np.array_equal(got_c, want_c)
+    # the non-compact layout (one record per list position, one workgroup per CU) derives the same way
+    monkeypatch.setenv("ENZYMM_AMD_TAB_COMPACT", "0")
+    for limit in ("0", str(1 << 60)):
+        monkeypatch.setenv("ENZYMM_AMD_TAB_DERIVE_MIN", limit)
+        got, got_c = q()
+        assert got.tobytes() == want.tobytes() and np.array_equal(got_c, want_c), limit
+
+
 def test_reference_call_pattern_through_the_sweep_planner(amy, af):
     """Jess(bucket).query(molecule) from a thread pool, bucket after bucket (jess_run.py:896-988), twice over different
     molecules: the second sweep is answered mostly from what pyjess._Sweeps computed ahead (one library over all the
