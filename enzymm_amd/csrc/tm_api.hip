@@ -587,6 +587,7 @@ struct tm_result {
     DevBuf<Cand> d_cands;
     DevBuf<PairEntry> d_pairs;
     DevBuf<unsigned long long> d_counters;  // [0] hits, [1] candidates, [2] pairs, [3] pages of triples
+    DevBuf<uint32_t> d_queue;  // the queued block search: next unit per chunk class (8 counters)
     // shared state of every (structure, template) pair: candidate count | cut short << 31, last candidate + 1
     DevBuf<uint32_t> d_pair_count, d_pair_last, d_pair_tie;
     DevBuf<unsigned long long> d_pair_min;  // (both initialised on the device per listed pair, not per query)
@@ -1714,6 +1715,18 @@ static int carry_build_outcome(tm_batch *b, tm_result *r, hipStream_t stream) {
 // pools are sized generously (or to what an earlier build reported); should one overflow, the structures that did
 // not fit are skipped by the search, bit 4 of the query's overflow word is set and tm_result_wait reports
 // TM_E_OVERFLOW so that the caller queries again with room.
+// ENZYMM_AMD_SYNC_EACH=1 (debugging): wait for every kernel of a query before the next is launched and say so on stderr --
+// a GPU fault then aborts the process right after the line of the last kernel that ran to its end.
+static void sync_each(hipStream_t stream, const char *what) {
+    static const bool on = std::getenv("ENZYMM_AMD_SYNC_EACH") != nullptr;
+    if (!on) return;
+    std::fprintf(stderr, "[sync] %s launched\n", what);
+    std::fflush(stderr);
+    (void)hipStreamSynchronize(stream);
+    std::fprintf(stderr, "[sync] %s done\n", what);
+    std::fflush(stderr);
+}
+
 static int build_tables(const tm_library *lib, tm_batch *b, const StagedSelection *S, hipStream_t stream) {
     const uint32_t nt = (uint32_t)S->tables.size(), ns = b->n_structs;
     b->n_tables = nt;
@@ -1829,13 +1842,16 @@ static int build_tables(const tm_library *lib, tm_batch *b, const StagedSelectio
     HIP_TRY(allow_dynamic_lds(reinterpret_cast<const void *>(tab_build), lds_bytes));
     hipLaunchKernelGGL(k_tab_layout, dim3(ns), dim3(256), 0, stream, lib->n_lead, B, S->d_tables.p, b->d_tab_dir.p,
                        b->d_tab_cursors.p, rows, b->d_tab_overflow.p, b->d_tab_ok.p);
+    sync_each(stream, "k_tab_layout");
     hipLaunchKernelGGL(tab_build, dim3(b->tab_work_items), dim3(kTabBlock), lds_bytes, stream, lib->n_lead, B,
                        S->d_tables.p, b->d_tab_work.p, b->d_tab_ok.p, b->d_tab_rows.p, b->d_tab_ent.p, b->d_tab_seg.p,
                        b->d_tab_cursors.p, ents, b->d_tab_overflow.p, lr_arg, shared_limit, atom_cap, derive_min);
+    sync_each(stream, "k_tab_build");
     {
         const uint32_t n_sel = (uint32_t)S->sel.size();
         hipLaunchKernelGGL(k_tab_refs, dim3(ns, (n_sel + 255) / 256), dim3(256), ((size_t)lib->n_lead + 15) & ~size_t(15), stream, B, lib->n_lead, n_sel, S->d_pair_table.p,
                            S->d_triple_table.p, S->d_lead8.p, b->d_tab_ref.p);
+        sync_each(stream, "k_tab_refs");
     }
     HIP_TRY(hipGetLastError());
     return TM_OK;
@@ -2080,6 +2096,7 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
     HIP_TRY(r->d_cands.alloc(ccap));
     HIP_TRY(r->d_cand_rmsd.alloc(ccap));
     HIP_TRY(r->d_counters.alloc(4));
+    HIP_TRY(r->d_queue.alloc(8));
     HIP_TRY(r->d_overflow.alloc(1));
     HIP_TRY(r->d_pool_used.alloc(1));
     HIP_TRY(r->d_tab_used.alloc(2));
@@ -2103,6 +2120,7 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
         z.p[4] = r->d_dir_n.p; z.words[4] = b->n_structs;
         z.p[5] = r->d_dir_head.p; z.words[5] = b->n_structs;
         z.p[6] = r->d_dir_triples.p; z.words[6] = b->n_structs;
+        z.p[7] = r->d_queue.p; z.words[7] = 8;
         hipLaunchKernelGGL(k_zero, dim3(1), dim3(256), 0, stream, z);
         HIP_TRY(hipGetLastError());
     }
@@ -2136,8 +2154,6 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
     Q.staged = S->d_staged.p; Q.hdr = S->d_hdr.p; Q.look = S->d_look.p; Q.rescheck = S->d_rescheck.p; Q.exact = S->d_exact.p; Q.bounds = S->d_bounds.p; Q.order = S->d_order.p; Q.max_candidates = p->max_candidates; Q.flags = p->flags;
     if (const char *env = std::getenv("ENZYMM_AMD_RUN_LIST"))  // test hook: k_deep claims by page position, as for a large complex
         if (std::atoi(env) == 0) Q.flags |= 0x4000u;
-    if (const char *env = std::getenv("ENZYMM_AMD_SAME_XCD"))  // experiment: a structure's template chunks on one XCD
-        if (std::atoi(env) == 1) Q.flags |= 0x10000u;
     if (const char *env = std::getenv("ENZYMM_AMD_LOCAL_DEEP"))  // test hook / A-B: every surviving triple is paged out to k_deep (round 3's flow)
         if (std::atoi(env) == 0) Q.flags |= 0x8000u;
     Q.n_tables = (uint32_t)S->tables.size(); Q.tables = S->d_tables.p;
@@ -2192,6 +2208,8 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
             Q.model_votes = r->d_model_votes.p; Q.models = r->d_models.p;
         }
     }
+    if (const char *env = std::getenv("ENZYMM_AMD_HANDOVER"))  // test hooks: 0 = a wave keeps every subtree it starts, 2 = it hands over whatever it can
+        Q.flags |= std::atoi(env) == 0 ? 0x10000u : std::atoi(env) == 2 ? 0x20000u : 0u;
     OutView O;
     O.cands = r->d_cands.p; O.cand_rmsd = r->d_cand_rmsd.p; O.n_cands = r->d_counters.p + 1; O.cand_capacity = ccap;
     O.pairs = r->d_pairs.p; O.n_pairs = r->d_counters.p + 2; O.pair_capacity = hcap;
@@ -2268,9 +2286,8 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
         }
         const uint32_t per_group = 8u >> cx;  // work items per group of 8 consecutive workgroups
         uint32_t grid = (b->work_items + per_group - 1) / per_group * 8u;
-        if (Q.flags & 0x10000u) grid = (b->work_items + 7u) / 8u * (8u << cx);  // (8 work items per group of 8 << cx workgroups)
         const bool ic = (p->flags & TM_FLAG_IGNORE_CHAIN) != 0;
-        SearchArgs args{lib->view(), b->view(), Q, O, b->d_work.p, b->work_items, cx, b->max_atoms, b->max_res, 0u, nullptr, 0u};
+        SearchArgs args{lib->view(), b->view(), Q, O, b->d_work.p, b->work_items, cx, b->max_atoms, b->max_res, 0u, nullptr, 0u, nullptr, 0u};
         // One launch of k_search in `mode`: the structure of a workgroup goes to LDS when the mode's per-wave scratch
         // leaves room for the largest structure of the batch; whatever LDS is left after that holds the structure's
         // kind lists (one workgroup per CU either way).
@@ -2288,7 +2305,21 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
             kernel = mode == kModeBlocks ? TM_PICK(kModeBlocks) : mode == kModeSingly ? TM_PICK(kModeSingly) : TM_PICK(kModeDeep);
 #undef TM_PICK
             HIP_TRY(allow_dynamic_lds(reinterpret_cast<const void *>(kernel), lds_bytes));
-            hipLaunchKernelGGL(kernel, dim3(grid), dim3(kSearchBlock), lds_bytes, stream, args);
+            // the block search over structures in LDS holds a whole CU per workgroup: one workgroup per CU, each taking
+            // units from the launch's queues (k_search); ENZYMM_AMD_QUEUED=0: one workgroup per unit (tests, A/B)
+            static const int n_cus = [] {
+                int dev = 0, n = 0;
+                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+                return n;
+            }();
+            const char *queued_env = std::getenv("ENZYMM_AMD_QUEUED");
+            const bool queued = mode == kModeBlocks && lds_path;
+            const bool once = n_cus <= 0 || (queued_env && std::atoi(queued_env) == 0);
+            args.queue = queued ? r->d_queue.p : nullptr;
+            args.queue_once = once ? 1u : 0u;
+            const uint32_t launch_grid = queued && !once ? std::min<uint32_t>(grid, ((uint32_t)n_cus + 7u) & ~7u) : grid;
+            hipLaunchKernelGGL(kernel, dim3(launch_grid), dim3(kSearchBlock), lds_bytes, stream, args);
+            sync_each(stream, mode == kModeBlocks ? "k_search blocks" : mode == kModeSingly ? "k_search singly" : "k_deep");
             HIP_TRY(hipGetLastError());
             return TM_OK;
         };
@@ -2314,12 +2345,15 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
     if (n_sel && b->n_structs) {
         // candidate and pair counts live on the device: fixed grids with grid-stride loops, no host sync
         hipLaunchKernelGGL(k_superpose, dim3(512), dim3(256), 0, stream, lib->view(), b->view(), Q, O);
+        sync_each(stream, "k_superpose");
         HIP_TRY(hipGetLastError());
         if (p->flags & TM_FLAG_BEST_MATCH) {
             hipLaunchKernelGGL(k_ties, dim3(512), dim3(256), 0, stream, Q, O);
+            sync_each(stream, "k_ties");
             HIP_TRY(hipGetLastError());
         }
         hipLaunchKernelGGL(k_select, dim3(256), dim3(256), 0, stream, lib->view(), b->view(), Q, O);
+        sync_each(stream, "k_select");
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(r->ev[3], stream));
@@ -2548,9 +2582,26 @@ int tm_result_append_hits(tm_result *r, void *rows, uint64_t capacity, uint64_t 
 // diagnostic build only (make stats): read and reset the search counters
 int tm_debug_stats(unsigned long long *out) {
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(tmx::g_stats), 192 * sizeof(unsigned long long)));
-    unsigned long long zero[192] = {0};
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(tmx::g_stats), 320 * sizeof(unsigned long long)));
+    unsigned long long zero[320] = {0};
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(tmx::g_stats), zero, sizeof zero));
+    return TM_OK;
+}
+#endif
+
+#ifdef TM_ABLATE
+// timing build only (make ablate): read and reset the block search's log of units -- n x {start, end, hw_id | xcc_id << 32, first wave's end, sum of the waves' ends}
+int tm_debug_wg_log(unsigned long long *out, unsigned int n) {
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<tmx::WgLog> log(tmx::kWgLog);
+    HIP_TRY(hipMemcpyFromSymbol(log.data(), HIP_SYMBOL(tmx::g_wg_log), log.size() * sizeof(tmx::WgLog)));
+    for (unsigned int i = 0; i < n && i < tmx::kWgLog; ++i) {
+        out[5 * i] = log[i].start; out[5 * i + 1] = log[i].end;
+        out[5 * i + 2] = (unsigned long long)log[i].hw_id | ((unsigned long long)log[i].xcc_id << 32);
+        out[5 * i + 3] = log[i].first_end; out[5 * i + 4] = log[i].sum_end;
+    }
+    std::fill(log.begin(), log.end(), tmx::WgLog{0, 0, ~0ull, 0, 0, 0});
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(tmx::g_wg_log), log.data(), log.size() * sizeof(tmx::WgLog)));
     return TM_OK;
 }
 #endif

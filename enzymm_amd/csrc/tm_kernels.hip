@@ -27,12 +27,21 @@ namespace tmx {
 // former, [63] items of the latter, [55] workgroups, [56] workgroups with their kind lists in LDS,
 // [57] kind-list entries of their structures
 // [96+b] / [120+b]: distance tests of swept leader / non-leader tables whose cross product has bit length b; [144+b] / [168+b]: their entries
-__device__ unsigned long long g_stats[192];
+// [192+b]: queue entries whose search took 2^b ticks of 10 ns, [216+b]: their ticks in sum; [240+d]: entries of depth d
+// [256+d]: entries handed over at depth d (lanes that wrote one)
+__device__ unsigned long long g_stats[320];
 #define TM_STAT(i, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_stats[i], (unsigned long long)(v)); } while (0)
 // Ablation (diagnostic and timing builds): query flag bit 8 (0x100) drops the pair-scan survivors, bit 9 (0x200)
 // skips the search after template staging, bit 10 (0x400) drops the triple-scan survivors.
 #else
 #define TM_STAT(i, v) do { } while (0)
+#endif
+#ifdef TM_ABLATE
+// timing build only: when every workgroup of the block search started and ended (10 ns ticks) and where it ran
+// (HW_ID: CU, SE; XCC_ID), for tests/gpu_wg_timeline.py
+struct WgLog { unsigned long long start, end, first_end, sum_end; uint32_t hw_id, xcc_id; };
+constexpr uint32_t kWgLog = 16384;
+__device__ WgLog g_wg_log[kWgLog];
 #endif
 
 // ------------------------------------------------------------------ wave helpers
@@ -883,7 +892,7 @@ __global__ __launch_bounds__(kTabBlock) __attribute__((amdgpu_waves_per_eu(kComp
     __shared__ unsigned long long s_first;
     const TabWork w = work[blockIdx.x];
 #ifdef TM_STATS
-    const unsigned long long t_wg = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_wg = __builtin_amdgcn_s_memrealtime();
 #endif
     // Bit 0 of tab_ok[s]: the structure's row slots fit (k_tab_layout; never changes while this kernel runs).  Bit 1 is
     // set by whichever workgroup of the structure runs out of entries -- at any moment, so nothing here branches on it:
@@ -935,7 +944,7 @@ __global__ __launch_bounds__(kTabBlock) __attribute__((amdgpu_waves_per_eu(kComp
 #ifdef TM_STATS
             // [93] sum of the waves' working ticks, [94] (last wave's end - start of work) x waves, [95] staging ticks x waves
             __shared__ unsigned long long s_end;
-            const unsigned long long t_work = __builtin_amdgcn_s_memtime();
+            const unsigned long long t_work = __builtin_amdgcn_s_memrealtime();
             if (threadIdx.x == 0) s_end = 0ull;
             __syncthreads();
 #endif
@@ -943,7 +952,7 @@ __global__ __launch_bounds__(kTabBlock) __attribute__((amdgpu_waves_per_eu(kComp
                                 ent_capacity, overflow, tab_ok, dbg_mode, s_count, &s_first, n_lead, nullptr, 0u, shared_limit, rows_ok, derive_min);
 #ifdef TM_STATS
             {
-                const unsigned long long t_done = __builtin_amdgcn_s_memtime();
+                const unsigned long long t_done = __builtin_amdgcn_s_memrealtime();
                 TM_STAT(93, t_done - t_work);
                 if ((threadIdx.x & 63) == 0) atomicMax(&s_end, t_done);
                 __syncthreads();
@@ -1049,7 +1058,10 @@ struct __align__(16) WaveScratchT {
 // The block search also runs the depth-first search below the (few) triples its stage D0/D1 lets through, at the end of
 // each block: by then the stage queues are empty, so the template's pair bounds and the lead-list chunks of that search
 // use the same LDS.
-constexpr uint32_t kSharedTriples = 256;
+#ifndef TM_SHARED_TRIPLES
+#define TM_SHARED_TRIPLES 320
+#endif
+constexpr uint32_t kSharedTriples = TM_SHARED_TRIPLES;
 #ifndef TM_MIN_BLOCK
 #define TM_MIN_BLOCK 32
 #endif
@@ -1077,9 +1089,19 @@ struct __align__(16) WaveScratchT<kModeBlocks> {
 // The workgroup's queue of triples that passed D0/D1 (in LDS, filled once: no wrap-around): any wave that comes to the end
 // of a block takes triples from it and searches below them, so a block with many survivors is not its wave's burden
 // alone.  What does not fit goes to the structure's pages in global memory (k_deep).
+// An entry is a partial assignment: the target atoms of the first `depth` search levels (lead levels: at most kMaxG).
+// The block search queues triples (depth 3); a wave deep in a large subtree hands the other survivors of a lead level
+// to waves that have run out of work (dfs: give_away) -- one subtree of thousands of evaluations held its workgroup's
+// CU for 0.25 ms after the other fifteen waves had finished (tests/gpu_wg_timeline.py).
+struct SharedEntry {
+    uint16_t atoms[kMaxK];
+    uint32_t depth;
+    uint32_t ti;  // staged template; 0xffffffff: reserved, not written yet
+};
 struct SharedTriples {
-    DeepEntry entry[kSharedTriples];  // .ti == 0xffffffff: reserved, not written yet
-    uint32_t head, tail;              // next to take; next to reserve (may run past kSharedTriples: those went to pages)
+    SharedEntry entry[kSharedTriples];
+    uint32_t head, tail;  // next to take; next to reserve (may run past kSharedTriples: those went to pages, or were not handed over)
+    uint32_t busy;        // waves of the workgroup that have not run out of work
 };
 
 // Search state of one wave, held in VGPRs and indexed BY LANE: lane L holds the entry of search
@@ -1135,6 +1157,7 @@ struct __align__(16) ResCache {
 template <bool kIgnoreChain, bool kPoolLds, int kMode, bool kCache = false>
 struct SearchCtx {
     static constexpr bool kResCache = kCache;
+    static constexpr int kLaunchMode = kMode;
     ResCache *rc;               // kResCache: this wave's slots
     const float4 *rec;          // structure atom records (LDS or global)
     const uint16_t *res_start;  // residue -> first atom (LDS or global)
@@ -1328,6 +1351,11 @@ struct SearchArgs {
     // three residues; every template when a structure is large enough for a pair table of 2^25 entries)
     const uint32_t *singly;
     uint32_t n_singly;
+    // block search with the structure in LDS: one counter per chunk class (1 << chunk_xcd_shift of them) -- the launch is
+    // one workgroup per CU, every workgroup takes (work item, chunk of its class) units until none are left (nullptr: one
+    // unit per workgroup, found from blockIdx)
+    uint32_t *queue;
+    uint32_t queue_once;  // experiments and tests: a workgroup leaves after one unit (the launch then has one workgroup per unit)
 };
 typedef const __attribute__((address_space(4))) SearchArgs *ColdArgsPtr;
 __device__ __forceinline__ ColdArgsPtr cold_args() {
@@ -1414,6 +1442,9 @@ __device__ __forceinline__ bool on_complete(const Ctx &C, WaveRegs &W, PairState
             // (the query is run again with room: tm_result_needed.  From here on the wave asks for ONE slot per candidate, so
             // that the counter ends on what the query needs, not on up to 64 times that)
             if (lane == 0) { atomicOr(A->O.overflow, 1u); S.slab[2] = 1u; }
+            // (the slots between the counter's old value and the end of the buffer are nobody's now: marked invalid like the
+            // unused rest of a slab -- k_superpose reads every slot below the capacity, whatever memory it was handed)
+            if (base + (unsigned long long)lane < A->O.cand_capacity) A->O.cands[base + (unsigned long long)lane].s = 0xffffffffu;
             return true;
         }
         next = (uint32_t)base;
@@ -1460,8 +1491,53 @@ __device__ __forceinline__ void slab_release(const Ctx &C) {
 
 // Depth-first search over levels >= floor (levels < floor are already assigned).
 // Returns false when the pair was cut short by max_candidates.
+// Survivors `give` of a chunk of lead level `level` (levels below it assigned): queued as partial assignments of
+// level + 1 atoms for the waves that wait for work.  Returns what stays with this wave.
 template <class Ctx>
-__device__ __forceinline__ bool dfs(const Ctx &C, WaveRegs &W, PairState &P, int floor) {
+__device__ __forceinline__ unsigned long long give_away(const Ctx &C, const WaveRegs &W, const PairState &P, int level,
+                                                        unsigned long long pend, unsigned long long give, uint32_t chunk_base,
+                                                        SharedTriples &Q2) {
+    const uint32_t lane = (uint32_t)C.lane;
+    const uint32_t n = (uint32_t)__popcll(give);
+    uint32_t base = 0;
+    if (lane == 0u) base = atomicAdd(&Q2.tail, n);
+    base = uni(base);
+    // (what fits: written as block_look writes it -- `base < capacity ? min(n, capacity - base) : 0` came out of the compiler as
+    // min(n, capacity - base) without the guard, and a reservation past the end of the queue, which happens as soon as the
+    // queue is full, sent every lane's entry to the last slot: subtrees lost -- test_queued_block_search_and_subtree_handover)
+    const uint32_t r = rank_in(give);
+    const bool here = ((give >> lane) & 1ull) != 0ull && base + r < kSharedTriples;
+    // (one 16-bit store per level, the value a scalar: this runs once per large subtree and must not cost the search
+    // loop around it a register)
+    SharedEntry *e = &Q2.entry[min(base + r, kSharedTriples - 1u)];
+    for (int j = 0; j < level; ++j) {
+        const uint32_t a = RL(W.aidx, j);
+        if (here) e->atoms[j] = (uint16_t)a;
+    }
+    if (here) {
+        // (a lead level: the chunk's candidates sit in LDS; any other: lane b is atom b of the chunk of its residue)
+        e->atoms[level] = RL(W.lead, level) != 0u ? C.S->surv[lvl_group(RL(W.pk, level))][lane]
+                                                  : (uint16_t)(RL(W.lo, level) + chunk_base + lane);
+        e->depth = (uint32_t)level + 1u;
+#ifdef TM_STATS
+        {  // [300]: entries whose atoms do not add up to what their writer stored with them (a publication race would show here)
+            uint32_t sum = 0;
+            for (int j = 0; j < level; ++j) sum += RL(W.aidx, j) & 0xffffu;
+            sum += e->atoms[level];
+            e->depth |= sum << 8;
+        }
+#endif
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __hip_atomic_store(&e->ti, P.ti, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+#ifdef TM_STATS
+    if (here) atomicAdd(&g_stats[256 + level + 1], 1ull);
+#endif
+    return pend & ~ballot64(here);
+}
+
+template <class Ctx>
+__device__ __forceinline__ bool dfs(const Ctx &C, WaveRegs &W, PairState &P, int floor, SharedTriples *share = nullptr) {
     const int k = C.k;
     // every atom a lead and at most three of them (a template of one atom per residue): the tables placed them all
     if (floor >= k) return on_complete(C, W, P);
@@ -1487,6 +1563,24 @@ __device__ __forceinline__ bool dfs(const Ctx &C, WaveRegs &W, PairState &P, int
             }
             WL(W.cur, level, cur);
             WL(W.base, level, base);
+            if constexpr (Ctx::kLaunchMode == kModeBlocks) {
+                // survivors while waves of the workgroup wait for work: they take all but one -- all of them when this level
+                // has further chunks to look at (a long kind list with a survivor here and there: the subtrees are searched
+                // while the list is still being read).  At ANY level: the subtrees that held a CU for 0.25 ms after fifteen
+                // waves had finished fan out below the lead levels -- two interchangeable atoms per residue (OD1/OD2,
+                // NH1/NH2, ring flips), eight residues
+                const unsigned long long give = cur < cnt ? pend : pend & (pend - 1ull);
+                if (share != nullptr && give != 0ull && level < k - 1) {
+                    const uint32_t busy = uni(__hip_atomic_load(&share->busy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                    const uint32_t tail = uni(__hip_atomic_load(&share->tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                    // (test hooks, ENZYMM_AMD_HANDOVER: 0 = never; 2 = always, whether or not a wave waits -- every queue
+                    // entry of a small selection then goes through the hand-over)
+                    const uint32_t hook = cold_args()->Q.flags;
+                    if ((busy < (uint32_t)kSearchWaves || (hook & 0x20000u)) && tail < kSharedTriples && !(hook & 0x10000u))
+                        pend = give_away(C, W, P, level, pend, (hook & 0x20000u) ? pend : give, base, *share);
+                }
+                if (pend == 0ull) continue;  // all handed over: on with the level's next chunk (its pending mask is still empty)
+            }
         }
         const int b = __ffsll((long long)pend) - 1;
         pend &= pend - 1ull;
@@ -1760,7 +1854,10 @@ struct TemplateRegs {
 
 __device__ __forceinline__ void load_template(const QueryView &Q, uint32_t ti, int lane, TemplateRegs &R) {
     const Staged &T = Q.staged[ti];
-    const int l = lane < kMaxK ? lane : kMaxK - 1;  // every lane loads: no dependence on k
+    int l = lane < kMaxK ? lane : kMaxK - 1;  // every lane loads: no dependence on k
+    // (opaque to the optimiser: the per-lane offsets below are worked out here, per template -- hoisted out of the queued
+    // block search's loop over units they stayed in registers for the whole kernel, and nine of those went to scratch memory)
+    asm volatile("" : "+v"(l), "+v"(lane));
     const unsigned long long nm = T.namemask[l];
     R.pk = T.packed[l];
     R.resmask = T.resmask[l];
@@ -1801,7 +1898,9 @@ __device__ __forceinline__ bool setup_template(Ctx &C, WaveRegs &W, const Templa
     // every pair bound of the template goes to LDS (the first 64 came with the template's constants, the rest is fetched
     // now); the first windows are also read from the registers
     C.S->bnd[lane] = R.bound;
-    for (int p = 64 + lane; p < tri(k); p += 64) C.S->bnd[p] = C.bnd[p];
+    int p_first = 64 + lane;
+    asm volatile("" : "+v"(p_first));  // (as in load_template: the address of the lane's first bound is not kept across units)
+    for (int p = p_first; p < tri(k); p += 64) C.S->bnd[p] = C.bnd[p];
     W.bnd_lo = R.bound.x;
     W.bnd_hi = R.bound.y;
     wave_sync();
@@ -2124,8 +2223,10 @@ __device__ __forceinline__ void block_look(Ctx &C, const SearchArgs &A, SlotRegs
             const bool mine = ((keep >> lane) & 1ull) != 0ull;
             const bool here = mine && base + r < kSharedTriples;
             if (here) {
-                DeepEntry &e = Q2.entry[base + r];
-                e.a01 = t.x; e.c = c;
+                SharedEntry &e = Q2.entry[base + r];
+                uint32_t *a = reinterpret_cast<uint32_t *>(e.atoms);
+                a[0] = t.x; a[1] = c & 0xffffu;
+                e.depth = 3u;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __hip_atomic_store(&e.ti, ti, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
@@ -2258,7 +2359,20 @@ __device__ __forceinline__ void drain_shared(Ctx &C, const SearchArgs &A, PageWr
             ti = uni(__hip_atomic_load(&Q2.entry[idx].ti, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         } while (ti == 0xffffffffu);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        const uint32_t a01 = uni(Q2.entry[idx].a01), c = uni(Q2.entry[idx].c);
+#ifdef TM_STATS
+        const uint32_t depth_word = uni(Q2.entry[idx].depth), depth = depth_word & 0xffu;
+#else
+        const uint32_t depth = uni(Q2.entry[idx].depth);
+#endif
+        const uint32_t mine = Q2.entry[idx].atoms[min(lane, (uint32_t)kMaxK - 1u)];  // lane L < depth: the atom of level L
+#ifdef TM_STATS
+        if (depth > 3u) {
+            uint32_t sum = 0;
+            for (uint32_t j = 0; j < depth; ++j) sum += RL(mine, (int)j);
+            TM_STAT(300, (sum & 0xffffffu) != (depth_word >> 8) ? 1 : 0);
+            TM_STAT(301, 1);
+        }
+#endif
         if (ti != cur_ti) {
             TemplateRegs T;
             load_template(Q, ti, (int)lane, T);
@@ -2268,18 +2382,30 @@ __device__ __forceinline__ void drain_shared(Ctx &C, const SearchArgs &A, PageWr
             P.truncated = false;
         }
         if (P.truncated || !feasible) continue;
-        {  // the three placed leads: lane L < 3 fetches and keeps the entry of level L (lane = level)
-            const uint32_t mine = lane == 0u ? a01 & 0xffffu : lane == 1u ? a01 >> 16 : c;
-            const float4 r = C.rec[mine];
-            if (lane < 3u) {
-                W.aidx = mine;
+        {  // the placed leads: lane L < depth fetches and keeps the entry of level L (lane = level)
+            const uint32_t atom = lane < depth ? mine : 0u;
+            const float4 r = C.rec[atom];
+            if (lane < depth) {
+                W.aidx = atom;
                 W.ax = r.x; W.ay = r.y; W.az = r.z;
                 W.ameta = __float_as_uint(r.w);
-                if (!C.ignore_chain) W.achain = (uint32_t)C.qchain[mine];
+                if (!C.ignore_chain) W.achain = (uint32_t)C.qchain[atom];
             }
         }
         TM_STAT(84 + min(C.n_groups, 8), 1);
-        dfs(C, W, P, 3);
+#ifdef TM_STATS
+        const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();
+#endif
+        dfs(C, W, P, (int)depth, &Q2);
+#ifdef TM_STATS
+        {
+            const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - t_entry;
+            const uint32_t bl = min(23u, 64u - (uint32_t)__clzll((long long)dt));
+            TM_STAT(192 + bl, 1);
+            TM_STAT(216 + bl, dt);
+            TM_STAT(240 + min(depth, 15u), 1);
+        }
+#endif
     }
     wave_sync();  // (the next block's stages write the queues again)
 }
@@ -2435,6 +2561,24 @@ __device__ __forceinline__ void search_templates(const SearchArgs &A, WaveScratc
         search_block(C, A, PW, s, m0, min(count, n_mine - m0), chunk, n_chunks, kl, tab_ref);
     }
     drain_shared(C, A, PW, s, kl);  // (what other waves queued since this wave's last block)
+    if (PW.shared != nullptr) {
+        // out of blocks: wait for what the waves still at work hand over (dfs: give_away) until none of them is left.
+        // (`busy` only tells a waiting wave when to stop looking: whoever queues an entry also comes back for the queue)
+        SharedTriples &Q2 = *PW.shared;
+        if (lane == 0) atomicSub(&Q2.busy, 1u);
+        for (;;) {
+            const uint32_t head = uni(__hip_atomic_load(&Q2.head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            const uint32_t tail = min(uni(__hip_atomic_load(&Q2.tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)), kSharedTriples);
+            if (head < tail) {
+                if (lane == 0) atomicAdd(&Q2.busy, 1u);
+                drain_shared(C, A, PW, s, kl);
+                if (lane == 0) atomicSub(&Q2.busy, 1u);
+                continue;
+            }
+            if (uni(__hip_atomic_load(&Q2.busy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0u) break;
+            __builtin_amdgcn_s_sleep(16);
+        }
+    }
     page_publish(PW, s, (uint32_t)lane);
     slab_release(C);
     }
@@ -2620,36 +2764,75 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
     // resident in its own 4 MB L2.  The structure a workgroup searches is copied into LDS once, so it does not
     // matter which XCD that is.  Work items are ordered heaviest structure first, and heavy structures are cut
     // into more rounds (host side), so that a few large structures in a batch do not become the tail.
-#ifdef TM_STATS
-    const unsigned long long t_wg = __builtin_amdgcn_s_memtime();
-#endif
-    const uint32_t bid = blockIdx.x;
-    const uint32_t xcd = bid & 7u;
+    // The QUEUED block search (structures in LDS; A.queue): the launch is one workgroup per CU and every workgroup takes
+    // units -- (work item, chunk of its XCD's class) -- from its class's counter until none are left, then from the
+    // other classes'.  A grid of one workgroup per unit left a CU idle between two workgroups (9 us median, 68 us at
+    // the 90th percentile: a 160 KB workgroup waits for a whole CU of the shader engine whose turn it is) and the four
+    // XCDs of the lighter class idle at the end: 76 % of the CU-time between the first start and the last end was held
+    // by a workgroup (tests/gpu_wg_timeline.py).
+    constexpr bool kQueued = kMode == kModeBlocks && kLds;
+    __shared__ uint32_t s_claim;
     const uint32_t cx = A.chunk_xcd_shift;
-    uint32_t item_index = ((bid >> 3) << (3u - cx)) + (xcd >> cx);
-    uint32_t chunk_low = xcd & ((1u << cx) - 1u);
-    if (Q.flags & 0x10000u) {
-        // experiment (ENZYMM_AMD_SAME_XCD=1): the 2^cx chunks of a work item on ONE XCD (workgroups b, b + 8, ... of a group
-        // of 8 << cx), so that a structure's pair tables enter one L2 -- every XCD then touches all staged templates
-        const uint32_t group = bid >> (3u + cx), within = bid & ((8u << cx) - 1u);
-        item_index = group * 8u + (within & 7u);
-        chunk_low = within >> 3;
+    for (;;) {
+#ifdef TM_STATS
+    const unsigned long long t_wg = __builtin_amdgcn_s_memrealtime();
+#endif
+    uint32_t item_index, chunk_low;
+    if constexpr (kQueued) {
+        // (what the claim needs is read from the kernel-argument segment again: nothing of it stays in registers through
+        // the search of a unit)
+        __syncthreads();  // the previous unit's searches are over: its structure may leave LDS, s_claim be written again
+        if (threadIdx.x == 0) {
+            const ColdArgsPtr cold = cold_args();
+            uint32_t *queue = cold->queue;
+            const uint32_t n_items = cold->n_items, mask = (1u << cold->chunk_xcd_shift) - 1u, own = blockIdx.x & mask;
+            uint32_t got = 0xffffffffu;
+            for (uint32_t k = 0; k <= mask && got == 0xffffffffu; ++k) {
+                const uint32_t c = (own + k) & mask;
+                // (look before adding: the counter of a class that ran dry does not run away)
+                if (__hip_atomic_load(&queue[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n_items) continue;
+                const uint32_t v = atomicAdd(&queue[c], 1u);
+                if (v < n_items) got = (v << 3) | c;
+            }
+            s_claim = got;
+        }
+        __syncthreads();
+        const uint32_t got = s_claim;
+        if (got == 0xffffffffu) return;
+        item_index = got >> 3;
+        chunk_low = got & 7u;
+    } else {
+        // one unit per workgroup: workgroups b and b + 8 share an XCD, workgroup b takes the chunk class b & mask
+        const uint32_t bid = blockIdx.x, xcd = bid & 7u;
+        item_index = ((bid >> 3) << (3u - cx)) + (xcd >> cx);
+        chunk_low = xcd & ((1u << cx) - 1u);
     }
-    if (item_index >= A.n_items) return;
+    if (item_index >= A.n_items) { if constexpr (kQueued) continue; else return; }
+#ifdef TM_ABLATE
+    const uint32_t log_at = (item_index << cx) + chunk_low;
+    if (kMode == kModeBlocks && threadIdx.x == 0 && log_at < kWgLog) {
+        uint32_t hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_wg_log[log_at].start = __builtin_amdgcn_s_memrealtime();
+        g_wg_log[log_at].hw_id = hw;
+        g_wg_log[log_at].xcc_id = xcc;
+    }
+#endif
     const WorkItem item = A.work[item_index];
     const uint32_t s = item.s;
     const uint32_t chunk = ((uint32_t)item.round << cx) + chunk_low;
     const uint32_t n_chunks = (uint32_t)item.rounds << cx;
-    if (chunk >= (kSingly ? A.n_singly : Q.n_sel)) return;
+    if (chunk >= (kSingly ? A.n_singly : Q.n_sel)) { if constexpr (kQueued) continue; else return; }
 
-    if (B.tab_ok[s] != 1u) return;  // pair tables incomplete (pool overflow, reported with the result): nothing to search
+    if (B.tab_ok[s] != 1u) { if constexpr (kQueued) continue; else return; }  // pair tables incomplete (pool overflow, reported with the result): nothing to search
     uint32_t n_listed = 0;
     if (kMode == kModeDeep) {  // pages of triples the block search left for this structure (its share of the directory)
         n_listed = min(A.O.dir_n[s], A.O.dir_off[s + 1] - A.O.dir_off[s]);
-        if (n_listed == 0u) return;
+        if (n_listed == 0u) { if constexpr (kQueued) continue; else return; }
         // a structure with few triples is not worth all its workgroups (each stages the structure in LDS and queues at the
         // structure's counter): as many take part as there are 8 triples per wave for
-        if ((unsigned long long)chunk * (kDeepShare * kSearchWaves) >= A.O.dir_triples[s]) return;
+        if ((unsigned long long)chunk * (kDeepShare * kSearchWaves) >= A.O.dir_triples[s]) { if constexpr (kQueued) continue; else return; }
     }
     const uint32_t a0 = B.s_off[s], n = B.s_off[s + 1] - a0;
     const uint32_t r0 = B.s_roff[s], nres1 = B.s_roff[s + 1] - r0;  // n_res + 1 entries
@@ -2664,7 +2847,9 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
         const uint32_t p0 = kl_off[0], plen = kl_off[L.n_lead] - p0;
         pool_in_lds = plen + 7u <= pool_cap;
         const uint32_t rebase = pool_in_lds ? p0 & ~7u : 0u;
-        const uint32_t tid = threadIdx.x, step = blockDim.x;
+        uint32_t tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));  // (per unit: see load_template)
+        const uint32_t step = blockDim.x;
         const uint4 *g_rec = reinterpret_cast<const uint4 *>(B.q_rec + a0);
         const uint4 *g_pool = reinterpret_cast<const uint4 *>(B.kl_pool + rebase);
         uint4 *l_rec = reinterpret_cast<uint4 *>(s_rec), *l_pool = reinterpret_cast<uint4 *>(s_pool);
@@ -2701,7 +2886,10 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
         __shared__ SharedTriples s_shared;
         shared = &s_shared;
         for (uint32_t i = threadIdx.x; i < kSharedTriples; i += blockDim.x) s_shared.entry[i].ti = 0xffffffffu;
-        if (threadIdx.x == 0) { s_shared.head = 0u; s_shared.tail = 0u; }
+        // (threads 0..2, one word each: as one 12-byte store of a constant the value was kept in three registers through
+        // the whole kernel -- and spilled)
+        if (threadIdx.x < 3u) (&s_shared.head)[threadIdx.x] = threadIdx.x == 2u ? (uint32_t)kSearchWaves : 0u;
+        static_assert(offsetof(SharedTriples, tail) == offsetof(SharedTriples, head) + 4 && offsetof(SharedTriples, busy) == offsetof(SharedTriples, head) + 8, "head, tail, busy");
     }
     TM_STAT(55, threadIdx.x == 0 ? 1 : 0);
     TM_STAT(56, threadIdx.x == 0 && pool_in_lds ? 1 : 0);
@@ -2712,7 +2900,7 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
     // how long the workgroup's waves work against how long the workgroup holds its CU: [70 + 4 mode] sum of the waves'
     // working ticks, [71 + 4 mode] sum over workgroups of (last wave's end - start) x waves, [72 + 4 mode] staging ticks x waves
     __shared__ unsigned long long s_end;
-    const unsigned long long t_work = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_work = __builtin_amdgcn_s_memrealtime();
     if (threadIdx.x == 0) s_end = 0ull;
     __syncthreads();
 #endif
@@ -2756,9 +2944,17 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
         else
             search_templates<kLds, kIgnoreChain, false, kSingly>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, &s_next, s, a0, r0, chunk, n_chunks, shared);
     }
+#ifdef TM_ABLATE
+    if (kMode == kModeBlocks && (threadIdx.x & 63) == 0 && log_at < kWgLog) {
+        const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
+        atomicMax(&g_wg_log[log_at].end, t_end);
+        atomicMin(&g_wg_log[log_at].first_end, t_end);
+        atomicAdd(&g_wg_log[log_at].sum_end, t_end);
+    }
+#endif
 #ifdef TM_STATS
     {
-        const unsigned long long t_done = __builtin_amdgcn_s_memtime();
+        const unsigned long long t_done = __builtin_amdgcn_s_memrealtime();
         TM_STAT(70 + 4 * kMode, t_done - t_work);
         if ((threadIdx.x & 63) == 0) atomicMax(&s_end, t_done);
         __syncthreads();
@@ -2768,6 +2964,9 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
         }
     }
 #endif
+    if constexpr (!kQueued) return;
+    else if (cold_args()->queue_once != 0u) return;  // (ENZYMM_AMD_QUEUED=0: one unit per workgroup, in launch order)
+    }  // the next unit of the queue
 }
 
 #define TM_INSTANTIATE(mode)                                       \

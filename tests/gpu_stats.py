@@ -25,7 +25,7 @@ else:
     mols = synthetic.structures(n)
 lib = _native.load()
 print("loaded", flush=True)
-buf = (C.c_ulonglong * 192)()
+buf = (C.c_ulonglong * 320)()
 print("stats0", lib.tm_debug_stats(buf), flush=True)
 t0 = time.time()
 table = jess.query_batch(mols, 2.0, cut, cut, max_candidates=10000, ignore_chain=True, template_index=idx,
@@ -34,6 +34,8 @@ print("query s", time.time() - t0, "hits", len(table), "atoms per structure", su
 lib.tm_debug_stats(buf)
 s = np.array(list(buf), dtype=np.float64)
 searches = s[49]
+print("raw evaluations per level", [int(v) for v in s[0:24]])
+print("raw survivors per level  ", [int(v) for v in s[24:48]])
 print("searches", int(searches), "completes", int(s[48]), "fp64 rejects", int(s[51]))
 print("per search: pair passes %.3f  pair survivors %.3f  triple passes %.3f  triple survivors %.3f" %
       (s[52] / searches, s[53] / searches, s[67] / searches, s[68] / searches))
@@ -50,6 +52,15 @@ for mode, name in ((0, "k_search blocks"), (2, "k_deep")):
     busy, held, staging = s[70 + 4 * mode], s[71 + 4 * mode], s[72 + 4 * mode]
     print("%s: waves working %.1f %% of the time their workgroup holds its CU after staging; staging %.1f %% of that time" %
           (name, 100.0 * busy / max(held, 1), 100.0 * staging / max(held, 1)))
+print("queue entries of the block search by how long the search below them took (10 ns ticks, bit length): count, share of the time")
+tot = max(s[216:240].sum(), 1)
+for b in range(24):
+    if s[192 + b]:
+        print("  2^%-2d  %9.0f  %5.1f %%" % (b, s[192 + b], 100.0 * s[216 + b] / tot))
+print("  entries by depth (3 = triples of the table stages, more = handed over by a wave in a large subtree):", [int(v) for v in s[240:256]])
+print("  handed-over entries whose atoms do not add up to their writer's sum: %d of %d" % (int(s[300]), int(s[301])))
+print("  handed over by depth:", [int(v) for v in s[256:280]])
+print("  taken by depth:      ", [int(v) for v in s[240:256]])
 print("k_tab_build (compact layout): waves working %.1f %% of the time their workgroup holds its CU after staging; staging %.1f %% of that time" %
       (100.0 * s[93] / max(s[94], 1), 100.0 * s[95] / max(s[94], 1)))
 print("table build, by bit length of the cross product: tests of swept leaders / non-leaders, entries of both (per structure)")
@@ -68,3 +79,14 @@ for label, extra in (("full", 0), ("no k_deep work", 0x800), ("stage A only", 0x
         times.append(res.timing()[1])
         res.close()
     print("k_search ms (%s): %.3f" % (label, min(times)))
+    if label == "full":
+        # the same launch again with the counters: how long the 256 CUs were held in sum against how long the kernel took
+        lib.tm_debug_stats(buf)
+        res = _native.query(packed.native, batch, idx, 2.0, cut, cut, 10000, base)
+        t = res.timing()[1]
+        res.close()
+        lib.tm_debug_stats(buf)
+        s2 = np.array(list(buf), dtype=np.float64)
+        held = (s2[71] + s2[72]) / 16.0 / 256.0 / 1e5  # ticks of 10 ns, 16 waves per workgroup, 256 CUs
+        print("k_search blocks: CUs held %.3f ms each on average, search %.3f ms (both launches): %.1f %% of the CU-time in use"
+              % (held, t, 100.0 * held / t))

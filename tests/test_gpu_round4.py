@@ -252,6 +252,47 @@ def test_derived_tables_equal_swept_tables(amy, af, monkeypatch):
         assert got.tobytes() == want.tobytes() and np.array_equal(got_c, want_c), limit
 
 
+def test_queued_block_search_and_subtree_handover(amy, af, monkeypatch):
+    """The block search over structures in LDS runs as one workgroup per CU taking (work item, chunk) units from a
+    queue, and a wave in a large subtree hands survivors of a level to the waves that have run out of work (partial
+    assignments in the workgroup's queue).  Neither may change a result: hit tables and candidate counts are equal
+    with one workgroup per unit (ENZYMM_AMD_QUEUED=0), without hand-over (ENZYMM_AMD_HANDOVER=0) and with everything
+    handed over that can be (=2) -- (a) for a library selection over a batch, (b) for a small selection of implanted
+    templates at a loose cutoff, where most waves of a workgroup have no block of their own, the queue runs full and
+    interchangeable atoms (OD1/OD2, ring flips) make deep subtrees; (b) is also checked against the oracle (round 4 lost
+    a few completions there while the hand-over's overflow guard was wrong)."""
+    idx, cut = helpers.default_selection()
+    jess = pyjess.Jess(helpers.product_library_templates())
+    mols = [amy] + synthetic.structures(40, start=900) + [af]
+    q = lambda: jess.query_batch(mols, 2.0, cut, cut, max_candidates=10000, ignore_chain=True, template_index=idx,
+                                 count_candidates=True, return_raw=True)
+    rng = np.random.default_rng(11)
+    lib = helpers.product_library_templates()
+    tpls = helpers.implant_templates(af, lib, rng, max_templates=150) + \
+        helpers.implant_templates(af, [t for t in lib if len(t) >= 15], rng, max_templates=50)
+    dense = pyjess.Jess(tpls)
+    qd = lambda: dense.query_batch([af], 2.0, 2.0, 2.0, max_candidates=10000, ignore_chain=True, count_candidates=True,
+                                   return_raw=True)
+    want, want_c = q()
+    dwant, dwant_c = qd()
+    assert len(want) > 60 and len(dwant) > 100
+    olib = oracle.OracleLibrary([helpers.to_oracle_template(t) for t in tpls])
+    r = oracle.query_library(helpers.to_oracle_molecule(af), olib, 2.0, 2.0, 2.0, max_candidates=10000, ignore_chain=True)
+    assert compare(dwant, dwant_c, 0, r, olib) > 100
+    for env in ({"ENZYMM_AMD_QUEUED": "0"}, {"ENZYMM_AMD_HANDOVER": "0"}, {"ENZYMM_AMD_HANDOVER": "2"},
+                {"ENZYMM_AMD_QUEUED": "0", "ENZYMM_AMD_HANDOVER": "2"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for rep in range(3):
+            got, got_c = q()
+            assert got.tobytes() == want.tobytes() and np.array_equal(got_c, want_c), (env, rep)
+            got, got_c = qd()
+            assert np.array_equal(got_c, dwant_c), (env, rep)
+            assert got.tobytes() == dwant.tobytes(), (env, rep)
+        for k in env:
+            monkeypatch.delenv(k)
+
+
 def test_reference_call_pattern_through_the_sweep_planner(amy, af):
     """Jess(bucket).query(molecule) from a thread pool, bucket after bucket (jess_run.py:896-988), twice over different
     molecules: the second sweep is answered mostly from what pyjess._Sweeps computed ahead (one library over all the
