@@ -1740,7 +1740,8 @@ static int build_tables(const tm_library *lib, tm_batch *b, const StagedSelectio
     // a structure's tables are dealt to `parts` workgroups, parts growing with the square of its atom count (a
     // 300-residue structure is one item); a batch too small to fill the GPU with one workgroup per structure (a single
     // query structure, say) has every structure's tables dealt to more workgroups
-    const double spread = ns < 256 ? std::ceil(256.0 / std::max(1u, ns)) : 1.0;
+    double spread = ns < 256 ? std::ceil(256.0 / std::max(1u, ns)) : 1.0;
+    if (const char *env = std::getenv("ENZYMM_AMD_TAB_PARTS")) spread = std::max(spread, (double)std::atoi(env));  // experiments: workgroups per structure at least
     auto parts_of = [&](uint32_t s) {
         const double n = (double)(b->s_off[s + 1] - b->s_off[s]);
         return (uint32_t)std::min<double>(std::min<double>(64.0, std::max(1u, nt / 4u)),
@@ -2591,17 +2592,22 @@ int tm_debug_stats(unsigned long long *out) {
 
 #ifdef TM_ABLATE
 // timing build only (make ablate): read and reset the block search's log of units -- n x {start, end, hw_id | xcc_id << 32, first wave's end, sum of the waves' ends}
+// (n with bit 31 set: the log of k_tab_build's workgroups instead)
 int tm_debug_wg_log(unsigned long long *out, unsigned int n) {
     HIP_TRY(hipDeviceSynchronize());
+    const bool tab = (n & 0x80000000u) != 0u;
+    n &= 0x7fffffffu;
     std::vector<tmx::WgLog> log(tmx::kWgLog);
-    HIP_TRY(hipMemcpyFromSymbol(log.data(), HIP_SYMBOL(tmx::g_wg_log), log.size() * sizeof(tmx::WgLog)));
+    if (tab) HIP_TRY(hipMemcpyFromSymbol(log.data(), HIP_SYMBOL(tmx::g_tab_log), log.size() * sizeof(tmx::WgLog)));
+    else HIP_TRY(hipMemcpyFromSymbol(log.data(), HIP_SYMBOL(tmx::g_wg_log), log.size() * sizeof(tmx::WgLog)));
     for (unsigned int i = 0; i < n && i < tmx::kWgLog; ++i) {
         out[5 * i] = log[i].start; out[5 * i + 1] = log[i].end;
         out[5 * i + 2] = (unsigned long long)log[i].hw_id | ((unsigned long long)log[i].xcc_id << 32);
         out[5 * i + 3] = log[i].first_end; out[5 * i + 4] = log[i].sum_end;
     }
     std::fill(log.begin(), log.end(), tmx::WgLog{0, 0, ~0ull, 0, 0, 0});
-    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(tmx::g_wg_log), log.data(), log.size() * sizeof(tmx::WgLog)));
+    if (tab) HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(tmx::g_tab_log), log.data(), log.size() * sizeof(tmx::WgLog)));
+    else HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(tmx::g_wg_log), log.data(), log.size() * sizeof(tmx::WgLog)));
     return TM_OK;
 }
 #endif

@@ -42,6 +42,7 @@ __device__ unsigned long long g_stats[320];
 struct WgLog { unsigned long long start, end, first_end, sum_end; uint32_t hw_id, xcc_id; };
 constexpr uint32_t kWgLog = 16384;
 __device__ WgLog g_wg_log[kWgLog];
+__device__ WgLog g_tab_log[kWgLog];  // the same for the workgroups of k_tab_build
 #endif
 
 // ------------------------------------------------------------------ wave helpers
@@ -729,7 +730,15 @@ __device__ __forceinline__ void tab_build_tables(const BatchView &B, const Table
     const uint32_t kTabChunk = tab_chunk(B.s_off[w.s + 1] - B.s_off[w.s]);
     unsigned long long chunk = ~0ull;  // the wave's current chunk and how much of it is used
     uint32_t used = kTabChunk;
-    for (uint32_t t = w.part + w.parts * wave; t < nt; t += w.parts * n_waves) {
+    // (tables are taken one at a time from a counter of the workgroup, not dealt out by wave number: with a fixed share
+    // the waves of a workgroup ran out of tables after 0.87 of its duration on average, the first after 0.75 --
+    // tests/gpu_wg_timeline.py)
+    uint32_t *next_table = s_count + kTabBlock / 64;
+    for (;;) {
+        uint32_t taken = 0;
+        if (lane == 0) taken = atomicAdd(next_table, 1u);
+        const uint32_t t = w.part + w.parts * uni(taken);
+        if (t >= nt) break;
         const TableDesc T = tables[t];
         // wave-uniform values, said so: loop counters and branches of the sweep stay scalar
         const uint32_t a_lo = uni(kl[T.li_a]), n_a = uni(kl[T.li_a + 1]) - a_lo, b_lo = uni(kl[T.li_b]),
@@ -888,11 +897,23 @@ __global__ __launch_bounds__(kTabBlock) __attribute__((amdgpu_waves_per_eu(kComp
                                                           uint32_t lr_cap, unsigned long long shared_limit,
                                                           uint32_t atom_cap, unsigned long long derive_min) {
     extern __shared__ __align__(16) unsigned char tab_smem[];
-    __shared__ uint32_t s_count[kTabBlock / 64];
+    __shared__ uint32_t s_count[kTabBlock / 64 + 1];  // (the last word: the next table of the workgroup's share)
     __shared__ unsigned long long s_first;
     const TabWork w = work[blockIdx.x];
+    if (threadIdx.x == 0) s_count[kTabBlock / 64] = 0u;
+    __syncthreads();
 #ifdef TM_STATS
     const unsigned long long t_wg = __builtin_amdgcn_s_memrealtime();
+#endif
+#ifdef TM_ABLATE
+    if (threadIdx.x == 0 && blockIdx.x < kWgLog) {
+        uint32_t hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_tab_log[blockIdx.x].start = __builtin_amdgcn_s_memrealtime();
+        g_tab_log[blockIdx.x].hw_id = hw;
+        g_tab_log[blockIdx.x].xcc_id = xcc;
+    }
 #endif
     // Bit 0 of tab_ok[s]: the structure's row slots fit (k_tab_layout; never changes while this kernel runs).  Bit 1 is
     // set by whichever workgroup of the structure runs out of entries -- at any moment, so nothing here branches on it:
@@ -950,6 +971,14 @@ __global__ __launch_bounds__(kTabBlock) __attribute__((amdgpu_waves_per_eu(kComp
 #endif
             tab_build_tables<2>(B, tables, w, s_atoms, s_pool, nullptr, s_kl2, tab_rows, tab_ent, tab_seg, cursors,
                                 ent_capacity, overflow, tab_ok, dbg_mode, s_count, &s_first, n_lead, nullptr, 0u, shared_limit, rows_ok, derive_min);
+#ifdef TM_ABLATE
+            if ((threadIdx.x & 63) == 0 && blockIdx.x < kWgLog) {
+                const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
+                atomicMax(&g_tab_log[blockIdx.x].end, t_end);
+                atomicMin(&g_tab_log[blockIdx.x].first_end, t_end);
+                atomicAdd(&g_tab_log[blockIdx.x].sum_end, t_end);
+            }
+#endif
 #ifdef TM_STATS
             {
                 const unsigned long long t_done = __builtin_amdgcn_s_memrealtime();

@@ -19,15 +19,17 @@ mols = synthetic.structures(n)
 packed = pyjess._packed(jess._templates, jess._device)
 batch = pyjess.make_batch(mols, jess._device)
 lib = _native.load()
-flags = _native.TM_FLAG_BEST_MATCH | _native.TM_FLAG_IGNORE_CHAIN | (int(sys.argv[2], 0) if len(sys.argv) > 2 else 0)  # (ablation bits: 0x800 no depth-first search, 0x400 no triples)
+TAB = len(sys.argv) > 3 and sys.argv[3] == "tables"  # third argument "tables": k_tab_build's workgroups (the index is rebuilt by every query)
+flags = _native.TM_FLAG_BEST_MATCH | _native.TM_FLAG_IGNORE_CHAIN | (int(sys.argv[2], 0) if len(sys.argv) > 2 else 0) | (_native.TM_FLAG_REBUILD_INDEX if TAB else 0)  # (ablation bits: 0x800 no depth-first search, 0x400 no triples)
 N = 16384
 buf = (C.c_ulonglong * (5 * N))()
-lib.tm_debug_wg_log(buf, N)  # (resets the log: first_end starts from all ones)
+WHICH = N | (0x80000000 if TAB else 0)
+lib.tm_debug_wg_log(buf, WHICH)  # (resets the log: first_end starts from all ones)
 for rep in range(4):
     res = _native.query(packed.native, batch, idx, 2.0, cut, cut, 10000, flags)
     t = res.timing()
     res.close()
-    lib.tm_debug_wg_log(buf, N)
+    lib.tm_debug_wg_log(buf, WHICH)
 log = np.array(list(buf), dtype=np.uint64).reshape(N, 5)
 log = log[log[:, 1] != 0]
 start, end = log[:, 0].astype(np.int64), log[:, 1].astype(np.int64)
@@ -37,6 +39,7 @@ where = ((xcc * 8 + se) * 2 + sh) * 16 + cu
 t0, t1 = start.min(), end.max()
 span = (t1 - t0) / 1e5
 dur = (end - start) / 1e5
+print("k_tab_build's workgroups (two per CU: 'CU-time' below counts slots of half a CU, divide by 2)" if TAB else "block search")
 print("search %.3f ms by its events; %d workgroups over %d distinct CUs, first start to last end %.3f ms" %
       (t[1], len(log), len(np.unique(where)), span))
 print("workgroup duration ms: mean %.3f, median %.3f, p90 %.3f, max %.3f; sum / (256 x span) = %.1f %% of the CU-time held" %
