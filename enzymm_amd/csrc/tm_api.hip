@@ -1839,7 +1839,7 @@ static int build_tables(const tm_library *lib, tm_batch *b, const StagedSelectio
 #ifdef TM_ABLATE
     if (const char *env = std::getenv("ENZYMM_AMD_TAB_DEBUG")) lr_arg |= (uint32_t)std::atoi(env) << 30;
 #endif
-    const auto tab_build = atom_cap != 0u ? k_tab_build<true> : k_tab_build<false>;
+    const auto tab_build = atom_cap != 0u ? k_tab_build<kTabCompact> : mostly_large ? k_tab_build<kTabLarge> : k_tab_build<kTabRecords>;
     HIP_TRY(allow_dynamic_lds(reinterpret_cast<const void *>(tab_build), lds_bytes));
     hipLaunchKernelGGL(k_tab_layout, dim3(ns), dim3(256), 0, stream, lib->n_lead, B, S->d_tables.p, b->d_tab_dir.p,
                        b->d_tab_cursors.p, rows, b->d_tab_overflow.p, b->d_tab_ok.p);

@@ -887,8 +887,13 @@ __device__ __forceinline__ void tab_build_tables(const BatchView &B, const Table
 #ifndef TM_TAB_EU
 #define TM_TAB_EU 8
 #endif
-template <bool kCompact>
-__global__ __launch_bounds__(kTabBlock) __attribute__((amdgpu_waves_per_eu(kCompact ? TM_TAB_EU : 4, kCompact ? TM_TAB_EU : 4))) void k_tab_build(uint32_t n_lead, BatchView B, const TableDesc *__restrict__ tables,
+// kLayout 0: a record per list position in LDS (one workgroup per CU); 1: the compact layout; 2: a batch of mostly large
+// structures (complexes of tens of thousands of atoms): records through L2, 64 KB of LDS for the staged list B of the big
+// tables -- two workgroups per CU as well, and the same eight waves per SIMD (as part of layout 0's kernel that path had
+// 75 VGPRs: one workgroup per CU where the host had sized the LDS for two).
+constexpr int kTabRecords = 0, kTabCompact = 1, kTabLarge = 2;
+template <int kLayout>
+__global__ __launch_bounds__(kTabBlock) __attribute__((amdgpu_waves_per_eu(kLayout == kTabRecords ? 4 : TM_TAB_EU, kLayout == kTabRecords ? 4 : TM_TAB_EU))) void k_tab_build(uint32_t n_lead, BatchView B, const TableDesc *__restrict__ tables,
                                                           const TabWork *__restrict__ work, uint32_t *__restrict__ tab_ok,
                                                           uint32_t *__restrict__ tab_rows, uint2 *__restrict__ tab_ent,
                                                           uint2 *__restrict__ tab_seg,
@@ -929,7 +934,7 @@ __global__ __launch_bounds__(kTabBlock) __attribute__((amdgpu_waves_per_eu(kComp
     const uint32_t *kl = B.kl_off + (size_t)w.s * (n_lead + 1);
     const float4 *rec = B.q_rec + B.s_off[w.s];
     const uint32_t p0 = kl[0], plen = kl[n_lead] - p0;
-    if constexpr (kCompact) {
+    if constexpr (kLayout == kTabCompact) {
         // compact layout (host: the batch's largest structure leaves room for two workgroups per CU):
         // [float4 x atom_cap] atom records, [u16 x lr_cap] kind lists, [u32 x (n_lead + 1)] their offsets
         const uint32_t n = B.s_off[w.s + 1] - B.s_off[w.s];
@@ -995,6 +1000,11 @@ __global__ __launch_bounds__(kTabBlock) __attribute__((amdgpu_waves_per_eu(kComp
             tab_build_tables<0>(B, tables, w, rec, B.kl_pool, nullptr, kl, tab_rows, tab_ent, tab_seg, cursors,
                                 ent_capacity, overflow, tab_ok, dbg_mode, s_count, &s_first, n_lead, s_atoms, atom_cap, shared_limit, rows_ok, derive_min);
         }
+    } else if constexpr (kLayout == kTabLarge) {
+        float4 *s_lr = reinterpret_cast<float4 *>(tab_smem);
+        (void)p0; (void)plen;
+        tab_build_tables<0>(B, tables, w, rec, B.kl_pool, nullptr, kl, tab_rows, tab_ent, tab_seg, cursors,
+                            ent_capacity, overflow, tab_ok, dbg_mode, s_count, &s_first, n_lead, s_lr, lr_cap, shared_limit, rows_ok, derive_min);
     } else {
         float4 *s_lr = reinterpret_cast<float4 *>(tab_smem);
         uint32_t *s_kl = reinterpret_cast<uint32_t *>(s_lr + lr_cap);
@@ -1010,10 +1020,14 @@ __global__ __launch_bounds__(kTabBlock) __attribute__((amdgpu_waves_per_eu(kComp
         }
     }
 }
-template __global__ void k_tab_build<true>(uint32_t, BatchView, const TableDesc *, const TabWork *, uint32_t *, uint32_t *, uint2 *, uint2 *,
-                                           unsigned long long *, unsigned long long, uint32_t *, uint32_t, unsigned long long, uint32_t, unsigned long long);
-template __global__ void k_tab_build<false>(uint32_t, BatchView, const TableDesc *, const TabWork *, uint32_t *, uint32_t *, uint2 *, uint2 *,
-                                            unsigned long long *, unsigned long long, uint32_t *, uint32_t, unsigned long long, uint32_t, unsigned long long);
+#define TM_TAB_INSTANTIATE(layout)                                                                                                          \
+    template __global__ void k_tab_build<layout>(uint32_t, BatchView, const TableDesc *, const TabWork *, uint32_t *, uint32_t *, uint2 *, \
+                                                 uint2 *, unsigned long long *, unsigned long long, uint32_t *, uint32_t,                    \
+                                                 unsigned long long, uint32_t, unsigned long long);
+TM_TAB_INSTANTIATE(kTabRecords)
+TM_TAB_INSTANTIATE(kTabCompact)
+TM_TAB_INSTANTIATE(kTabLarge)
+#undef TM_TAB_INSTANTIATE
 
 constexpr uint32_t kRefLenMask = (1u << 25) - 1u;
 constexpr uint32_t kRefSingly = 1u << 31;
