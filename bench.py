@@ -364,6 +364,10 @@ def main():
                     sock.bind(("127.0.0.1", 0))
                     os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
         if one_gpu:
+            # (the test hook's ranks meet on this host: gloo over the loopback interface, whatever the container's hostname
+            # resolves to -- or fails to)
+            if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
+                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))

@@ -253,3 +253,25 @@ def tie_case(golden):
     mol = concat_molecules(copies, id="tied_sites")
     n = len(site)
     return mol, tpl, [np.arange(c * n, (c + 1) * n) for c in range(3)], 1
+
+
+def run_child(cmd, env, timeout=300, cwd=None):
+    """A child python process (a bench line, an RCCL world-size-1 group) with a deadline: when it does not finish in time
+    its whole process group is killed and it is started ONCE more.  In round 4 one such child in a few dozen hung on a
+    fresh GPU box -- python processes importing torch and meeting over gloo / RCCL while the box is still paging the
+    image in; none of the three children that use this hung when run alone in a loop (6, 4 and 4 runs in a row)."""
+    import os
+    import signal
+    import subprocess
+    for attempt in range(2):
+        child = subprocess.Popen(cmd, cwd=cwd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                 start_new_session=True)
+        try:
+            stdout, stderr = child.communicate(timeout=timeout)
+            return subprocess.CompletedProcess(cmd, child.returncode, stdout, stderr)
+        except subprocess.TimeoutExpired:
+            os.killpg(child.pid, signal.SIGKILL)  # (the launcher and its ranks: exactly the process group started above)
+            child.communicate()
+            if attempt == 1:
+                raise
+

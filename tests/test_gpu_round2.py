@@ -443,8 +443,7 @@ def test_rccl_gather_world_size_1():
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    out = subprocess.run([sys.executable, str(helpers.ROOT / "tests" / "gpu_rccl_world1.py")], env=env, timeout=300,
-                         capture_output=True, text=True)
+    out = helpers.run_child([sys.executable, str(helpers.ROOT / "tests" / "gpu_rccl_world1.py")], env, timeout=300)
     assert out.returncode == 0 and "RCCL world-size-1 gather ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 

@@ -301,28 +301,12 @@ def _bench_line(args, env_extra, nproc=None, timeout=300):
     env = dict(os.environ)
     env.update(env_extra)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    out = None
-    # (a child that does not finish in time is started ONCE more: in round 4 the two-rank child hung once in a dozen runs
-    # of the suite, on a fresh box, and an unrelated world-size-1 child once before it -- two python processes importing
-    # torch and meeting over gloo while the box is still paging the image in; neither was reproduced in isolation)
-    for attempt in range(2):
-        cmd = [sys.executable]
-        if nproc:
-            cmd += ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
-                    "--master-port", str(_free_port())]
-        cmd += [str(helpers.ROOT / "bench.py")] + args
-        import signal
-        child = subprocess.Popen(cmd, cwd=str(helpers.ROOT), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
-                                 start_new_session=True)
-        try:
-            stdout, stderr = child.communicate(timeout=timeout)
-            out = subprocess.CompletedProcess(cmd, child.returncode, stdout, stderr)
-            break
-        except subprocess.TimeoutExpired:
-            os.killpg(child.pid, signal.SIGKILL)  # (the launcher and its ranks: exactly the process group started above)
-            child.communicate()
-            if attempt == 1:
-                raise
+    cmd = [sys.executable]
+    if nproc:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+                "--master-port", str(_free_port())]
+    cmd += [str(helpers.ROOT / "bench.py")] + args
+    out = helpers.run_child(cmd, env, timeout=timeout, cwd=str(helpers.ROOT))  # (started once more if it hangs)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
