@@ -262,6 +262,33 @@ def untimed_extras(args, device, templates, idx, cut, molecules, search, flags):
                     found.setdefault(mi, []).extend(hits)
         return found
 
+    # cold: what enzymm's CLI does ONCE per process (/root/reference/enzymm/_cli.py:248 -> jess_run.py:896-988): one sweep
+    # with nothing known -- the planner empty, the six buckets' template lists never seen (their device libraries are
+    # packed and staged on the way), the molecules new objects.  HIP and the package are initialised (the headline ran).
+    pyjess._sweeps.clear()
+    cold_mols = [m.copy() for m in mols]
+    del pyjess._sweeps.launches[:]
+    t0 = time.perf_counter()
+    found = reference_pattern(cold_mols)
+    dt = time.perf_counter() - t0
+    launches = list(pyjess._sweeps.launches)
+    out["reference_call_pattern_cold_structures_per_s"] = len(cold_mols) / dt
+    out["reference_call_pattern_cold"] = {"seconds": dt, "launches": len(launches),
+                                          "molecules_searched": int(sum(l[0] for l in launches)),
+                                          "ms_inside_launches": float(1e3 * sum(l[3] for l in launches)),
+                                          "note": "first sweep of the process over 256 new molecules: six template lists packed "
+                                                  "for the device and staged inside the timed region"}
+    sample = min(len(cold_mols), max(2, cores))
+    position = {id(templates[int(i)]): n for n, i in enumerate(idx)}
+    by_s = {}
+    for mi in range(sample):
+        for h in found.get(mi, []):
+            atoms = np.array(h._atom_index, dtype=np.uint32)
+            by_s.setdefault(mi, {})[position[id(h.template)]] = {"n_atoms": len(atoms), "atoms": atoms, "rmsd": h.rmsd}
+    cold_oracle = oracle_hits(cold_mols[:sample])
+    out["reference_call_pattern_cold_parity_sample"] = {"structures": sample, "mismatches": mismatches(by_s, cold_oracle)}
+    del cold_mols, found
+
     # warm: the libraries of the six buckets packed and their selections staged (first sweep), the library over all six the
     # sweep planner searches once the buckets are known (pyjess._Sweeps) built and staged (second sweep, other molecules)
     spare = molecules[len(mols):]
@@ -303,7 +330,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--structures", type=int, default=1000, help="synthetic structures per GPU")
     ap.add_argument("--batch", type=int, default=1000, help="structures per resident batch (one search launch each)")
-    ap.add_argument("--streamed-passes", type=int, default=2,
+    ap.add_argument("--streamed-passes", type=int, default=8,
                     help="extra passes with the batches uploaded from host memory under the timer (reported in "
                          "config.streamed_structures_per_s, never in value); 0 = skip")
     ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2, 3],
@@ -542,6 +569,15 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_gpu else "cuda")
+    per_rank = None
+    if world > 1 or force_sharded:
+        # every rank's own clock over the timed region and its mean gather time, for reading the scaling curve: an
+        # imbalance (one rank's host slower than the others') shows as one small per-rank value, not only in the MAX
+        mine = torch.tensor([elapsed, float(np.mean(gather_ms)) if gather_ms else 0.0], dtype=torch.float64,
+                            device="cpu" if one_gpu else "cuda")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [[float(v[0]), float(v[1])] for v in every]
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -597,45 +633,50 @@ def main():
         streams = saved
         index_ms, search_ms, finish_ms, front_ms, deep_ms, hit_total, last_hits = timed
 
-    # ---- not part of `value`: the same pass with the structures coming from HOST memory (encoded atom tables), batch
-    # i + 1 flattened and uploaded on a worker thread while batch i is searched -- the PCIe-inclusive rate
-    streamed = None
+    # ---- not part of `value`: the same pass with the structures coming from HOST memory (the molecules' atom tables):
+    # batches i + 1, i + 2 are encoded on worker threads and handed over in the compact format (17 bytes per atom, laid
+    # out on the device by k_flatten; the constructor returns with its copies queued) while batch i is searched and the
+    # hit table of batch i - 1 is fetched -- the PCIe-inclusive rate, pipelined the way Matcher.run drives the library
+    streamed, streamed_tables, h2d_bytes = None, None, None
     if args.streamed_passes > 0:
-        import queue
-        import threading
+        import collections
+        from enzymm_amd import ingest
 
-        def one_streamed_pass():
-            q = queue.Queue(maxsize=2)
+        def stream_passes(n_passes, keep=None):
+            """n_passes x this rank's structures as ONE stream of batches: encode + hand-over of batches i + 1, i + 2 on
+            two worker threads, search of batch i, hit table of batch i - 1 -- all at once."""
+            todo = [c for _ in range(n_passes) for c in chunks]
+            made = ingest._prefetched(todo, lambda c: pyjess.make_batch(c, local_rank), 3, 2)
+            in_flight = collections.deque()
+            sent = 0
 
-            def producer():
-                for chunk in chunks:
-                    q.put(pyjess.make_batch(chunk, local_rank))
-                q.put(None)
-            threading.Thread(target=producer, daemon=True).start()
-            fresh = []
-            while True:
-                b = q.get()
-                if b is None:
-                    break
-                fresh.append(b)
-                res = search(b)
-                res.hits()
+            def collect():
+                b, res = in_flight.popleft()
+                t = res.hits()
+                if keep is not None:
+                    keep.append(t)
                 res.close()
-                if len(fresh) > 2:
-                    fresh.pop(0).close()
-            for b in fresh:
                 b.close()
+            for n, b in enumerate(made):
+                sent += b.upload_bytes()
+                in_flight.append((b, search(b, streams[n % len(streams)].handle)))
+                if len(in_flight) >= max(2, len(streams)):
+                    collect()
+            while in_flight:
+                collect()
+            return sent / max(1, n_passes)
 
-        one_streamed_pass()
+        stream_passes(2)
         fence()
         t0 = time.perf_counter()
-        for _ in range(args.streamed_passes):
-            one_streamed_pass()
+        streamed_tables = []
+        h2d_bytes = stream_passes(args.streamed_passes, streamed_tables)
         fence()
         dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cpu" if one_gpu else "cuda")
         if world > 1:
             dist.all_reduce(dt, op=dist.ReduceOp.MAX)
         streamed = args.structures * world * args.streamed_passes / float(dt.item())
+        streamed_tables = streamed_tables[:len(chunks)]  # (the first pass's tables: the parity sample below reads them)
 
     # ---- not part of `value` (N = 1 only): the two rates VERDICT r02 asked to see beside the headline
     extras = {}
@@ -656,25 +697,34 @@ def main():
         # distances x 4 B = 4.2 MB) read once per batch -- about 44 KB per 2 350-atom structure in a batch of 1000
         lib_bytes = 98808 * 16 + 659760 * 4
         algo_bytes = (n_atoms * 16 + hit_total * 128) / len(batches) + lib_bytes  # per launch = per resident batch
-        k_ms = float(np.mean(search_ms))
-        achieved = algo_bytes / (k_ms * 1e-3) / 1e9
-        # HBM traffic of one search (its two launches: the block search k_search and the depth-first part k_deep) from the
-        # committed PMC passes of this workload (rocprofv3 cannot run inside the timed process); null when no summary is
-        # present.  profiles/LATEST names the summaries of the CURRENT kernels (profiles/collect.sh).
-        traffic, traffic_src, secondary = None, None, None
+        k_ms = float(np.mean(search_ms))  # HIP events on the search's own stream over the timed region (two searches in flight)
+        # roofline.achieved / frac are priced on the dominant kernel's duration ALONE on the GPU (one search in flight,
+        # measured live after the timed region: what rocprofv3 --kernel-trace --stats of `--pipeline 1` shows); with two
+        # searches in flight the events also span the other search's kernels -- that figure is roofline.overlapped_frac
+        dom_ms = exclusive_ms["search"] if exclusive_ms is not None else k_ms
+        achieved = algo_bytes / (dom_ms * 1e-3) / 1e9
+        # HBM traffic of one step's three hot kernels (the block search k_search, the depth-first part k_deep, the pair-table
+        # build k_tab_build) from the committed PMC passes of this workload (rocprofv3 cannot run inside the timed
+        # process); null when no summary is present.  profiles/LATEST names the summaries of the CURRENT kernels
+        # (profiles/collect.sh).
+        traffic, traffic_src, secondary, traffic_parts = None, None, None, None
         latest = ROOT / "profiles" / "LATEST"
         if latest.exists() and args.structures == 1000 and args.generator == "v2":
             try:
                 pointer = json.loads(latest.read_text())
-                traffic, secondary, names = 0.0, {}, []
-                for key in ("k_search_pmc", "k_deep_pmc"):
+                traffic, secondary, names, traffic_parts = 0.0, {}, [], {}
+                for key in ("k_search_pmc", "k_deep_pmc", "k_tab_build_pmc"):
                     pmc = json.loads((ROOT / "profiles" / pointer[key]).read_text())
-                    traffic += pmc["hbm_traffic_bytes_per_launch"]["total_corrected"]
+                    traffic_parts[key[:-4]] = pmc["hbm_traffic_bytes_per_launch"]["total_corrected"]
+                    traffic += traffic_parts[key[:-4]]
                     secondary[key[:-4]] = pmc.get("secondary")
                     names.append(f"profiles/{pointer[key]}")
                 traffic_src = " + ".join(names) + " (FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
             except (KeyError, ValueError, OSError):
-                traffic, traffic_src, secondary = None, None, None
+                traffic, traffic_src, secondary, traffic_parts = None, None, None, None
+        valu_issue = None
+        if secondary and secondary.get("k_search"):
+            valu_issue = secondary["k_search"].get("valu_issue_frac")
         out = {
             "metric": "structures_per_sec_vs_full_mcsa_library",
             "value": total_structs / (elapsed / args.steps),
@@ -695,6 +745,9 @@ def main():
                 "sustained": sustained,  # the same loop for >= --sustained-seconds (not `value`)
                 "hbm_bytes_in_use_rank0": hbm_in_use,
                 "streamed_structures_per_s": streamed,  # upload-inclusive (host atom tables -> HBM overlapped with the search)
+                # host-to-device bytes per structure of those passes (packed word + chain ordinal + int32 thousandths of
+                # an Angstrom per atom, 32 B per structure; 46 B per atom before round 5)
+                "h2d_bytes_per_structure": None if h2d_bytes is None else h2d_bytes / max(1, len(molecules)),
                 "atoms_per_structure": n_atoms / max(1, len(molecules)),
                 "parallelism": f"structures sharded over {world} GPU(s), hit-table gather to rank 0" + (" (N > 1 loop forced on one GPU over RCCL)" if force_sharded else ""),
                 "hits_rank0": int(hit_total), "hits_total": int(len(last_hits)),
@@ -704,6 +757,13 @@ def main():
                 # N > 1: host milliseconds of the one gather per pass (it runs while the next pass's searches do) and
                 # of rank 0's sort of the gathered rows (after the timed region)
                 "gather_ms_per_pass": float(np.mean(gather_ms)) if gather_ms else None, "merge_ms": merge_ms,
+                # N > 1: every rank's own rate over the timed region (its structures / its clock; `value` divides by the
+                # slowest), the gather's host time per pass across the ranks, and which rank was slowest
+                "per_rank_structures_per_s": None if per_rank is None else [args.structures * args.steps / e for e, _ in per_rank],
+                "gather_ms_per_pass_max": None if per_rank is None else max(g for _, g in per_rank),
+                "gather_ms_per_pass_mean": None if per_rank is None else float(np.mean([g for _, g in per_rank])),
+                "slowest_rank": None if per_rank is None else int(np.argmax([e for e, _ in per_rank])),
+                "host_threads_per_rank": _native.host_threads(),
                 "index_ms": float(np.mean(index_ms)), "search_ms": k_ms,
                 "finish_ms": float(np.mean(finish_ms)),
                 # searches in flight per rank; with 2, index_ms/search_ms/finish_ms (HIP events on each search's own
@@ -712,16 +772,27 @@ def main():
                 **extras,
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         # the same with the event durations of the timed region (two searches in flight)
+                         "overlapped_frac": algo_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         # measured HBM bytes of a step's three hot kernels, and how many times the algorithmic bytes
+                         # that is (the path is not HBM-bound: the tables are built, written and read per structure)
+                         "traffic": traffic, "traffic_parts": traffic_parts,
+                         "traffic_ratio": None if traffic is None else traffic / algo_bytes,
+                         "traffic_source": traffic_src,
+                         # HBM is not what binds the dominant kernel: its VALU issue rate as a fraction of the MEASURED
+                         # ceiling (profiles/valu_probe.hip), from the same PMC set
+                         "valu_issue_frac": valu_issue,
                          # one search = two launches back to back on the search's stream: the block search over the pair tables
                          # (k_search<mode 0>) and the depth-first part below the surviving triples (k_deep = k_search<mode 2>)
                          "kernel": "k_search + k_deep",
                          "algorithmic_bytes_per_launch": algo_bytes,
-                         # average duration of the pair over the timed region (HIP events on the search's own stream), and its parts
-                         "kernel_ms": k_ms,
+                         # duration the fraction is priced on: the pair alone on the GPU (one search in flight) ...
+                         "kernel_ms": dom_ms,
+                         # ... and its average over the timed region (two in flight: includes the neighbour's kernels), with its parts
+                         "kernel_ms_timed_region": k_ms,
                          "kernel_ms_parts": {"k_search": float(np.mean(front_ms)), "k_deep": float(np.mean(deep_ms))},
-                         # the same kernel with one search in flight, measured after the timed region, and the
-                         # fraction of peak that duration gives
+                         # the same kernels with one search in flight, measured after the timed region
                          "exclusive": None if exclusive_ms is None else {
                              "kernel_ms": exclusive_ms["search"], "k_search_ms": exclusive_ms["front"], "k_deep_ms": exclusive_ms["deep"],
                              "index_ms": exclusive_ms["index"],
@@ -752,6 +823,25 @@ def main():
                             abs(mine[ti]["rmsd"] - r["rmsd"][ti]) > 1e-5:
                         mism += 1
             out["parity_sample"] = {"structures": len(oracle_results), "mismatches": mism}
+            # ... and of the STREAMED output (the last upload-inclusive pass: its first batch holds structures 0 ..)
+            if streamed_tables:
+                smism = 0
+                first = streamed_tables[0]
+                by_structure = {}
+                for h in first:
+                    by_structure.setdefault(int(h["structure"]), {})[int(h["template_sel"])] = h
+                checked = min(len(oracle_results), len(chunks[0]))
+                for s_ in range(checked):
+                    r = oracle_results[s_]
+                    mine = by_structure.get(s_, {})
+                    theirs = set(np.nonzero(r["hit"])[0].tolist())
+                    smism += len(theirs ^ set(mine))
+                    for ti in theirs & set(mine):
+                        k = int(mine[ti]["n_atoms"])
+                        if not np.array_equal(mine[ti]["atoms"][:k], r["atoms"][ti][:k]) or \
+                                abs(mine[ti]["rmsd"] - r["rmsd"][ti]) > 1e-5:
+                            smism += 1
+                out["parity_sample_streamed"] = {"structures": checked, "mismatches": smism}
         # (RCCL keeps a version banner in the C library's stdout buffer until the process ends: out with it first, so that
         # the JSON line is the last thing this process prints)
         sys.stdout.flush()

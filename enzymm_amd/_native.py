@@ -95,6 +95,8 @@ EXPORTS = (
     "tm_result_append_hits", "tm_result_destroy", "tm_pdb_count_host", "tm_pdb_parse_host", "tm_pdb_count_host_many",
     "tm_pdb_parse_host_many", "tm_files_sizes", "tm_files_read", "tm_batch_create_from_files", "tm_batch_file_text",
     "tm_stream_create", "tm_stream_destroy", "tm_batch_text_layout",
+    "tm_batch_wait", "tm_batch_upload_bytes", "tm_batch_copy_layout", "tm_batch_line_offsets_at",
+    "tm_batch_pick_records", "tm_host_threads",
 )
 
 _lock = threading.Lock()
@@ -305,6 +307,11 @@ class Stream:
     __del__ = close
 
 
+def host_threads() -> int:
+    """Host threads one native call of this process may use (``tm_host_threads``)."""
+    return int(load().tm_host_threads())
+
+
 def device_count() -> int:
     n = C.c_int(0)
     _check(load().tm_device_count(C.byref(n)))
@@ -465,6 +472,30 @@ class Batch:
         _check(lib.tm_batch_atom_counts(self._h, _ptr(self.atom_offsets)))
         return self
 
+    def wait(self):
+        """Block until the batch is resident (``from_structures`` / ``from_columns`` return with their copies queued;
+        queries wait for them on their own stream, so nothing needs to call this)."""
+        _check(load().tm_batch_wait(self._h))
+
+    def upload_bytes(self) -> int:
+        """Host-to-device bytes the constructor sent (0 for constructors that do not report it)."""
+        n = C.c_uint64(0)
+        _check(load().tm_batch_upload_bytes(self._h, C.byref(n)))
+        return n.value
+
+    def copy_layout(self):
+        """Diagnostic: the batch as it lies in HBM -- dict of xyz [n, 3] f8, records [n, 4] f4 (centred xyz + the packed
+        word's bits), chain u1, orig u4, residue_offsets [structures + 1] u4, residue_start u2 (``tm_batch_copy_layout``)."""
+        lib = load()
+        n, ns = int(self.atom_offsets[-1]), self.n_structures
+        roff = np.zeros(ns + 1, dtype=np.uint32)
+        _check(lib.tm_batch_copy_layout(self._h, None, None, None, None, _ptr(roff), None))
+        out = dict(xyz=np.zeros((n, 3), np.float64), records=np.zeros((n, 4), np.float32), chain=np.zeros(n, np.uint8),
+                   orig=np.zeros(n, np.uint32), residue_offsets=roff, residue_start=np.zeros(int(roff[-1]), np.uint16))
+        _check(lib.tm_batch_copy_layout(self._h, _ptr(out["xyz"]), _ptr(out["records"]), _ptr(out["chain"]), _ptr(out["orig"]),
+                                        None, _ptr(out["residue_start"])))
+        return out
+
     def refused(self):
         """``[(structure index, atoms it came with)]``: structures beyond TM_MAX_STRUCTURE_ATOMS.  They stay in the batch
         as empty structures (no hits); the others are searched as usual."""
@@ -499,6 +530,26 @@ class Batch:
         out = np.zeros(int(self.atom_offsets[-1]), dtype=np.uint32)
         _check(load().tm_batch_line_offsets(self._h, _ptr(out), C.c_uint64(out.size)))
         return out
+
+    def line_offsets_at(self, records: np.ndarray) -> np.ndarray:
+        """``line_offsets()[records]`` without copying every offset back: a gather on the device."""
+        records = _arr(records, np.uint32)
+        out = np.zeros(len(records), dtype=np.uint32)
+        _check(load().tm_batch_line_offsets_at(self._h, _ptr(records), C.c_uint64(len(records)), _ptr(out)))
+        return out
+
+    def pick_records(self, table: np.ndarray, width: int = 96):
+        """(keys uint64 = structure << 32 | atom, lines uint8 [n, width]): the records of the atoms ``table`` (HIT_DTYPE)
+        matched, per structure distinct and ascending, copied out of the batch's text buffer by the library
+        (``tm_batch_pick_records``; batches made by ``from_files``)."""
+        table = np.ascontiguousarray(table)
+        cap = int(table["n_atoms"].sum())
+        keys = np.empty(cap, dtype=np.uint64)
+        lines = np.empty((cap, width), dtype=np.uint8)
+        count = C.c_uint64(0)
+        _check(load().tm_batch_pick_records(self._h, _ptr(table) if len(table) else None, C.c_uint64(len(table)), C.c_uint32(width),
+                                            C.c_uint64(cap), _ptr(keys), _ptr(lines), C.byref(count)))
+        return keys[:count.value], lines[:count.value]
 
     def residue_counts(self) -> np.ndarray:
         """Per file: distinct residue numbers among the atoms of the counted residue names."""

@@ -28,6 +28,9 @@
 
 #include "tm_kernels.hip"  // single translation unit: kernels + host API
 #include "tm_pdb.hip"
+#include "tm_ingest.hip"
+
+#include <emmintrin.h>
 
 using namespace tmx;
 
@@ -55,7 +58,8 @@ struct PhaseTrace {
 };
 
 // Host threads one native call may use: ENZYMM_AMD_HOST_THREADS, else the smallest of the hardware threads, the
-// affinity mask, the container's CPU quota (cgroup v2 cpu.max; a box that shows 256 CPUs may grant 16) and 16.
+// affinity mask, the container's CPU quota (cgroup v2 cpu.max; a box that shows 256 CPUs may grant 16) and 16, divided
+// by LOCAL_WORLD_SIZE (the ranks of one node share its host).
 // More threads than the quota grants are throttled in bursts, which shows as run-to-run variance.
 // Atoms a slice of a batch-creation loop holds at least (ENZYMM_AMD_HOST_GRAIN): the loops run on a persistent team
 // (HostPool), so a slice of a few thousand atoms -- 50 microseconds of work -- is worth handing out.
@@ -98,6 +102,12 @@ uint32_t host_team() {
                 std::fclose(fp);
             }
             if (q > 0 && period > 0) n = std::min<uint32_t>(n, (uint32_t)std::max<long>(1, q / period));
+        }
+        // one process per GPU on one node (torch.distributed.run exports LOCAL_WORLD_SIZE): the ranks share the host, each
+        // takes its share of the quota instead of sizing its team as if it were alone (8 ranks x 16 threads on 16 cores)
+        if (const char *e = std::getenv("LOCAL_WORLD_SIZE")) {
+            const long ranks = std::strtol(e, nullptr, 10);
+            if (ranks > 1) n = std::max<uint32_t>(1u, n / (uint32_t)std::min<long>(ranks, 1024));
         }
         return std::min(n, 16u);
     }();
@@ -209,6 +219,32 @@ int fail(int code, const std::string &msg) {
         if (e_ != hipSuccess) return fail(TM_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+// Waits for `stream` without spinning: an event with hipEventBlockingSync behind what is queued, one per host thread
+// and device.  The ingest threads wait for uploads of a few milliseconds several times per batch; a spinning wait
+// (hipStreamSynchronize) holds a core of the container's CPU quota each, which the threads reading the next files want.
+// ENZYMM_AMD_SPIN_WAIT=1: the spinning wait (A/B).
+hipError_t wait_blocking(hipStream_t stream) {
+    static const bool spin = [] { const char *e = std::getenv("ENZYMM_AMD_SPIN_WAIT"); return e && e[0] == '1'; }();
+    if (spin) return hipStreamSynchronize(stream);
+    struct Events {
+        std::map<int, hipEvent_t> by_device;
+        ~Events() { for (auto &kv : by_device) if (hipSetDevice(kv.first) == hipSuccess) (void)hipEventDestroy(kv.second); }
+    };
+    thread_local Events events;
+    int device = 0;
+    hipError_t e = hipGetDevice(&device);
+    if (e != hipSuccess) return e;
+    auto it = events.by_device.find(device);
+    if (it == events.by_device.end()) {
+        hipEvent_t ev = nullptr;
+        e = hipEventCreateWithFlags(&ev, hipEventBlockingSync | hipEventDisableTiming);
+        if (e != hipSuccess) return e;
+        it = events.by_device.emplace(device, ev).first;
+    }
+    e = hipEventRecord(it->second, stream);
+    return e != hipSuccess ? e : hipEventSynchronize(it->second);
+}
+
 // Device memory is recycled through a process-wide cache: a query allocates a dozen buffers, and
 // hipMalloc / hipFree (which synchronises the device) would otherwise cost more than a millisecond
 // per call.  Blocks are rounded up to size classes and handed back on release; a block is only
@@ -238,12 +274,12 @@ class DevicePool {
         const size_t c = size_class(bytes);
         {
             std::lock_guard<std::mutex> lock(mu_);
-            auto it = free_.find({device, c});
-            if (it != free_.end()) {
+            auto it = free_.lower_bound({device, c});  // the smallest cached block of this device that fits, within a quarter
+            if (it != free_.end() && it->first.first == device && it->first.second <= c + c / 4) {
                 *p = it->second;
-                *granted = c;
+                *granted = it->first.second;
+                cached_ -= it->first.second;
                 free_.erase(it);
-                cached_ -= c;
                 return hipSuccess;
             }
         }
@@ -302,6 +338,7 @@ struct DevBuf {
         n = 0;
         bytes = 0;
     }
+    void swap(DevBuf &o) { std::swap(p, o.p); std::swap(n, o.n); std::swap(bytes, o.bytes); }
     hipError_t alloc(size_t count) {
         const size_t need = std::max<size_t>(count, 1) * sizeof(T);
         if (p && bytes >= need && bytes <= 2 * DevicePool::size_class(need)) {  // keep a block that still fits
@@ -324,7 +361,7 @@ struct DevBuf {
         if (e != hipSuccess || v.empty()) return e;
         if (!stream) return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
         e = hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, stream);
-        return e != hipSuccess ? e : hipStreamSynchronize(stream);
+        return e != hipSuccess ? e : wait_blocking(stream);
     }
 };
 
@@ -339,13 +376,16 @@ class PinnedPool {
     hipError_t acquire(size_t bytes, void **p, size_t *granted) {
         const size_t c = DevicePool::size_class(bytes);
         {
+            // the smallest cached block that holds the request and is not more than half as large again: batches of a
+            // thousand files differ by a few per cent in size, and a miss is a hipHostMalloc -- 8 ms for 190 MB, measured
+            // in every second tm_batch_create_from_files while blocks were matched by their exact size class
             std::lock_guard<std::mutex> lock(mu_);
-            auto it = free_.find(c);
-            if (it != free_.end()) {
+            auto it = free_.lower_bound(c);
+            if (it != free_.end() && it->first <= c + c / 2) {
                 *p = it->second;
-                *granted = c;
+                *granted = it->first;
+                cached_ -= it->first;
                 free_.erase(it);
-                cached_ -= c;
                 return hipSuccess;
             }
         }
@@ -377,8 +417,10 @@ struct PinnedBuf {
     PinnedBuf() = default;
     PinnedBuf(const PinnedBuf &) = delete;
     PinnedBuf &operator=(const PinnedBuf &) = delete;
-    ~PinnedBuf() {
+    ~PinnedBuf() { release(); }
+    void release() {
         if (p) PinnedPool::get().release(p, bytes);
+        p = nullptr; n = 0; bytes = 0;
     }
     hipError_t alloc(size_t count) {
         const size_t need = std::max<size_t>(count, 1) * sizeof(T);
@@ -391,6 +433,19 @@ struct PinnedBuf {
     T &operator[](size_t i) { return p[i]; }
     const T &operator[](size_t i) const { return p[i]; }
 };
+
+// compute units of a device, looked up once per device
+int device_cus(int device) {
+    static std::mutex mu;
+    static std::map<int, int> known;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = known.find(device);
+    if (it != known.end()) return it->second;
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) n = 0;
+    known[device] = n;
+    return n;
+}
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a ceiling: it is raised when a launch needs more dynamic LDS than any
 // launch of that kernel on that device before it, not set again with every query (the call costs as much as a launch).
@@ -540,6 +595,20 @@ struct tm_batch {
     DevBuf<unsigned long long> d_cursor;
     DevBuf<uint32_t> d_overflow;
     DevBuf<uint32_t> d_line_off;  // device-parsed batches: byte offset of every atom record in its file
+    // tm_batch_create_from_structures (round 5): the hand-over arena on both sides and the event behind k_flatten.  The
+    // constructor returns when its copies are queued; queries wait for `ready` on their stream; the staging memory goes
+    // back to its pools once the event has been seen complete (settle).
+    PinnedBuf<uint8_t> h_stage, h_side;
+    PinnedBuf<uint32_t> h_stage_off;
+    DevBuf<uint8_t> d_stage, d_side;
+    hipEvent_t ready = nullptr;
+    uint64_t upload_bytes = 0;  // host-to-device bytes the constructor queued (tm_batch_upload_bytes)
+    void settle() {  // the upload and k_flatten are known to have finished: release what only they needed
+        h_stage.release(); h_side.release(); h_stage_off.release(); d_stage.release(); d_side.release();
+        if (ready) { (void)hipEventDestroy(ready); ready = nullptr; }
+    }
+    ~tm_batch() { if (ready) (void)hipEventDestroy(ready); }
+    PinnedBuf<uint32_t> h_line_off;  // device-parsed batches: d_line_off on the host (copied behind the parse; tm_batch_pick_records)
     PinnedBuf<char> h_text;       // tm_batch_create_from_files: the files' text, kept for tm_batch_file_text
     std::vector<uint64_t> h_text_off;
     DevBuf<uint32_t> d_residue_count;  // device-parsed batches with counted residue names: distinct residue numbers
@@ -722,6 +791,8 @@ int tm_stream_destroy(int device, void *stream) {
     HIP_TRY(hipStreamDestroy((hipStream_t)stream));
     return TM_OK;
 }
+
+int tm_host_threads(void) { return (int)host_team(); }
 
 int tm_device_count(int *count) {
     if (!count) return fail(TM_E_INVALID, "count is NULL");
@@ -1036,12 +1107,50 @@ int tm_batch_create(int device, const tm_batch_desc *d, tm_batch **out) {
 
 namespace {
 
-// Raw atom-table columns, one tm_structure_columns per structure -> vocabulary ids and residue / chain ordinals (per
-// structure, on host threads), then batch_from_encoded.  Ordinals are numbered by first appearance; only their
-// equality matters.
+// Raw atom-table columns, one tm_structure_columns per structure -> the compact hand-over of tm_ingest.hip (round 5).
+// On host threads, per structure: vocabulary ids, residue ordinals (by first appearance; only their equality matters)
+// and chain ordinals into one packed word + one byte per atom, the coordinates as int32 thousandths of an Angstrom
+// when every one of them is such a value EXACTLY -- (double)k / 1000.0 has the bits of the caller's double; a PDB
+// file's 3-decimal fields always are -- else the structure's fp64 values go along in a side array.  17 bytes per atom
+// cross PCIe instead of 46, the host no longer sorts, centres or copies records (k_flatten does), and the call returns
+// when the copies are QUEUED: the batch carries an event (tm_batch::ready) that its queries wait for on their stream.
+// A structure whose residues are not contiguous in the file (rare) is sorted here, stably by residue ordinal, and sends
+// its file-order indices along.
+struct EncodedStructure {
+    uint32_t nres = 0;
+    bool exact = true, scattered = false;
+    double c[3] = {0, 0, 0};
+    float reach = 0.f;
+    std::vector<uint32_t> perm;  // scattered only: device position -> file index
+};
+
+// n3 doubles -> int32 thousandths; false when one of them is not (double)k / 1000.0 bit for bit (then out is garbage)
+inline bool to_milli(const double *x, size_t n3, int32_t *out) {
+    const __m128d k1000 = _mm_set1_pd(1000.0);
+    __m128i differ = _mm_setzero_si128();
+    size_t i = 0;
+    for (; i + 2 <= n3; i += 2) {
+        const __m128d v = _mm_loadu_pd(x + i);
+        const __m128i k = _mm_cvtpd_epi32(_mm_mul_pd(v, k1000));  // round to nearest; out of range or NaN: 0x80000000
+        const __m128d back = _mm_div_pd(_mm_cvtepi32_pd(k), k1000);
+        differ = _mm_or_si128(differ, _mm_xor_si128(_mm_castpd_si128(back), _mm_castpd_si128(v)));  // bitwise: -0.0 is not 0.0
+        _mm_storel_epi64(reinterpret_cast<__m128i *>(out + i), k);
+    }
+    bool exact = _mm_movemask_epi8(_mm_cmpeq_epi32(differ, _mm_setzero_si128())) == 0xffff;
+    for (; i < n3; ++i) {
+        const __m128d v = _mm_set_sd(x[i]);
+        const int32_t k = _mm_cvtsd_si32(_mm_mul_sd(v, k1000));
+        const double back = (double)k / 1000.0;
+        exact = exact && std::memcmp(&back, x + i, 8) == 0;
+        out[i] = k;
+    }
+    return exact;
+}
+
 int batch_from_structures(int device, uint32_t ns, const tm_structure_columns *src, const tm_vocab *vocab, tm_batch **out) {
     PhaseTrace trace("tm_batch_create_from_structures");
-    std::vector<uint32_t> atom_offsets(ns + 1, 0);
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(device));
     std::vector<uint32_t> refused, refused_atoms;
     std::vector<tm_structure_columns> kept;  // (a copy of the descriptors only when one has to be emptied)
     for (uint32_t s = 0; s < ns; ++s)
@@ -1052,6 +1161,12 @@ int batch_from_structures(int device, uint32_t ns, const tm_structure_columns *s
             kept[s].n_atoms = 0;
         }
     if (!kept.empty()) src = kept.data();
+    tm_batch *b = new (std::nothrow) tm_batch;
+    if (!b) return fail(TM_E_NOMEM, "out of host memory");
+    struct Guard { tm_batch *b; ~Guard() { if (b) { (void)hipDeviceSynchronize(); delete b; } } } guard{b};  // (copies may be queued)
+    b->device = device; b->n_structs = ns;
+    b->s_off.assign(ns + 1, 0);
+    std::vector<uint32_t> &atom_offsets = b->s_off;
     for (uint32_t s = 0; s < ns; ++s) {
         const uint64_t n = src[s].n_atoms;
         if (n && (!src[s].xyz || !src[s].name || !src[s].residue_name || !src[s].chain_id || !src[s].residue_number ||
@@ -1092,14 +1207,29 @@ int batch_from_structures(int device, uint32_t ns, const tm_structure_columns *s
     elements.build(vocab->n_elements, vocab->elements, 2, vocab->element_ids);
     residues.build(vocab->n_residues, vocab->residue_names, 3, vocab->residue_ids);
 
-    std::vector<uint8_t> res_type(na), name_id(na), chain(na);
-    std::vector<uint32_t> residue(na), nres_of(ns, 0);
+    // one page-locked arena: [descriptors | packed words | thousandths | chain ordinals]; the side arrays (fp64
+    // coordinates of inexact structures, file-order indices of scattered ones) follow in a second, usually empty, one
+    const size_t o_desc = 0, o_meta = o_desc + sizeof(FlatDesc) * (size_t)ns, o_milli = o_meta + 4 * (size_t)na,
+                 o_chain = o_milli + 12 * (size_t)na, arena_bytes = (o_chain + (size_t)na + 15) & ~(size_t)15;
+    HIP_TRY(b->h_stage.alloc(arena_bytes));
+    FlatDesc *h_desc = reinterpret_cast<FlatDesc *>(b->h_stage.p + o_desc);
+    uint32_t *h_meta = reinterpret_cast<uint32_t *>(b->h_stage.p + o_meta);
+    int32_t *h_milli = reinterpret_cast<int32_t *>(b->h_stage.p + o_milli);
+    uint8_t *h_chain = reinterpret_cast<uint8_t *>(b->h_stage.p + o_chain);
+    std::vector<EncodedStructure> enc(ns);
+    trace.mark("setup");
+
     auto encode = [&](uint32_t s_begin, uint32_t s_end) {
         std::vector<uint16_t> seen_chain;
         std::vector<std::pair<uint64_t, uint32_t>> table;  // residue key -> ordinal, open addressing, per structure
+        std::vector<uint32_t> count, fill, t_meta;
+        std::vector<int32_t> t_milli;
+        std::vector<uint8_t> t_chain;
         for (uint32_t s = s_begin; s < s_end; ++s) {
             const tm_structure_columns &c = src[s];
             const uint32_t o = atom_offsets[s], n = atom_offsets[s + 1] - o;
+            EncodedStructure &E = enc[s];
+            if (n == 0) continue;
             seen_chain.clear();
             uint32_t cap = 64;
             while (cap < 2 * n) cap <<= 1;  // at most one residue per atom
@@ -1108,7 +1238,7 @@ int batch_from_structures(int device, uint32_t ns, const tm_structure_columns *s
             uint64_t last_key = ~0ull;
             uint32_t last_ord = 0;
             uint32_t last_res = 0, last_res_id = TM_RES_OTHER;
-            bool have_res = false;
+            bool have_res = false, scattered = false;
             uint16_t last_chain = 0;
             uint8_t last_chain_ord = 0;
             bool have_chain = false;
@@ -1118,7 +1248,6 @@ int batch_from_structures(int device, uint32_t ns, const tm_structure_columns *s
                 std::memcpy(&nm, c.name + 4 * (size_t)i, 4);
                 uint32_t id = TM_NAME_OTHER;
                 if (!names.find(nm, &id) || id == TM_NAME_OTHER) (void)elements.find(nm & 0xffffu, &id);  // by element (cols 13-14)
-                name_id[a] = (uint8_t)id;
                 uint32_t rn = 0;
                 std::memcpy(&rn, c.residue_name + 3 * (size_t)i, 3);
                 if (!have_res || rn != last_res) {
@@ -1126,7 +1255,6 @@ int batch_from_structures(int device, uint32_t ns, const tm_structure_columns *s
                     (void)residues.find(rn, &rid);
                     last_res = rn; last_res_id = rid; have_res = true;
                 }
-                res_type[a] = (uint8_t)last_res_id;
                 const uint16_t ch = (uint16_t)((uint8_t)c.chain_id[2 * (size_t)i] << 8 | (uint8_t)c.chain_id[2 * (size_t)i + 1]);
                 const uint64_t key = ((uint64_t)ch << 40) | ((uint64_t)(uint32_t)(c.residue_number[i] + (1 << 24)) << 8) |
                                      (uint8_t)c.insertion_code[i];
@@ -1134,19 +1262,68 @@ int batch_from_structures(int device, uint32_t ns, const tm_structure_columns *s
                     uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & (cap - 1);
                     while (table[h].first != ~0ull && table[h].first != key) h = (h + 1) & (cap - 1);
                     if (table[h].first == ~0ull) table[h] = {key, n_keys++};
+                    else scattered = true;  // a residue seen before, and not the one just left: its atoms have to be gathered
                     last_key = key;
                     last_ord = table[h].second;
                 }
-                residue[a] = last_ord;
+                h_meta[a] = meta_pack(last_ord, std::min<uint32_t>(id, TM_NAME_OTHER), std::min<uint32_t>(last_res_id, TM_RES_OTHER));
                 if (!have_chain || ch != last_chain) {
                     uint32_t k = 0;
                     while (k < seen_chain.size() && seen_chain[k] != ch) ++k;
                     if (k == seen_chain.size()) seen_chain.push_back(ch);
                     last_chain = ch; last_chain_ord = (uint8_t)(k & 0xffu); have_chain = true;
                 }
-                chain[a] = last_chain_ord;
+                h_chain[a] = last_chain_ord;
             }
-            nres_of[s] = n_keys;
+            E.nres = n_keys;
+            E.scattered = scattered;
+            if (n_keys > TM_MAX_STRUCTURE_RESIDUES) continue;  // (the caller fails the batch)
+            int32_t *mk = h_milli + 3 * (size_t)o;
+            E.exact = to_milli(c.xyz, 3 * (size_t)n, mk);
+            if (E.exact) {
+                long long sum[3] = {0, 0, 0};
+                int32_t lo[3] = {mk[0], mk[1], mk[2]}, hi[3] = {mk[0], mk[1], mk[2]};
+                for (uint32_t i = 0; i < n; ++i)
+                    for (int ax = 0; ax < 3; ++ax) {
+                        const int32_t v = mk[3 * (size_t)i + ax];
+                        sum[ax] += v;
+                        lo[ax] = std::min(lo[ax], v); hi[ax] = std::max(hi[ax], v);
+                    }
+                float reach = 0.f;
+                for (int ax = 0; ax < 3; ++ax) {
+                    E.c[ax] = ((double)sum[ax] / 1000.0) / (double)n;
+                    // (what k_flatten computes for the outermost atoms; x -> (float)(x - c) is monotone)
+                    reach = std::max(reach, std::fabs((float)((double)lo[ax] / 1000.0 - E.c[ax])));
+                    reach = std::max(reach, std::fabs((float)((double)hi[ax] / 1000.0 - E.c[ax])));
+                }
+                E.reach = reach;
+            } else {
+                double cc[3] = {0, 0, 0};
+                for (uint32_t i = 0; i < n; ++i)
+                    for (int ax = 0; ax < 3; ++ax) cc[ax] += c.xyz[3 * (size_t)i + ax];
+                float reach = 0.f;
+                for (int ax = 0; ax < 3; ++ax) E.c[ax] = cc[ax] / (double)n;
+                for (uint32_t i = 0; i < n; ++i)
+                    for (int ax = 0; ax < 3; ++ax) reach = std::max(reach, std::fabs((float)(c.xyz[3 * (size_t)i + ax] - E.c[ax])));
+                E.reach = reach <= 3.0e38f ? reach : 3.0e38f;  // a NaN or infinite coordinate: the widest slack there is
+            }
+            if (scattered) {
+                // counting sort by residue ordinal: atoms of a residue become contiguous, file order kept inside
+                count.assign(n_keys + 1, 0);
+                for (uint32_t i = 0; i < n; ++i) count[meta_res(h_meta[o + i]) + 1]++;
+                for (uint32_t r = 0; r < n_keys; ++r) count[r + 1] += count[r];
+                fill.assign(count.begin(), count.end() - 1);
+                E.perm.assign(n, 0);
+                for (uint32_t i = 0; i < n; ++i) E.perm[fill[meta_res(h_meta[o + i])]++] = i;
+                t_meta.assign(h_meta + o, h_meta + o + n);
+                t_chain.assign(h_chain + o, h_chain + o + n);
+                t_milli.assign(mk, mk + 3 * (size_t)n);
+                for (uint32_t j = 0; j < n; ++j) {
+                    const uint32_t i = E.perm[j];
+                    h_meta[o + j] = t_meta[i]; h_chain[o + j] = t_chain[i];
+                    for (int ax = 0; ax < 3; ++ax) mk[3 * (size_t)j + ax] = t_milli[3 * (size_t)i + ax];
+                }
+            }
         }
     };
     {
@@ -1154,12 +1331,15 @@ int batch_from_structures(int device, uint32_t ns, const tm_structure_columns *s
         if (team <= 1) {
             encode(0, ns);
         } else {
+            // slices of about a quarter of a thread's share: the team takes them from a counter, so a thread that is
+            // descheduled for a while (the box grants a CPU quota, not cores) does not hold the others up
+            const uint32_t n_slices = team * 4;
             std::vector<std::pair<uint32_t, uint32_t>> slices;
             uint32_t s0 = 0;
-            for (uint32_t t = 0; t < team; ++t) {
-                const uint64_t target = (uint64_t)na * (t + 1) / team;
+            for (uint32_t t = 0; t < n_slices; ++t) {
+                const uint64_t target = (uint64_t)na * (t + 1) / n_slices;
                 uint32_t s1 = s0;
-                while (s1 < ns && (t + 1 == team || atom_offsets[s1 + 1] <= target)) ++s1;
+                while (s1 < ns && (t + 1 == n_slices || atom_offsets[s1 + 1] <= target)) ++s1;
                 if (s1 > s0) slices.emplace_back(s0, s1);
                 s0 = s1;
             }
@@ -1167,19 +1347,98 @@ int batch_from_structures(int device, uint32_t ns, const tm_structure_columns *s
         }
     }
     trace.mark("encode");
-    std::vector<const double *> xyz_of(ns);
-    for (uint32_t s = 0; s < ns; ++s) xyz_of[s] = src[s].xyz;
-    tm_batch_desc enc;
-    enc.n_structures = ns;
-    enc.atom_offsets = atom_offsets.data();
-    enc.xyz = nullptr;
-    enc.res_type = res_type.data();
-    enc.name_id = name_id.data();
-    enc.residue = residue.data();
-    enc.chain = chain.data();
-    const int rc = batch_from_encoded(device, &enc, xyz_of.data(), nres_of.data(), out);
-    if (rc == TM_OK) { (*out)->refused = std::move(refused); (*out)->refused_atoms = std::move(refused_atoms); }
-    return rc;
+
+    // limits, residue-table offsets, the side arrays' layout, the batch's extent
+    PinnedBuf<uint32_t> &h_off = b->h_stage_off;  // [s_off | s_roff]
+    HIP_TRY(h_off.alloc(2 * ((size_t)ns + 1)));
+    uint32_t *h_s_off = h_off.p, *h_s_roff = h_off.p + ns + 1;
+    std::memcpy(h_s_off, atom_offsets.data(), ((size_t)ns + 1) * sizeof(uint32_t));
+    h_s_roff[0] = 0;
+    uint32_t max_atoms = 0, max_res = 0;
+    size_t side_xyz = 0, side_orig = 0;
+    float extent = 0.f;
+    for (uint32_t s = 0; s < ns; ++s) {
+        const uint32_t n = atom_offsets[s + 1] - atom_offsets[s];
+        const EncodedStructure &E = enc[s];
+        if (E.nres > TM_MAX_STRUCTURE_RESIDUES)
+            return fail(TM_E_UNSUPPORTED, "structure " + std::to_string(s) + " has more than " +
+                                              std::to_string(TM_MAX_STRUCTURE_RESIDUES) + " residues");
+        h_s_roff[s + 1] = h_s_roff[s] + E.nres + 1;
+        max_atoms = std::max(max_atoms, n); max_res = std::max(max_res, E.nres);
+        extent = std::max(extent, E.reach);
+        FlatDesc &D = h_desc[s];
+        D.c[0] = E.c[0]; D.c[1] = E.c[1]; D.c[2] = E.c[2];
+        D.xyz_off = kNoOffset; D.orig_off = kNoOffset;
+        if (n && !E.exact) { D.xyz_off = (uint32_t)side_xyz; side_xyz += n; }
+        if (n && E.scattered) { D.orig_off = (uint32_t)side_orig; side_orig += n; }
+    }
+    b->n_atoms = na; b->max_atoms = max_atoms; b->max_res = max_res; b->extent = extent;
+    const size_t side_bytes = 24 * side_xyz + 4 * side_orig;
+    double *h_side_xyz = nullptr;
+    uint32_t *h_side_orig = nullptr;
+    if (side_bytes) {
+        HIP_TRY(b->h_side.alloc(side_bytes));
+        h_side_xyz = reinterpret_cast<double *>(b->h_side.p);
+        h_side_orig = reinterpret_cast<uint32_t *>(b->h_side.p + 24 * side_xyz);
+        std::vector<uint32_t> todo;
+        for (uint32_t s = 0; s < ns; ++s)
+            if (h_desc[s].xyz_off != kNoOffset || h_desc[s].orig_off != kNoOffset) todo.push_back(s);
+        auto fill_side = [&](uint32_t t) {
+            const uint32_t s = todo[t], n = atom_offsets[s + 1] - atom_offsets[s];
+            const FlatDesc &D = h_desc[s];
+            const EncodedStructure &E = enc[s];
+            if (D.orig_off != kNoOffset) std::memcpy(h_side_orig + D.orig_off, E.perm.data(), 4 * (size_t)n);
+            if (D.xyz_off != kNoOffset) {
+                double *dst = h_side_xyz + 3 * (size_t)D.xyz_off;
+                if (!E.scattered) std::memcpy(dst, src[s].xyz, 24 * (size_t)n);
+                else
+                    for (uint32_t j = 0; j < n; ++j)
+                        for (int ax = 0; ax < 3; ++ax) dst[3 * (size_t)j + ax] = src[s].xyz[3 * (size_t)E.perm[j] + ax];
+            }
+        };
+        if (todo.size() >= 8 && side_bytes >= (1u << 20)) HostPool::run_anywhere((uint32_t)todo.size(), fill_side);
+        else
+            for (uint32_t t = 0; t < todo.size(); ++t) fill_side(t);
+    }
+    trace.mark("layout");
+
+    hipStream_t stream = nullptr;
+    HIP_TRY(ingest_stream(device, &stream));
+    HIP_TRY(b->d_stage.alloc(arena_bytes));
+    HIP_TRY(b->d_xyz.alloc(3 * (size_t)na)); HIP_TRY(b->d_rec.alloc(na)); HIP_TRY(b->d_chain.alloc(na)); HIP_TRY(b->d_orig.alloc(na));
+    HIP_TRY(b->d_res_start.alloc(h_s_roff[ns]));
+    HIP_TRY(b->d_s_off.alloc((size_t)ns + 1)); HIP_TRY(b->d_s_roff.alloc((size_t)ns + 1));
+    HIP_TRY(b->d_cursor.alloc(1)); HIP_TRY(b->d_overflow.alloc(1));
+    HIP_TRY(hipMemcpyAsync(b->d_stage.p, b->h_stage.p, o_chain, hipMemcpyHostToDevice, stream));
+    if (na) HIP_TRY(hipMemcpyAsync(b->d_chain.p, h_chain, na, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(b->d_s_off.p, h_s_off, ((size_t)ns + 1) * 4, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(b->d_s_roff.p, h_s_roff, ((size_t)ns + 1) * 4, hipMemcpyHostToDevice, stream));
+    if (side_bytes) {
+        HIP_TRY(b->d_side.alloc(side_bytes));
+        HIP_TRY(hipMemcpyAsync(b->d_side.p, b->h_side.p, side_bytes, hipMemcpyHostToDevice, stream));
+    }
+    b->upload_bytes = o_chain + na + 8 * ((size_t)ns + 1) + side_bytes;
+    if (ns) {
+        const uint32_t chunks = std::max(1u, (max_atoms + kFlattenChunk - 1) / kFlattenChunk);
+        hipLaunchKernelGGL(k_flatten, dim3(ns, chunks), dim3(256), 0, stream, b->d_s_off.p, b->d_s_roff.p,
+                           reinterpret_cast<const FlatDesc *>(b->d_stage.p + o_desc),
+                           reinterpret_cast<const uint32_t *>(b->d_stage.p + o_meta),
+                           reinterpret_cast<const int32_t *>(b->d_stage.p + o_milli),
+                           reinterpret_cast<const double *>(b->d_side.p),
+                           reinterpret_cast<const uint32_t *>(b->d_side.p ? b->d_side.p + 24 * side_xyz : nullptr),
+                           b->d_xyz.p, b->d_rec.p, b->d_orig.p, b->d_res_start.p);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventCreateWithFlags(&b->ready, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(b->ready, stream));
+    // ENZYMM_AMD_SYNC_UPLOAD=1 (A/B, tests): wait here, as every batch constructor did before round 5
+    static const bool sync_upload = [] { const char *e = std::getenv("ENZYMM_AMD_SYNC_UPLOAD"); return e && e[0] == '1'; }();
+    if (sync_upload) { HIP_TRY(hipEventSynchronize(b->ready)); b->settle(); }
+    trace.mark("queue");
+    b->refused = std::move(refused); b->refused_atoms = std::move(refused_atoms);
+    guard.b = nullptr;
+    *out = b;
+    return TM_OK;
 }
 
 }  // namespace
@@ -1379,16 +1638,26 @@ extern "C" {
 
 static int batch_from_pdb_text(int device, uint32_t n_files, const char *const *text, const uint64_t *length,
                                const tm_vocab *vocab, uint32_t flags, double min_bfactor, tm_batch **out,
-                               std::vector<uint32_t> *oversized, std::vector<uint32_t> *oversized_atoms);
+                               std::vector<uint32_t> *oversized, std::vector<uint32_t> *oversized_atoms,
+                               DevBuf<char> *uploaded = nullptr);
+static int batch_from_pdb(int device, uint32_t n_files, const char *const *text, const uint64_t *length,
+                          const tm_vocab *vocab, uint32_t flags, double min_bfactor, tm_batch **out, DevBuf<char> *uploaded);
 
 // A file with more than TM_MAX_STRUCTURE_ATOMS kept atoms is found out only after the device has classified its lines:
 // the batch is then laid out once more with that file's text left out -- it stays in the batch as an empty structure,
 // listed by tm_batch_refused -- instead of failing the other files with it.
 int tm_batch_create_from_pdb(int device, uint32_t n_files, const char *const *text, const uint64_t *length,
                              const tm_vocab *vocab, uint32_t flags, double min_bfactor, tm_batch **out) {
+    return batch_from_pdb(device, n_files, text, length, vocab, flags, min_bfactor, out, nullptr);
+}
+
+// `uploaded`: the text as it already lies in device memory (tm_batch_create_from_files sends it up chunk by chunk while
+// it reads the next files), copies queued on this thread's ingest stream
+static int batch_from_pdb(int device, uint32_t n_files, const char *const *text, const uint64_t *length,
+                          const tm_vocab *vocab, uint32_t flags, double min_bfactor, tm_batch **out, DevBuf<char> *uploaded) {
     if (!out || !vocab || (n_files && (!text || !length))) return fail(TM_E_INVALID, "tm_batch_create_from_pdb: NULL argument");
     std::vector<uint32_t> oversized, oversized_atoms;
-    int rc = batch_from_pdb_text(device, n_files, text, length, vocab, flags, min_bfactor, out, &oversized, &oversized_atoms);
+    int rc = batch_from_pdb_text(device, n_files, text, length, vocab, flags, min_bfactor, out, &oversized, &oversized_atoms, uploaded);
     if (rc != TM_OK || oversized.empty()) return rc;
     std::vector<uint64_t> kept(length, length + n_files);
     for (uint32_t f : oversized) kept[f] = 0;
@@ -1399,7 +1668,8 @@ int tm_batch_create_from_pdb(int device, uint32_t n_files, const char *const *te
 
 static int batch_from_pdb_text(int device, uint32_t n_files, const char *const *text, const uint64_t *length,
                                const tm_vocab *vocab, uint32_t flags, double min_bfactor, tm_batch **out,
-                               std::vector<uint32_t> *oversized, std::vector<uint32_t> *oversized_atoms) {
+                               std::vector<uint32_t> *oversized, std::vector<uint32_t> *oversized_atoms,
+                               DevBuf<char> *uploaded) {
     *out = nullptr;
     HIP_TRY(hipSetDevice(device));
     hipStream_t stream = nullptr;
@@ -1419,7 +1689,9 @@ static int batch_from_pdb_text(int device, uint32_t n_files, const char *const *
     DevBuf<uint64_t> d_file_off, d_nl;
     DevBuf<uint32_t> d_counts, d_rank, d_sums, d_total, d_line_file, d_first_end, d_keep, d_atom_rank, d_bad;
     DevBuf<uint8_t> d_kind;
-    HIP_TRY(d_text.alloc(n_bytes + 16));
+    const bool have_text = uploaded && uploaded->p && uploaded->bytes >= n_bytes + 16;
+    if (have_text) d_text.swap(*uploaded);
+    else HIP_TRY(d_text.alloc(n_bytes + 16));
     trace.mark("text alloc");
     HIP_TRY(hipMemsetAsync(d_text.p + file_off[n_files], ' ', n_bytes + 16 - file_off[n_files], stream));
     // files that already sit back to back in host memory, each ending in a newline (tm_batch_create_from_files
@@ -1427,7 +1699,9 @@ static int batch_from_pdb_text(int device, uint32_t n_files, const char *const *
     bool contiguous = n_files > 0;
     for (uint32_t f = 0; f < n_files && contiguous; ++f)
         contiguous = file_off[f + 1] - file_off[f] == length[f] && (f + 1 == n_files || text[f] + length[f] == text[f + 1]);
-    if (contiguous) {
+    if (have_text) {
+        // (already on its way: tm_batch_create_from_files)
+    } else if (contiguous) {
         if (file_off[n_files]) HIP_TRY(hipMemcpyAsync(d_text.p, text[0], file_off[n_files], hipMemcpyHostToDevice, stream));
     } else {
         for (uint32_t f = 0; f < n_files; ++f) {
@@ -1447,7 +1721,7 @@ static int batch_from_pdb_text(int device, uint32_t n_files, const char *const *
         int rc = device_scan(d_counts.p, n_gran, d_rank.p, d_total.p, d_sums, stream);
         if (rc != TM_OK) return rc;
         HIP_TRY(hipMemcpyAsync(&n_lines, d_total.p, sizeof n_lines, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(wait_blocking(stream));
         trace.mark("sync0");
     }
     HIP_TRY(d_nl.alloc(n_lines)); HIP_TRY(d_line_file.alloc(n_lines)); HIP_TRY(d_kind.alloc(n_lines));
@@ -1469,7 +1743,7 @@ static int batch_from_pdb_text(int device, uint32_t n_files, const char *const *
         int rc = device_scan(d_keep.p, n_lines, d_atom_rank.p, d_total.p + 1, d_sums, stream);
         if (rc != TM_OK) return rc;
         HIP_TRY(hipMemcpyAsync(&n_atoms, d_total.p + 1, sizeof n_atoms, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(wait_blocking(stream));
         trace.mark("sync1");
     }
 
@@ -1531,7 +1805,7 @@ static int batch_from_pdb_text(int device, uint32_t n_files, const char *const *
         HIP_TRY(hipMemcpyAsync(needs_host.data(), d_needs_host.p, n_files * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     }
     HIP_TRY(hipMemcpyAsync(&bad, d_bad.p, sizeof bad, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(wait_blocking(stream));
     trace.mark("sync2");
     if (bad) return fail(TM_E_INVALID, "malformed ATOM/HETATM record in the PDB text");
     std::vector<uint32_t> s_roff(n_files + 1, 0);
@@ -1589,6 +1863,12 @@ static int batch_from_pdb_text(int device, uint32_t n_files, const char *const *
                                hipMemcpyHostToDevice, stream));
         HIP_TRY(hipMemcpyAsync(b->d_residue_count.p + h.file, &h.residue_count, sizeof(uint32_t), hipMemcpyHostToDevice, stream));
     }
+    // the records' byte offsets also go to the host (the other direction of the link, idle during ingestion): reporting
+    // a match needs the text of its atoms' records, and the main thread then finds them without asking the device
+    if (n_atoms) {
+        HIP_TRY(b->h_line_off.alloc(n_atoms));
+        HIP_TRY(hipMemcpyAsync(b->h_line_off.p, b->d_line_off.p, (size_t)n_atoms * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    }
     // the batch's extent (tm_batch::extent), measured where the records are
     DevBuf<uint32_t> d_extent;
     PinnedBuf<uint32_t> h_extent;
@@ -1601,7 +1881,7 @@ static int batch_from_pdb_text(int device, uint32_t n_files, const char *const *
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(h_extent.p, d_extent.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     }
-    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(wait_blocking(stream));
     std::memcpy(&b->extent, h_extent.p, 4);
     trace.mark("sync3");
     guard.b = nullptr;
@@ -1625,12 +1905,69 @@ int tm_batch_atom_counts(tm_batch *b, uint32_t *atom_offsets) {
     return TM_OK;
 }
 
+int tm_batch_upload_bytes(const tm_batch *b, uint64_t *bytes) {
+    if (!b || !bytes) return fail(TM_E_INVALID, "NULL argument");
+    *bytes = b->upload_bytes;
+    return TM_OK;
+}
+
+int tm_batch_wait(tm_batch *b) {
+    if (!b) return fail(TM_E_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(b->device));
+    if (b->ready) {
+        HIP_TRY(hipEventSynchronize(b->ready));
+        b->settle();
+    }
+    return TM_OK;
+}
+
+int tm_batch_copy_layout(tm_batch *b, double *xyz, float *records, uint8_t *chain, uint32_t *orig, uint32_t *residue_offsets,
+                         uint16_t *residue_start) {
+    if (!b) return fail(TM_E_INVALID, "NULL argument");
+    int rc = tm_batch_wait(b);
+    if (rc != TM_OK) return rc;
+    if (b->queried) HIP_TRY(hipStreamSynchronize(b->last_stream));
+    const size_t na = b->n_atoms, ns = b->n_structs;
+    std::vector<uint32_t> roff(ns + 1, 0);
+    HIP_TRY(hipMemcpy(roff.data(), b->d_s_roff.p, (ns + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (residue_offsets) std::memcpy(residue_offsets, roff.data(), (ns + 1) * sizeof(uint32_t));
+    if (xyz && na) HIP_TRY(hipMemcpy(xyz, b->d_xyz.p, 24 * na, hipMemcpyDeviceToHost));
+    if (records && na) HIP_TRY(hipMemcpy(records, b->d_rec.p, 16 * na, hipMemcpyDeviceToHost));
+    if (chain && na) HIP_TRY(hipMemcpy(chain, b->d_chain.p, na, hipMemcpyDeviceToHost));
+    if (orig && na) HIP_TRY(hipMemcpy(orig, b->d_orig.p, 4 * na, hipMemcpyDeviceToHost));
+    if (residue_start && roff[ns]) HIP_TRY(hipMemcpy(residue_start, b->d_res_start.p, 2 * (size_t)roff[ns], hipMemcpyDeviceToHost));
+    return TM_OK;
+}
+
 int tm_batch_line_offsets(tm_batch *b, uint32_t *out, uint64_t n) {
     if (!b || (!out && n)) return fail(TM_E_INVALID, "NULL argument");
     if (b->d_line_off.n != b->n_atoms) return fail(TM_E_INVALID, "batch was not created from PDB text");
     if (n < b->n_atoms) return fail(TM_E_INVALID, "output buffer too small");
     HIP_TRY(hipSetDevice(b->device));
     if (b->n_atoms) HIP_TRY(hipMemcpy(out, b->d_line_off.p, b->n_atoms * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return TM_OK;
+}
+
+int tm_batch_line_offsets_at(tm_batch *b, const uint32_t *records, uint64_t n, uint32_t *out) {
+    if (!b || (n && (!records || !out))) return fail(TM_E_INVALID, "NULL argument");
+    if (b->d_line_off.n != b->n_atoms) return fail(TM_E_INVALID, "batch was not created from PDB text");
+    if (n == 0) return TM_OK;
+    if (n > 0xffffffffull) return fail(TM_E_UNSUPPORTED, "more than 2^32 records");
+    for (uint64_t i = 0; i < n; ++i)
+        if (records[i] >= b->n_atoms) return fail(TM_E_INVALID, "record index out of range");
+    HIP_TRY(hipSetDevice(b->device));
+    hipStream_t stream = nullptr;
+    HIP_TRY(ingest_stream(b->device, &stream));
+    DevBuf<uint32_t> d_idx, d_out;
+    PinnedBuf<uint32_t> h;
+    HIP_TRY(d_idx.alloc(n)); HIP_TRY(d_out.alloc(n)); HIP_TRY(h.alloc(n));
+    std::memcpy(h.p, records, n * sizeof(uint32_t));
+    HIP_TRY(hipMemcpyAsync(d_idx.p, h.p, n * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_gather_u32, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, b->d_line_off.p, d_idx.p, (uint32_t)n, d_out.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h.p, d_out.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    std::memcpy(out, h.p, n * sizeof(uint32_t));
     return TM_OK;
 }
 
@@ -1651,6 +1988,7 @@ void tm_batch_destroy(tm_batch *b) {
     // after its creation returned, so waiting for the last query's stream is enough (a device-wide wait would
     // also wait for another thread's ingestion of the next batch).
     if (b->queried) (void)hipStreamSynchronize(b->last_stream);
+    if (b->ready) (void)hipEventSynchronize(b->ready);  // (a batch destroyed before its upload has finished)
     delete b;
 }
 
@@ -1869,6 +2207,12 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
         if (p->template_index[i] >= lib->n_templates) return fail(TM_E_INVALID, "template index out of range");
     HIP_TRY(hipSetDevice(lib->device));
     hipStream_t stream = (hipStream_t)p->stream;
+    // a batch whose constructor returned with its copies queued (tm_batch_create_from_structures): this stream waits
+    // for them on the device, the host does not
+    if (b->ready) {
+        if (hipEventQuery(b->ready) == hipSuccess) b->settle();
+        else HIP_TRY(hipStreamWaitEvent(stream, b->ready, 0));
+    }
 
     tm_result *r = new (std::nothrow) tm_result;
     if (!r) return fail(TM_E_NOMEM, "out of host memory");
@@ -2308,11 +2652,7 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
             HIP_TRY(allow_dynamic_lds(reinterpret_cast<const void *>(kernel), lds_bytes));
             // the block search over structures in LDS holds a whole CU per workgroup: one workgroup per CU, each taking
             // units from the launch's queues (k_search); ENZYMM_AMD_QUEUED=0: one workgroup per unit (tests, A/B)
-            static const int n_cus = [] {
-                int dev = 0, n = 0;
-                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
-                return n;
-            }();
+            const int n_cus = device_cus(r->device);  // (per device: a process may drive GPUs of different sizes)
             const char *queued_env = std::getenv("ENZYMM_AMD_QUEUED");
             const bool queued = mode == kModeBlocks && lds_path;
             const bool once = n_cus <= 0 || (queued_env && std::atoi(queued_env) == 0);
@@ -2569,7 +2909,7 @@ const void *tm_result_device_hits(tm_result *r) { return r ? r->d_hits.p : nullp
 int tm_result_append_hits(tm_result *r, void *rows, uint64_t capacity, uint64_t *count, uint32_t structure_offset) {
     if (!r || !count || (!rows && capacity)) return fail(TM_E_INVALID, "tm_result_append_hits: NULL argument");
     HIP_TRY(hipSetDevice(r->device));
-    hipLaunchKernelGGL(k_append_hits, dim3(1), dim3(1024), 0, r->stream, r->d_hits.p, r->d_counters.p, r->hit_capacity,
+    hipLaunchKernelGGL(k_append_hits, dim3(128), dim3(256), 0, r->stream, r->d_hits.p, r->d_counters.p, r->hit_capacity,
                        reinterpret_cast<tm_hit *>(rows), (unsigned long long)capacity,
                        reinterpret_cast<unsigned long long *>(count), structure_offset);
     HIP_TRY(hipGetLastError());
@@ -2904,39 +3244,150 @@ int tm_batch_create_from_files(int device, uint32_t n_files, const char *const *
     PinnedBuf<char> text;
     HIP_TRY(text.alloc(off[n_files] + 16));
     trace.mark("pinned");
+    // The files are read in a few chunks, and each chunk's bytes go up while the next one is read (round 5: reading
+    // 190 MB took 2.6 ms and uploading them 4 ms, one after the other; the device parse starts behind the last copy)
+    DevBuf<char> d_text;
+    hipStream_t stream = nullptr;
+    HIP_TRY(ingest_stream(device, &stream));
+    const uint64_t n_bytes = (off[n_files] + 15) & ~15ull;
+    HIP_TRY(d_text.alloc(n_bytes + 16));
     {
-        std::vector<uint64_t> read_off(n_files + 1, 0);  // tm_files_read wants [off[f], off[f] + size) ranges
         std::vector<uint8_t> failed(n_files, 0);
-        parallel_for(n_files, 16, [&](uint32_t f) {
-            const uint64_t want = sizes[f];
-            const int fd = ::open(paths[f], O_RDONLY | O_CLOEXEC);
-            if (fd < 0) { failed[f] = 1; return; }
-            uint64_t got = 0;
-            while (got < want) {
-                const ssize_t r = ::read(fd, text.p + off[f] + got, want - got);
-                if (r <= 0) break;
-                got += (uint64_t)r;
-            }
-            ::close(fd);
-            if (got != want) failed[f] = 1;
-            text.p[off[f] + want] = '\n';
-        });
+        static const uint32_t n_chunks = [] {
+            if (const char *e = std::getenv("ENZYMM_AMD_READ_CHUNKS")) { const long v = std::strtol(e, nullptr, 10); if (v >= 1 && v <= 64) return (uint32_t)v; }
+            return 6u;
+        }();
+        uint32_t f0 = 0;
+        for (uint32_t c = 0; c < n_chunks && f0 < n_files; ++c) {
+            const uint64_t target = off[n_files] * (c + 1) / n_chunks;
+            uint32_t f1 = f0;
+            while (f1 < n_files && (c + 1 == n_chunks || off[f1 + 1] <= target || f1 == f0)) ++f1;
+            // (one chunk is read at a time, process-wide: reading is bound by memory bandwidth -- 190 MB in 2.6 ms on sixteen
+            // threads, twice that when two ingest threads read at once -- so the ingest threads of a pipeline take turns at
+            // the full rate, chunk by chunk, instead of running forty-eight threads on sixteen cores; what overlaps is one
+            // thread's reads with the others' uploads and device parses)
+            static std::mutex read_turn;
+            std::lock_guard<std::mutex> turn(read_turn);
+            parallel_for(f1 - f0, 4, [&](uint32_t i) {
+                const uint32_t f = f0 + i;
+                const uint64_t want = sizes[f];
+                const int fd = ::open(paths[f], O_RDONLY | O_CLOEXEC);
+                if (fd < 0) { failed[f] = 1; return; }
+                uint64_t got = 0;
+                while (got < want) {
+                    const ssize_t r = ::read(fd, text.p + off[f] + got, want - got);
+                    if (r <= 0) break;
+                    got += (uint64_t)r;
+                }
+                ::close(fd);
+                if (got != want) failed[f] = 1;
+                text.p[off[f] + want] = '\n';
+            });
+            bool any = false;
+            for (uint32_t f = f0; f < f1; ++f) any = any || failed[f];
+            if (!any && off[f1] > off[f0])
+                HIP_TRY(hipMemcpyAsync(d_text.p + off[f0], text.p + off[f0], off[f1] - off[f0], hipMemcpyHostToDevice, stream));
+            f0 = f1;
+        }
         for (uint32_t f = 0; f < n_files; ++f)
             if (failed[f]) {
+                (void)hipStreamSynchronize(stream);  // (copies out of `text` may be in flight)
                 if (bad_file) *bad_file = f;
                 return fail(TM_E_INVALID, std::string("cannot read ") + paths[f]);
             }
     }
-    trace.mark("read");
+    trace.mark("read+upload");
     std::vector<const char *> ptr(n_files);
     std::vector<uint64_t> len(n_files);
     for (uint32_t f = 0; f < n_files; ++f) { ptr[f] = text.p + off[f]; len[f] = sizes[f] + 1; }
-    rc = tm_batch_create_from_pdb(device, n_files, ptr.data(), len.data(), vocab, flags, min_bfactor, out);
+    rc = batch_from_pdb(device, n_files, ptr.data(), len.data(), vocab, flags, min_bfactor, out, &d_text);
     trace.mark("from_pdb");
-    if (rc != TM_OK) return rc;
+    if (rc != TM_OK) { (void)hipStreamSynchronize(stream); return rc; }
     tm_batch *b = *out;
     std::swap(b->h_text.p, text.p); std::swap(b->h_text.n, text.n); std::swap(b->h_text.bytes, text.bytes);
     b->h_text_off = std::move(off);
+    return TM_OK;
+}
+
+// The records (text lines) of the atoms a hit table matched, for a batch made by tm_batch_create_from_files: per
+// structure the distinct matched atoms in ascending order, each with the first `width` bytes of its record's line (read
+// from the batch's text buffer, clamped at its end).  keys[i] = structure << 32 | atom (file-order index), lines[i * width ..].
+// Host-side only (text and offsets are kept in page-locked memory by the batch); on a team of host threads.
+int tm_batch_pick_records(tm_batch *b, const tm_hit *hits, uint64_t n_hits, uint32_t width, uint64_t capacity, uint64_t *keys,
+                          uint8_t *lines, uint64_t *count) {
+    if (!b || !count || (n_hits && !hits) || (capacity && (!keys || !lines)) || width == 0)
+        return fail(TM_E_INVALID, "tm_batch_pick_records: bad argument");
+    if (b->h_text_off.size() != (size_t)b->n_structs + 1 || b->h_line_off.n != b->n_atoms)
+        return fail(TM_E_INVALID, "batch was not created from files");
+    *count = 0;
+    // runs of equal structure (the table is sorted by structure; an unsorted table just gives several runs per structure)
+    std::vector<std::pair<uint64_t, uint64_t>> runs;
+    for (uint64_t i = 0; i < n_hits;) {
+        uint64_t j = i + 1;
+        while (j < n_hits && hits[j].structure == hits[i].structure) ++j;
+        if (hits[i].structure >= b->n_structs) return fail(TM_E_INVALID, "tm_batch_pick_records: structure index out of range");
+        runs.emplace_back(i, j);
+        i = j;
+    }
+    std::vector<std::vector<uint32_t>> atoms(runs.size());
+    std::vector<uint64_t> first(runs.size() + 1, 0);
+    std::atomic<int> bad{0};
+    auto collect = [&](uint32_t r) {
+        std::vector<uint32_t> &a = atoms[r];
+        const uint32_t s = hits[runs[r].first].structure, n = b->s_off[s + 1] - b->s_off[s];
+        for (uint64_t i = runs[r].first; i < runs[r].second; ++i)
+            for (uint32_t k = 0; k < hits[i].n_atoms && k < TM_MAX_TEMPLATE_ATOMS; ++k) {
+                if (hits[i].atoms[k] >= n) { bad.store(1); return; }
+                a.push_back(hits[i].atoms[k]);
+            }
+        std::sort(a.begin(), a.end());
+        a.erase(std::unique(a.begin(), a.end()), a.end());
+    };
+    const uint32_t nr = (uint32_t)runs.size();
+    if (nr >= 64) parallel_for(nr, 16, collect);
+    else for (uint32_t r = 0; r < nr; ++r) collect(r);
+    if (bad.load()) return fail(TM_E_INVALID, "tm_batch_pick_records: atom index out of range");
+    for (uint32_t r = 0; r < nr; ++r) first[r + 1] = first[r] + atoms[r].size();
+    *count = first[nr];
+    if (first[nr] > capacity) return fail(TM_E_OVERFLOW, "tm_batch_pick_records: output too small");
+    const uint64_t text_end = b->h_text_off[b->n_structs];
+    // Two passes per slice of runs: where every record starts (a load from the offsets' table per atom), then the copies
+    // with the lines of the record a few rows ahead asked for -- the text is a few hundred megabytes that no cache holds,
+    // and a copy that waits for its own miss costs a hundred nanoseconds (the team of host threads is usually busy
+    // reading the next batch's files, so this often runs on the calling thread alone)
+    auto fill = [&](uint32_t r0, uint32_t r1) {
+        std::vector<uint64_t> at;
+        at.reserve(first[r1] - first[r0]);
+        for (uint32_t r = r0; r < r1; ++r) {
+            const uint32_t s = hits[runs[r].first].structure;
+            uint64_t o = first[r];
+            for (uint32_t atom : atoms[r]) {
+                keys[o++] = ((uint64_t)s << 32) | atom;
+                at.push_back(b->h_text_off[s] + b->h_line_off[b->s_off[s] + atom]);
+            }
+        }
+        constexpr size_t kAhead = 12;
+        const char *text = b->h_text.p;
+        for (size_t i = 0; i < at.size(); ++i) {
+            if (i + kAhead < at.size() && at[i + kAhead] < text_end) {
+                __builtin_prefetch(text + at[i + kAhead]);
+                __builtin_prefetch(text + std::min<uint64_t>(at[i + kAhead] + 64, text_end - 1));
+            }
+            const uint64_t take = at[i] < text_end ? std::min<uint64_t>(width, text_end - at[i]) : 0;
+            uint8_t *dst = lines + (first[r0] + i) * width;
+            if (take) std::memcpy(dst, text + at[i], take);
+            if (take < width) std::memset(dst + take, '\n', width - take);
+        }
+    };
+    const uint32_t slices = std::min<uint32_t>(std::max(1u, nr / 64), host_team());
+    if (slices > 1) {
+        bool done = false;
+        for (int t = 0; t < HostPool::kTeams && !done; ++t)
+            done = HostPool::get(t).run(slices, [&](uint32_t k) { fill((uint32_t)((uint64_t)nr * k / slices), (uint32_t)((uint64_t)nr * (k + 1) / slices)); }, false);
+        if (!done) fill(0, nr);
+    } else {
+        fill(0, nr);
+    }
     return TM_OK;
 }
 

@@ -25,7 +25,8 @@ constexpr int kTripleQueue = 128;  // triple survivors waiting for their subtree
 // residues and within the limit, stored row by row (CSR over i) as {i | j << 16, squared fp32 distance}.
 struct TableDesc {
     uint16_t li_a, li_b;  // lead-kind indices
-    float dmax2;          // squared distance limit (already holds the prefilter slack); +inf: every pair
+    float dmax2;          // squared distance limit (already holds the prefilter slack); FINITE -- the widest class uses 3.0e38f:
+                          // tab_sweep folds its lane mask into the comparison as (counts ? d2 : +inf) <= dmax2
     // Tables of the same two kind lists differ in their distance limit only: the one with the largest limit (the group's
     // LEADER, src == its own index) is built by testing the lists' cross product; the others hold a subset of its
     // entries in the same order and are DERIVED from it by filtering (k_tab_build), which costs its entries, not the

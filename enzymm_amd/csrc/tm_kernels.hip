@@ -200,7 +200,10 @@ __global__ __launch_bounds__(64) void k_stage_templates(LibView L, uint32_t n_se
             r.resmask = L.k_resmask[kind];
             r.ref_any = (uint32_t)L.a_ref[off + lane] | (L.k_any[kind] ? 256u : 0u);
             r.w0 = window(lane, 0); r.w1 = window(lane, 1); r.w2 = window(lane, 2);
-            rescheck[(size_t)ti * kResChecks + rank_in(rc_mask)] = r;
+            // a template whose first three residues hold more than kResChecks such levels (one residue of 23 or 24 atoms)
+            // keeps the first kResChecks: D0 is a necessary-condition filter, a level it does not ask about is left to the search
+            const uint32_t slot = rank_in(rc_mask);
+            if (slot < (uint32_t)kResChecks) rescheck[(size_t)ti * kResChecks + slot] = r;
         }
     }
     if (lane == 0) {
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(64) void k_stage_templates(LibView L, uint32_t n_se
             q.li3 = 0xffffu;
             q.flags = 2u;
         }
-        q.n_rescheck = (uint32_t)__popcll(rc_mask);
+        q.n_rescheck = min((uint32_t)__popcll(rc_mask), (uint32_t)kResChecks);
         look[ti] = q;
         for (int i = 0; i < kMaxG; ++i) lead8[(size_t)ti * kMaxG + i] = i < g ? (uint16_t)L.k_lead[L.a_kind[off + i]] : (uint16_t)0xffffu;
     }
@@ -3297,23 +3300,30 @@ __global__ __launch_bounds__(256) void k_select(LibView L, BatchView B, QueryVie
 // A query's hit rows appended to a table that collects a rank's hits over several queries (tm_result_append_hits).
 // ONE workgroup: one reservation, rows copied 8 bytes per lane (a hit table is a few thousand rows of 232 bytes).
 static_assert(sizeof(tm_hit) % 8 == 0 && offsetof(tm_hit, structure) == 0, "k_append_hits copies rows as 64-bit words");
-__global__ __launch_bounds__(1024) void k_append_hits(const tm_hit *__restrict__ src, const unsigned long long *__restrict__ n_src,
-                                                       unsigned long long src_capacity, tm_hit *__restrict__ dst,
-                                                       unsigned long long dst_capacity, unsigned long long *__restrict__ dst_count,
-                                                       uint32_t structure_offset) {
+// Grid-wide (round 5; one 1024-thread workgroup before: on the critical path of every pass of a sharded run): workgroup b
+// takes the b-th slice of the source rows and reserves as many rows of the destination with one atomic -- the rows of a
+// pass table are unordered (rank 0 sorts after the gather), so the slices may land in any order.
+__global__ __launch_bounds__(256) void k_append_hits(const tm_hit *__restrict__ src, const unsigned long long *__restrict__ n_src,
+                                                      unsigned long long src_capacity, tm_hit *__restrict__ dst,
+                                                      unsigned long long dst_capacity, unsigned long long *__restrict__ dst_count,
+                                                      uint32_t structure_offset) {
     __shared__ unsigned long long s_base;
     unsigned long long n = *n_src;
     if (n > src_capacity) n = src_capacity;
-    if (threadIdx.x == 0) s_base = atomicAdd(dst_count, n);
+    const unsigned long long per = (n + gridDim.x - 1) / gridDim.x;
+    const unsigned long long row0 = per * blockIdx.x;
+    if (row0 >= n) return;
+    const unsigned long long rows = n - row0 < per ? n - row0 : per;
+    if (threadIdx.x == 0) s_base = atomicAdd(dst_count, rows);
     __syncthreads();
     const unsigned long long base = s_base;
     constexpr uint32_t kWords = sizeof(tm_hit) / 8;
-    const unsigned long long total = n * kWords;
+    const unsigned long long total = rows * kWords;
     for (unsigned long long w = threadIdx.x; w < total; w += blockDim.x) {
         const unsigned long long row = w / kWords;
         const uint32_t col = (uint32_t)(w % kWords);
         if (base + row >= dst_capacity) continue;
-        unsigned long long v = reinterpret_cast<const unsigned long long *>(src + row)[col];
+        unsigned long long v = reinterpret_cast<const unsigned long long *>(src + row0 + row)[col];
         // tm_hit.structure is the LOW word of a row's first 8 bytes: the offset is added to that word alone (a sum beyond
         // 2^32 must not carry into template_sel, the high word)
         if (col == 0) v = (v & 0xffffffff00000000ull) | (uint32_t)((uint32_t)v + structure_offset);

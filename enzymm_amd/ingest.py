@@ -178,35 +178,24 @@ class PdbBatch:
             return
         if not self._from_files:
             return self.annotate(np.unique(table["structure"]).tolist())
-        if not self._annotated:
-            self._line_off = self.native.line_offsets()
+        if getattr(self, "_res_counts_read", None) is None:
             self._res_counts = self.native.residue_counts() if self.native.has_residue_counts else None
-            self._text_view = self.native.text_view()
-            self._annotated = True
-        buffer, text_off = self._text_view
-        n = len(table)
-        valid = np.arange(table["atoms"].shape[1])[None, :] < table["n_atoms"][:, None]
-        structure = np.broadcast_to(table["structure"].astype(np.int64)[:, None], valid.shape)[valid]
-        key = np.unique(structure * 65536 + table["atoms"][valid].astype(np.int64))  # (structure, atom), sorted
-        structure, atom = key >> 16, key & 0xFFFF
-        record = self.native.atom_offsets.astype(np.int64)[structure] + atom
-        start = text_off.astype(np.int64)[structure] + self._line_off[record].astype(np.int64)
-        if len(start) and int(start.max()) + 96 <= len(buffer):
-            # rows of a sliding 96-byte window over the buffer: one 96-byte copy per matched atom
-            lines = np.lib.stride_tricks.sliding_window_view(buffer, 96)[start]
-        else:  # a record within 96 bytes of the end of the buffer: byte by byte, clamped
-            index = np.minimum(start[:, None] + np.arange(96, dtype=np.int64)[None, :], len(buffer) - 1)
-            lines = buffer[index]
-        # lines: [matched atoms, 96] bytes, a private copy
-        bounds = np.searchsorted(structure, np.arange(len(self.molecules) + 1))
-        counts = self._res_counts
-        for mi in np.unique(structure).tolist():
-            mol = self.molecules[mi]
-            lo, hi = bounds[mi], bounds[mi + 1]
-            mol._picked_idx = atom[lo:hi]
-            mol._picked_lines = lines[lo:hi]
+            self._res_counts_read = True
+        # per structure the distinct matched atoms, ascending, with 96 bytes from the start of each one's record: found
+        # and copied by the library on host threads (text and record offsets are on the host with the batch)
+        keys, lines = self.native.pick_records(table, 96)
+        structure = (keys >> np.uint64(32)).astype(np.int64)
+        atom = (keys & np.uint64(0xFFFFFFFF)).astype(np.int64)
+        matched, lo = np.unique(structure, return_index=True)
+        hi = np.append(lo[1:], len(structure)).tolist()
+        counts = self._res_counts.tolist() if self._res_counts is not None else None
+        molecules = self.molecules
+        for mi, a, b in zip(matched.tolist(), lo.tolist(), hi):
+            mol = molecules[mi]
+            mol._picked_idx = atom[a:b]
+            mol._picked_lines = lines[a:b]
             if counts is not None:
-                mol._residue_count = int(counts[mi])
+                mol._residue_count = counts[mi]
 
     @classmethod
     def from_paths(cls, paths: Sequence, **kw) -> "PdbBatch":
@@ -281,7 +270,7 @@ def _prefetched(items, build, prefetch: int, workers: int):
 
 
 def iter_molecule_batches(molecules: Sequence[pyjess.Molecule], batch_size: int = 2000, max_atoms: int = 8_000_000,
-                          prefetch: int = 2, workers: int = 1, device: Optional[int] = None):
+                          prefetch: int = 3, workers: int = 2, device: Optional[int] = None):
     """Yield ``MoleculeBatch`` objects over consecutive slices of ``molecules`` (at most ``batch_size`` molecules
     or ``max_atoms`` atoms each, at least one molecule), flattened and uploaded on a worker thread ahead of the
     consumer (the native call releases the GIL).  The consumer closes each batch."""
@@ -297,7 +286,7 @@ def iter_molecule_batches(molecules: Sequence[pyjess.Molecule], batch_size: int 
     return _prefetched(chunks, lambda c: MoleculeBatch(c, device), prefetch, workers)
 
 
-def iter_batches(paths: Sequence, batch_size: int = 1000, prefetch: int = 2, workers: int = 2, **kw):
+def iter_batches(paths: Sequence, batch_size: int = 1000, prefetch: int = 3, workers: int = 3, **kw):
     """Yield ``PdbBatch`` objects over ``paths`` in slices of ``batch_size`` files, in order, built on ``workers``
     ingest threads up to ``prefetch`` batches ahead: reading, uploading and parsing batch i+1 (and i+2) overlaps
     the search of batch i, and with two workers the file reads of one batch overlap the upload and the device parse

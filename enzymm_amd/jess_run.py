@@ -510,6 +510,7 @@ class Matcher:
         result is then keyed by its lazy ``Molecule`` objects.  A list longer than ``batch_size`` (default
         ``RUN_BATCH``) goes through the GPU in batches, pipelined like ``run_files``; the result -- its insertion
         order included -- is that of one pass over the whole list."""
+        self.refused = []  # (of THIS run: structures beyond the engine's atom limit, see _submit)
         if hasattr(molecules, "native") and hasattr(molecules, "molecules"):
             return self._collect(self._submit(molecules))
         molecules = list(molecules)
@@ -764,6 +765,7 @@ class Matcher:
         drops it), ``ignore_endmdl``, and ``workers`` / ``prefetch`` of ``iter_batches`` (2 / 2).  The result is
         that of ``run(load_molecules(paths))``, insertion order included, keyed by lazy molecules."""
         from . import ingest
+        self.refused = []
         return self._run_pipelined(ingest.iter_batches(paths, batch_size=batch_size, **ingest_options))
 
     def _run_pipelined(self, batches) -> Dict[pyjess.Molecule, List[Match]]:

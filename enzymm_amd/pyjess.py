@@ -711,9 +711,13 @@ def _settle_library_objects(n_templates: int) -> None:
     if _settled or n_templates < 512 or os.environ.get("ENZYMM_AMD_GC_FREEZE", "1") == "0":
         return
     import gc
+    import warnings
     _settled = True
     gc.collect()
     gc.freeze()
+    warnings.warn(f"enzymm_amd: a library of {n_templates} templates was packed; the objects alive now were moved to the "
+                  "garbage collector's permanent generation (gc.freeze) so that full collections stop walking them "
+                  "(ENZYMM_AMD_GC_FREEZE=0 leaves the collector alone)", UserWarning, stacklevel=3)
 
 
 _pack_lock = threading.Lock()
@@ -1248,7 +1252,13 @@ class _Sweeps:
             info.asked, info.planned, info.requests, info._pack = {}, {}, 0, None
             info.sel = np.arange(len(jess._templates), dtype=np.uint32)
             while len(self._keys) > 64:
-                self._keys.popitem(last=False)
+                # what was computed ahead for an evicted key goes with it: the key holds id(template tuple), and once the
+                # tuple is gone a new one may get its address
+                old_key, _ = self._keys.popitem(last=False)
+                for pair in [p for p in self._results if p[0] == old_key]:
+                    del self._results[pair]
+                for ukey in [u for u in self._unions if old_key in u]:
+                    del self._unions[ukey]
         info.last_seen = now
         return info
 

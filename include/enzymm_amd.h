@@ -189,6 +189,9 @@ typedef struct tm_hit {
 int tm_abi_version(void);
 const char *tm_last_error(void);
 int tm_device_count(int *count);
+/* Host threads one native call of this process may use: $ENZYMM_AMD_HOST_THREADS, else min(hardware threads, affinity
+ * mask, cgroup CPU quota, 16) / $LOCAL_WORLD_SIZE -- the ranks of a node (one process per GPU) share its host. */
+int tm_host_threads(void);
 /* A stream of its own for tm_query_params.stream (non-blocking with respect to the null stream): queries on
  * different streams overlap, e.g. the next batch's search with fetching the previous batch's hits. */
 int tm_stream_create(int device, void **stream);
@@ -224,8 +227,31 @@ int tm_batch_text_layout(tm_batch *batch, const char **base, uint64_t *offsets);
  * they came with.  *count receives how many there are; up to `capacity` of them are written. */
 int tm_batch_refused(const tm_batch *batch, uint32_t *structures, uint32_t *atoms, uint32_t capacity, uint32_t *count);
 int tm_batch_atom_counts(tm_batch *batch, uint32_t *atom_offsets);            /* [n_structures + 1] */
+/* tm_batch_create_from_structures / _from_columns return when their host-to-device copies are QUEUED (17 bytes per atom:
+ * one packed word, a chain ordinal, the coordinates as int32 thousandths of an Angstrom when they are such values exactly,
+ * else the structure's fp64 values; laid out in HBM by a kernel behind the copies); tm_query waits for them on its stream.
+ * tm_batch_wait blocks until the batch is resident; tm_batch_upload_bytes reports what the constructor sent. */
+int tm_batch_wait(tm_batch *batch);
+int tm_batch_upload_bytes(const tm_batch *batch, uint64_t *bytes);
+/* Diagnostic: the batch as it lies in HBM (any pointer may be NULL) -- fp64 coordinates [n_atoms * 3], records
+ * [n_atoms * 4] (centred fp32 xyz + packed word), chain ordinals, file-order indices, per structure the offset of its
+ * residue table [n_structures + 1] and the tables themselves (local index of every residue's first atom, n_res + 1 each).
+ * Atoms are residue-contiguous.  Tests compare the layouts the different constructors produce. */
+int tm_batch_copy_layout(tm_batch *batch, double *xyz, float *records, uint8_t *chain, uint32_t *orig,
+                         uint32_t *residue_offsets, uint16_t *residue_start);
 int tm_batch_line_offsets(tm_batch *batch, uint32_t *out, uint64_t n);        /* byte offset of each kept record in its file */
+/* the same for n chosen records (indices into the batch's concatenated atoms, e.g. the matched atoms of a hit table):
+ * a gather on the device instead of a copy of every offset */
+int tm_batch_line_offsets_at(tm_batch *batch, const uint32_t *records, uint64_t n, uint32_t *out);
 int tm_batch_residue_counts(tm_batch *batch, uint32_t *out);                  /* [n_structures]; TM_E_UNSUPPORTED without tm_vocab.counted_residue_names */
+/* Batches made by tm_batch_create_from_files: the text records of the atoms a hit table matched -- what a report row of
+ * enzymm needs of a matched molecule (Match.dump / dump2pdb, /root/reference/enzymm/jess_run.py:203-265) -- without a
+ * host-side parse of the file and without asking the device: per structure the distinct matched atoms, ascending, as
+ * keys[i] = structure << 32 | atom (file-order index) with the first `width` bytes of the atom's record in
+ * lines[i * width ..] (padded with newlines past the end of the text).  *count = rows written (or needed, with
+ * TM_E_OVERFLOW, when capacity is too small; the sum of tm_hit.n_atoms always suffices). */
+int tm_batch_pick_records(tm_batch *batch, const tm_hit *hits, uint64_t n_hits, uint32_t width, uint64_t capacity,
+                          uint64_t *keys, uint8_t *lines, uint64_t *count);
 void tm_batch_destroy(tm_batch *batch);
 
 /* Asynchronous on params->stream; the result owns the device-side hit table. */
