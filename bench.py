@@ -330,7 +330,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--structures", type=int, default=1000, help="synthetic structures per GPU")
     ap.add_argument("--batch", type=int, default=1000, help="structures per resident batch (one search launch each)")
-    ap.add_argument("--streamed-passes", type=int, default=8,
+    ap.add_argument("--streamed-passes", type=int, default=16,
                     help="extra passes with the batches uploaded from host memory under the timer (reported in "
                          "config.streamed_structures_per_s, never in value); 0 = skip")
     ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2, 3],

@@ -52,8 +52,12 @@ struct PhaseTrace {
         last = now;
     }
     ~PhaseTrace() {
-        if (on) std::fprintf(stderr, "%s host ms: %s total %.3f\n", label, line.c_str(),
-                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        // (start: milliseconds since the first traced call of the process; thread: which host thread made the call -- enough
+        // to lay the calls of a pipeline's threads side by side)
+        static const std::chrono::steady_clock::time_point origin = std::chrono::steady_clock::now();
+        if (on) std::fprintf(stderr, "%s host ms: %s total %.3f | start %.3f thread %lx\n", label, line.c_str(),
+                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(),
+                             std::chrono::duration<double, std::milli>(t0 - origin).count(), (unsigned long)pthread_self() & 0xffffff);
     }
 };
 
@@ -3262,12 +3266,6 @@ int tm_batch_create_from_files(int device, uint32_t n_files, const char *const *
             const uint64_t target = off[n_files] * (c + 1) / n_chunks;
             uint32_t f1 = f0;
             while (f1 < n_files && (c + 1 == n_chunks || off[f1 + 1] <= target || f1 == f0)) ++f1;
-            // (one chunk is read at a time, process-wide: reading is bound by memory bandwidth -- 190 MB in 2.6 ms on sixteen
-            // threads, twice that when two ingest threads read at once -- so the ingest threads of a pipeline take turns at
-            // the full rate, chunk by chunk, instead of running forty-eight threads on sixteen cores; what overlaps is one
-            // thread's reads with the others' uploads and device parses)
-            static std::mutex read_turn;
-            std::lock_guard<std::mutex> turn(read_turn);
             parallel_for(f1 - f0, 4, [&](uint32_t i) {
                 const uint32_t f = f0 + i;
                 const uint64_t want = sizes[f];

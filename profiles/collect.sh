@@ -50,8 +50,29 @@ PY
         --valu-ceiling "$out/${tag}_valu_ceiling.json" --head "$head" \
         "$out"/pmc_SQ_INSTS_VALU "$out"/pmc_SQ_ACTIVE_INST_ANY "$out"/pmc_SQ_INSTS_BRANCH "$out"/pmc_FETCH_SIZE "$out"/pmc_WRITE_SIZE "$out"/pmc_TCC_HIT_sum >> "$out/summary.log" 2>&1
 done
+# The kept bench JSON is printed AFTER profiles/LATEST (on this box) points at this very PMC set, so that the traffic and
+# the secondary figures inside it are its own (the set above was collected with an earlier LATEST)
+for short in k_search k_deep k_tab_build; do cp "$out/${tag}_${short}_pmc.json" profiles/ 2>/dev/null; done
+cp "$out/${tag}_valu_ceiling.json" profiles/ 2>/dev/null
+python3 - "$tag" "$head" > "$out/LATEST" <<'PY'
+import json, sys
+tag, head = sys.argv[1], sys.argv[2]
+print(json.dumps({"git_head": head, "k_search_pmc": f"{tag}_k_search_pmc.json", "k_deep_pmc": f"{tag}_k_deep_pmc.json",
+                  "k_tab_build_pmc": f"{tag}_k_tab_build_pmc.json", "kernel_stats": f"{tag}_bench1000_kernel_stats.csv",
+                  "kernel_stats_one_in_flight": f"{tag}_bench1000_pipeline1_kernel_stats.csv",
+                  "valu_ceiling": f"{tag}_valu_ceiling.json", "bench": f"{tag}_bench1000.json",
+                  "parity_census": [f"{tag}_parity_census_1000.json", f"{tag}_parity_census_real64.json", f"{tag}_parity_census_config5.json"]}, indent=1))
+PY
+cp "$out/LATEST" profiles/LATEST
+mv "$out/${tag}_bench1000.json" "$out/${tag}_bench1000_before_pmc.json"
+timeout 900 python3 bench.py --steps 10 --warmup 2 > "$out/${tag}_bench1000.json" 2> "$out/bench2.err"
+# The whole-batch parity census on the SAME build, in the SAME call: 1000 x 6780 of the headline batch,
+# a 64-structure sample of the real-structure batch, configs[4] at the default cutoffs -- each stamped with .build_head
+timeout 900 python3 tests/gpu_parity_census.py 1000 0 synthetic > "$out/census1000.log" 2>&1 && mv gpurun_out/parity_census.json "$out/${tag}_parity_census_1000.json"
+timeout 600 python3 tests/gpu_parity_census.py 64 0 real > "$out/census_real.log" 2>&1 && mv gpurun_out/parity_census.json "$out/${tag}_parity_census_real64.json"
+timeout 900 python3 tests/gpu_parity_census.py 10 0 config5 > "$out/census_c5.log" 2>&1 && mv gpurun_out/parity_census.json "$out/${tag}_parity_census_config5.json"
 # (the raw traces stay on the box: gpurun copies back 64 MiB at most)
 rm -rf "$out"/trace "$out"/trace1
 find "$out" -name "*.csv" -path "*pmc_*" -size +4M -delete
-cat "$out/${tag}_bench1000.json" "$out/summary.log"
+cat "$out/${tag}_bench1000.json" "$out/summary.log" "$out"/${tag}_parity_census_*.json
 [ -f "$out/${tag}_bench1000_kernel_stats.csv" ] && head -8 "$out/${tag}_bench1000_kernel_stats.csv"

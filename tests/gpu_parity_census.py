@@ -19,11 +19,20 @@ from oracle import oracle  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 start = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+workload = sys.argv[3] if len(sys.argv) > 3 else "synthetic"
 idx, cut = helpers.default_selection()
 jess = pyjess.Jess(helpers.product_library_templates())
 otpl = helpers.oracle_library_templates()
 olib = oracle.OracleLibrary([otpl[i] for i in idx])
-mols = synthetic.structures(n, start=start)
+if workload == "real":  # the first n structures of bench.py's real-structure batch (rigid copies of 1AMY and AF-P0DUB6, shuffled)
+    real = [pyjess.Molecule.load(helpers.GOLDEN / f) for f in ("1AMY.pdb", "AF-P0DUB6-F1-model_v4.pdb")]
+    copies = synthetic.rigid_copies(real[0], 500, seed=7) + synthetic.rigid_copies(real[1], 500, seed=8)
+    order = np.random.default_rng(5).permutation(len(copies))
+    mols = [copies[i] for i in order][start:start + n]
+elif workload == "config5":  # BASELINE.json configs[4]: multi-chain complexes of ~6300 residues, conserved(70), default cutoffs
+    mols = [synthetic.complex_structure(start + i, 6000).conserved(70) for i in range(n)]
+else:
+    mols = synthetic.structures(n, start=start)
 t0 = time.time()
 table, cands = jess.query_batch(mols, 2.0, cut, cut, max_candidates=10000, ignore_chain=True, template_index=idx,
                                 count_candidates=True, return_raw=True)
@@ -37,7 +46,7 @@ t_cpu = time.time() - t0
 by_s = {}
 for h in table:
     by_s.setdefault(int(h["structure"]), {})[int(h["template_sel"])] = h
-out = dict(structures=n, first_structure=start, templates=int(len(idx)), hits_gpu=int(len(table)), hits_oracle=0, hit_set_mismatches=0,
+out = dict(workload=workload, structures=n, first_structure=start, atoms_per_structure=float(np.mean([len(m) for m in mols])), templates=int(len(idx)), hits_gpu=int(len(table)), hits_oracle=0, hit_set_mismatches=0,
            atom_mismatches=0, rmsd_beyond_1e5=0, max_rmsd_difference=0.0, candidate_count_mismatches=0, truncation_mismatches=0,
            truncated_pairs=0, candidates_total=0, gpu_seconds_first_call=round(t_gpu, 3), oracle_seconds=round(t_cpu, 1), oracle_threads=cores)
 for s, r in enumerate(results):
