@@ -2583,7 +2583,9 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
         // square of the atom count), at least one; heaviest structures first
         if (b->work_cx != cx || b->work_n_sel != n_sel) {
             const uint32_t ns = b->n_structs;
-            const uint32_t per_class_target = std::max<uint32_t>(ns, 2048u >> cx);
+            // (ENZYMM_AMD_UNITS: work items per chunk class to aim for -- experiments with finer units at the end of a queued launch)
+            static const uint32_t units_env = [] { const char *e = std::getenv("ENZYMM_AMD_UNITS"); return e ? (uint32_t)std::max(0, std::atoi(e)) : 0u; }();
+            const uint32_t per_class_target = units_env ? std::max<uint32_t>(ns, units_env) : std::max<uint32_t>(ns, 2048u >> cx);
             const uint32_t max_rounds = std::min<uint32_t>(std::max<uint32_t>(1u, n_sel / (min_chunk << cx)), 0xffffu);
             std::vector<double> cost(ns);
             double total = 0.0;
