@@ -14,7 +14,8 @@ import numpy as np
 
 TM_MAX_TEMPLATE_ATOMS = 24
 TM_MAX_TEMPLATE_GROUPS = 8
-TM_MAX_STRUCTURE_ATOMS = 65535
+TM_MAX_STRUCTURE_ATOMS = 16777215   # beyond it a structure is refused (kept in its batch as an empty one)
+TM_NARROW_STRUCTURE_ATOMS = 65535  # up to here the 16-bit atom indices of the tuned kernels; larger: the template-at-a-time launch, 24-bit indices
 TM_RES_OTHER = 31
 TM_NAME_OTHER = 63
 

@@ -586,6 +586,12 @@ struct IndexShared {
 struct tm_batch {
     int device = 0;
     uint32_t n_structs = 0, n_atoms = 0, max_atoms = 0, max_res = 0;
+    // WIDE structures (more than TM_NARROW_STRUCTURE_ATOMS atoms, round 5): the upper bits of their atom indices live in
+    // byte arrays beside the 16-bit ones (allocated only when the batch holds one); the LDS layouts of the tuned kernels
+    // are sized for the largest NARROW structure -- the wide ones are searched by a launch of their own (tm_query)
+    bool has_wide = false;
+    uint32_t max_atoms_narrow = 0, max_res_narrow = 0;
+    DevBuf<uint8_t> d_res_start_hi, d_kl_pool_hi;
     // structures beyond TM_MAX_STRUCTURE_ATOMS: kept in the batch as EMPTY structures (no hits), listed here with the
     // atom counts they came with (tm_batch_refused) -- one oversized file does not fail the batch it arrives in
     std::vector<uint32_t> refused, refused_atoms;
@@ -645,6 +651,7 @@ struct tm_batch {
         v.n_structs = n_structs; v.s_off = d_s_off.p; v.s_roff = d_s_roff.p; v.q_xyz = d_xyz.p;
         v.q_rec = d_rec.p; v.q_chain = d_chain.p; v.q_orig = d_orig.p; v.res_start = d_res_start.p;
         v.kl_off = d_kl_off.p; v.kl_pool = d_kl_pool.p;
+        v.kl_pool_hi = has_wide ? d_kl_pool_hi.p : nullptr; v.res_start_hi = has_wide ? d_res_start_hi.p : nullptr;
         v.n_tables = n_tables; v.tab_dir = d_tab_dir.p; v.tab_rows = d_tab_rows.p; v.tab_ent = d_tab_ent.p;
         v.tab_seg = d_tab_seg.p; v.tab_ok = d_tab_ok.p; v.tab_ref = d_tab_ref.p;
         return v;
@@ -658,6 +665,9 @@ struct tm_result {
     unsigned long long hit_capacity = 0, cand_capacity = 0;
     DevBuf<tm_hit> d_hits;
     DevBuf<Cand> d_cands;
+    DevBuf<uint8_t> d_cands_hi;  // bits 16-23 of the candidates' atoms (batches with a wide structure)
+    DevBuf<WorkItem> d_wide_work;  // the work items of the wide structures' launch
+    PinnedBuf<WorkItem> h_wide_work;
     DevBuf<PairEntry> d_pairs;
     DevBuf<unsigned long long> d_counters;  // [0] hits, [1] candidates, [2] pairs, [3] pages of triples
     DevBuf<uint32_t> d_queue;  // the queued block search: next unit per chunk class (8 counters)
@@ -947,9 +957,11 @@ int batch_from_encoded(int device, const tm_batch_desc *d, const double *const *
     PinnedBuf<uint8_t> chain;
     PinnedBuf<uint32_t> orig;
     PinnedBuf<uint16_t> res_start;
+    PinnedBuf<uint8_t> res_start_hi;  // (bits 16-23: a batch with a structure of more than 65535 atoms)
     HIP_TRY(xyz.alloc(3 * (size_t)na)); HIP_TRY(rec.alloc(na)); HIP_TRY(chain.alloc(na)); HIP_TRY(orig.alloc(na));
     std::vector<uint32_t> s_roff(ns + 1, 0), nres_of(ns, 0);
-    uint32_t max_atoms = 0, max_res = 0;
+    uint32_t max_atoms = 0, max_res = 0, max_atoms_narrow = 0, max_res_narrow = 0;
+    bool has_wide = false;
 
     // pass 1: limits and residue counts (they fix where every structure's residue table starts)
     for (uint32_t s = 0; s < ns; ++s) {
@@ -967,8 +979,11 @@ int batch_from_encoded(int device, const tm_batch_desc *d, const double *const *
         s_roff[s + 1] = s_roff[s] + nres + 1;
         max_atoms = std::max(max_atoms, n);
         max_res = std::max(max_res, nres);
+        if (n > TM_NARROW_STRUCTURE_ATOMS) has_wide = true;
+        else { max_atoms_narrow = std::max(max_atoms_narrow, n); max_res_narrow = std::max(max_res_narrow, nres); }
     }
     HIP_TRY(res_start.alloc(s_roff[ns]));
+    if (has_wide) HIP_TRY(res_start_hi.alloc(s_roff[ns]));
     trace.mark("limits");
 
     // pass 2: the structures are independent; a small team of threads flattens them
@@ -982,7 +997,10 @@ int batch_from_encoded(int device, const tm_batch_desc *d, const double *const *
             count.assign(nres + 1, 0);
             for (uint32_t i = 0; i < n; ++i) count[d->residue[o + i] + 1]++;
             for (uint32_t r = 0; r < nres; ++r) count[r + 1] += count[r];
-            for (uint32_t r = 0; r <= nres; ++r) res_start[s_roff[s] + r] = (uint16_t)count[r];
+            for (uint32_t r = 0; r <= nres; ++r) {
+                res_start[s_roff[s] + r] = (uint16_t)count[r];
+                if (has_wide) res_start_hi[s_roff[s] + r] = (uint8_t)(count[r] >> 16);
+            }
             perm.assign(n, 0);
             fill.assign(count.begin(), count.end() - 1);
             for (uint32_t i = 0; i < n; ++i) perm[fill[d->residue[o + i]]++] = i;
@@ -1039,6 +1057,7 @@ int batch_from_encoded(int device, const tm_batch_desc *d, const double *const *
     if (!b) return fail(TM_E_NOMEM, "out of host memory");
     b->device = device;
     b->n_structs = ns; b->n_atoms = na; b->max_atoms = max_atoms; b->max_res = max_res;
+    b->has_wide = has_wide; b->max_atoms_narrow = max_atoms_narrow; b->max_res_narrow = max_res_narrow;
     {
         const uint32_t bits = extent_bits.load();
         std::memcpy(&b->extent, &bits, 4);
@@ -1051,6 +1070,7 @@ int batch_from_encoded(int device, const tm_batch_desc *d, const double *const *
     up(b->d_xyz.upload_async(xyz.p, xyz.n, stream)); up(b->d_rec.upload_async(rec.p, rec.n, stream));
     up(b->d_chain.upload_async(chain.p, chain.n, stream)); up(b->d_orig.upload_async(orig.p, orig.n, stream));
     up(b->d_res_start.upload_async(res_start.p, res_start.n, stream));
+    if (has_wide) up(b->d_res_start_hi.upload_async(res_start_hi.p, res_start_hi.n, stream));
     up(b->d_s_off.upload(b->s_off, stream)); up(b->d_s_roff.upload(s_roff, stream));  // these also wait for the stream
     up(b->d_cursor.alloc(1)); up(b->d_overflow.alloc(1));
     if (e == hipSuccess && stream) up(hipStreamSynchronize(stream));
@@ -1369,6 +1389,8 @@ int batch_from_structures(int device, uint32_t ns, const tm_structure_columns *s
                                               std::to_string(TM_MAX_STRUCTURE_RESIDUES) + " residues");
         h_s_roff[s + 1] = h_s_roff[s] + E.nres + 1;
         max_atoms = std::max(max_atoms, n); max_res = std::max(max_res, E.nres);
+        if (n > TM_NARROW_STRUCTURE_ATOMS) b->has_wide = true;
+        else { b->max_atoms_narrow = std::max(b->max_atoms_narrow, n); b->max_res_narrow = std::max(b->max_res_narrow, E.nres); }
         extent = std::max(extent, E.reach);
         FlatDesc &D = h_desc[s];
         D.c[0] = E.c[0]; D.c[1] = E.c[1]; D.c[2] = E.c[2];
@@ -1411,6 +1433,7 @@ int batch_from_structures(int device, uint32_t ns, const tm_structure_columns *s
     HIP_TRY(b->d_stage.alloc(arena_bytes));
     HIP_TRY(b->d_xyz.alloc(3 * (size_t)na)); HIP_TRY(b->d_rec.alloc(na)); HIP_TRY(b->d_chain.alloc(na)); HIP_TRY(b->d_orig.alloc(na));
     HIP_TRY(b->d_res_start.alloc(h_s_roff[ns]));
+    if (b->has_wide) HIP_TRY(b->d_res_start_hi.alloc(h_s_roff[ns]));
     HIP_TRY(b->d_s_off.alloc((size_t)ns + 1)); HIP_TRY(b->d_s_roff.alloc((size_t)ns + 1));
     HIP_TRY(b->d_cursor.alloc(1)); HIP_TRY(b->d_overflow.alloc(1));
     HIP_TRY(hipMemcpyAsync(b->d_stage.p, b->h_stage.p, o_chain, hipMemcpyHostToDevice, stream));
@@ -1430,7 +1453,7 @@ int batch_from_structures(int device, uint32_t ns, const tm_structure_columns *s
                            reinterpret_cast<const int32_t *>(b->d_stage.p + o_milli),
                            reinterpret_cast<const double *>(b->d_side.p),
                            reinterpret_cast<const uint32_t *>(b->d_side.p ? b->d_side.p + 24 * side_xyz : nullptr),
-                           b->d_xyz.p, b->d_rec.p, b->d_orig.p, b->d_res_start.p);
+                           b->d_xyz.p, b->d_rec.p, b->d_orig.p, b->d_res_start.p, b->has_wide ? b->d_res_start_hi.p : nullptr);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventCreateWithFlags(&b->ready, hipEventDisableTiming));
@@ -1528,6 +1551,7 @@ struct HostFlattened {
     std::vector<uint8_t> chain;
     std::vector<uint32_t> orig;    // device position -> kept-record index in file order
     std::vector<uint16_t> res_start;
+    std::vector<uint8_t> res_start_hi;  // bits 16-23 (a file of more than 65535 kept atoms)
 };
 
 }  // namespace
@@ -1614,7 +1638,8 @@ static int flatten_pdb_on_host(const char *text, uint64_t length, uint32_t flags
     out->n_res = nres;
     out->residue_count = distinct_counted;
     out->res_start.resize(nres + 1);
-    for (uint32_t r = 0; r <= nres; ++r) out->res_start[r] = (uint16_t)count[r];
+    out->res_start_hi.resize(nres + 1);
+    for (uint32_t r = 0; r <= nres; ++r) { out->res_start[r] = (uint16_t)count[r]; out->res_start_hi[r] = (uint8_t)(count[r] >> 16); }
     fill.assign(count.begin(), count.end() - 1);
     out->orig.resize(n);
     for (uint32_t j = 0; j < n; ++j) out->orig[fill[residue[j]]++] = j;
@@ -1841,12 +1866,19 @@ static int batch_from_pdb_text(int device, uint32_t n_files, const char *const *
         s_roff[f + 1] = s_roff[f] + runs[f] + 1;
         max_atoms = std::max(max_atoms, n);
         max_res = std::max(max_res, runs[f]);
+        // (a file of more than 65535 kept atoms came through the host path above: k_pdb_residues sends it there)
+        if (n > TM_NARROW_STRUCTURE_ATOMS) b->has_wide = true;
+        else { b->max_atoms_narrow = std::max(b->max_atoms_narrow, n); b->max_res_narrow = std::max(b->max_res_narrow, runs[f]); }
     }
     if (oversized && !oversized->empty()) return TM_OK;  // (*out is still NULL: tm_batch_create_from_pdb lays the batch out again)
     b->max_atoms = max_atoms; b->max_res = max_res; b->s_off = s_off;
     HIP_TRY(b->d_s_off.upload(s_off, stream)); HIP_TRY(b->d_s_roff.upload(s_roff, stream));
     HIP_TRY(b->d_rec.alloc(n_atoms)); HIP_TRY(b->d_chain.alloc(n_atoms)); HIP_TRY(b->d_orig.alloc(n_atoms));
     HIP_TRY(b->d_res_start.alloc(s_roff[n_files]));
+    if (b->has_wide) {
+        HIP_TRY(b->d_res_start_hi.alloc(s_roff[n_files]));
+        HIP_TRY(hipMemsetAsync(b->d_res_start_hi.p, 0, s_roff[n_files], stream));  // (zero for every file the device finalises)
+    }
     HIP_TRY(b->d_cursor.alloc(1)); HIP_TRY(b->d_overflow.alloc(1));
     HIP_TRY(b->d_residue_count.alloc(n_files));
     b->has_residue_count = n_counted != 0;
@@ -1865,6 +1897,8 @@ static int batch_from_pdb_text(int device, uint32_t n_files, const char *const *
         }
         HIP_TRY(hipMemcpyAsync(b->d_res_start.p + s_roff[h.file], h.res_start.data(), h.res_start.size() * sizeof(uint16_t),
                                hipMemcpyHostToDevice, stream));
+        if (b->has_wide)
+            HIP_TRY(hipMemcpyAsync(b->d_res_start_hi.p + s_roff[h.file], h.res_start_hi.data(), h.res_start_hi.size(), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipMemcpyAsync(b->d_residue_count.p + h.file, &h.residue_count, sizeof(uint32_t), hipMemcpyHostToDevice, stream));
     }
     // the records' byte offsets also go to the host (the other direction of the link, idle during ingestion): reporting
@@ -2017,6 +2051,10 @@ static int build_index(const tm_library *lib, tm_batch *b, tm_result *r, hipStre
         if (b->queried) HIP_TRY(hipStreamSynchronize(b->last_stream));  // an earlier query may still read the old pool
         HIP_TRY(b->d_kl_pool.alloc(cap + 8));
     }
+    if (b->has_wide && b->d_kl_pool_hi.n != cap + 8) {
+        if (b->queried) HIP_TRY(hipStreamSynchronize(b->last_stream));
+        HIP_TRY(b->d_kl_pool_hi.alloc(cap + 8));
+    }
     b->pool_capacity = cap;
     {
         ZeroList z = {};
@@ -2033,8 +2071,8 @@ static int build_index(const tm_library *lib, tm_batch *b, tm_result *r, hipStre
                            (size_t)std::min<uint32_t>(b->max_atoms, bucket_cap) * 2 * sizeof(uint16_t) + 16;
         HIP_TRY(allow_dynamic_lds(reinterpret_cast<const void *>(k_kind_lists), lds));
         hipLaunchKernelGGL(k_kind_lists, dim3(b->n_structs), dim3(512), lds, stream,
-                           lib->view(), b->view(), b->d_kl_off.p, b->d_kl_pool.p, b->d_cursor.p, cap,
-                           b->d_overflow.p, bucket_cap);
+                           lib->view(), b->view(), b->d_kl_off.p, b->d_kl_pool.p, b->has_wide ? b->d_kl_pool_hi.p : nullptr,
+                           b->d_cursor.p, cap, b->d_overflow.p, bucket_cap);
         HIP_TRY(hipGetLastError());
     }
     b->index_for = lib->serial;
@@ -2154,7 +2192,8 @@ static int build_tables(const tm_library *lib, tm_batch *b, const StagedSelectio
     const bool mostly_large = (size_t)b->n_atoms > (size_t)3800 * ns;
     // (such a batch still reserves 4096 records = 64 KB, two workgroups per CU: the staging area for list B of the
     // big tables its workgroups build together)
-    uint32_t lr_cap = mostly_large ? 4096u : (uint32_t)std::min<size_t>(9600, std::max<size_t>(1024, 3 * (size_t)b->max_atoms));
+    // (sized for the largest NARROW structure: a wide one reads its records through L2 inside whichever layout runs)
+    uint32_t lr_cap = mostly_large ? 4096u : (uint32_t)std::min<size_t>(9600, std::max<size_t>(1024, 3 * (size_t)b->max_atoms_narrow));
     size_t lds_bytes = (size_t)lr_cap * sizeof(float4) + ((size_t)lib->n_lead + 2) * sizeof(uint32_t);  // s_lr + s_kl
     // Compact layout -- atom records once (16 B per atom) and the kind lists as positions (2 B each) instead of a record
     // per position: when the batch's largest structure then leaves room for TWO workgroups per CU (80 KB each), the
@@ -2164,9 +2203,9 @@ static int build_tables(const tm_library *lib, tm_batch *b, const StagedSelectio
         const char *compact_env = std::getenv("ENZYMM_AMD_TAB_COMPACT");  // experiments and tests: 0 = a record per list position
         const bool off = compact_env && std::atoi(compact_env) == 0;
         const size_t budget = 80 * 1024 - 512;  // static LDS of the kernel and allocation granularity
-        const size_t fixed = (size_t)b->max_atoms * sizeof(float4) + ((size_t)lib->n_lead + 2) * sizeof(uint32_t);
-        if (!off && !mostly_large && fixed + 2 * 2 * (size_t)b->max_atoms + 16 <= budget) {  // room for two positions per atom at least
-            atom_cap = b->max_atoms;
+        const size_t fixed = (size_t)b->max_atoms_narrow * sizeof(float4) + ((size_t)lib->n_lead + 2) * sizeof(uint32_t);
+        if (!off && !mostly_large && b->max_atoms_narrow && fixed + 2 * 2 * (size_t)b->max_atoms_narrow + 16 <= budget) {  // room for two positions per atom at least
+            atom_cap = b->max_atoms_narrow;
             lr_cap = (uint32_t)std::min<size_t>(65528, ((budget - fixed) / sizeof(uint16_t)) & ~size_t(7));
             lds_bytes = (size_t)atom_cap * sizeof(float4) + (size_t)lr_cap * sizeof(uint16_t) + ((size_t)lib->n_lead + 2) * sizeof(uint32_t);
         }
@@ -2444,6 +2483,11 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
     HIP_TRY(r->d_pairs.alloc(hcap));
     HIP_TRY(r->d_cands.alloc(ccap));
     HIP_TRY(r->d_cand_rmsd.alloc(ccap));
+    if (b->has_wide) {
+        // (zeroed per query: the launches that search the narrow structures write no upper bits)
+        HIP_TRY(r->d_cands_hi.alloc((size_t)ccap * kMaxK));
+        HIP_TRY(hipMemsetAsync(r->d_cands_hi.p, 0, (size_t)ccap * kMaxK, stream));
+    }
     HIP_TRY(r->d_counters.alloc(4));
     HIP_TRY(r->d_queue.alloc(8));
     HIP_TRY(r->d_overflow.alloc(1));
@@ -2560,7 +2604,7 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
     if (const char *env = std::getenv("ENZYMM_AMD_HANDOVER"))  // test hooks: 0 = a wave keeps every subtree it starts, 2 = it hands over whatever it can
         Q.flags |= std::atoi(env) == 0 ? 0x10000u : std::atoi(env) == 2 ? 0x20000u : 0u;
     OutView O;
-    O.cands = r->d_cands.p; O.cand_rmsd = r->d_cand_rmsd.p; O.n_cands = r->d_counters.p + 1; O.cand_capacity = ccap;
+    O.cands = r->d_cands.p; O.cands_hi = b->has_wide ? r->d_cands_hi.p : nullptr; O.cand_rmsd = r->d_cand_rmsd.p; O.n_cands = r->d_counters.p + 1; O.cand_capacity = ccap;
     O.pairs = r->d_pairs.p; O.n_pairs = r->d_counters.p + 2; O.pair_capacity = hcap;
     O.hits = r->d_hits.p; O.n_hits = r->d_counters.p; O.hit_capacity = hcap; O.overflow = r->d_overflow.p;
     O.pair_count = r->d_pair_count.p; O.pair_last = r->d_pair_last.p;
@@ -2638,17 +2682,18 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
         const uint32_t per_group = 8u >> cx;  // work items per group of 8 consecutive workgroups
         uint32_t grid = (b->work_items + per_group - 1) / per_group * 8u;
         const bool ic = (p->flags & TM_FLAG_IGNORE_CHAIN) != 0;
-        SearchArgs args{lib->view(), b->view(), Q, O, b->d_work.p, b->work_items, cx, b->max_atoms, b->max_res, 0u, nullptr, 0u, nullptr, 0u};
+        // (the LDS layouts are sized for the largest NARROW structure: the wide ones are passed over by these launches)
+        SearchArgs args{lib->view(), b->view(), Q, O, b->d_work.p, b->work_items, cx, b->max_atoms_narrow, b->max_res_narrow, 0u, nullptr, 0u, nullptr, 0u, 0u};
         // One launch of k_search in `mode`: the structure of a workgroup goes to LDS when the mode's per-wave scratch
         // leaves room for the largest structure of the batch; whatever LDS is left after that holds the structure's
         // kind lists (one workgroup per CU either way).
-        auto launch = [&](int mode) -> int {
+        auto launch = [&](int mode, bool force_global = false) -> int {
             const size_t scratch = search_scratch_bytes(mode);
-            const size_t base = scratch + (size_t)b->max_atoms * sizeof(float4) + search_res_bytes(b->max_res) +
+            const size_t base = scratch + (size_t)b->max_atoms_narrow * sizeof(float4) + search_res_bytes(b->max_res_narrow) +
                                 search_kl_words(lib->view().n_lead) * sizeof(uint32_t);
             static const size_t lds_budget = std::getenv("ENZYMM_AMD_LDS_BUDGET") ? (size_t)std::atol(std::getenv("ENZYMM_AMD_LDS_BUDGET")) : 160 * 1024;  // experiments
             const size_t lds_limit = lds_budget - 64 - search_static_bytes(mode);
-            const bool lds_path = base <= lds_limit;
+            const bool lds_path = base <= lds_limit && !force_global;
             args.pool_cap = lds_path ? (uint32_t)((lds_limit - base) / sizeof(uint16_t)) & ~7u : 0u;  // (copied in 16-byte words)
             const size_t lds_bytes = lds_path ? lds_limit : scratch + (mode == kModeDeep ? search_cache_bytes() : 0);
             void (*kernel)(SearchArgs) = nullptr;
@@ -2673,11 +2718,35 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
         int rc = launch(kModeBlocks);
         if (rc != TM_OK) return rc;
         // templates the block search leaves out (k_tab_refs marks them kRefSingly), one template per wave at a time
-        const bool huge = (uint64_t)b->max_atoms * b->max_atoms >= (uint64_t)kRefLenMask;
+        const bool huge = (uint64_t)b->max_atoms_narrow * b->max_atoms_narrow >= (uint64_t)kRefLenMask;
         if (huge || !S->small.empty()) {
             args.singly = huge ? S->d_all.p : S->d_small.p;
             args.n_singly = huge ? n_sel : (uint32_t)S->small.size();
             rc = launch(kModeSingly);
+            if (rc != TM_OK) return rc;
+        }
+        if (b->has_wide) {
+            // The wide structures (more than 65535 atoms: 24-bit atom indices): every template, one per wave at a time, the
+            // structure's records in global memory -- a launch of its own over work items of its own (k_tab_refs marked
+            // every template of such a structure for it; the launches above passed those structures over).
+            std::vector<WorkItem> items;
+            const uint32_t max_rounds = std::min<uint32_t>(std::max<uint32_t>(1u, n_sel / ((2u * kSearchWaves) << cx)), 0xffffu);
+            uint32_t n_wide = 0;
+            for (uint32_t s = 0; s < b->n_structs; ++s) n_wide += b->s_off[s + 1] - b->s_off[s] > TM_NARROW_STRUCTURE_ATOMS ? 1u : 0u;
+            const uint32_t rounds = std::min<uint32_t>(max_rounds, std::max<uint32_t>(1u, (512u >> cx) / std::max(1u, n_wide)));
+            for (uint32_t s = 0; s < b->n_structs; ++s)
+                if (b->s_off[s + 1] - b->s_off[s] > TM_NARROW_STRUCTURE_ATOMS)
+                    for (uint32_t k = 0; k < rounds; ++k) items.push_back(WorkItem{s, (uint16_t)k, (uint16_t)rounds});
+            HIP_TRY(r->h_wide_work.alloc(items.size()));
+            std::copy(items.begin(), items.end(), r->h_wide_work.p);
+            HIP_TRY(r->d_wide_work.upload_async(r->h_wide_work.p, items.size(), stream));
+            const WorkItem *narrow_work = args.work;
+            const uint32_t narrow_items = args.n_items, narrow_grid = grid;
+            args.work = r->d_wide_work.p; args.n_items = (uint32_t)items.size(); args.wide_only = 1u;
+            args.singly = S->d_all.p; args.n_singly = n_sel;
+            grid = ((uint32_t)items.size() + per_group - 1) / per_group * 8u;
+            rc = launch(kModeSingly, true);
+            args.work = narrow_work; args.n_items = narrow_items; args.wide_only = 0u; grid = narrow_grid;
             if (rc != TM_OK) return rc;
         }
         HIP_TRY(hipEventRecord(r->ev[4], stream));
@@ -2792,6 +2861,9 @@ int tm_result_wait(tm_result *r) {
             r->index_shared->stale = true;
         }
     }
+    if (r->overflow & 0x100u)
+        return fail(TM_E_UNSUPPORTED, "a structure of this batch has more than 65535 atoms admissible to one template atom kind: "
+                                      "beyond the 16-bit list positions of the pair tables");
     if (r->overflow & 16u)
         return fail(TM_E_OVERFLOW, "pair-table pools too small (" + std::to_string(r->row_capacity) + " row slots, " +
                                        std::to_string(r->ent_capacity) +

@@ -51,6 +51,13 @@ inline double prefilter_slack(double extent) {
     return slack;
 }
 
+// Atoms a structure may have for the 16-bit local atom indices of the tuned paths (kind lists, residue tables, queue
+// entries, pages, candidates).  A WIDE structure -- more than that, up to TM_MAX_STRUCTURE_ATOMS -- keeps the upper bits of
+// its atom indices in byte arrays beside the 16-bit ones (kl_pool_hi, res_start_hi, cands_hi; allocated only for batches
+// that hold such a structure) and is searched by the template-at-a-time launch alone, with its records in global memory;
+// the block search and k_deep pass it over (round 5: it was refused before).
+constexpr uint32_t kNarrowAtoms = TM_NARROW_STRUCTURE_ATOMS;
+
 // best_match: candidates within this of the (global) minimum RMSD are tied with it; the smallest atom-index tuple wins.
 constexpr double kTieEps = 1e-9;
 
@@ -98,7 +105,9 @@ struct BatchView {
     const uint16_t *res_start;  // per structure: n_res+1 local atom indices
     // candidate index for one library: for each (structure, lead kind) the admissible atoms
     const uint32_t *kl_off;   // [n_structs*(n_lead+1)] offsets into kl_pool
-    const uint16_t *kl_pool;  // local atom indices, ascending
+    const uint16_t *kl_pool;  // local atom indices, ascending (low 16 bits)
+    const uint8_t *kl_pool_hi;   // bits 16-23 of the same entries; NULL: the batch has no wide structure
+    const uint8_t *res_start_hi; // bits 16-23 of res_start, same indexing; NULL likewise
     // pair tables for one staged selection: row r of table t of structure s is entries
     // [tab_rows[tab_dir[s * n_tables + t] + r], tab_rows[... + r + 1]) of tab_ent
     uint32_t n_tables;
@@ -228,6 +237,7 @@ struct PairEntry {
 
 struct OutView {
     Cand *cands;
+    uint8_t *cands_hi;       // [cand_capacity * kMaxK] bits 16-23 of Cand::atoms; NULL: the batch has no wide structure
     double *cand_rmsd;
     unsigned long long *n_cands;
     unsigned long long cand_capacity;

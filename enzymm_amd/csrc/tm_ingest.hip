@@ -31,14 +31,17 @@ __global__ __launch_bounds__(256) void k_flatten(const uint32_t *__restrict__ s_
                                                   const int32_t *__restrict__ milli, const double *__restrict__ xyz_side,
                                                   const uint32_t *__restrict__ orig_side, double *__restrict__ q_xyz,
                                                   float4 *__restrict__ q_rec, uint32_t *__restrict__ q_orig,
-                                                  uint16_t *__restrict__ res_start) {
+                                                  uint16_t *__restrict__ res_start, uint8_t *__restrict__ res_start_hi) {
     const uint32_t s = blockIdx.x;
     const uint32_t a0 = s_off[s], n = s_off[s + 1] - a0;
     const uint32_t begin = blockIdx.y * kFlattenChunk;
     if (begin >= n && !(n == 0 && blockIdx.y == 0)) return;
     const uint32_t r0 = s_roff[s];
     if (n == 0) {
-        if (threadIdx.x == 0) res_start[r0] = 0;
+        if (threadIdx.x == 0) {
+            res_start[r0] = 0;
+            if (res_start_hi) res_start_hi[r0] = 0;
+        }
         return;
     }
     const FlatDesc d = desc[s];
@@ -60,8 +63,15 @@ __global__ __launch_bounds__(256) void k_flatten(const uint32_t *__restrict__ s_
         q_rec[a] = make_float4((float)(x - d.c[0]), (float)(y - d.c[1]), (float)(z - d.c[2]), __uint_as_float(m));
         q_orig[a] = d.orig_off == kNoOffset ? i : orig_side[(size_t)d.orig_off + i];
         const uint32_t ord = meta_res(m);
-        if (i == 0 || meta_res(meta[a - 1]) != ord) res_start[r0 + ord] = (uint16_t)i;
-        if (i + 1 == n) res_start[r0 + ord + 1] = (uint16_t)n;
+        // (res_start_hi: bits 16-23, for batches that hold a structure of more than 65535 atoms)
+        if (i == 0 || meta_res(meta[a - 1]) != ord) {
+            res_start[r0 + ord] = (uint16_t)i;
+            if (res_start_hi) res_start_hi[r0 + ord] = (uint8_t)(i >> 16);
+        }
+        if (i + 1 == n) {
+            res_start[r0 + ord + 1] = (uint16_t)n;
+            if (res_start_hi) res_start_hi[r0 + ord + 1] = (uint8_t)(n >> 16);
+        }
     }
 }
 

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(64) void k_stage_templates(LibView L, uint32_t n_se
 // Dynamic LDS: [n_lead + 1] counts/offsets, then (when n <= bucket_cap) one u16 per atom: name id | residue-type id << 8,
 // then one u16 per atom: the atom indices grouped by name id.
 __global__ __launch_bounds__(512) void k_kind_lists(LibView L, BatchView B, uint32_t *__restrict__ kl_off,
-                                                     uint16_t *__restrict__ kl_pool,
+                                                     uint16_t *__restrict__ kl_pool, uint8_t *__restrict__ kl_pool_hi,
                                                      unsigned long long *__restrict__ cursor,
                                                      unsigned long long capacity, uint32_t *__restrict__ overflow,
                                                      uint32_t bucket_cap) {
@@ -365,10 +365,16 @@ __global__ __launch_bounds__(512) void k_kind_lists(LibView L, BatchView B, uint
         }
     };
 
+    __shared__ uint32_t s_long;
+    if (threadIdx.x == 0) s_long = 0u;
+    __syncthreads();
     for (uint32_t j = 0, li = wave; li < L.n_lead; ++j, li += nwaves) {
         uint32_t c = 0;
         scan_kind(j, [&](unsigned long long mask, bool, uint32_t) { c += __popcll(mask); });
-        if (lane == 0) s_cnt[li] = c;
+        if (lane == 0) {
+            s_cnt[li] = c;
+            if (c > 0xffffu) s_long = 1u;  // (the pair tables hold list POSITIONS in 16 bits)
+        }
     }
     __syncthreads();
     if (wave == 0) {  // exclusive scan of the counts, 64 at a time
@@ -382,9 +388,10 @@ __global__ __launch_bounds__(512) void k_kind_lists(LibView L, BatchView B, uint
         }
         if (lane == 0) {
             s_cnt[L.n_lead] = run;
+            if (s_long) atomicOr(overflow, 0x100u);  // a kind list beyond 65535 atoms (a wide structure): not searchable
             unsigned long long base = atomicAdd(cursor, (unsigned long long)run);
             if (base + run > capacity) {
-                *overflow = 1u;
+                atomicOr(overflow, 1u);
                 base = ~0ull;
             }
             s_base = base;
@@ -400,7 +407,10 @@ __global__ __launch_bounds__(512) void k_kind_lists(LibView L, BatchView B, uint
     for (uint32_t j = 0, li = wave; li < L.n_lead; ++j, li += nwaves) {
         unsigned long long w = base + s_cnt[li];
         scan_kind(j, [&](unsigned long long mask, bool ok, uint32_t atom) {
-            if (ok) kl_pool[w + rank_in(mask)] = (uint16_t)atom;
+            if (ok) {
+                kl_pool[w + rank_in(mask)] = (uint16_t)atom;
+                if (kl_pool_hi) kl_pool_hi[w + rank_in(mask)] = (uint8_t)(atom >> 16);  // (a batch with a wide structure)
+            }
             w += __popcll(mask);
         });
     }
@@ -437,7 +447,8 @@ __global__ void k_carry_outcome(const unsigned long long *__restrict__ index_cur
                                 unsigned long long *__restrict__ pool_used, unsigned long long *__restrict__ tab_used,
                                 uint32_t *__restrict__ query_overflow) {
     *pool_used = *index_cursor;
-    uint32_t bits = *index_overflow ? 8u : 0u;
+    uint32_t bits = (*index_overflow & 1u) ? 8u : 0u;
+    if (*index_overflow & 0x100u) bits |= 0x100u;  // a kind list beyond 16-bit positions (tm_result_wait: TM_E_UNSUPPORTED)
     if (tab_cursors) {
         tab_used[0] = tab_cursors[0];
         tab_used[1] = tab_cursors[1];
@@ -693,7 +704,8 @@ __host__ __device__ inline uint32_t tab_chunk(uint32_t n_atoms) {
 // of the record per POSITION in LDS (one read per operand, 16 B per position: about 100 KB for a 300-residue structure,
 // one workgroup per CU); 2: the structure's atom records and its kind lists in LDS (two dependent reads per operand,
 // 16 B per atom + 2 B per position: about 50 KB, two workgroups per CU).
-template <int kSrc>
+// kWide (kSrc 0 only): a structure of more than kNarrowAtoms atoms -- a kind-list entry is pool | pool_hi << 16.
+template <int kSrc, bool kWide = false>
 __device__ __forceinline__ void tab_build_tables(const BatchView &B, const TableDesc *__restrict__ tables,
                                                  const TabWork w, const float4 *rec, const uint16_t *pool,
                                                  const float4 *s_lr, const uint32_t *kl,
@@ -715,6 +727,9 @@ __device__ __forceinline__ void tab_build_tables(const BatchView &B, const Table
             const uint32_t atom = ((const __attribute__((address_space(3))) uint16_t *)pool)[first + k];
             const auto *r = (const __attribute__((address_space(3))) float *)rec + 4u * atom;
             return make_float4(r[0], r[1], r[2], r[3]);
+        } else if constexpr (kWide) {
+            const uint32_t at = first + (valid ? k : 0u);
+            return rec[(uint32_t)pool[at] | ((uint32_t)B.kl_pool_hi[at] << 16)];
         } else return rec[pool[first + (valid ? k : 0u)]];
     };
     // entries [first, first + n) of the pool, or ~0 when the pool is exhausted (the query then reports the overflow)
@@ -848,7 +863,7 @@ __device__ __forceinline__ void tab_build_tables(const BatchView &B, const Table
         // per operand): list B of a big table, which every row block sweeps in full, is staged in that unused LDS
         const bool staged = kSrc == 0 && n_b <= stage_cap;
         if (staged) {
-            for (uint32_t j = threadIdx.x; j < n_b; j += blockDim.x) s_stage[j] = rec[pool[b_lo + j]];
+            for (uint32_t j = threadIdx.x; j < n_b; j += blockDim.x) s_stage[j] = lead(b_lo, j, true);
             __syncthreads();
         }
         // (two instantiations: a run-time choice per operand load would compile into a flat load)
@@ -881,6 +896,13 @@ __device__ __forceinline__ void tab_build_tables(const BatchView &B, const Table
         else build(lead);
         __syncthreads();  // s_count, s_first and the staged list are reused by the next big table
     }
+}
+
+// the records-through-L2 build of a work item's structure: a wide structure (24-bit kind-list entries) takes its own instantiation
+template <class... Args>
+__device__ __forceinline__ void tab_build_global(const BatchView &B, const TableDesc *__restrict__ tables, const TabWork w, Args... args) {
+    if (B.s_off[w.s + 1] - B.s_off[w.s] > kNarrowAtoms) tab_build_tables<0, true>(B, tables, w, args...);
+    else tab_build_tables<0, false>(B, tables, w, args...);
 }
 
 // Dynamic LDS: [float4 x lr_cap] lead records (the record of the atom at every position of the structure's kind
@@ -1000,13 +1022,13 @@ __global__ __launch_bounds__(kTabBlock) __attribute__((amdgpu_waves_per_eu(kLayo
             }
 #endif
         } else {
-            tab_build_tables<0>(B, tables, w, rec, B.kl_pool, nullptr, kl, tab_rows, tab_ent, tab_seg, cursors,
+            tab_build_global(B, tables, w, rec, B.kl_pool, nullptr, kl, tab_rows, tab_ent, tab_seg, cursors,
                                 ent_capacity, overflow, tab_ok, dbg_mode, s_count, &s_first, n_lead, s_atoms, atom_cap, shared_limit, rows_ok, derive_min);
         }
     } else if constexpr (kLayout == kTabLarge) {
         float4 *s_lr = reinterpret_cast<float4 *>(tab_smem);
         (void)p0; (void)plen;
-        tab_build_tables<0>(B, tables, w, rec, B.kl_pool, nullptr, kl, tab_rows, tab_ent, tab_seg, cursors,
+        tab_build_global(B, tables, w, rec, B.kl_pool, nullptr, kl, tab_rows, tab_ent, tab_seg, cursors,
                             ent_capacity, overflow, tab_ok, dbg_mode, s_count, &s_first, n_lead, s_lr, lr_cap, shared_limit, rows_ok, derive_min);
     } else {
         float4 *s_lr = reinterpret_cast<float4 *>(tab_smem);
@@ -1018,7 +1040,7 @@ __global__ __launch_bounds__(kTabBlock) __attribute__((amdgpu_waves_per_eu(kLayo
             tab_build_tables<1>(B, tables, w, rec, B.kl_pool, s_lr, s_kl, tab_rows, tab_ent, tab_seg, cursors,
                                 ent_capacity, overflow, tab_ok, dbg_mode, s_count, &s_first, n_lead, nullptr, 0u, shared_limit, rows_ok, derive_min);
         } else {
-            tab_build_tables<0>(B, tables, w, rec, B.kl_pool, nullptr, kl, tab_rows, tab_ent, tab_seg, cursors,
+            tab_build_global(B, tables, w, rec, B.kl_pool, nullptr, kl, tab_rows, tab_ent, tab_seg, cursors,
                                 ent_capacity, overflow, tab_ok, dbg_mode, s_count, &s_first, n_lead, s_lr, lr_cap, shared_limit, rows_ok, derive_min);
         }
     }
@@ -1065,8 +1087,9 @@ __global__ __launch_bounds__(256) void k_tab_refs(BatchView B, uint32_t n_lead, 
         if (li != 0xffffu && s_has[li] == 0) feasible = false;
     }
     uint4 r = make_uint4(0u, 0u, 0u, 0u);
+    const bool wide = B.s_off[s + 1] - B.s_off[s] > kNarrowAtoms;  // (searched template at a time, whatever the template)
     if (B.tab_ok[s] == 1u && feasible) {
-        if (tt == 0xffffu) {
+        if (tt == 0xffffu || wide) {
             r.y = kRefSingly;
         } else {
             const uint2 seg = B.tab_seg[base + tp], seg3 = B.tab_seg[base + tt];
@@ -1094,6 +1117,7 @@ struct __align__(16) WaveScratchT {
     static constexpr bool kQueues = kMode != kModeDeep;      // runs the table stages
     float2 bnd[kSearches ? kMaxPairs : 1];           // every pair bound of the current template (pair (i, j < i) at tri(i) + j)
     uint16_t surv[kSearches ? kMaxG : 1][64];        // per template residue: one 64-entry chunk of its lead list
+    uint8_t surv_hi[kMode == 1 ? kMaxG : 1][64];     // the template-at-a-time launch on a wide structure: bits 16-23 of surv
     uint2 pairs[kQueues ? kPairQueue : 1];           // pair-table survivors {position in list 0 | position in list 1 << 16, slot}
     uint2 triples[kQueues ? kTripleQueue : 1];       // triple survivors {a0 | a1 << 16, a2 | slot << 16} waiting for the look at level 3
     uint32_t owner[64];                              // item-parallel stages: who owns the item at which its segment / row starts
@@ -1200,7 +1224,7 @@ struct __align__(16) ResCache {
     uint32_t count[kMaxG];  // its atoms
 };
 
-template <bool kIgnoreChain, bool kPoolLds, int kMode, bool kCache = false>
+template <bool kIgnoreChain, bool kPoolLds, int kMode, bool kCache = false, bool kWideOk = false>
 struct SearchCtx {
     static constexpr bool kResCache = kCache;
     static constexpr int kLaunchMode = kMode;
@@ -1213,9 +1237,19 @@ struct SearchCtx {
     // arithmetic per lane, both wait counters) or a branch per load, and both measured slower.
     const __attribute__((address_space(3))) uint16_t *pool_lds;
     const uint16_t *pool_glb;
+    // a WIDE structure (more than kNarrowAtoms atoms; the template-at-a-time launch on global memory only): bits 16-23 of
+    // its kind-list entries and of its residue table, NULL for every other structure and in every other launch mode
+    const uint8_t *pool_hi;
+    const uint8_t *res_hi;
+    static constexpr bool kMayBeWide = kMode == 1 && !kPoolLds && kWideOk;  // (kModeSingly, records in global memory)
     __device__ __forceinline__ uint32_t pool_at(uint32_t i) const {
         if constexpr (kPoolLds) return pool_lds[i];
+        else if constexpr (kMayBeWide) return pool_hi ? (uint32_t)pool_glb[i] | ((uint32_t)pool_hi[i] << 16) : (uint32_t)pool_glb[i];
         else return pool_glb[i];
+    }
+    __device__ __forceinline__ uint32_t res_at(uint32_t r) const {  // first atom of residue r
+        if constexpr (kMayBeWide) return res_hi ? (uint32_t)res_start[r] | ((uint32_t)res_hi[r] << 16) : (uint32_t)res_start[r];
+        else return res_start[r];
     }
     const uint8_t *qchain;      // global, per atom of this structure
     const uint32_t *tab_rows;   // pair tables: row offsets (global) ...
@@ -1253,11 +1287,14 @@ __device__ __forceinline__ unsigned long long eval_chunk(const Ctx &C, WaveRegs 
     uint32_t cand;
     if (lead) {
         if (RL(W.surv_base, (int)mygroup) != base) {  // the chunk is not the one cached in LDS
-            S.surv[mygroup][lane] = ok ? (uint16_t)C.pool_at(lo + idx) : (uint16_t)0;
+            const uint32_t entry = ok ? C.pool_at(lo + idx) : 0u;
+            S.surv[mygroup][lane] = (uint16_t)entry;
+            if constexpr (Ctx::kMayBeWide) S.surv_hi[mygroup][lane] = (uint8_t)(entry >> 16);
             WL(W.surv_base, (int)mygroup, base);
             wave_sync();
         }
         cand = S.surv[mygroup][lane];
+        if constexpr (Ctx::kMayBeWide) cand |= (uint32_t)S.surv_hi[mygroup][lane] << 16;
     } else {
         cand = ok ? lo + idx : lo;
     }
@@ -1328,7 +1365,7 @@ __device__ __forceinline__ void init_level(const Ctx &C, WaveRegs &W, int level)
             ResCache &R = *C.rc;
             if (uni(R.tag[g]) != lead_atom) {  // the slot holds another residue (or none): fetch this one
                 const uint32_t res = meta_res(RL(W.ameta, ref));
-                const uint32_t s0 = C.res_start[res], n = C.res_start[res + 1] - s0;
+                const uint32_t s0 = C.res_at(res), n = C.res_at(res + 1) - s0;
                 wave_sync();  // (earlier reads of the slot are done)
                 if ((uint32_t)C.lane < min(n, kResCacheAtoms)) R.rec[g][C.lane] = C.rec[s0 + (uint32_t)C.lane];
                 if (C.lane == 0) { R.tag[g] = lead_atom; R.first[g] = s0; R.count[g] = n; }
@@ -1338,7 +1375,7 @@ __device__ __forceinline__ void init_level(const Ctx &C, WaveRegs &W, int level)
             WL(W.cnt, level, uni(R.count[g]));
         } else {
             const uint32_t res = meta_res(RL(W.ameta, ref));
-            const uint32_t s0 = C.res_start[res], s1 = C.res_start[res + 1];  // uniform address: same value in every lane
+            const uint32_t s0 = C.res_at(res), s1 = C.res_at(res + 1);  // uniform address: same value in every lane
             WL(W.lo, level, s0);
             WL(W.cnt, level, s1 - s0);
         }
@@ -1402,6 +1439,7 @@ struct SearchArgs {
     // unit per workgroup, found from blockIdx)
     uint32_t *queue;
     uint32_t queue_once;  // experiments and tests: a workgroup leaves after one unit (the launch then has one workgroup per unit)
+    uint32_t wide_only;   // 1: the launch searches the wide structures (template at a time, global memory); 0: every other structure
 };
 typedef const __attribute__((address_space(4))) SearchArgs *ColdArgsPtr;
 __device__ __forceinline__ ColdArgsPtr cold_args() {
@@ -1517,6 +1555,10 @@ __device__ __forceinline__ bool on_complete(const Ctx &C, WaveRegs &W, PairState
     if (lane < kMaxK) {
         if (lane < k) c->atoms[lvl_orig(W.pk)] = (uint16_t)W.aidx;
         else c->atoms[lane] = 0xffffu;
+        if constexpr (Ctx::kMayBeWide) {  // (a batch with a wide structure: bits 16-23 of every candidate's atoms)
+            uint8_t *hi = A->O.cands_hi;
+            if (hi) hi[slot * kMaxK + (lane < k ? lvl_orig(W.pk) : (uint32_t)lane)] = lane < k ? (uint8_t)(W.aidx >> 16) : (uint8_t)0;
+        }
     }
     return true;
 }
@@ -1633,8 +1675,10 @@ __device__ __forceinline__ bool dfs(const Ctx &C, WaveRegs &W, PairState &P, int
         WL(W.pend_lo, level, (uint32_t)pend);
         WL(W.pend_hi, level, (uint32_t)(pend >> 32));
         uint32_t cand;
-        if (RL(W.lead, level)) cand = uni((uint32_t)C.S->surv[lvl_group(RL(W.pk, level))][b]);
-        else cand = RL(W.lo, level) + RL(W.base, level) + (uint32_t)b;
+        if (RL(W.lead, level)) {
+            cand = uni((uint32_t)C.S->surv[lvl_group(RL(W.pk, level))][b]);
+            if constexpr (Ctx::kMayBeWide) cand |= uni((uint32_t)C.S->surv_hi[lvl_group(RL(W.pk, level))][b]) << 16;
+        } else cand = RL(W.lo, level) + RL(W.base, level) + (uint32_t)b;
         assign_level(C, W, level, cand);
         if (level < k - 1) {
             ++level;
@@ -1682,7 +1726,7 @@ __device__ __forceinline__ bool level3_has_candidate(const Ctx &C, const WaveReg
     // another atom of an assigned residue: the atoms of that target residue (at most a few dozen)
     const uint32_t ref = lvl_ref(RL(W.pk, 3));
     const uint32_t res = ref == 0u ? res0 : ref == 1u ? res1 : res2, own = ref == 0u ? x0 : ref == 1u ? x1 : x2;
-    const uint32_t s0 = C.res_start[res], s1 = C.res_start[res + 1];
+    const uint32_t s0 = C.res_at(res), s1 = C.res_at(res + 1);
     const unsigned long long nm = ((unsigned long long)RL(W.nm_hi, 3) << 32) | RL(W.nm_lo, 3);
     const uint32_t rm = RL(W.resmask, 3);
     const bool any = lvl_any(RL(W.pk, 3)) != 0u;
@@ -1734,7 +1778,7 @@ __device__ __forceinline__ bool table_scan(const Ctx &C, WaveRegs &W, PairState 
     auto &S = *C.S;
     // (the template-at-a-time path keeps its own layout of the two queues inside the block search's)
     uint32_t *queue = reinterpret_cast<uint32_t *>(S.pairs);
-    uint32_t (*queue3)[2] = reinterpret_cast<uint32_t (*)[2]>(S.triples);
+    uint32_t (*queue3)[3] = reinterpret_cast<uint32_t (*)[3]>(S.triples);  // (64 triples x 12 B: the atoms in full words -- a wide structure's do not fit 16 bits)
     const int lane = C.lane;
     const int G = C.n_groups;
     const uint32_t lo0 = RL(W.lo, 0), lo1 = RL(W.lo, 1), lo2 = RL(W.lo, 2);
@@ -1860,14 +1904,14 @@ __device__ __forceinline__ bool table_scan(const Ctx &C, WaveRegs &W, PairState 
                 if (m == 0ull) continue;
                 if (ok) {
                     const uint32_t slot = rank_in(m);
-                    queue3[slot][0] = a0 | (a1 << 16);
-                    queue3[slot][1] = c2;
+                    queue3[slot][0] = a0;
+                    queue3[slot][1] = a1;
+                    queue3[slot][2] = c2;
                 }
                 const uint32_t nq3 = (uint32_t)__popcll(m);
                 wave_sync();
                 for (uint32_t q = 0; q < nq3; ++q) {
-                    const uint32_t ab = uni(queue3[q][0]), c = uni(queue3[q][1]);
-                    const uint32_t x0 = ab & 0xffffu, x1 = ab >> 16;
+                    const uint32_t x0 = uni(queue3[q][0]), x1 = uni(queue3[q][1]), c = uni(queue3[q][2]);
                     const float4 q0 = C.rec[x0], q1 = C.rec[x1], q2 = C.rec[c];
                     if (C.k > 3 && !level3_has_candidate(C, W, x0, x1, c, q0, q1, q2)) continue;
 #if defined(TM_STATS) || defined(TM_ABLATE)
@@ -2556,12 +2600,17 @@ __device__ __forceinline__ void search_templates(const SearchArgs &A, WaveScratc
                                                  uint32_t r0, uint32_t chunk, uint32_t n_chunks, SharedTriples *shared = nullptr) {
     const BatchView &B = A.B;
     const QueryView &Q = A.Q;
-    SearchCtx<kIgnoreChain, kPoolLds, kSingly ? kModeSingly : kModeBlocks> C;
+    SearchCtx<kIgnoreChain, kPoolLds, kSingly ? kModeSingly : kModeBlocks, false, kSingly && !kLds> C;
     C.rc = nullptr;
     C.rec = kLds ? s_rec : B.q_rec + a0;
     C.res_start = kLds ? s_res : B.res_start + r0;
     C.pool_lds = (const __attribute__((address_space(3))) uint16_t *)s_pool;
     C.pool_glb = B.kl_pool;
+    // (a wide structure: the upper bits of its kind-list entries and residue starts; k_search lets one through to the
+    // template-at-a-time launch on global memory only)
+    const bool wide = B.s_off[s + 1] - a0 > kNarrowAtoms;
+    C.pool_hi = wide ? B.kl_pool_hi : nullptr;
+    C.res_hi = wide && B.res_start_hi ? B.res_start_hi + r0 : nullptr;
     C.qchain = B.q_chain + a0;
     C.tab_rows = B.tab_rows;
     C.tab_ent = B.tab_ent;
@@ -2881,6 +2930,9 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
         if ((unsigned long long)chunk * (kDeepShare * kSearchWaves) >= A.O.dir_triples[s]) { if constexpr (kQueued) continue; else return; }
     }
     const uint32_t a0 = B.s_off[s], n = B.s_off[s + 1] - a0;
+    // A wide structure (more than kNarrowAtoms atoms: 24-bit atom indices) is searched by ONE launch -- the
+    // template-at-a-time search on global memory over the wide structures alone (A.wide_only) -- and passed over by every other.
+    if ((n > kNarrowAtoms) != (A.wide_only != 0u)) { if constexpr (kQueued) continue; else return; }
     const uint32_t r0 = B.s_roff[s], nres1 = B.s_roff[s + 1] - r0;  // n_res + 1 entries
     const uint32_t *kl_off = B.kl_off + (size_t)s * (L.n_lead + 1);
     bool pool_in_lds = false;
@@ -3108,8 +3160,16 @@ __device__ void horn_rotation(const double S[3][3], double R[9]) {
 
 // Superposes candidate `c` onto its template: proper rotation R, translation T with
 // x_template = R x_target + T, and RMSD = sqrt(sum |R q + T - p|^2 / k) evaluated directly.
+// atom i (template order) of candidate c; hi: bits 16-23 of its atoms (a batch with a wide structure) or NULL
+__device__ __forceinline__ uint32_t cand_atom(const Cand &c, const uint8_t *hi, int i) {
+    return hi ? (uint32_t)c.atoms[i] | ((uint32_t)hi[i] << 16) : (uint32_t)c.atoms[i];
+}
+__device__ __forceinline__ const uint8_t *cand_hi(const OutView &O, const Cand &c) {
+    return O.cands_hi ? O.cands_hi + (size_t)(&c - O.cands) * kMaxK : nullptr;
+}
+
 __device__ double superpose_candidate(const LibView &L, const BatchView &B, const QueryView &Q, const Cand &c,
-                                      double R[9], double T[3]) {
+                                      const uint8_t *hi, double R[9], double T[3]) {
     const uint32_t off = L.t_off[Q.sel[c.ti]];
     const Staged &St = Q.staged[c.ti];
     const int k = (int)St.k();
@@ -3117,7 +3177,7 @@ __device__ double superpose_candidate(const LibView &L, const BatchView &B, cons
     // candidate atoms are stored in TEMPLATE order, library coordinates in SEARCH order
     double qc[3] = {0, 0, 0}, pc[3] = {0, 0, 0};
     for (int pos = 0; pos < k; ++pos) {
-        const double *q = qx + 3 * (size_t)c.atoms[St.orig[pos]];
+        const double *q = qx + 3 * (size_t)cand_atom(c, hi, St.orig[pos]);
         const double *p = L.a_xyz + 3 * (size_t)(off + pos);
         for (int a = 0; a < 3; ++a) { qc[a] += q[a]; pc[a] += p[a]; }
     }
@@ -3125,7 +3185,7 @@ __device__ double superpose_candidate(const LibView &L, const BatchView &B, cons
     for (int a = 0; a < 3; ++a) { qc[a] *= inv_k; pc[a] *= inv_k; }
     double Sm[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
     for (int pos = 0; pos < k; ++pos) {
-        const double *q = qx + 3 * (size_t)c.atoms[St.orig[pos]];
+        const double *q = qx + 3 * (size_t)cand_atom(c, hi, St.orig[pos]);
         const double *p = L.a_xyz + 3 * (size_t)(off + pos);
         const double qv[3] = {q[0] - qc[0], q[1] - qc[1], q[2] - qc[2]};
         const double pv[3] = {p[0] - pc[0], p[1] - pc[1], p[2] - pc[2]};
@@ -3138,7 +3198,7 @@ __device__ double superpose_candidate(const LibView &L, const BatchView &B, cons
     for (int a = 0; a < 3; ++a) T[a] = pc[a] - (R[3 * a] * qc[0] + R[3 * a + 1] * qc[1] + R[3 * a + 2] * qc[2]);
     double sum = 0.0;
     for (int pos = 0; pos < k; ++pos) {
-        const double *q = qx + 3 * (size_t)c.atoms[St.orig[pos]];
+        const double *q = qx + 3 * (size_t)cand_atom(c, hi, St.orig[pos]);
         const double *p = L.a_xyz + 3 * (size_t)(off + pos);
         const double ex = R[0] * q[0] + R[1] * q[1] + R[2] * q[2] + T[0] - p[0];
         const double ey = R[3] * q[0] + R[4] * q[1] + R[5] * q[2] + T[1] - p[1];
@@ -3156,7 +3216,7 @@ __global__ __launch_bounds__(256) void k_superpose(LibView L, BatchView B, Query
         double R[9], T[3];
         const Cand &cand = O.cands[c];
         if (cand.s == 0xffffffffu) continue;  // a reserved slot no candidate was written to
-        const double r = superpose_candidate(L, B, Q, cand, R, T);
+        const double r = superpose_candidate(L, B, Q, cand, cand_hi(O, cand), R, T);
         O.cand_rmsd[c] = r;
         // the pair's minimum within the threshold (non-negative doubles order like their bit patterns)
         if (O.pair_min && r <= Q.rmsd_thr[cand.ti])
@@ -3182,9 +3242,10 @@ __global__ __launch_bounds__(256) void k_ties(QueryView Q, OutView O) {
 }
 
 // true when tuple a (TEMPLATE order, file-order atom indices) is lexicographically smaller than b
-__device__ __forceinline__ bool tuple_less(const uint32_t *orig, const Cand &a, const Cand &b, int k) {
+__device__ __forceinline__ bool tuple_less(const OutView &O, const uint32_t *orig, const Cand &a, const Cand &b, int k) {
+    const uint8_t *ha = cand_hi(O, a), *hb = cand_hi(O, b);
     for (int i = 0; i < k; ++i) {
-        const uint32_t x = orig[a.atoms[i]], y = orig[b.atoms[i]];
+        const uint32_t x = orig[cand_atom(a, ha, i)], y = orig[cand_atom(b, hb, i)];
         if (x != y) return x < y;
     }
     return false;
@@ -3199,7 +3260,8 @@ __device__ void emit_hit(const LibView &L, const BatchView &B, const QueryView &
     }
     tm_hit *h = O.hits + slot;
     double R[9], T[3];
-    h->rmsd = superpose_candidate(L, B, Q, c, R, T);
+    const uint8_t *hi = cand_hi(O, c);
+    h->rmsd = superpose_candidate(L, B, Q, c, hi, R, T);
     for (int a = 0; a < 9; ++a) h->rot[a] = R[a];
     for (int a = 0; a < 3; ++a) h->trans[a] = T[a];
     h->structure = pe.s;
@@ -3210,7 +3272,7 @@ __device__ void emit_hit(const LibView &L, const BatchView &B, const QueryView &
     h->n_atoms = (uint32_t)k;
     h->reserved = 0;
     const uint32_t a0 = B.s_off[pe.s];
-    for (int i = 0; i < kMaxK; ++i) h->atoms[i] = i < k ? B.q_orig[a0 + c.atoms[i]] : 0xffffffffu;
+    for (int i = 0; i < kMaxK; ++i) h->atoms[i] = i < k ? B.q_orig[a0 + cand_atom(c, hi, i)] : 0xffffffffu;
 
     // ---- fused epilogue: residue-orientation angle and logistic filter
     // (what enzymm computes per hit in Python: jess_run.py:425-478 and 298-346)
@@ -3223,7 +3285,7 @@ __device__ void emit_hit(const LibView &L, const BatchView &B, const QueryView &
         for (uint32_t r = 0; r < nres; ++r) {
             double p[3][3];  // the residue's three matched atoms in the template frame
             for (int n = 0; n < 3; ++n) {
-                const double *q = qx + 3 * (size_t)c.atoms[3 * r + n];
+                const double *q = qx + 3 * (size_t)cand_atom(c, hi, (int)(3 * r) + n);
                 for (int a = 0; a < 3; ++a) p[n][a] = R[3 * a] * q[0] + R[3 * a + 1] * q[1] + R[3 * a + 2] * q[2] + T[a];
             }
             const int fi = L.r_first[r0 + r] < 3 ? L.r_first[r0 + r] : 0, se = L.r_second[r0 + r];
@@ -3291,7 +3353,7 @@ __global__ __launch_bounds__(256) void k_select(LibView L, BatchView B, QueryVie
         (void)last;
         uint32_t best = 0xffffffffu;
         for (uint32_t c = O.pair_tie[(size_t)pe.s * Q.n_sel + Q.order[pe.ti]]; c != 0u; c = O.cands[c - 1u].tie_next)
-            if (best == 0xffffffffu || tuple_less(orig, O.cands[c - 1u], O.cands[best], k)) best = c - 1u;
+            if (best == 0xffffffffu || tuple_less(O, orig, O.cands[c - 1u], O.cands[best], k)) best = c - 1u;
         if (best != 0xffffffffu) emit_hit(L, B, Q, O, pe, O.cands[best], k);
     }
 }

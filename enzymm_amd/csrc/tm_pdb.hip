@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void k_pdb_residues(const uint32_t *__restrict
     __syncthreads();
     const uint32_t runs = s_count;
     if (threadIdx.x == 0) n_runs[s] = runs;
-    if (runs > (uint32_t)kMaxSortedRuns || n > TM_MAX_STRUCTURE_ATOMS) {
+    if (runs > (uint32_t)kMaxSortedRuns || n > TM_NARROW_STRUCTURE_ATOMS) {
         if (threadIdx.x == 0) needs_host[s] = 1u;  // too many residues to check here (or too many atoms)
         return;
     }

@@ -40,7 +40,9 @@ extern "C" {
 /* limits of this build */
 #define TM_MAX_TEMPLATE_ATOMS 24   /* 8 residues x 3 atoms: enzymm's largest size bucket (jess_run.py:564-571) */
 #define TM_MAX_TEMPLATE_GROUPS 8   /* template residues */
-#define TM_MAX_STRUCTURE_ATOMS 65535
+#define TM_MAX_STRUCTURE_ATOMS 16777215   /* 2^24 - 1: beyond it a structure is refused (kept in its batch as an empty one) */
+#define TM_NARROW_STRUCTURE_ATOMS 65535   /* up to here the 16-bit atom indices of the tuned kernels; a larger ("wide")
+                                             structure is searched by the template-at-a-time launch with 24-bit indices */
 #define TM_MAX_STRUCTURE_RESIDUES 65533  /* residue numbers 0xfffd..0xffff are reserved by the search kernel */
 #define TM_RES_OTHER 31            /* residue-type id of "not in the vocabulary" */
 #define TM_NAME_OTHER 63           /* atom-name id of "not in the vocabulary" */
@@ -221,10 +223,12 @@ int tm_batch_create_from_files(int device, uint32_t n_files, const char *const *
 int tm_batch_file_text(tm_batch *batch, uint32_t file, const char **text, uint64_t *length);
 /* the whole text buffer: file f occupies [offsets[f], offsets[f + 1] - 1) of it; offsets has n_structures + 1 entries */
 int tm_batch_text_layout(tm_batch *batch, const char **base, uint64_t *offsets);
-/* Structures that came with more than TM_MAX_STRUCTURE_ATOMS atoms (pyjess.Molecule.load takes any PDB file,
- * /root/reference/enzymm/jess_run.py:538; this build indexes a structure's atoms with 16 bits): they are kept in the batch
- * as EMPTY structures -- no hits, the other structures of the batch unaffected -- and listed here with the atom counts
- * they came with.  *count receives how many there are; up to `capacity` of them are written. */
+/* pyjess.Molecule.load takes any PDB file (/root/reference/enzymm/jess_run.py:538).  A structure of up to
+ * TM_NARROW_STRUCTURE_ATOMS atoms runs on the tuned kernels (16-bit atom indices); a larger one, up to
+ * TM_MAX_STRUCTURE_ATOMS, is searched as well -- template at a time, its records in global memory, 24-bit indices --
+ * with the same results at a lower rate.  Structures beyond TM_MAX_STRUCTURE_ATOMS are kept in the batch as EMPTY
+ * structures -- no hits, the other structures of the batch unaffected -- and listed here with the atom counts they came
+ * with.  *count receives how many there are; up to `capacity` of them are written. */
 int tm_batch_refused(const tm_batch *batch, uint32_t *structures, uint32_t *atoms, uint32_t capacity, uint32_t *count);
 int tm_batch_atom_counts(tm_batch *batch, uint32_t *atom_offsets);            /* [n_structures + 1] */
 /* tm_batch_create_from_structures / _from_columns return when their host-to-device copies are QUEUED (17 bytes per atom:

@@ -38,6 +38,13 @@ def test_search_and_build_kernels_use_no_scratch(tmp_path):
             # values reloaded once per unit or template, none inside a search loop (checked in the ISA)
             assert v.get("ScratchSize [bytes/lane]") <= 16 and v.get("VGPRs Spill") <= 3, (k, v)
             continue
+        if "k_searchILb0ELb0ELi1E" in k:
+            # the template-at-a-time search on global memory, chain-aware (ignore_chain=False: not enzymm's default): since
+            # round 5 the one launch that searches structures of more than 65 535 atoms (24-bit atom indices: the upper
+            # bits of kind-list entries and residue starts come from byte arrays) -- nine scalars of its set-up code live
+            # in scratch memory; no vector register is spilled
+            assert v.get("ScratchSize [bytes/lane]") <= 40 and v.get("VGPRs Spill") == 0, (k, v)
+            continue
         assert v.get("ScratchSize [bytes/lane]") == 0, (k, v)
         assert v.get("VGPRs Spill") == 0, (k, v)
         # scalars parked in spare VGPR lanes cost instructions, not memory: none in the two launches of the headline

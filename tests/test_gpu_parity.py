@@ -281,7 +281,7 @@ def test_large_structure_global_memory_path(af, default_library):
 
 
 def test_structure_near_the_atom_limit(af, default_library):
-    """16 copies of a 4079-atom chain = 65 264 atoms, just under TM_MAX_STRUCTURE_ATOMS: u16 atom indices and
+    """16 copies of a 4079-atom chain = 65 264 atoms, just under TM_NARROW_STRUCTURE_ATOMS: u16 atom indices and
     residue tables at their upper end, kind lists of thousands of entries, work items cut into many rounds."""
     jess, olib, idx, cut = default_library
     cols = {k: np.concatenate([v] * 16) for k, v in af._cols.items()}
@@ -290,7 +290,7 @@ def test_structure_near_the_atom_limit(af, default_library):
                                        for c in range(16)])
     big = pyjess.Molecule.__new__(pyjess.Molecule)
     big._init_columns(cols, xyz, "AFx16")
-    assert len(big) == 16 * 4079 <= _native.TM_MAX_STRUCTURE_ATOMS
+    assert len(big) == 16 * 4079 <= _native.TM_NARROW_STRUCTURE_ATOMS
     sel = np.arange(3, len(idx), 41)
     sub = oracle.OracleLibrary([olib.templates[i] for i in sel])
     small = synthetic.structure(3)
@@ -301,13 +301,22 @@ def test_structure_near_the_atom_limit(af, default_library):
                                  ignore_chain=True)
         n = compare(table, cands, s, r, sub)
     assert n >= 1
-    # one atom too many: the structure is refused (a warning, no hits), not truncated -- and not its batch
-    # (tests/test_gpu_round4.py::test_oversized_structure_is_refused_not_its_batch)
-    extra = {k: np.concatenate([v, v[: 65536 - len(big)]]) for k, v in cols.items()}
+    # one atom beyond the 16-bit range: 65 536 atoms, the smallest structure the template-at-a-time launch with 24-bit
+    # indices takes (round 5; refused before: tests/test_gpu_round4.py::test_structure_beyond_65535_atoms_is_searched).
+    # The 272 extra atoms are a shifted copy of the chain's first residues under a seventeenth chain id.
+    m = 65536 - len(big)
+    extra = {k: np.concatenate([v, v[:m]]) for k, v in cols.items()}
+    extra["chain_id"] = np.concatenate([cols["chain_id"], np.full(m, b" Q", dtype="S2")])
     over = pyjess.Molecule.__new__(pyjess.Molecule)
-    over._init_columns(extra, np.concatenate([xyz, xyz[: 65536 - len(big)]]), "too_big")
-    with pytest.warns(UserWarning, match="too_big"):
-        assert len(jess.query_batch([over], 2.0, cut[sel], cut[sel], template_index=idx[sel], return_raw=True)) == 0
+    over._init_columns(extra, np.concatenate([xyz, xyz[:m] + np.array([0.0, 0.0, 90.0])]), "one_beyond")
+    assert len(over) == _native.TM_NARROW_STRUCTURE_ATOMS + 1
+    table, cands = jess.query_batch([small, over], 2.0, cut[sel], cut[sel], max_candidates=10000, ignore_chain=True,
+                                    template_index=idx[sel], count_candidates=True, return_raw=True)
+    for s, mol in enumerate((small, over)):
+        r = oracle.query_library(helpers.to_oracle_molecule(mol), sub, 2.0, cut[sel], cut[sel], max_candidates=10000,
+                                 ignore_chain=True)
+        n = compare(table, cands, s, r, sub)
+    assert n >= 1
 
 
 def test_index_pool_overflow_is_reported_and_retried(amy, af, monkeypatch):
