@@ -104,6 +104,18 @@ def test_structure_beyond_65535_atoms_is_searched(af, amy, tmp_path):
     assert beyond >= 3  # (hits among the atoms a 16-bit index cannot name)
     assert np.array_equal(dcands[0] & 0x7FFFFFFF, dwant["candidates"]) and int(dwant["candidates"].sum()) > 2000
     assert np.array_equal((dcands[0] >> 31).astype(bool), dwant["truncated"].astype(bool))
+    # the chain-aware variant of that launch (ignore_chain=False: template atoms of one chain must come from one chain
+    # of the complex, of different chains from different ones -- the twenty copies carry twenty chain ids)
+    ctable, ccands = dense.query_batch([big], 2.0, 1.2, 1.2, max_candidates=10000, ignore_chain=False, count_candidates=True, return_raw=True)
+    cwant = oracle.query_library(helpers.to_oracle_molecule(big), dlib, 2.0, 1.2, 1.2, max_candidates=10000, ignore_chain=False)
+    cok = ~cwant["truncated"].astype(bool)
+    assert sorted(int(t) for t in ctable["template_sel"] if cok[t]) == np.nonzero(cwant["hit"] & cok)[0].tolist()
+    for h in ctable:
+        t = int(h["template_sel"])
+        if cok[t]:
+            k = dlib.templates[t].k
+            assert np.array_equal(h["atoms"][:k], cwant["atoms"][t][:k]) and abs(h["rmsd"] - cwant["rmsd"][t]) < 1e-9, t
+    assert np.array_equal(ccands[0] & 0x7FFFFFFF, cwant["candidates"]) and 0 < int(cwant["candidates"].sum()) <= int(dwant["candidates"].sum())
     # inside a batch of ordinary structures
     ref = q(others)
     assert len(ref) > 5
