@@ -163,6 +163,11 @@ def test_structure_beyond_65535_atoms_is_searched(af, amy, tmp_path):
     rest = q([amy, af, synthetic.structure(41)]).copy()
     rest["structure"] = np.array([0, 2, 3], dtype=np.uint32)[rest["structure"]]
     assert got[got["structure"] != 1].tobytes() == rest.tobytes()
+    # ... and through Matcher.run_files (the records of its matched atoms are picked out of the text by 32-bit indices)
+    from_files = matcher.run_files(paths)
+    by_id = {m.id: v for m, v in from_files.items()}
+    summary = lambda ms: sorted((tpls.index(x.hit.template), round(x.hit.rmsd, 6), tuple(a.serial for a in x.hit.atoms())) for x in ms)
+    assert matcher.refused == [] and summary(by_id["s1"]) == summary(result[big]) and summary(by_id["s2"]) == summary(result[af])
     # beyond TM_MAX_STRUCTURE_ATOMS: refused on its own (a handcrafted descriptor: the library does not touch its columns)
     rows = np.stack([amy._pointer_row(), amy._pointer_row(), af._pointer_row()]).copy()
     rows[1, 0] = _native.TM_MAX_STRUCTURE_ATOMS + 1
