@@ -2642,9 +2642,15 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
             std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return cost[x] > cost[y]; });
             std::vector<WorkItem> items;
             items.reserve(ns);
+            // (ENZYMM_AMD_TAIL = f, experiments: the structures that hold the last fraction f of the estimated cost -- the
+            // units a queued launch ends on -- are cut into twice the rounds: a finer tail for a shorter drain)
+            static const double tail_env = [] { const char *e = std::getenv("ENZYMM_AMD_TAIL"); return e ? std::atof(e) : 0.0; }();
+            double seen = 0.0;
             for (uint32_t s : order) {
                 const double share = cost[s] * (double)per_class_target / total;
-                const uint32_t rounds = (uint32_t)std::min<double>(max_rounds, std::max<double>(1.0, std::floor(share + 0.5)));
+                uint32_t rounds = (uint32_t)std::min<double>(max_rounds, std::max<double>(1.0, std::floor(share + 0.5)));
+                if (tail_env > 0.0 && seen >= (1.0 - tail_env) * total) rounds = std::min<uint32_t>(max_rounds, 2u * rounds);
+                seen += cost[s];
                 for (uint32_t r = 0; r < rounds; ++r) items.push_back(WorkItem{s, (uint16_t)r, (uint16_t)rounds});
             }
             if (b->d_work.p) HIP_TRY(hipStreamSynchronize(stream));  // a previous query may still read the old list
