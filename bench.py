@@ -330,7 +330,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--structures", type=int, default=1000, help="synthetic structures per GPU")
     ap.add_argument("--batch", type=int, default=1000, help="structures per resident batch (one search launch each)")
-    ap.add_argument("--streamed-passes", type=int, default=16,
+    ap.add_argument("--streamed-passes", type=int, default=48,
                     help="extra passes with the batches uploaded from host memory under the timer (reported in "
                          "config.streamed_structures_per_s, never in value); 0 = skip")
     ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2, 3],
@@ -748,6 +748,9 @@ def main():
                 # host-to-device bytes per structure of those passes (packed word + chain ordinal + int32 thousandths of
                 # an Angstrom per atom, 32 B per structure; 46 B per atom before round 5)
                 "h2d_bytes_per_structure": None if h2d_bytes is None else h2d_bytes / max(1, len(molecules)),
+                # how long that stream was: passes x resident batches, one after the other (a stream pays its fill and its
+                # drain once: 16 batches 215-245 k/s, 208 batches 321-344 k/s on the boxes of round 5)
+                "streamed_batches": args.streamed_passes * len(chunks),
                 "atoms_per_structure": n_atoms / max(1, len(molecules)),
                 "parallelism": f"structures sharded over {world} GPU(s), hit-table gather to rank 0" + (" (N > 1 loop forced on one GPU over RCCL)" if force_sharded else ""),
                 "hits_rank0": int(hit_total), "hits_total": int(len(last_hits)),
