@@ -1139,6 +1139,9 @@ constexpr uint32_t kMinBlock = TM_MIN_BLOCK;  // templates a wave claims at leas
 #ifndef TM_RES_FIRST
 #define TM_RES_FIRST 2
 #endif
+#ifndef TM_D0_UNROLL
+#define TM_D0_UNROLL 1  // stage D0's loop over a residue's atoms: atoms looked at per trip (experiments: 2)
+#endif
 constexpr uint32_t kResFirst = TM_RES_FIRST;  // stage D0: levels looked at in its first round
 template <>
 struct __align__(16) WaveScratchT<kModeBlocks> {
@@ -2190,6 +2193,26 @@ __device__ __forceinline__ void block_look(Ctx &C, const SearchArgs &A, SlotRegs
                 const float2 w0b = make_float2(__uint_as_float(rb.x), __uint_as_float(rb.y)), w1b = make_float2(__uint_as_float(rb.z), __uint_as_float(rb.w)),
                              w2b = make_float2(__uint_as_float(rw2.x), __uint_as_float(rw2.y));
                 bool found = false;
+#if TM_D0_UNROLL == 2
+                // two atoms of the residue per trip: their packed words are asked for together (one LDS round trip for two
+                // names; the loop is a chain of dependent round trips -- five on average, one per atom)
+                auto admits = [&](uint32_t m, uint32_t at) {
+                    return (((nm >> meta_name(m)) & 1ull) != 0ull) & (any | (((ra.z >> meta_rtype(m)) & 1u) != 0u)) & (at != px0) & (at != px1) & (at != pc);
+                };
+                for (; a < a_end && !found; a += 2u) {
+                    const uint32_t b = a + 1u < a_end ? a + 1u : a;
+                    const uint32_t m0 = __float_as_uint(C.rec[a].w), m1 = __float_as_uint(C.rec[b].w);
+                    const bool c0 = admits(m0, a), c1 = admits(m1, b) & (b != a);
+                    if (c0) {
+                        const float4 r = C.rec[a];
+                        found = in_window(r, l0, w0b) & in_window(r, l1, w1b) & in_window(r, l2, w2b);
+                    }
+                    if (c1 & !found) {
+                        const float4 r = C.rec[b];
+                        found = in_window(r, l0, w0b) & in_window(r, l1, w1b) & in_window(r, l2, w2b);
+                    }
+                }
+#else
                 for (; a < a_end && !found; ++a) {  // (a dozen atoms at most; the name leaves one of them, usually)
                     const uint32_t m = __float_as_uint(C.rec[a].w);
                     if ((((nm >> meta_name(m)) & 1ull) != 0ull) & (any | (((ra.z >> meta_rtype(m)) & 1u) != 0u)) & (a != px0) & (a != px1) & (a != pc)) {
@@ -2197,6 +2220,7 @@ __device__ __forceinline__ void block_look(Ctx &C, const SearchArgs &A, SlotRegs
                         found = in_window(r, l0, w0b) & in_window(r, l1, w1b) & in_window(r, l2, w2b);
                     }
                 }
+#endif
                 const unsigned long long missing = ballot64(item && !found);
                 TM_STAT(63, 1);
                 // does any of MY triple's levels of this pass lack a candidate?  (items [max(excl, w0), min(incl, w0 + 64)) - w0)
