@@ -3341,6 +3341,13 @@ int tm_batch_create_from_files(int device, uint32_t n_files, const char *const *
             if (const char *e = std::getenv("ENZYMM_AMD_READ_CHUNKS")) { const long v = std::strtol(e, nullptr, 10); if (v >= 1 && v <= 64) return (uint32_t)v; }
             return 6u;
         }();
+        // ENZYMM_AMD_READ_TURNS=1 (experiment): one call reads its files at a time, process-wide -- the ingest threads of a
+        // pipeline then stagger (one reads while another's upload finishes and a third's text is parsed) instead of all
+        // reading, then all uploading, in step
+        static const bool read_turns = [] { const char *e = std::getenv("ENZYMM_AMD_READ_TURNS"); return e && e[0] == '1'; }();
+        static std::mutex read_turn;
+        std::unique_lock<std::mutex> turn(read_turn, std::defer_lock);
+        if (read_turns) turn.lock();
         uint32_t f0 = 0;
         for (uint32_t c = 0; c < n_chunks && f0 < n_files; ++c) {
             const uint64_t target = off[n_files] * (c + 1) / n_chunks;

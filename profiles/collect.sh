@@ -61,7 +61,7 @@ print(json.dumps({"git_head": head, "k_search_pmc": f"{tag}_k_search_pmc.json", 
                   "k_tab_build_pmc": f"{tag}_k_tab_build_pmc.json", "kernel_stats": f"{tag}_bench1000_kernel_stats.csv",
                   "kernel_stats_one_in_flight": f"{tag}_bench1000_pipeline1_kernel_stats.csv",
                   "valu_ceiling": f"{tag}_valu_ceiling.json", "bench": f"{tag}_bench1000.json",
-                  "parity_census": [f"{tag}_parity_census_1000.json", f"{tag}_parity_census_real64.json", f"{tag}_parity_census_config5.json"]}, indent=1))
+                  "parity_census": [f"{tag}_parity_census_1000.json", f"{tag}_parity_census_real256.json", f"{tag}_parity_census_2000_from_1000.json", f"{tag}_parity_census_config5.json"]}, indent=1))
 PY
 cp "$out/LATEST" profiles/LATEST
 mv "$out/${tag}_bench1000.json" "$out/${tag}_bench1000_before_pmc.json"
@@ -69,7 +69,9 @@ timeout 900 python3 bench.py --steps 10 --warmup 2 > "$out/${tag}_bench1000.json
 # The whole-batch parity census on the SAME build, in the SAME call: 1000 x 6780 of the headline batch,
 # a 64-structure sample of the real-structure batch, configs[4] at the default cutoffs -- each stamped with .build_head
 timeout 900 python3 tests/gpu_parity_census.py 1000 0 synthetic > "$out/census1000.log" 2>&1 && mv gpurun_out/parity_census.json "$out/${tag}_parity_census_1000.json"
-timeout 600 python3 tests/gpu_parity_census.py 64 0 real > "$out/census_real.log" 2>&1 && mv gpurun_out/parity_census.json "$out/${tag}_parity_census_real64.json"
+timeout 600 python3 tests/gpu_parity_census.py 256 0 real > "$out/census_real.log" 2>&1 && mv gpurun_out/parity_census.json "$out/${tag}_parity_census_real256.json"
+# (structures the bench never sees: seeds 1000 .. 2999 of the same generator)
+timeout 900 python3 tests/gpu_parity_census.py 2000 1000 synthetic > "$out/census2000.log" 2>&1 && mv gpurun_out/parity_census.json "$out/${tag}_parity_census_2000_from_1000.json"
 timeout 900 python3 tests/gpu_parity_census.py 10 0 config5 > "$out/census_c5.log" 2>&1 && mv gpurun_out/parity_census.json "$out/${tag}_parity_census_config5.json"
 # (the raw traces stay on the box: gpurun copies back 64 MiB at most)
 rm -rf "$out"/trace "$out"/trace1
