@@ -531,6 +531,10 @@ class Template:
             if not isinstance(a, TemplateAtom):
                 raise TypeError(f"expected TemplateAtom, found {type(a).__name__}")
         self.id = id
+        # What the device library needs of this template, made here, once: PyJess builds the C template when a
+        # ``Template`` is constructed and ``Jess(templates)`` only collects them; round 5 does the same -- ``Jess`` on a list
+        # of 6780 templates used to walk their 90 543 atoms in Python (0.18 s before the first query of a process).
+        self._rows = _template_rows(self._atoms)
 
     @classmethod
     def loads(cls, text: str, id: Optional[str] = None) -> "Template":
@@ -588,6 +592,44 @@ class Template:
 # ---------------------------------------------------------------------------------- packing
 
 
+_atom_kinds: dict = {}          # (match_mode, raw names, raw residues) -> number, in order of first appearance
+_atom_kind_list: list = []      # ... and back
+_atom_kinds_lock = threading.Lock()
+
+
+def _kind_numbers(keys) -> np.ndarray:
+    """Process-wide numbers of the atoms' (match_mode, raw names, raw residues) keys: a library's masks are then two
+    table look-ups over the concatenated numbers instead of a dictionary access per atom."""
+    out = np.empty(len(keys), dtype=np.uint32)
+    get = _atom_kinds.get
+    for i, key in enumerate(keys):
+        n = get(key)
+        if n is None:
+            with _atom_kinds_lock:
+                n = _atom_kinds.get(key)
+                if n is None:
+                    n = len(_atom_kind_list)
+                    _atom_kind_list.append(key)
+                    _atom_kinds[key] = n
+        out[i] = n
+    return out
+
+
+def _template_rows(atoms) -> tuple:
+    """(xyz [k, 3] f8, weight [k] f8, any-residue [k] u1, group [k] u1, chain [k] u1, keys, kind numbers [k] u4): the
+    per-atom rows of one template as the device library takes them -- group / chain = ordinal of (chain, resSeq) / chain
+    id by first appearance, keys = (match_mode, raw names, raw residues) per atom, what the vocabulary turns into masks."""
+    k = len(atoms)
+    xyz = np.array([(a.x, a.y, a.z) for a in atoms], dtype=np.float64).reshape(k, 3)
+    weight = np.array([a.distance_weight for a in atoms], dtype=np.float64)
+    groups, chains = {}, {}
+    group = np.array([groups.setdefault((a.chain_id, a.residue_number), len(groups)) for a in atoms], dtype=np.uint8)
+    chain = np.array([chains.setdefault(a.chain_id, len(chains)) for a in atoms], dtype=np.uint8)
+    keys = tuple((a.match_mode, a._raw_names, a._raw_residues) for a in atoms)
+    any_res = np.array([1 if key[0] >= 100 else 0 for key in keys], dtype=np.uint8)
+    return xyz, weight, any_res, group, chain, keys, _kind_numbers(keys)
+
+
 class _PackedLibrary:
     """Host tables + device handle of a list of templates (what ``Jess(templates)`` builds)."""
 
@@ -601,39 +643,35 @@ class _PackedLibrary:
             self.device = device
             _settle_library_objects(len(self.offsets) - 1)
             return
+        rows = []
         for t in templates:
             if len(t._atoms) == 0:
                 raise ValueError("cannot search an empty template")
-            for a in t._atoms:
-                VOCAB.register_template_atom(a.match_mode, a._raw_names, a._raw_residues)
+            r = getattr(t, "_rows", None)
+            if r is None or len(r) != 7 or len(r[5]) != len(t._atoms):  # (an object made without Template.__init__)
+                r = _template_rows(t._atoms)
+                try:
+                    t._rows = r
+                except AttributeError:
+                    pass
+            rows.append(r)
+        self.offsets = np.zeros(len(rows) + 1, dtype=np.uint32)
+        np.cumsum([len(r[5]) for r in rows], out=self.offsets[1:])
+        cat = lambda c, dt, shape: np.concatenate([r[c] for r in rows]) if rows else np.zeros(shape, dtype=dt)
+        xyz, weight = cat(0, np.float64, (0, 3)), cat(1, np.float64, 0)
+        any_res, group, chain = cat(2, np.uint8, 0), cat(3, np.uint8, 0), cat(4, np.uint8, 0)
+        kinds = cat(6, np.uint32, 0)
+        distinct = np.unique(kinds)
+        for n in distinct.tolist():  # every name first, the masks after that (a mask names every id of its element)
+            VOCAB.register_template_atom(*_atom_kind_list[n])
         self.vocab_version = VOCAB.version
-        n_atoms = sum(len(t._atoms) for t in templates)
-        self.offsets = np.zeros(len(templates) + 1, dtype=np.uint32)
-        xyz = np.empty((n_atoms, 3), dtype=np.float64)
-        weight = np.empty(n_atoms, dtype=np.float64)
-        res_mask = np.empty(n_atoms, dtype=np.uint32)
-        name_mask = np.empty(n_atoms, dtype=np.uint64)
-        any_res = np.empty(n_atoms, dtype=np.uint8)
-        group = np.empty(n_atoms, dtype=np.uint8)
-        chain = np.empty(n_atoms, dtype=np.uint8)
-        mask_cache = {}
-        i = 0
-        for ti, t in enumerate(templates):
-            groups, chains = {}, {}
-            for a in t._atoms:
-                key = (a.match_mode, a._raw_names, a._raw_residues)
-                masks = mask_cache.get(key)
-                if masks is None:
-                    masks = mask_cache[key] = (VOCAB.res_mask(a.match_mode, a._raw_residues),
-                                               VOCAB.name_mask(a.match_mode, a._raw_names))
-                xyz[i] = (a.x, a.y, a.z)
-                weight[i] = a.distance_weight
-                res_mask[i], name_mask[i] = masks
-                any_res[i] = 1 if a.match_mode >= 100 else 0
-                group[i] = groups.setdefault((a.chain_id, a.residue_number), len(groups))
-                chain[i] = chains.setdefault(a.chain_id, len(chains))
-                i += 1
-            self.offsets[ti + 1] = i
+        res_table = np.zeros(len(_atom_kind_list), dtype=np.uint32)
+        name_table = np.zeros(len(_atom_kind_list), dtype=np.uint64)
+        for n in distinct.tolist():
+            key = _atom_kind_list[n]
+            res_table[n] = VOCAB.res_mask(key[0], key[2])
+            name_table[n] = VOCAB.name_mask(key[0], key[1])
+        res_mask, name_mask = res_table[kinds], name_table[kinds]
         orientation = self._orientation_table(templates)
         # (the host tables are kept: a library over several template lists is put together from theirs, `concat`)
         self.tables = (self.offsets, xyz, weight, res_mask, name_mask, any_res, group, chain, orientation)
@@ -679,22 +717,41 @@ class _PackedLibrary:
     def _orientation_table(templates):
         """Residue-orientation definitions of enzymm-style templates (objects with ``.residues`` whose
         members expose ``orientation_vector`` / ``orientation_vector_indices``, template.py:409-422) for the
-        fused hit epilogue; None when any template lacks them."""
-        offsets, first, second, vec = [0], [], [], []
+        fused hit epilogue; None when any template lacks them.  A template's rows are made once and kept on it
+        (``_orient_rows``: its residues never change)."""
+        first, second, vec, counts = [], [], [], []
         for t in templates:
-            residues = getattr(t, "residues", None)
-            if residues is None or 3 * len(residues) != len(t._atoms):
+            rows = getattr(t, "_orient_rows", None)
+            if rows is None:
+                rows = _PackedLibrary._orientation_rows(t)
+                try:
+                    t._orient_rows = rows
+                except AttributeError:
+                    pass
+            if rows is False:
                 return None
-            flat = [a for r in residues for a in r.atoms]
-            if any(x is not y for x, y in zip(flat, t._atoms)):
-                return None
-            for r in residues:
-                i, j = r.orientation_vector_indices
-                v = r.orientation_vector
-                first.append(i); second.append(j); vec.append((v.x, v.y, v.z))
-            offsets.append(len(first))
-        return (np.array(offsets, dtype=np.uint32), np.array(first, dtype=np.uint8),
-                np.array(second, dtype=np.uint8), np.array(vec, dtype=np.float64).reshape(-1, 3))
+            first.append(rows[0]); second.append(rows[1]); vec.append(rows[2]); counts.append(len(rows[0]))
+        offsets = np.zeros(len(counts) + 1, dtype=np.uint32)
+        np.cumsum(counts, out=offsets[1:])
+        if not counts:
+            return offsets, np.zeros(0, np.uint8), np.zeros(0, np.uint8), np.zeros((0, 3), np.float64)
+        return offsets, np.concatenate(first), np.concatenate(second), np.concatenate(vec).reshape(-1, 3)
+
+    @staticmethod
+    def _orientation_rows(t):
+        """(first u1 [r], second u1 [r], vectors f8 [r, 3]) of one template, or False when it has no usable residues."""
+        residues = getattr(t, "residues", None)
+        if residues is None or 3 * len(residues) != len(t._atoms):
+            return False
+        flat = [a for r in residues for a in r.atoms]
+        if any(x is not y for x, y in zip(flat, t._atoms)):
+            return False
+        first, second, vec = [], [], []
+        for r in residues:
+            i, j = r.orientation_vector_indices
+            v = r.orientation_vector
+            first.append(i); second.append(j); vec.append((v.x, v.y, v.z))
+        return (np.array(first, dtype=np.uint8), np.array(second, dtype=np.uint8), np.array(vec, dtype=np.float64).reshape(-1, 3))
 
 
 _settled = False
@@ -978,14 +1035,23 @@ class Query(collections.abc.Iterator):
 def register_vocabulary(templates) -> None:
     """Give every atom/residue name the templates refer to its id now, so that batches encoded after
     this call stay valid for queries with these templates."""
-    for t in templates:
-        if getattr(t, "_vocab_version", None) is None:
-            for a in t._atoms:
-                VOCAB.register_template_atom(a.match_mode, a._raw_names, a._raw_residues)
-            try:
-                t._vocab_version = VOCAB.version
-            except AttributeError:
-                pass
+    todo = [t for t in templates if getattr(t, "_vocab_version", None) is None]
+    if not todo:
+        return
+    keys = set()
+    for t in todo:  # (the distinct (match mode, names, residues) of their atoms: a thousand for the whole library)
+        rows = getattr(t, "_rows", None)
+        if rows is not None and len(rows[5]) == len(t._atoms):
+            keys.update(rows[5])
+        else:
+            keys.update((a.match_mode, a._raw_names, a._raw_residues) for a in t._atoms)
+    for key in keys:
+        VOCAB.register_template_atom(*key)
+    for t in todo:
+        try:
+            t._vocab_version = VOCAB.version
+        except AttributeError:
+            pass
 
 
 _jess_cache: "dict[tuple, tuple]" = {}  # (id(template list), device) -> (tuple of its templates, _PackedLibrary or None, the list, a copy of the list)

@@ -317,6 +317,9 @@ class Template(pyjess.Template):
         self.enzyme_discription, self.represented_sites = enzyme_discription, represented_sites
         self.ec = tuple(sorted({*ec, *self._annotations("ec")}))
         self.cath = tuple(sorted({*cath, *self._annotations("cath")}))
+        # the residue-orientation rows of the device library's fused hit epilogue, made with the template like its atom rows
+        # (pyjess.Template.__init__): Jess(templates) then only concatenates
+        self._orient_rows = pyjess._PackedLibrary._orientation_rows(self)
 
     def _annotations(self, what: str) -> List[str]:
         """EC / CATH numbers known for this template's M-CSA entry and PDB chains
