@@ -78,11 +78,52 @@ def reference_baseline(molecules, idx, cut, target_seconds):
                 list(pool.map(one, chunk))
                 done += len(chunk)
         dt = time.perf_counter() - t0
+        try:
+            dump_reference_vectors(real, texts)
+        except Exception:
+            pass
         return dict(value=done / dt, unit="structures/s", cores=cores, kind="reference",
                     sample=f"first {done} structures of the bench batch vs the same 6780 templates, "
                            f"pyjess {getattr(real, '__version__', '?')} Jess.query on {cores} threads ({dt:.1f} s)")
     except Exception:  # absent, or not the API of pyjess ~= 0.5
         return None
+
+
+def dump_reference_vectors(real, texts):
+    """Should a box ever have the real PyJess: answers to what the reference's own tests leave unpinned, written
+    to gpurun_out/pyjess_golden_vectors.json so that they can be committed as fixtures -- match mode 1 (treated like 3 here),
+    one-letter X / U / O residue lists, the dynamic distance with weights, ignore_chain=False, the all-hits mode, and
+    log_evalue, on the two structures the reference ships.  Inputs are named by template id and file; outputs are hits as
+    (rmsd, log_evalue, atom serials).  Never runs in this image (no pyjess); never fails the bench."""
+    golden = ROOT / "tests" / "golden"
+    molecules = {name: real.Molecule.load(str(golden / name)) for name in ("1AMY.pdb", "AF-P0DUB6-F1-model_v4.pdb")}
+    picks, seen = [], set()
+    for name, text in texts:  # a few templates of every kind of interest, by what their ATOM lines hold
+        lines = [l for l in text.splitlines() if l.startswith("ATOM")]
+        modes = {int(l[6:11]) for l in lines}
+        letters = set("".join(l[54:60].strip() for l in lines))
+        weighted = any(l[60:66].strip() not in ("", "0.00", "0.0", "0") for l in lines)
+        for tag, hit in (("mode1", 1 in modes), ("mode100", any(m >= 100 for m in modes)), ("X", "X" in letters),
+                         ("U", "U" in letters), ("O", "O" in letters), ("weighted", weighted)):
+            if hit and sum(1 for t, _ in picks if t == tag) < 4 and (tag, name) not in seen:
+                picks.append((tag, name)); seen.add((tag, name))
+    by_name = dict(texts)
+    out = {"pyjess_version": getattr(real, "__version__", None), "cases": []}
+    settings = (dict(rmsd_threshold=2.0, distance_cutoff=1.5, max_dynamic_distance=1.5, max_candidates=10000, best_match=True, ignore_chain=True),
+                dict(rmsd_threshold=2.0, distance_cutoff=1.0, max_dynamic_distance=2.0, max_candidates=10000, best_match=True, ignore_chain=True),
+                dict(rmsd_threshold=2.0, distance_cutoff=1.5, max_dynamic_distance=1.5, max_candidates=10000, best_match=True, ignore_chain=False),
+                dict(rmsd_threshold=2.0, distance_cutoff=1.5, max_dynamic_distance=1.5, max_candidates=50, best_match=False, ignore_chain=True))
+    for tag, name in picks:
+        tpl = real.Template.loads(by_name[name], id=name)
+        for mname, mol in molecules.items():
+            for kw in settings:
+                hits = list(real.Jess([tpl]).query(mol, **kw))
+                out["cases"].append({"kind": tag, "template": name, "molecule": mname, "arguments": kw,
+                                     "hits": [{"rmsd": h.rmsd, "log_evalue": getattr(h, "log_evalue", None),
+                                               "serials": [a.serial for a in h.atoms(transform=False)]} for h in hits]})
+    target = ROOT / "gpurun_out"
+    target.mkdir(exist_ok=True)
+    (target / "pyjess_golden_vectors.json").write_text(json.dumps(out, indent=1) + "\n")
 
 
 def usable_cores() -> int:

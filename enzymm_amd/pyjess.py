@@ -523,7 +523,10 @@ class TemplateAtom:
 
 class Template:
     """A Jess template: an ordered list of ``TemplateAtom``.  Meant to be subclassed
-    (enzymm/template.py:455 adds residues, cluster, EC/CATH ... on top)."""
+    (enzymm/template.py:455 adds residues, cluster, EC/CATH ... on top).
+
+    The atoms of a constructed template must not be changed afterwards (PyJess's ``TemplateAtom`` is immutable; this
+    mirror's is a plain object for convenience): what the device needs of them is taken when the template is made."""
 
     def __init__(self, atoms: Iterable[TemplateAtom] = (), id: Optional[str] = None):
         self._atoms = tuple(atoms)
