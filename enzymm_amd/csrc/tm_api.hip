@@ -623,6 +623,14 @@ struct tm_batch {
     std::vector<uint64_t> h_text_off;
     DevBuf<uint32_t> d_residue_count;  // device-parsed batches with counted residue names: distinct residue numbers
     bool has_residue_count = false;
+    // index build of long structures (more than kKindSeg atoms): their segments, made at the first build (build_index)
+    DevBuf<KindSeg> d_kind_segs;
+    PinnedBuf<KindSeg> h_kind_segs;
+    DevBuf<KindLong> d_kind_longs;
+    PinnedBuf<KindLong> h_kind_longs;
+    DevBuf<uint32_t> d_kind_seg_cnt;  // [segments][lead kinds]: counts, then places
+    uint32_t n_kind_segs = 0, n_kind_longs = 0;
+    bool kind_segs_made = false;
     // search work items (structure, round), cached for the (cx, n_sel) they were planned for
     DevBuf<WorkItem> d_work;
     PinnedBuf<WorkItem> h_work;      // page-locked source of d_work: uploaded on the query's stream without a host wait
@@ -2064,16 +2072,55 @@ static int build_index(const tm_library *lib, tm_batch *b, tm_result *r, hipStre
         HIP_TRY(hipGetLastError());
     }
     if (b->n_structs && lib->n_lead) {
-        // LDS for the per-name atom buckets (4 B per atom of the largest structure): structures above the cap scan all
-        // their atoms for every lead kind -- 3.5 ms per batch of 25 k-atom complexes when the cap was 12 288 atoms
-        const uint32_t bucket_cap = 38912;  // 152 KB at 4 bytes per atom
-        const size_t lds = ((size_t)lib->n_lead + 1) * sizeof(uint32_t) +
-                           (size_t)std::min<uint32_t>(b->max_atoms, bucket_cap) * 2 * sizeof(uint16_t) + 16;
-        HIP_TRY(allow_dynamic_lds(reinterpret_cast<const void *>(k_kind_lists), lds));
-        hipLaunchKernelGGL(k_kind_lists, dim3(b->n_structs), dim3(512), lds, stream,
-                           lib->view(), b->view(), b->d_kl_off.p, b->d_kl_pool.p, b->has_wide ? b->d_kl_pool_hi.p : nullptr,
-                           b->d_cursor.p, cap, b->d_overflow.p, bucket_cap);
+        const uint32_t cap_atoms = (std::min<uint32_t>(b->max_atoms, kKindSeg) + 1u) & ~1u;
+        const size_t lds = kind_lds_bytes(lib->n_lead, cap_atoms);
+        uint8_t *pool_hi = b->has_wide ? b->d_kl_pool_hi.p : nullptr;
+        HIP_TRY(allow_dynamic_lds(reinterpret_cast<const void *>(k_kind_lists<kKindWhole>), lds));
+        hipLaunchKernelGGL(k_kind_lists<kKindWhole>, dim3(b->n_structs), dim3(512), lds, stream, lib->view(), b->view(),
+                           (const KindSeg *)nullptr, (uint32_t *)nullptr, b->d_kl_off.p, b->d_kl_pool.p, pool_hi,
+                           b->d_cursor.p, cap, b->d_overflow.p, cap_atoms);
         HIP_TRY(hipGetLastError());
+        if (b->max_atoms > kKindSeg) {
+            // long structures (large complexes): segments of kKindSeg atoms, counted, placed and written by three launches
+            if (!b->kind_segs_made) {
+                std::vector<KindSeg> segs;
+                std::vector<KindLong> longs;
+                for (uint32_t s = 0; s < b->n_structs; ++s) {
+                    const uint32_t n = b->s_off[s + 1] - b->s_off[s];
+                    if (n <= kKindSeg) continue;
+                    longs.push_back({s, (uint32_t)segs.size(), (n + kKindSeg - 1) / kKindSeg});
+                    for (uint32_t lo = 0; lo < n; lo += kKindSeg) segs.push_back({s, lo});
+                }
+                HIP_TRY(b->h_kind_segs.alloc(segs.size()));
+                std::copy(segs.begin(), segs.end(), b->h_kind_segs.p);
+                HIP_TRY(b->d_kind_segs.upload_async(b->h_kind_segs.p, segs.size(), stream));  // no host wait: see build_tables
+                HIP_TRY(b->h_kind_longs.alloc(longs.size()));
+                std::copy(longs.begin(), longs.end(), b->h_kind_longs.p);
+                HIP_TRY(b->d_kind_longs.upload_async(b->h_kind_longs.p, longs.size(), stream));
+                b->n_kind_segs = (uint32_t)segs.size(); b->n_kind_longs = (uint32_t)longs.size();
+                b->kind_segs_made = true;
+            }
+            const size_t cnt_n = (size_t)b->n_kind_segs * lib->n_lead;
+            if (b->d_kind_seg_cnt.n < cnt_n) {
+                if (b->queried) HIP_TRY(hipStreamSynchronize(b->last_stream));
+                HIP_TRY(b->d_kind_seg_cnt.alloc(cnt_n));
+            }
+            const size_t lds_seg = kind_lds_bytes(lib->n_lead, kKindSeg);
+            HIP_TRY(allow_dynamic_lds(reinterpret_cast<const void *>(k_kind_lists<kKindCount>), lds_seg));
+            HIP_TRY(allow_dynamic_lds(reinterpret_cast<const void *>(k_kind_lists<kKindWrite>), lds_seg));
+            hipLaunchKernelGGL(k_kind_lists<kKindCount>, dim3(b->n_kind_segs), dim3(512), lds_seg, stream, lib->view(), b->view(),
+                               (const KindSeg *)b->d_kind_segs.p, b->d_kind_seg_cnt.p, b->d_kl_off.p, b->d_kl_pool.p, pool_hi,
+                               b->d_cursor.p, cap, b->d_overflow.p, kKindSeg);
+            HIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL(k_kind_seg_offsets, dim3(b->n_kind_longs), dim3(256), ((size_t)lib->n_lead + 1) * sizeof(uint32_t), stream,
+                               lib->n_lead, (const KindLong *)b->d_kind_longs.p, b->d_kind_seg_cnt.p, b->d_kl_off.p,
+                               b->d_cursor.p, cap, b->d_overflow.p);
+            HIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL(k_kind_lists<kKindWrite>, dim3(b->n_kind_segs), dim3(512), lds_seg, stream, lib->view(), b->view(),
+                               (const KindSeg *)b->d_kind_segs.p, b->d_kind_seg_cnt.p, b->d_kl_off.p, b->d_kl_pool.p, pool_hi,
+                               b->d_cursor.p, cap, b->d_overflow.p, kKindSeg);
+            HIP_TRY(hipGetLastError());
+        }
     }
     b->index_for = lib->serial;
     return TM_OK;

@@ -243,151 +243,242 @@ __global__ __launch_bounds__(64) void k_stage_templates(LibView L, uint32_t n_se
 
 // ------------------------------------------------------------------ k_kind_lists
 
-// One workgroup per structure.  The atoms are first bucketed by atom-name id (ascending atom index
-// inside a bucket); a lead kind that accepts a single name -- nearly all of them -- then only scans
-// that bucket for its residue types instead of the whole structure.  Pass A counts the admissible
-// atoms of every lead kind, a bump allocation reserves the structure's slice of the pool, pass B
-// writes the lists (ascending atom index).
-// The thousand workgroups of a batch are resident together, so the launch takes as long as one workgroup does: nothing
-// in it waits on global memory inside a loop -- the atoms' name and residue-type ids are read once (into LDS, 2 bytes
-// per atom), a wave holds the constants of the lead kinds it handles in its lanes (kind j of the wave in lane j), and
-// the two prefix sums (name buckets, list offsets) are wave scans, not one thread's loop.
-//
-// Dynamic LDS: [n_lead + 1] counts/offsets, then (when n <= bucket_cap) one u16 per atom: name id | residue-type id << 8,
-// then one u16 per atom: the atom indices grouped by name id.
-__global__ __launch_bounds__(512) void k_kind_lists(LibView L, BatchView B, uint32_t *__restrict__ kl_off,
+// The candidate index: for every lead kind the ascending list of admissible atoms of every structure.
+// One workgroup per structure of at most kKindSeg atoms (kKindWhole); a longer structure (a large complex) is cut into
+// segments of kKindSeg atoms that are counted (kKindCount), given their places (k_kind_seg_offsets) and written
+// (kKindWrite) by one workgroup each -- one workgroup per structure took 0.77 ms per 25 k-atom complex, on one CU.
+//   1. the atoms' name and residue-type ids go to LDS (2 bytes per atom) and into a (name x residue type) histogram: the
+//      length of every kind's list is a sum over the histogram (one thread per kind), not a scan of the atoms;
+//   2. the atoms are bucketed by atom-name id, ascending inside a bucket: per 64-atom block one vote per distinct name
+//      gives every atom its rank among the block's atoms of that name and the block's count, a scan over the blocks per
+//      name and one over the names give the bucket positions (before: every wave scanned ALL atoms once per name);
+//   3. a lead kind that accepts a single name -- nearly all of them -- scans that bucket for its residue types, a kind
+//      that matches by element (ten names) scans the segment; the waves take kinds one at a time from a counter.
+// Nothing in it waits on global memory inside a loop.
+// Dynamic LDS (kind_lds_bytes): [n_lead + 1] counts/offsets, [n_lead] kind constants, the histogram, the per-(name, block)
+// counts, then per atom: name | residue type << 8 (u16), the buckets (u16), the rank in its block (u8).
+constexpr uint32_t kKindSeg = 4096;  // atoms a workgroup of the index build handles (64 blocks of 64: one lane per block)
+struct KindSeg { uint32_t s, lo; };          // a segment of a long structure: structure, first atom
+struct KindLong { uint32_t s, first, n; };   // a long structure: its segments are [first, first + n) of the segment list
+enum { kKindWhole = 0, kKindCount = 1, kKindWrite = 2 };
+__host__ __device__ inline size_t kind_lds_bytes(uint32_t n_lead, uint32_t cap_atoms) {
+    return ((((size_t)n_lead + 1) * 4 + 15) & ~(size_t)15) + (size_t)n_lead * 16 + 2048 * 4 + 4096 * 2 + (size_t)cap_atoms * 5 + 16;
+}
+
+template <int kMode>
+__global__ __launch_bounds__(512) void k_kind_lists(LibView L, BatchView B, const KindSeg *__restrict__ segs,
+                                                     uint32_t *__restrict__ seg_cnt, uint32_t *__restrict__ kl_off,
                                                      uint16_t *__restrict__ kl_pool, uint8_t *__restrict__ kl_pool_hi,
                                                      unsigned long long *__restrict__ cursor,
                                                      unsigned long long capacity, uint32_t *__restrict__ overflow,
-                                                     uint32_t bucket_cap) {
-    extern __shared__ uint32_t s_dyn[];
-    uint32_t *s_cnt = s_dyn;                      // [n_lead + 1]
-    uint16_t *s_meta = reinterpret_cast<uint16_t *>(s_dyn + L.n_lead + 1);  // [n] when bucketed
+                                                     uint32_t cap_atoms) {
+    extern __shared__ __align__(16) unsigned char kind_smem[];
+    const uint32_t nl = L.n_lead;
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(kind_smem);                                          // [nl + 1]
+    uint4 *s_kc = reinterpret_cast<uint4 *>(kind_smem + ((((size_t)nl + 1) * 4 + 15) & ~(size_t)15));   // [nl] {resmask, names lo, hi, any}
+    uint32_t *s_hist = reinterpret_cast<uint32_t *>(s_kc + nl);                                         // [64 names][32 residue types]
+    uint16_t *s_bc = reinterpret_cast<uint16_t *>(s_hist + 2048);                                       // [64 names][64 blocks]
+    uint16_t *s_meta = s_bc + 4096;                                                                     // [m]
+    uint16_t *s_bucket = s_meta + cap_atoms;                                                            // [m]
+    uint8_t *s_rank = reinterpret_cast<uint8_t *>(s_bucket + cap_atoms);                                // [m]
     __shared__ unsigned long long s_base;
-    __shared__ uint32_t s_noff[65];               // bucket of name id i: [s_noff[i], s_noff[i + 1])
-    const uint32_t s = blockIdx.x;
+    __shared__ uint32_t s_noff[65];  // bucket of name id i: [s_noff[i], s_noff[i + 1])
+    __shared__ uint32_t s_next;
+    uint32_t s, lo = 0;
+    if (kMode == kKindWhole) s = blockIdx.x;
+    else { s = segs[blockIdx.x].s; lo = segs[blockIdx.x].lo; }
     const uint32_t a0 = B.s_off[s], n = B.s_off[s + 1] - a0;
-    const int lane = lane_id(), wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    const float4 *rec = B.q_rec + a0;
-    const bool bucketed = n <= bucket_cap;
-    uint16_t *s_bucket = s_meta + (bucketed ? n : 0u);                         // [n] when bucketed
+    if (kMode == kKindWhole && n > kKindSeg) return;  // a long structure: the segment launches
+    const uint32_t m = kMode == kKindWhole ? n : min(kKindSeg, n - lo);
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const float4 *rec = B.q_rec + a0 + lo;
+    const uint32_t nblocks = (m + 63u) >> 6;
 
-    // the lead kinds this wave handles: kind number j of the wave (li = wave + nwaves j) sits in lane j
-    uint32_t my_rm = 0, my_nm_lo = 0, my_nm_hi = 0, my_any = 0;
-    {
-        const uint32_t li = (uint32_t)wave + (uint32_t)nwaves * (uint32_t)lane;
-        if (li < L.n_lead) {
-            const uint32_t kind = L.lead_kind[li];
-            const uint64_t nm = L.k_namemask[kind];
-            my_rm = L.k_resmask[kind];
-            my_nm_lo = (uint32_t)nm; my_nm_hi = (uint32_t)(nm >> 32);
-            my_any = L.k_any[kind] != 0 ? 1u : 0u;
-        }
+    for (uint32_t i = threadIdx.x; i < 2048u; i += blockDim.x) {
+        s_hist[i] = 0u;
+        reinterpret_cast<uint32_t *>(s_bc)[i] = 0u;
     }
-
-    if (bucketed) {
-        if (threadIdx.x < 65) s_noff[threadIdx.x] = 0;
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-            const uint32_t m = __float_as_uint(rec[i].w);
-            s_meta[i] = (uint16_t)(meta_name(m) | (meta_rtype(m) << 8));
-            atomicAdd(&s_noff[meta_name(m) + 1], 1u);
-        }
-        __syncthreads();
-        if (wave == 0) s_noff[lane + 1] = wave_scan_add(s_noff[lane + 1]);  // (64 name ids: one per lane)
-        __syncthreads();
-        // every wave takes the names w, w + nwaves, ...: ordered compaction of the atoms carrying that name
-        for (uint32_t name = wave; name < 64; name += nwaves) {
-            uint32_t w = s_noff[name];
-            if (s_noff[name + 1] == w) continue;
-            for (uint32_t b0 = 0; b0 < n; b0 += 64) {
-                const uint32_t i = b0 + lane;
-                uint32_t m = 0;
-                bool ok = false;
-                if (i < n) {
-                    m = s_meta[i];
-                    ok = (m & 0xffu) == name;
-                }
-                const unsigned long long mask = ballot64(ok);
-                if (ok) s_bucket[w + rank_in(mask)] = (uint16_t)i;
-                w += __popcll(mask);
+    if (threadIdx.x == 0) s_next = 0u;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {
+        const uint32_t mw = __float_as_uint(rec[i].w);
+        s_meta[i] = (uint16_t)(meta_name(mw) | (meta_rtype(mw) << 8));
+        atomicAdd(&s_hist[meta_name(mw) * 32u + meta_rtype(mw)], 1u);
+    }
+    __syncthreads();
+    // one thread per lead kind: its constants to LDS, and the length of its list from the histogram
+    for (uint32_t li = threadIdx.x; li < nl; li += blockDim.x) {
+        const uint32_t kind = L.lead_kind[li];
+        const uint64_t nm = L.k_namemask[kind];
+        const uint32_t rm = L.k_any[kind] != 0 ? 0xffffffffu : L.k_resmask[kind];
+        s_kc[li] = make_uint4(rm, (uint32_t)nm, (uint32_t)(nm >> 32), 0u);
+        if (kMode != kKindWrite) {
+            uint32_t c = 0;
+            for (uint64_t names = nm; names != 0ull; names &= names - 1ull) {
+                const uint32_t *row = s_hist + 32u * ((uint32_t)__ffsll((long long)names) - 1u);
+                for (uint32_t types = rm; types != 0u; types &= types - 1u) c += row[__ffs((int)types) - 1];
             }
+            if (kMode == kKindCount) seg_cnt[(size_t)blockIdx.x * nl + li] = c;
+            else s_cnt[li] = c;
         }
-        __syncthreads();
     }
+    if (kMode == kKindCount) return;
 
-    // admissible atoms of the wave's lead kind number j, in ascending order, handed to `emit(mask, ok, atom)` 64 at a time
-    auto scan_kind = [&](uint32_t j, auto emit) {
-        uint32_t rm, nm_lo, nm_hi, any_u;
-        if (j < 64u) {
-            rm = __builtin_amdgcn_readlane(my_rm, (int)j); nm_lo = __builtin_amdgcn_readlane(my_nm_lo, (int)j);
-            nm_hi = __builtin_amdgcn_readlane(my_nm_hi, (int)j); any_u = __builtin_amdgcn_readlane(my_any, (int)j);
-        } else {  // (more lead kinds than 64 per wave: read where they are)
-            const uint32_t kind = L.lead_kind[(uint32_t)wave + (uint32_t)nwaves * j];
-            const uint64_t nm64 = L.k_namemask[kind];
-            rm = L.k_resmask[kind]; nm_lo = (uint32_t)nm64; nm_hi = (uint32_t)(nm64 >> 32); any_u = L.k_any[kind] != 0 ? 1u : 0u;
+    // ---- the name buckets.  Per block of 64 atoms: one vote per distinct name in it
+    for (uint32_t b = wave; b < nblocks; b += nwaves) {
+        const uint32_t i = (b << 6) + lane;
+        const uint32_t name = i < m ? (uint32_t)s_meta[i] & 0xffu : 0xffu;
+        unsigned long long remaining = ballot64(i < m);
+        uint32_t rank = 0;
+        while (remaining != 0ull) {
+            const uint32_t cur = (uint32_t)__builtin_amdgcn_readlane((int)name, __ffsll((long long)remaining) - 1);
+            const unsigned long long same = ballot64(name == cur);
+            if (name == cur) rank = rank_in(same);
+            if (lane == 0) s_bc[(cur << 6) + b] = (uint16_t)__popcll(same);
+            remaining &= ~same;
         }
-        const uint64_t nm = ((uint64_t)nm_hi << 32) | nm_lo;
-        const bool any = any_u != 0u;
-        if (bucketed && (nm & (nm - 1)) == 0ull && nm != 0ull) {
+        if (i < m) s_rank[i] = (uint8_t)rank;
+    }
+    __syncthreads();
+    // per name: the atoms of that name before every block (lane = block), and the bucket's length
+    for (uint32_t name = wave; name < 64u; name += nwaves) {
+        const uint32_t c = s_bc[(name << 6) + lane];
+        const uint32_t incl = wave_scan_add(c);
+        s_bc[(name << 6) + lane] = (uint16_t)(incl - c);
+        if (lane == 63u) s_noff[name + 1] = incl;
+    }
+    if (threadIdx.x == 0) s_noff[0] = 0u;
+    __syncthreads();
+    if (wave == 0) s_noff[lane + 1] = wave_scan_add(s_noff[lane + 1]);  // (64 name ids: one per lane)
+    if (kMode == kKindWhole && wave == 1) {  // exclusive scan of the kinds' counts, 64 at a time; the structure's slice of the pool
+        uint32_t run = 0;
+        for (uint32_t l0 = 0; l0 < nl; l0 += 64u) {
+            const uint32_t li = l0 + lane;
+            const uint32_t c = li < nl ? s_cnt[li] : 0u;
+            const uint32_t incl = wave_scan_add(c);
+            if (li < nl) s_cnt[li] = run + incl - c;
+            run += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+        if (lane == 0) {
+            s_cnt[nl] = run;
+            unsigned long long base = atomicAdd(cursor, (unsigned long long)run);
+            if (base + run > capacity) {
+                atomicOr(overflow, 1u);
+                base = ~0ull;
+            }
+            s_base = base;
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {
+        const uint32_t name = (uint32_t)s_meta[i] & 0xffu;
+        s_bucket[s_noff[name] + s_bc[(name << 6) + (i >> 6)] + s_rank[i]] = (uint16_t)i;
+    }
+    unsigned long long base = 0;
+    if (kMode == kKindWhole) {
+        base = s_base;
+        uint32_t *off_out = kl_off + (size_t)s * (nl + 1);
+        for (uint32_t li = threadIdx.x; li <= nl; li += blockDim.x)
+            off_out[li] = base == ~0ull ? 0u : (uint32_t)(base + s_cnt[li]);
+        if (base == ~0ull) return;
+    }
+    __syncthreads();
+
+    // ---- the lists: a wave takes the next kind, 64 candidates at a time in ascending order
+    for (;;) {
+        uint32_t taken = 0;
+        if (lane == 0) taken = atomicAdd(&s_next, 1u);
+        const uint32_t li = uni(taken);
+        if (li >= nl) break;
+        const uint4 kc = s_kc[li];
+        const uint32_t rm = uni(kc.x);
+        const uint64_t nm = ((uint64_t)uni(kc.z) << 32) | uni(kc.y);
+        unsigned long long w;
+        if (kMode == kKindWhole) w = base + s_cnt[li];
+        else {
+            const uint32_t at = uni(seg_cnt[(size_t)blockIdx.x * nl + li]);  // (k_kind_seg_offsets: where this segment's part goes)
+            if (at == 0xffffffffu) break;                                    // the structure did not fit the pool
+            w = at;
+        }
+        auto emit = [&](bool ok, uint32_t v) {
+            const unsigned long long mask = ballot64(ok);
+            if (ok) {
+                const uint32_t atom = lo + v;
+                kl_pool[w + rank_in(mask)] = (uint16_t)atom;
+                if (kl_pool_hi) kl_pool_hi[w + rank_in(mask)] = (uint8_t)(atom >> 16);  // (a batch with a wide structure)
+            }
+            w += __popcll(mask);
+        };
+        if ((nm & (nm - 1ull)) == 0ull && nm != 0ull) {
             const uint32_t name = (uint32_t)__ffsll((long long)nm) - 1u;
             const uint32_t e1 = s_noff[name + 1];
-            for (uint32_t e0 = s_noff[name]; e0 < e1; e0 += 64) {
+            for (uint32_t e0 = s_noff[name]; e0 < e1; e0 += 64u) {
                 const uint32_t e = e0 + lane;
                 uint32_t v = 0;
                 bool ok = false;
                 if (e < e1) {
                     v = s_bucket[e];
-                    ok = any || ((rm >> (s_meta[v] >> 8)) & 1u);
+                    ok = (rm >> (s_meta[v] >> 8)) & 1u;
                 }
-                emit(ballot64(ok), ok, v);
-            }
-        } else if (bucketed) {
-            for (uint32_t b0 = 0; b0 < n; b0 += 64) {
-                const uint32_t i = b0 + lane;
-                bool ok = false;
-                if (i < n) {
-                    const uint32_t m = s_meta[i];
-                    ok = ((nm >> (m & 0xffu)) & 1ull) && (any || ((rm >> (m >> 8)) & 1u));
-                }
-                emit(ballot64(ok), ok, i);
+                emit(ok, v);
             }
         } else {
-            for (uint32_t b0 = 0; b0 < n; b0 += 64) {
+            for (uint32_t b0 = 0; b0 < m; b0 += 64u) {
                 const uint32_t i = b0 + lane;
                 bool ok = false;
-                if (i < n) {
-                    const uint32_t m = __float_as_uint(rec[i].w);
-                    ok = ((nm >> meta_name(m)) & 1ull) && (any || ((rm >> meta_rtype(m)) & 1u));
+                if (i < m) {
+                    const uint32_t mt = s_meta[i];
+                    ok = ((nm >> (mt & 0xffu)) & 1ull) && ((rm >> (mt >> 8)) & 1u);
                 }
-                emit(ballot64(ok), ok, i);
+                emit(ok, i);
             }
         }
-    };
+    }
+}
+template __global__ void k_kind_lists<kKindWhole>(LibView, BatchView, const KindSeg *, uint32_t *, uint32_t *, uint16_t *, uint8_t *,
+                                                  unsigned long long *, unsigned long long, uint32_t *, uint32_t);
+template __global__ void k_kind_lists<kKindCount>(LibView, BatchView, const KindSeg *, uint32_t *, uint32_t *, uint16_t *, uint8_t *,
+                                                  unsigned long long *, unsigned long long, uint32_t *, uint32_t);
+template __global__ void k_kind_lists<kKindWrite>(LibView, BatchView, const KindSeg *, uint32_t *, uint32_t *, uint16_t *, uint8_t *,
+                                                  unsigned long long *, unsigned long long, uint32_t *, uint32_t);
 
+// Between the two segment launches, one workgroup per long structure: the segments' counts of every kind become the
+// places of their parts -- a running sum over the segments per kind, the exclusive scan over the kinds, the structure's
+// slice of the pool -- and the structure's list offsets are written.  Dynamic LDS: [n_lead + 1] words.
+__global__ __launch_bounds__(256) void k_kind_seg_offsets(uint32_t nl, const KindLong *__restrict__ longs,
+                                                           uint32_t *__restrict__ seg_cnt, uint32_t *__restrict__ kl_off,
+                                                           unsigned long long *__restrict__ cursor, unsigned long long capacity,
+                                                           uint32_t *__restrict__ overflow) {
+    extern __shared__ uint32_t s_tot[];  // [nl + 1]
+    __shared__ unsigned long long s_base;
     __shared__ uint32_t s_long;
+    const KindLong g = longs[blockIdx.x];
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    uint32_t *cnt = seg_cnt + (size_t)g.first * nl;
     if (threadIdx.x == 0) s_long = 0u;
     __syncthreads();
-    for (uint32_t j = 0, li = wave; li < L.n_lead; ++j, li += nwaves) {
-        uint32_t c = 0;
-        scan_kind(j, [&](unsigned long long mask, bool, uint32_t) { c += __popcll(mask); });
-        if (lane == 0) {
-            s_cnt[li] = c;
-            if (c > 0xffffu) s_long = 1u;  // (the pair tables hold list POSITIONS in 16 bits)
+    for (uint32_t li = threadIdx.x; li < nl; li += blockDim.x) {
+        uint32_t run = 0;
+        for (uint32_t k = 0; k < g.n; ++k) {
+            const uint32_t c = cnt[(size_t)k * nl + li];
+            cnt[(size_t)k * nl + li] = run;
+            run += c;
         }
+        s_tot[li] = run;
+        if (run > 0xffffu) s_long = 1u;  // (the pair tables hold list POSITIONS in 16 bits)
     }
     __syncthreads();
-    if (wave == 0) {  // exclusive scan of the counts, 64 at a time
+    if (wave == 0) {
         uint32_t run = 0;
-        for (uint32_t l0 = 0; l0 < L.n_lead; l0 += 64u) {
-            const uint32_t li = l0 + (uint32_t)lane;
-            const uint32_t c = li < L.n_lead ? s_cnt[li] : 0u;
+        for (uint32_t l0 = 0; l0 < nl; l0 += 64u) {
+            const uint32_t li = l0 + lane;
+            const uint32_t c = li < nl ? s_tot[li] : 0u;
             const uint32_t incl = wave_scan_add(c);
-            if (li < L.n_lead) s_cnt[li] = run + incl - c;
-            run += __builtin_amdgcn_readlane(incl, 63);
+            if (li < nl) s_tot[li] = run + incl - c;
+            run += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         }
         if (lane == 0) {
-            s_cnt[L.n_lead] = run;
+            s_tot[nl] = run;
             if (s_long) atomicOr(overflow, 0x100u);  // a kind list beyond 65535 atoms (a wide structure): not searchable
             unsigned long long base = atomicAdd(cursor, (unsigned long long)run);
             if (base + run > capacity) {
@@ -399,21 +490,12 @@ __global__ __launch_bounds__(512) void k_kind_lists(LibView L, BatchView B, uint
     }
     __syncthreads();
     const unsigned long long base = s_base;
-    uint32_t *off_out = kl_off + (size_t)s * (L.n_lead + 1);
-    for (uint32_t li = threadIdx.x; li <= L.n_lead; li += blockDim.x)
-        off_out[li] = base == ~0ull ? 0u : (uint32_t)(base + s_cnt[li]);
-    if (base == ~0ull) return;
-
-    for (uint32_t j = 0, li = wave; li < L.n_lead; ++j, li += nwaves) {
-        unsigned long long w = base + s_cnt[li];
-        scan_kind(j, [&](unsigned long long mask, bool ok, uint32_t atom) {
-            if (ok) {
-                kl_pool[w + rank_in(mask)] = (uint16_t)atom;
-                if (kl_pool_hi) kl_pool_hi[w + rank_in(mask)] = (uint8_t)(atom >> 16);  // (a batch with a wide structure)
-            }
-            w += __popcll(mask);
-        });
-    }
+    uint32_t *off_out = kl_off + (size_t)g.s * (nl + 1);
+    for (uint32_t li = threadIdx.x; li <= nl; li += blockDim.x)
+        off_out[li] = base == ~0ull ? 0u : (uint32_t)(base + s_tot[li]);
+    for (uint32_t li = threadIdx.x; li < nl; li += blockDim.x)
+        for (uint32_t k = 0; k < g.n; ++k)
+            cnt[(size_t)k * nl + li] = base == ~0ull ? 0xffffffffu : (uint32_t)(base + s_tot[li]) + cnt[(size_t)k * nl + li];
 }
 
 // Largest |centred coordinate| of a batch's atom records, as float bits (non-negative floats order like integers):
@@ -803,6 +885,7 @@ __device__ __forceinline__ void tab_build_tables(const BatchView &B, const Table
             const uint32_t bl = min(23u, 64u - (uint32_t)__clzll((long long)bound));
             TM_STAT((T.src == t ? 96 : 120) + bl, bound);
             TM_STAT((T.src == t ? 144 : 168) + bl, total);
+            TM_STAT(284 + min(15u, bl), 1);
         }
 #endif
         // ---- the tables derived from this one (same lists, smaller limits): its entries within their limit
@@ -874,6 +957,7 @@ __device__ __forceinline__ void tab_build_tables(const BatchView &B, const Table
             if (threadIdx.x == 0) {
                 uint32_t run = 0;
                 for (uint32_t k = 0; k < n_waves; ++k) { const uint32_t c = s_count[k]; s_count[k] = run; run += c; }
+                TM_STAT(280, 1); TM_STAT(281, (unsigned long long)n_a * n_b); TM_STAT(282, run); TM_STAT(283, n_b > stage_cap ? 1 : 0);
                 unsigned long long first = atomicAdd(&cursors[1], (unsigned long long)run);
                 if (first + run > ent_capacity) {
                     atomicOr(overflow, 2u);

@@ -15,7 +15,7 @@ packed = pyjess._packed(jess._templates, jess._device)
 base = _native.TM_FLAG_BEST_MATCH | _native.TM_FLAG_IGNORE_CHAIN | _native.TM_FLAG_REBUILD_INDEX
 mols = [synthetic.complex_structure(i, 6000).conserved(70) for i in range(n)]
 batch = pyjess.make_batch(mols, jess._device)
-c = np.full(len(idx), 2.5)
+c = cut if len(sys.argv) > 2 and sys.argv[2] == "default" else np.full(len(idx), 2.5)
 for rep in range(4):
     res = _native.query(packed.native, batch, idx, 2.0, c, c, 10000, base)
     print(rep, res.hit_count(), [round(x, 2) for x in res.timing()], [round(x, 2) for x in res.search_split()], flush=True)

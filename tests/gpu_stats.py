@@ -15,9 +15,10 @@ from enzymm_amd import pyjess, synthetic, _native  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 idx, cut = helpers.default_selection()
 jess = pyjess.Jess(helpers.product_library_templates())
-if len(sys.argv) > 2 and sys.argv[2] == "complexes":  # BASELINE.json configs[4]: large complexes, loosened thresholds
+if len(sys.argv) > 2 and sys.argv[2].startswith("complexes"):  # BASELINE.json configs[4]: large complexes, loosened thresholds ("complexes_default": the default ones)
     mols = [synthetic.complex_structure(i, 6000).conserved(70) for i in range(n)]
-    cut = np.full(len(idx), 2.5)
+    if sys.argv[2] == "complexes":
+        cut = np.full(len(idx), 2.5)
 elif len(sys.argv) > 2 and sys.argv[2] == "real":  # rigid copies of the two structures the reference's tests ship (bench.py's real_* figures)
     real = [pyjess.Molecule.load(ROOT / "tests" / "golden" / f) for f in ("1AMY.pdb", "AF-P0DUB6-F1-model_v4.pdb")]
     mols = synthetic.rigid_copies(real[0], (n + 1) // 2, seed=7) + synthetic.rigid_copies(real[1], n // 2, seed=8)
@@ -67,6 +68,10 @@ print("table build, by bit length of the cross product: tests of swept leaders /
 for b in range(24):
     if s[96 + b] or s[120 + b]:
         print("  2^%-2d  %10.0f %10.0f   %9.0f %9.0f" % (b, s[96 + b] / len(mols), s[120 + b] / len(mols), s[144 + b] / len(mols), s[168 + b] / len(mols)))
+print("tables swept by a wave (leaders and tables of small groups), by bit length of the cross product (0..15+), per structure:",
+      [round(v / len(mols), 1) for v in s[284:300]])
+print("big tables (all waves of a workgroup build them together): %.1f per structure, %.0f tests and %.0f entries per structure, %d with list B beyond the staged capacity" %
+      (s[280] / len(mols), s[281] / len(mols), s[282] / len(mols), int(s[283])))
 print("workgroups", int(s[55]), "with kind lists in LDS", int(s[56]), "mean kind-list pool entries", s[57] / max(s[55], 1))
 # ablation: k_search time with (a) everything, (b) no subtrees below the joint scan, (c) staging only
 packed = pyjess._packed(jess._templates, jess._device)
