@@ -649,6 +649,13 @@ struct tm_batch {
     DevBuf<TabWork> d_tab_work;
     PinnedBuf<TabWork> h_tab_work;   // likewise
     uint32_t tab_work_items = 0, tab_work_tables = 0xffffffffu;
+    uint32_t tab_work_small = 0, tab_work_long_from = 0xffffffffu;  // items [0, small): the batch's LDS layout; the rest: long structures
+    // long structures: position records and chunk spheres for their table build (k_tab_gather), regions laid out by the host
+    DevBuf<TabGather> d_tab_gather;
+    PinnedBuf<TabGather> h_tab_gather;
+    uint32_t n_tab_gather = 0;
+    DevBuf<float4> d_tab_lr, d_tab_sph;
+    DevBuf<uint32_t> d_tab_lr_base, d_tab_sph_base;
     unsigned long long row_capacity = 0, ent_capacity = 0;
     // The index build is not waited for: a query whose build overflowed the kind-list pool finds out in
     // tm_result_wait and leaves the size it needed here (shared with the results, which may outlive a batch);
@@ -2213,25 +2220,6 @@ static int build_tables(const tm_library *lib, tm_batch *b, const StagedSelectio
         HIP_TRY(hipMemsetAsync(b->d_tab_ref.p, 0, std::max<size_t>(ref_n, 1) * sizeof(uint4), stream));
         return TM_OK;
     }
-    // work items of the build: one per (structure, part)
-    if (b->tab_work_tables != nt) {
-        std::vector<TabWork> items;
-        for (uint32_t s = 0; s < ns; ++s) {
-            const uint32_t parts = parts_of(s);
-            for (uint32_t r = 0; r < parts; ++r) items.push_back(TabWork{s, (uint16_t)r, (uint16_t)parts});
-        }
-        // heaviest structures first
-        std::stable_sort(items.begin(), items.end(), [&](const TabWork &x, const TabWork &y) {
-            return b->s_off[x.s + 1] - b->s_off[x.s] > b->s_off[y.s + 1] - b->s_off[y.s];
-        });
-        // (a plain hipMemcpy from the vector would wait for everything enqueued so far -- the candidate index of this
-        // very query: the list goes through a page-locked copy owned by the batch, asynchronously on the stream)
-        if (b->d_tab_work.p) HIP_TRY(hipStreamSynchronize(stream));  // a previous query may still read the old list
-        HIP_TRY(b->h_tab_work.alloc(items.size()));
-        std::copy(items.begin(), items.end(), b->h_tab_work.p);
-        HIP_TRY(b->d_tab_work.upload_async(b->h_tab_work.p, items.size(), stream));
-        b->tab_work_items = (uint32_t)items.size(); b->tab_work_tables = nt;
-    }
     const BatchView B = b->view();
     // LDS of a build workgroup: the atom record of every kind-list position of its structure (about 2.5 per atom)
     // (a batch of mostly large structures would not use the copy: without it two workgroups fit a CU and hide the
@@ -2267,15 +2255,83 @@ static int build_tables(const tm_library *lib, tm_batch *b, const StagedSelectio
 #ifdef TM_ABLATE
     if (const char *env = std::getenv("ENZYMM_AMD_TAB_DEBUG")) lr_arg |= (uint32_t)std::atoi(env) << 30;
 #endif
-    const auto tab_build = atom_cap != 0u ? k_tab_build<kTabCompact> : mostly_large ? k_tab_build<kTabLarge> : k_tab_build<kTabRecords>;
-    HIP_TRY(allow_dynamic_lds(reinterpret_cast<const void *>(tab_build), lds_bytes));
+    // LONG structures -- more atoms than the LDS layout holds -- are built by the large-structure instantiation (a launch of
+    // their own beside the batch's layout, or the only one when the batch is mostly large), from position records and
+    // chunk spheres gathered first (k_tab_gather; ENZYMM_AMD_TAB_CULL=0: records through the kind lists, plain sweeps)
+    const uint32_t long_from = mostly_large ? 0u : atom_cap != 0u ? atom_cap : 4096u;
+    static const bool cull_on = [] { const char *e = std::getenv("ENZYMM_AMD_TAB_CULL"); return !(e && std::atoi(e) == 0); }();
+    // work items of the build: one per (structure, part); the long structures' items behind the others
+    if (b->tab_work_tables != nt || b->tab_work_long_from != long_from) {
+        std::vector<TabWork> items, items_long;
+        std::vector<TabGather> gather;
+        uint64_t lr_total = 0, sph_total = 0;
+        for (uint32_t s = 0; s < ns; ++s) {
+            const uint32_t parts = parts_of(s), n = b->s_off[s + 1] - b->s_off[s];
+            const bool is_long = n > long_from;
+            for (uint32_t r = 0; r < parts; ++r) (is_long ? items_long : items).push_back(TabWork{s, (uint16_t)r, (uint16_t)parts});
+            if (is_long && n) {
+                const uint64_t cap_pos = std::min<uint64_t>(6ull * n + 4096ull, 0xffffff00ull);
+                gather.push_back(TabGather{s, (uint32_t)lr_total, (uint32_t)sph_total, (uint32_t)cap_pos});
+                lr_total += cap_pos;
+                sph_total += (cap_pos >> 4) + lib->n_lead + 2;
+            }
+        }
+        if (lr_total > 0xfffffff0ull) { gather.clear(); lr_total = sph_total = 0; }  // (beyond 32-bit bases: built the old way)
+        // heaviest structures first
+        auto heavier = [&](const TabWork &x, const TabWork &y) {
+            return b->s_off[x.s + 1] - b->s_off[x.s] > b->s_off[y.s + 1] - b->s_off[y.s];
+        };
+        std::stable_sort(items.begin(), items.end(), heavier);
+        std::stable_sort(items_long.begin(), items_long.end(), heavier);
+        b->tab_work_small = (uint32_t)items.size();
+        items.insert(items.end(), items_long.begin(), items_long.end());
+        // (a plain hipMemcpy from the vector would wait for everything enqueued so far -- the candidate index of this
+        // very query: the list goes through a page-locked copy owned by the batch, asynchronously on the stream)
+        if (b->d_tab_work.p) HIP_TRY(hipStreamSynchronize(stream));  // a previous query may still read the old list
+        if (b->d_tab_work.p && b->queried && b->last_stream != stream) HIP_TRY(hipStreamSynchronize(b->last_stream));
+        HIP_TRY(b->h_tab_work.alloc(items.size()));
+        std::copy(items.begin(), items.end(), b->h_tab_work.p);
+        HIP_TRY(b->d_tab_work.upload_async(b->h_tab_work.p, items.size(), stream));
+        HIP_TRY(b->h_tab_gather.alloc(gather.size()));
+        std::copy(gather.begin(), gather.end(), b->h_tab_gather.p);
+        HIP_TRY(b->d_tab_gather.upload_async(b->h_tab_gather.p, gather.size(), stream));
+        b->n_tab_gather = (uint32_t)gather.size();
+        if (!gather.empty()) {
+            HIP_TRY(b->d_tab_lr.alloc(lr_total)); HIP_TRY(b->d_tab_sph.alloc(sph_total));
+            HIP_TRY(b->d_tab_lr_base.alloc(ns)); HIP_TRY(b->d_tab_sph_base.alloc(ns));
+        }
+        b->tab_work_items = (uint32_t)items.size(); b->tab_work_tables = nt; b->tab_work_long_from = long_from;
+    }
+    TabAux aux = {};
     hipLaunchKernelGGL(k_tab_layout, dim3(ns), dim3(256), 0, stream, lib->n_lead, B, S->d_tables.p, b->d_tab_dir.p,
                        b->d_tab_cursors.p, rows, b->d_tab_overflow.p, b->d_tab_ok.p);
     sync_each(stream, "k_tab_layout");
-    hipLaunchKernelGGL(tab_build, dim3(b->tab_work_items), dim3(kTabBlock), lds_bytes, stream, lib->n_lead, B,
-                       S->d_tables.p, b->d_tab_work.p, b->d_tab_ok.p, b->d_tab_rows.p, b->d_tab_ent.p, b->d_tab_seg.p,
-                       b->d_tab_cursors.p, ents, b->d_tab_overflow.p, lr_arg, shared_limit, atom_cap, derive_min);
-    sync_each(stream, "k_tab_build");
+    if (cull_on && b->n_tab_gather) {
+        hipLaunchKernelGGL(k_tab_gather, dim3(b->n_tab_gather, 32), dim3(256), 0, stream, lib->n_lead, B,
+                           (const TabGather *)b->d_tab_gather.p, b->d_tab_lr.p, b->d_tab_sph.p, b->d_tab_lr_base.p, b->d_tab_sph_base.p);
+        sync_each(stream, "k_tab_gather");
+        aux.lr = b->d_tab_lr.p; aux.sph = b->d_tab_sph.p; aux.lr_base = b->d_tab_lr_base.p; aux.sph_base = b->d_tab_sph_base.p;
+    }
+    if (b->tab_work_small) {
+        const auto tab_build = atom_cap != 0u ? k_tab_build<kTabCompact> : k_tab_build<kTabRecords>;
+        HIP_TRY(allow_dynamic_lds(reinterpret_cast<const void *>(tab_build), lds_bytes));
+        hipLaunchKernelGGL(tab_build, dim3(b->tab_work_small), dim3(kTabBlock), lds_bytes, stream, lib->n_lead, B,
+                           S->d_tables.p, b->d_tab_work.p, b->d_tab_ok.p, b->d_tab_rows.p, b->d_tab_ent.p, b->d_tab_seg.p,
+                           b->d_tab_cursors.p, ents, b->d_tab_overflow.p, lr_arg, shared_limit, atom_cap, derive_min, TabAux{});
+        sync_each(stream, "k_tab_build");
+    }
+    if (b->tab_work_items > b->tab_work_small) {
+        // (4096 records = 64 KB, two workgroups per CU: the staging area for list B of the big tables a structure that was
+        // not gathered has its workgroups build together)
+        const uint32_t stage = 4096u;
+        const size_t lds_long = (size_t)stage * sizeof(float4) + ((size_t)lib->n_lead + 2) * sizeof(uint32_t);
+        HIP_TRY(allow_dynamic_lds(reinterpret_cast<const void *>(k_tab_build<kTabLarge>), lds_long));
+        hipLaunchKernelGGL(k_tab_build<kTabLarge>, dim3(b->tab_work_items - b->tab_work_small), dim3(kTabBlock), lds_long, stream,
+                           lib->n_lead, B, S->d_tables.p, b->d_tab_work.p + b->tab_work_small, b->d_tab_ok.p, b->d_tab_rows.p,
+                           b->d_tab_ent.p, b->d_tab_seg.p, b->d_tab_cursors.p, ents, b->d_tab_overflow.p,
+                           stage | (lr_arg & 0xc0000000u), shared_limit, 0u, derive_min, aux);
+        sync_each(stream, "k_tab_build (long structures)");
+    }
     {
         const uint32_t n_sel = (uint32_t)S->sel.size();
         hipLaunchKernelGGL(k_tab_refs, dim3(ns, (n_sel + 255) / 256), dim3(256), ((size_t)lib->n_lead + 15) & ~size_t(15), stream, B, lib->n_lead, n_sel, S->d_pair_table.p,
@@ -2592,6 +2648,9 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
     QueryView Q;
     Q.n_sel = n_sel; Q.sel = S->d_sel.p; Q.rmsd_thr = S->d_rmsd.p; Q.cutoff = S->d_cut.p; Q.maxdyn = S->d_maxdyn.p;
     Q.staged = S->d_staged.p; Q.hdr = S->d_hdr.p; Q.look = S->d_look.p; Q.rescheck = S->d_rescheck.p; Q.exact = S->d_exact.p; Q.bounds = S->d_bounds.p; Q.order = S->d_order.p; Q.max_candidates = p->max_candidates; Q.flags = p->flags;
+#if defined(TM_STATS) || defined(TM_ABLATE)
+    if (const char *env = std::getenv("ENZYMM_AMD_DEBUG_FLAGS")) Q.flags |= (uint32_t)std::strtoul(env, nullptr, 0);  // phase ablation bits for every query of a process
+#endif
     if (const char *env = std::getenv("ENZYMM_AMD_RUN_LIST"))  // test hook: k_deep claims by page position, as for a large complex
         if (std::atoi(env) == 0) Q.flags |= 0x4000u;
     if (const char *env = std::getenv("ENZYMM_AMD_LOCAL_DEEP"))  // test hook / A-B: every surviving triple is paged out to k_deep (round 3's flow)
@@ -3066,19 +3125,18 @@ int tm_debug_stats(unsigned long long *out) {
 // (n with bit 31 set: the log of k_tab_build's workgroups instead)
 int tm_debug_wg_log(unsigned long long *out, unsigned int n) {
     HIP_TRY(hipDeviceSynchronize());
-    const bool tab = (n & 0x80000000u) != 0u;
-    n &= 0x7fffffffu;
+    const bool tab = (n & 0x80000000u) != 0u, deep = (n & 0x40000000u) != 0u;  // (bit 30: k_deep's workgroups)
+    n &= 0x3fffffffu;
     std::vector<tmx::WgLog> log(tmx::kWgLog);
-    if (tab) HIP_TRY(hipMemcpyFromSymbol(log.data(), HIP_SYMBOL(tmx::g_tab_log), log.size() * sizeof(tmx::WgLog)));
-    else HIP_TRY(hipMemcpyFromSymbol(log.data(), HIP_SYMBOL(tmx::g_wg_log), log.size() * sizeof(tmx::WgLog)));
+    const void *sym = tab ? HIP_SYMBOL(tmx::g_tab_log) : deep ? HIP_SYMBOL(tmx::g_deep_log) : HIP_SYMBOL(tmx::g_wg_log);
+    HIP_TRY(hipMemcpyFromSymbol(log.data(), sym, log.size() * sizeof(tmx::WgLog)));
     for (unsigned int i = 0; i < n && i < tmx::kWgLog; ++i) {
         out[5 * i] = log[i].start; out[5 * i + 1] = log[i].end;
         out[5 * i + 2] = (unsigned long long)log[i].hw_id | ((unsigned long long)log[i].xcc_id << 32);
         out[5 * i + 3] = log[i].first_end; out[5 * i + 4] = log[i].sum_end;
     }
     std::fill(log.begin(), log.end(), tmx::WgLog{0, 0, ~0ull, 0, 0, 0});
-    if (tab) HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(tmx::g_tab_log), log.data(), log.size() * sizeof(tmx::WgLog)));
-    else HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(tmx::g_wg_log), log.data(), log.size() * sizeof(tmx::WgLog)));
+    HIP_TRY(hipMemcpyToSymbol(sym, log.data(), log.size() * sizeof(tmx::WgLog)));
     return TM_OK;
 }
 #endif

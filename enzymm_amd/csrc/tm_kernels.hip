@@ -14,6 +14,7 @@
 // The enumeration ORDER is this kernel's own (lead atoms of all template residues first); the
 // SET of complete assignments does not depend on it.
 #include <cstddef>
+#include <type_traits>
 
 #include "tm_device.hpp"
 
@@ -43,6 +44,7 @@ struct WgLog { unsigned long long start, end, first_end, sum_end; uint32_t hw_id
 constexpr uint32_t kWgLog = 16384;
 __device__ WgLog g_wg_log[kWgLog];
 __device__ WgLog g_tab_log[kWgLog];  // the same for the workgroups of k_tab_build
+__device__ WgLog g_deep_log[kWgLog]; // ... and of k_deep
 #endif
 
 // ------------------------------------------------------------------ wave helpers
@@ -694,6 +696,77 @@ __device__ __forceinline__ uint32_t tab_sweep(Lead lead, LeadB lead_b, uint32_t 
     return running - row_base;
 }
 
+// The same sweep for a LONG structure (a complex of tens of thousands of atoms; k_tab_gather laid the record of every
+// kind-list position out in global memory and gave every 16 consecutive positions of a list their bounding sphere):
+// 97 % of the cross product of two lists of such a structure lies beyond any class limit, and the lists follow the
+// chains, so 16 consecutive entries are neighbours in space.  Per row (a wave-uniform atom) the chunks of list B are
+// tested first, lane = chunk -- centre within limit + radius (+ 0.01 A: the triangle inequality in fp32) --, and only the
+// surviving chunks are laid over the lanes, four (row, chunk) items of 16 columns per tile, rows ascending and chunks
+// ascending inside a row: the entries come out in the order of the plain sweep, so the tables are the same byte for
+// byte.  A row without a surviving chunk takes an empty item: the lane that starts a row writes the row's offset.
+constexpr uint32_t kCullMin = 128;  // list B at least this long
+template <bool kFill>
+__device__ __forceinline__ uint32_t tab_sweep_culled(const float4 *__restrict__ lr_a, uint32_t n_a,
+                                                     const float4 *__restrict__ lr_b, uint32_t n_b,
+                                                     const float4 *__restrict__ sph_b, float dmax2, uint32_t *rows, uint2 *ent,
+                                                     uint32_t row_base = 0u, uint32_t i_base = 0u) {
+    const uint32_t lane = threadIdx.x & 63, slot = lane >> 4, e = lane & 15u;
+    const uint32_t n_chunks = (n_b + 15u) >> 4;
+    const float lim = __builtin_sqrtf(dmax2) + 0.01f;
+    uint32_t running = row_base, filled = 0;
+    uint32_t my_row = 0, my_chunk = 0xffffffffu;
+    bool my_first = false;
+    auto flush = [&]() {
+        const bool item = slot < filled;
+        const uint32_t j = (my_chunk << 4) + e;  // (an empty item: beyond every list)
+        const bool valid = item & (my_chunk != 0xffffffffu) & (j < n_b);
+        const float4 rb = lr_b[valid ? j : 0u], ra = lr_a[item ? my_row : 0u];
+        const float dx = ra.x - rb.x, dy = ra.y - rb.y, dz = ra.z - rb.z;
+        const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+        const bool counts = valid & (meta_res(__float_as_uint(ra.w)) != meta_res(__float_as_uint(rb.w)));
+        const bool ok = (counts ? d2 : __builtin_inff()) <= dmax2;
+        const unsigned long long all = ballot64(ok);
+        if (kFill) {
+            const uint32_t rk = rank_in(all);
+            if (ok) *lane_at(ent + running, rk << 3) = make_uint2((my_row + i_base) | (j << 16), __float_as_uint(d2));
+            if (item && e == 0u && my_first) rows[my_row] = running + rk;
+        }
+        running += (uint32_t)__popcll(all);
+        filled = 0;
+    };
+    const float4 far = make_float4(1.0e18f, 1.0e18f, 1.0e18f, 0.f);
+    const float4 sp_first = lane < n_chunks ? sph_b[lane] : far;  // (a list of at most 1024 entries: one pass per row)
+    for (uint32_t i0 = 0; i0 < n_a; i0 += 64u) {
+        const uint32_t nrows = min(64u, n_a - i0);
+        const float4 ra = lr_a[i0 + min(lane, nrows - 1u)];  // the block's rows, lane = row
+        for (uint32_t r = 0; r < nrows; ++r) {
+            const float ax = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(ra.x), (int)r));
+            const float ay = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(ra.y), (int)r));
+            const float az = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(ra.z), (int)r));
+            bool first = true;
+            for (uint32_t c0 = 0; c0 < n_chunks; c0 += 64u) {
+                float4 sp = sp_first;
+                if (c0 != 0u) sp = c0 + lane < n_chunks ? sph_b[c0 + lane] : far;
+                const float dx = sp.x - ax, dy = sp.y - ay, dz = sp.z - az, t = lim + sp.w;
+                unsigned long long keep = ballot64(__builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)) <= t * t);
+                while (keep != 0ull) {
+                    const uint32_t c = c0 + (uint32_t)__ffsll((long long)keep) - 1u;
+                    keep &= keep - 1ull;
+                    if (slot == filled) { my_row = i0 + r; my_chunk = c; my_first = first; }
+                    first = false;
+                    if (++filled == 4u) flush();
+                }
+            }
+            if (first) {  // no chunk of list B near this row: an empty item carries the row's offset
+                if (slot == filled) { my_row = i0 + r; my_chunk = 0xffffffffu; my_first = true; }
+                if (++filled == 4u) flush();
+            }
+        }
+    }
+    if (filled != 0u) flush();
+    return running - row_base;
+}
+
 // A table derived from its group's leader (same kind lists, smaller distance limit): the leader's entries that lie
 // within the limit, in the leader's order -- exactly what a sweep of the cross product with that limit writes.  One
 // streaming pass, lane = entry of the leader: survivors are compacted into ent_c (ballot + rank), and the first entry the
@@ -787,6 +860,8 @@ __host__ __device__ inline uint32_t tab_chunk(uint32_t n_atoms) {
 // one workgroup per CU); 2: the structure's atom records and its kind lists in LDS (two dependent reads per operand,
 // 16 B per atom + 2 B per position: about 50 KB, two workgroups per CU).
 // kWide (kSrc 0 only): a structure of more than kNarrowAtoms atoms -- a kind-list entry is pool | pool_hi << 16.
+// 3: the record of every kind-list position in GLOBAL memory (k_tab_gather: s_lr[p - p0]) with the bounding spheres of its
+// 16-entry chunks (sph_s): one read per operand, and the sweeps of long lists skip the chunks beyond the limit.
 template <int kSrc, bool kWide = false>
 __device__ __forceinline__ void tab_build_tables(const BatchView &B, const TableDesc *__restrict__ tables,
                                                  const TabWork w, const float4 *rec, const uint16_t *pool,
@@ -797,14 +872,15 @@ __device__ __forceinline__ void tab_build_tables(const BatchView &B, const Table
                                                  uint32_t *__restrict__ tab_ok, uint32_t dbg_mode, uint32_t *s_count,
                                                  unsigned long long *s_first, uint32_t n_lead, float4 *s_stage,
                                                  uint32_t stage_cap, unsigned long long shared_limit, bool rows_ok,
-                                                 unsigned long long derive_min) {
+                                                 unsigned long long derive_min, const float4 *sph_s = nullptr, uint32_t p0 = 0u) {
     const uint32_t nt = B.n_tables;
     const uint32_t wave = uni(threadIdx.x >> 6), n_waves = blockDim.x >> 6, lane = threadIdx.x & 63;
     // the record at position `first + k` of a kind list; `valid`: k lies inside the list.  A lane beyond the list is
     // masked out of the vote whatever it reads: only a read from GLOBAL memory has to stay inside the arrays (position
     // `first` then) -- an LDS read past the list returns a neighbouring list's atom, past the allocation zero
     auto lead = [&](uint32_t first, uint32_t k, bool valid) -> float4 {
-        if constexpr (kSrc == 1) return s_lr[first + k];
+        if constexpr (kSrc == 3) return s_lr[first - p0 + (valid ? k : 0u)];
+        else if constexpr (kSrc == 1) return s_lr[first + k];
         else if constexpr (kSrc == 2) {
             const uint32_t atom = ((const __attribute__((address_space(3))) uint16_t *)pool)[first + k];
             const auto *r = (const __attribute__((address_space(3))) float *)rec + 4u * atom;
@@ -827,6 +903,19 @@ __device__ __forceinline__ void tab_build_tables(const BatchView &B, const Table
         }
         return uni64(first);
     };
+    // one sweep of rows [a_first, a_first + na) of list A against list B (li_b: its lead-kind index)
+    auto sweep_any = [&](auto fill_tag, uint32_t a_first, uint32_t na, uint32_t b_first, uint32_t nb, uint32_t li_b, float dmax2,
+                         uint32_t *rows, uint2 *ent, uint32_t row_base, uint32_t i_base) -> uint32_t {
+        constexpr bool kFill = decltype(fill_tag)::value;
+        if constexpr (kSrc == 3) {
+            if (nb >= kCullMin && dmax2 < 1.0e6f)
+                return tab_sweep_culled<kFill>(s_lr + (a_first - p0), na, s_lr + (b_first - p0), nb,
+                                               sph_s + (((b_first - p0) >> 4) + li_b), dmax2, rows, ent, row_base, i_base);
+        }
+        return tab_sweep<kFill>(lead, lead, a_first, na, b_first, nb, dmax2, rows, ent, row_base, i_base);
+    };
+    const std::true_type fill_yes{};
+    const std::false_type fill_no{};
     const uint32_t kTabChunk = tab_chunk(B.s_off[w.s + 1] - B.s_off[w.s]);
     unsigned long long chunk = ~0ull;  // the wave's current chunk and how much of it is used
     uint32_t used = kTabChunk;
@@ -862,19 +951,19 @@ __device__ __forceinline__ void tab_build_tables(const BatchView &B, const Table
             }
             if (rows_ok && chunk != ~0ull) {
                 first = chunk + used;
-                total = tab_sweep<true>(lead, lead, a_lo, n_a, b_lo, n_b, T.dmax2, rows, tab_ent + first);
+                total = sweep_any(fill_yes, a_lo, n_a, b_lo, n_b, T.li_b, T.dmax2, rows, tab_ent + first, 0u, 0u);
             } else {
                 // no room (or no row slots): count only, and let the wave's chunk fill up exactly as it would have --
                 // the entry cursor then ends on what a build with room hands out, and ONE retry is sized right
                 first = ~0ull;
-                total = tab_sweep<false>(lead, lead, a_lo, n_a, b_lo, n_b, T.dmax2, nullptr, nullptr);
+                total = sweep_any(fill_no, a_lo, n_a, b_lo, n_b, T.li_b, T.dmax2, nullptr, nullptr, 0u, 0u);
             }
             used += total;
         } else {
-            total = tab_sweep<false>(lead, lead, a_lo, n_a, b_lo, n_b, T.dmax2, nullptr, nullptr);
+            total = sweep_any(fill_no, a_lo, n_a, b_lo, n_b, T.li_b, T.dmax2, nullptr, nullptr, 0u, 0u);
             first = allocate(total);
             if (!rows_ok) first = ~0ull;
-            if (first != ~0ull && dbg_mode == 0u) tab_sweep<true>(lead, lead, a_lo, n_a, b_lo, n_b, T.dmax2, rows, tab_ent + first);
+            if (first != ~0ull && dbg_mode == 0u) sweep_any(fill_yes, a_lo, n_a, b_lo, n_b, T.li_b, T.dmax2, rows, tab_ent + first, 0u, 0u);
         }
         if (lane == 0 && rows_ok) {
             tab_seg[(size_t)w.s * nt + t] = first == ~0ull ? make_uint2(0u, 0u) : make_uint2((uint32_t)first, (uint32_t)first + total);
@@ -913,7 +1002,7 @@ __device__ __forceinline__ void tab_build_tables(const BatchView &B, const Table
                     total_d = total <= kDeriveVotes * 64u
                                   ? tab_derive_small(rows, tab_ent + first, total, n_a, Td.dmax2, rows_d, tab_ent + first_d, lane)
                                   : tab_derive(rows, tab_ent + first, total, n_a, Td.dmax2, rows_d, tab_ent + first_d, lane);
-                else total_d = tab_sweep<false>(lead, lead, a_lo, n_a, b_lo, n_b, Td.dmax2, nullptr, nullptr);
+                else total_d = sweep_any(fill_no, a_lo, n_a, b_lo, n_b, T.li_b, Td.dmax2, nullptr, nullptr, 0u, 0u);
                 if (total <= kTabChunk) used += total_d;
                 if (lane == 0 && rows_ok) {
                     tab_seg[(size_t)w.s * nt + d] = first_d == ~0ull ? make_uint2(0u, 0u) : make_uint2((uint32_t)first_d, (uint32_t)first_d + total_d);
@@ -951,7 +1040,9 @@ __device__ __forceinline__ void tab_build_tables(const BatchView &B, const Table
         }
         // (two instantiations: a run-time choice per operand load would compile into a flat load)
         auto build = [&](auto lead_b) {
-            const uint32_t mine = dbg_mode == 2u ? 0u : tab_sweep<false>(lead, lead_b, a_lo + i0, i1 - i0, b_lo, n_b, T.dmax2, nullptr, nullptr);
+            uint32_t mine = 0;
+            if constexpr (kSrc == 3) mine = dbg_mode == 2u ? 0u : sweep_any(fill_no, a_lo + i0, i1 - i0, b_lo, n_b, T.li_b, T.dmax2, nullptr, nullptr, 0u, 0u);
+            else mine = dbg_mode == 2u ? 0u : tab_sweep<false>(lead, lead_b, a_lo + i0, i1 - i0, b_lo, n_b, T.dmax2, nullptr, nullptr);
             if (lane == 0) s_count[wave] = mine;
             __syncthreads();
             if (threadIdx.x == 0) {
@@ -973,12 +1064,64 @@ __device__ __forceinline__ void tab_build_tables(const BatchView &B, const Table
             }
             __syncthreads();
             const unsigned long long first = *s_first;
-            if (first != ~0ull && dbg_mode == 0u)
-                tab_sweep<true>(lead, lead_b, a_lo + i0, i1 - i0, b_lo, n_b, T.dmax2, rows + i0, tab_ent + first, s_count[wave], i0);
+            if (first != ~0ull && dbg_mode == 0u) {
+                if constexpr (kSrc == 3) sweep_any(fill_yes, a_lo + i0, i1 - i0, b_lo, n_b, T.li_b, T.dmax2, rows + i0, tab_ent + first, s_count[wave], i0);
+                else tab_sweep<true>(lead, lead_b, a_lo + i0, i1 - i0, b_lo, n_b, T.dmax2, rows + i0, tab_ent + first, s_count[wave], i0);
+            }
         };
         if (staged) build([&](uint32_t first, uint32_t k, bool valid) -> float4 { return s_stage[k]; });
         else build(lead);
         __syncthreads();  // s_count, s_first and the staged list are reused by the next big table
+    }
+}
+
+// Before the table build of LONG structures (those the host sends to the large-structure launch): the record of every
+// kind-list position, position by position, and the bounding sphere of every 16 consecutive positions of a list (centre =
+// mean, radius = farthest member, rounded up).  A structure's region is laid out by the host (6 positions per atom: a
+// protein needs 3); a structure whose lists do not fit keeps ~0 as its base and is built the old way, records through
+// the kind lists.  The sphere of chunk c of list L sits at ((first position of L - p0) >> 4) + L + c of the structure's
+// sphere region: lists start at any position, chunks start at their list's start, and the + L keeps the slots of
+// neighbouring lists apart.
+struct TabGather { uint32_t s, lr_base, sph_base, cap; };
+struct TabAux {
+    const float4 *lr, *sph;
+    const uint32_t *lr_base, *sph_base;  // per structure; lr_base ~0: not gathered
+};
+__global__ __launch_bounds__(256) void k_tab_gather(uint32_t nl, BatchView B, const TabGather *__restrict__ items,
+                                                     float4 *__restrict__ lr, float4 *__restrict__ sph,
+                                                     uint32_t *__restrict__ lr_base_out, uint32_t *__restrict__ sph_base_out) {
+    const TabGather g = items[blockIdx.x];
+    const uint32_t *kl = B.kl_off + (size_t)g.s * (nl + 1);
+    const uint32_t p0 = kl[0], plen = kl[nl] - p0;
+    const bool fits = plen <= g.cap;
+    if (blockIdx.y == 0 && threadIdx.x == 0) {
+        lr_base_out[g.s] = fits ? g.lr_base : 0xffffffffu;
+        sph_base_out[g.s] = g.sph_base;
+    }
+    if (!fits) return;
+    const float4 *rec = B.q_rec + B.s_off[g.s];
+    const uint32_t grp = threadIdx.x >> 4, e = threadIdx.x & 15u;
+    for (uint32_t li = blockIdx.y; li < nl; li += gridDim.y) {
+        const uint32_t lo = kl[li] - p0, len = kl[li + 1] - kl[li];
+        for (uint32_t c = grp; (c << 4) < len; c += blockDim.x >> 4) {
+            const uint32_t k = (c << 4) + e;
+            const bool v = k < len;
+            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (v) {
+                const size_t p = (size_t)p0 + lo + k;
+                const uint32_t atom = (uint32_t)B.kl_pool[p] | (B.kl_pool_hi ? (uint32_t)B.kl_pool_hi[p] << 16 : 0u);
+                r = rec[atom];
+                lr[(size_t)g.lr_base + lo + k] = r;
+            }
+            float sx = r.x, sy = r.y, sz = r.z;  // (lanes beyond the list add zero)
+            for (int o = 8; o > 0; o >>= 1) { sx += __shfl_xor(sx, o, 16); sy += __shfl_xor(sy, o, 16); sz += __shfl_xor(sz, o, 16); }
+            const float inv = 1.f / (float)min(16u, len - (c << 4));
+            const float cx = sx * inv, cy = sy * inv, cz = sz * inv;
+            const float dx = r.x - cx, dy = r.y - cy, dz = r.z - cz;
+            float d2 = v ? dx * dx + dy * dy + dz * dz : 0.f;
+            for (int o = 8; o > 0; o >>= 1) d2 = fmaxf(d2, __shfl_xor(d2, o, 16));
+            if (e == 0u) sph[(size_t)g.sph_base + (lo >> 4) + li + c] = make_float4(cx, cy, cz, __builtin_sqrtf(d2) * 1.0001f + 1.0e-3f);
+        }
     }
 }
 
@@ -1009,7 +1152,7 @@ __global__ __launch_bounds__(kTabBlock) __attribute__((amdgpu_waves_per_eu(kLayo
                                                           unsigned long long *__restrict__ cursors,
                                                           unsigned long long ent_capacity, uint32_t *__restrict__ overflow,
                                                           uint32_t lr_cap, unsigned long long shared_limit,
-                                                          uint32_t atom_cap, unsigned long long derive_min) {
+                                                          uint32_t atom_cap, unsigned long long derive_min, TabAux aux) {
     extern __shared__ __align__(16) unsigned char tab_smem[];
     __shared__ uint32_t s_count[kTabBlock / 64 + 1];  // (the last word: the next table of the workgroup's share)
     __shared__ unsigned long long s_first;
@@ -1111,9 +1254,15 @@ __global__ __launch_bounds__(kTabBlock) __attribute__((amdgpu_waves_per_eu(kLayo
         }
     } else if constexpr (kLayout == kTabLarge) {
         float4 *s_lr = reinterpret_cast<float4 *>(tab_smem);
-        (void)p0; (void)plen;
-        tab_build_global(B, tables, w, rec, B.kl_pool, nullptr, kl, tab_rows, tab_ent, tab_seg, cursors,
-                            ent_capacity, overflow, tab_ok, dbg_mode, s_count, &s_first, n_lead, s_lr, lr_cap, shared_limit, rows_ok, derive_min);
+        (void)plen;
+        const uint32_t lrb = aux.lr_base ? aux.lr_base[w.s] : 0xffffffffu;
+        if (lrb != 0xffffffffu)  // gathered (k_tab_gather): position records and chunk spheres in global memory
+            tab_build_tables<3>(B, tables, w, rec, B.kl_pool, aux.lr + lrb, kl, tab_rows, tab_ent, tab_seg, cursors, ent_capacity,
+                                overflow, tab_ok, dbg_mode, s_count, &s_first, n_lead, s_lr, lr_cap, shared_limit, rows_ok, derive_min,
+                                aux.sph + aux.sph_base[w.s], p0);
+        else
+            tab_build_global(B, tables, w, rec, B.kl_pool, nullptr, kl, tab_rows, tab_ent, tab_seg, cursors,
+                             ent_capacity, overflow, tab_ok, dbg_mode, s_count, &s_first, n_lead, s_lr, lr_cap, shared_limit, rows_ok, derive_min);
     } else {
         float4 *s_lr = reinterpret_cast<float4 *>(tab_smem);
         uint32_t *s_kl = reinterpret_cast<uint32_t *>(s_lr + lr_cap);
@@ -1132,7 +1281,7 @@ __global__ __launch_bounds__(kTabBlock) __attribute__((amdgpu_waves_per_eu(kLayo
 #define TM_TAB_INSTANTIATE(layout)                                                                                                          \
     template __global__ void k_tab_build<layout>(uint32_t, BatchView, const TableDesc *, const TabWork *, uint32_t *, uint32_t *, uint2 *, \
                                                  uint2 *, unsigned long long *, unsigned long long, uint32_t *, uint32_t,                    \
-                                                 unsigned long long, uint32_t, unsigned long long);
+                                                 unsigned long long, uint32_t, unsigned long long, TabAux);
 TM_TAB_INSTANTIATE(kTabRecords)
 TM_TAB_INSTANTIATE(kTabCompact)
 TM_TAB_INSTANTIATE(kTabLarge)
@@ -1218,6 +1367,9 @@ struct __align__(16) WaveScratchT {
 constexpr uint32_t kSharedTriples = TM_SHARED_TRIPLES;
 #ifndef TM_MIN_BLOCK
 #define TM_MIN_BLOCK 32
+#endif
+#ifndef TM_MIN_BLOCK_GLOBAL
+#define TM_MIN_BLOCK_GLOBAL 2  // ... of a structure that is not in LDS (search_templates)
 #endif
 constexpr uint32_t kMinBlock = TM_MIN_BLOCK;  // templates a wave claims at least (guided block sizes: 64 while much of the chunk is left)
 #ifndef TM_RES_FIRST
@@ -1315,6 +1467,7 @@ template <bool kIgnoreChain, bool kPoolLds, int kMode, bool kCache = false, bool
 struct SearchCtx {
     static constexpr bool kResCache = kCache;
     static constexpr int kLaunchMode = kMode;
+    static constexpr bool kPoolInLds = kPoolLds;
     ResCache *rc;               // kResCache: this wave's slots
     const float4 *rec;          // structure atom records (LDS or global)
     const uint16_t *res_start;  // residue -> first atom (LDS or global)
@@ -2460,7 +2613,19 @@ __device__ __forceinline__ void block_pairs(Ctx &C, const SearchArgs &A, SlotReg
     const uint32_t trows = lane_get(R.trows, slot);
     // the row of the key atom (lanes without a pair read slot 0's first row: a valid address)
     const uint32_t r0 = C.tab_rows[trows + key], r1 = C.tab_rows[trows + key + 1u];
-    const uint32_t a0 = C.pool_at(lane_get(R.lo0, slot) + (pos & 0xffffu)), a1 = C.pool_at(lane_get(R.lo1, slot) + (pos >> 16));
+    // (A lane without a pair reads through slot 0: position 0 of that template's lead lists.  Should the template in slot 0 have
+    // no second lead, or an empty list, that position is the first entry BEHIND a list -- for the last list of the pool
+    // whatever the allocation held before --, and the atom record it names is read: harmless while the records are in LDS
+    // (a read beyond LDS returns zero), a memory fault in waiting when they are in global memory (round 5: a 25 k-atom
+    // complex against one- and two-atom templates, depending on what ran before).  With the kind lists in global memory
+    // such a lane reads the structure's first list entry instead.)
+    uint32_t i0 = lane_get(R.lo0, slot) + (pos & 0xffffu), i1 = lane_get(R.lo1, slot) + (pos >> 16);
+    if constexpr (!Ctx::kPoolInLds) {
+        const uint32_t safe = kl[0];
+        i0 = vp ? i0 : safe;
+        i1 = vp ? i1 : safe;
+    }
+    const uint32_t a0 = C.pool_at(i0), a1 = C.pool_at(i1);
     const float4 ro = C.rec[key1 ? a0 : a1];  // the lead that is NOT the key: its distance to lead 2 is computed
     const uint32_t a01 = a0 | (a1 << 16);
     const uint32_t lo2 = lane_get(R.lo2, slot);
@@ -2755,7 +2920,10 @@ __device__ __forceinline__ void search_templates(const SearchArgs &A, WaveScratc
         if (lane == 0) {
             const uint32_t seen = __atomic_load_n(s_next_p, __ATOMIC_RELAXED);
             const uint32_t left = seen < n_mine ? n_mine - seen : 0u;
-            count = min(64u, max(kMinBlock, (left / (2u * kSearchWaves)) & ~7u));
+            // (a structure that is not in LDS -- a large complex: hundreds of table entries per template, and a batch of few
+            // structures is cut into chunks of a few dozen templates -- takes blocks from 2 templates: with the LDS path's
+            // minimum one wave of sixteen took a workgroup's whole chunk: 7 % of the wave-time of the launch at work)
+            count = min(64u, max(kLds ? kMinBlock : (uint32_t)TM_MIN_BLOCK_GLOBAL, (left / (2u * kSearchWaves)) & ~7u));
             m0 = atomicAdd(s_next_p, count);
         }
         m0 = uni(m0);
@@ -2922,7 +3090,19 @@ __device__ __forceinline__ void deep_templates(const SearchArgs &A, WaveScratchT
                 }
             }
             TM_STAT(84 + min(C.n_groups, 8), 1);  // [87..92]: paged triples by residue count of their template
+#ifdef TM_STATS
+            const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();
+#endif
             dfs(C, W, D.P, 3);  // false: cut short by max_candidates (D.P.truncated is set)
+#ifdef TM_STATS
+            if (!kLds) {  // (a structure in global memory: the block search queues nothing, the histogram of entry durations is free)
+                const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - t_entry;
+                const uint32_t bl = min(23u, 64u - (uint32_t)__clzll((long long)dt));
+                TM_STAT(192 + bl, 1);
+                TM_STAT(216 + bl, dt);
+                TM_STAT(240 + 3, 1);
+            }
+#endif
         }
         run = run1;
         run1 = uni(claimed);
@@ -2950,6 +3130,11 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
     // [WaveScratchT<kMode> x kSearchWaves][rec float4 x max_atoms][res_start u16 x (max_res+1)]
     // [kind-list offsets u32 x (n_lead+1)][kind-list pool u16 x pool_cap]
     WaveScratchT<kMode> *scratch = reinterpret_cast<WaveScratchT<kMode> *>(smem);
+#ifdef TM_POISON_LDS
+    // debugging build: the waves' scratch starts from a recognisable pattern instead of what the last kernel left on this CU
+    for (uint32_t i = threadIdx.x; i < sizeof(WaveScratchT<kMode>) * kSearchWaves / 4; i += blockDim.x) reinterpret_cast<uint32_t *>(smem)[i] = 0xfffefffeu;
+    __syncthreads();
+#endif
     float4 *s_rec = reinterpret_cast<float4 *>(smem + sizeof(WaveScratchT<kMode>) * kSearchWaves);
     uint16_t *s_res = reinterpret_cast<uint16_t *>(s_rec + (kLds ? max_atoms : 0));
     uint32_t *s_kl = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(s_res) +
@@ -3013,13 +3198,14 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
     if (item_index >= A.n_items) { if constexpr (kQueued) continue; else return; }
 #ifdef TM_ABLATE
     const uint32_t log_at = (item_index << cx) + chunk_low;
-    if (kMode == kModeBlocks && threadIdx.x == 0 && log_at < kWgLog) {
+    WgLog *const wg_log = kMode == kModeDeep ? g_deep_log : g_wg_log;
+    if (kMode != kModeSingly && threadIdx.x == 0 && log_at < kWgLog) {
         uint32_t hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        g_wg_log[log_at].start = __builtin_amdgcn_s_memrealtime();
-        g_wg_log[log_at].hw_id = hw;
-        g_wg_log[log_at].xcc_id = xcc;
+        wg_log[log_at].start = __builtin_amdgcn_s_memrealtime();
+        wg_log[log_at].hw_id = hw;
+        wg_log[log_at].xcc_id = xcc;
     }
 #endif
     const WorkItem item = A.work[item_index];
@@ -3151,11 +3337,11 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
             search_templates<kLds, kIgnoreChain, false, kSingly>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, &s_next, s, a0, r0, chunk, n_chunks, shared);
     }
 #ifdef TM_ABLATE
-    if (kMode == kModeBlocks && (threadIdx.x & 63) == 0 && log_at < kWgLog) {
+    if (kMode != kModeSingly && (threadIdx.x & 63) == 0 && log_at < kWgLog) {
         const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
-        atomicMax(&g_wg_log[log_at].end, t_end);
-        atomicMin(&g_wg_log[log_at].first_end, t_end);
-        atomicAdd(&g_wg_log[log_at].sum_end, t_end);
+        atomicMax(&wg_log[log_at].end, t_end);
+        atomicMin(&wg_log[log_at].first_end, t_end);
+        atomicAdd(&wg_log[log_at].sum_end, t_end);
     }
 #endif
 #ifdef TM_STATS
