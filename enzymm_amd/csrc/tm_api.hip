@@ -705,7 +705,7 @@ struct tm_result {
     DevBuf<unsigned long long> d_tab_used;                          // pair-table row slots, entries the build needed
     unsigned long long pool_capacity = 0, row_capacity = 0, ent_capacity = 0;
     DevBuf<uint32_t> d_overflow;
-    DevBuf<double> d_cand_rmsd, d_models;
+    DevBuf<double> d_cand_rmsd, d_cand_fit, d_models;
     DevBuf<int32_t> d_model_set;
     DevBuf<uint32_t> d_model_offsets, d_model_votes;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // [4]: between the table stages and the depth-first part
@@ -2586,6 +2586,8 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
     HIP_TRY(r->d_pairs.alloc(hcap));
     HIP_TRY(r->d_cands.alloc(ccap));
     HIP_TRY(r->d_cand_rmsd.alloc(ccap));
+    const unsigned long long fit_cap = std::min<unsigned long long>(ccap, 1ull << 20);  // (96 B each: at most 96 MB)
+    HIP_TRY(r->d_cand_fit.alloc((size_t)fit_cap * 12));
     if (b->has_wide) {
         // (zeroed per query: the launches that search the narrow structures write no upper bits)
         HIP_TRY(r->d_cands_hi.alloc((size_t)ccap * kMaxK));
@@ -2710,7 +2712,7 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
     if (const char *env = std::getenv("ENZYMM_AMD_HANDOVER"))  // test hooks: 0 = a wave keeps every subtree it starts, 2 = it hands over whatever it can
         Q.flags |= std::atoi(env) == 0 ? 0x10000u : std::atoi(env) == 2 ? 0x20000u : 0u;
     OutView O;
-    O.cands = r->d_cands.p; O.cands_hi = b->has_wide ? r->d_cands_hi.p : nullptr; O.cand_rmsd = r->d_cand_rmsd.p; O.n_cands = r->d_counters.p + 1; O.cand_capacity = ccap;
+    O.cands = r->d_cands.p; O.cands_hi = b->has_wide ? r->d_cands_hi.p : nullptr; O.cand_rmsd = r->d_cand_rmsd.p; O.cand_fit = r->d_cand_fit.p; O.cand_fit_capacity = fit_cap; O.n_cands = r->d_counters.p + 1; O.cand_capacity = ccap;
     O.pairs = r->d_pairs.p; O.n_pairs = r->d_counters.p + 2; O.pair_capacity = hcap;
     O.hits = r->d_hits.p; O.n_hits = r->d_counters.p; O.hit_capacity = hcap; O.overflow = r->d_overflow.p;
     O.pair_count = r->d_pair_count.p; O.pair_last = r->d_pair_last.p;

@@ -239,6 +239,8 @@ struct OutView {
     Cand *cands;
     uint8_t *cands_hi;       // [cand_capacity * kMaxK] bits 16-23 of Cand::atoms; NULL: the batch has no wide structure
     double *cand_rmsd;
+    double *cand_fit;        // [cand_fit_capacity * 12] rotation and translation of the candidates within their threshold
+    unsigned long long cand_fit_capacity;  // (k_superpose keeps them for k_select; a candidate beyond is superposed again there)
     unsigned long long *n_cands;
     unsigned long long cand_capacity;
     PairEntry *pairs;

@@ -3512,6 +3512,12 @@ __global__ __launch_bounds__(256) void k_superpose(LibView L, BatchView B, Query
         if (cand.s == 0xffffffffu) continue;  // a reserved slot no candidate was written to
         const double r = superpose_candidate(L, B, Q, cand, cand_hi(O, cand), R, T);
         O.cand_rmsd[c] = r;
+        // (a candidate that may become a hit keeps its superposition: k_select repeated the 40 us of it for every hit)
+        if (c < O.cand_fit_capacity && r <= Q.rmsd_thr[cand.ti]) {
+            double *fit = O.cand_fit + 12 * c;
+            for (int a = 0; a < 9; ++a) fit[a] = R[a];
+            for (int a = 0; a < 3; ++a) fit[9 + a] = T[a];
+        }
         // the pair's minimum within the threshold (non-negative doubles order like their bit patterns)
         if (O.pair_min && r <= Q.rmsd_thr[cand.ti])
             atomicMin(&O.pair_min[(size_t)cand.s * Q.n_sel + Q.order[cand.ti]], (unsigned long long)__double_as_longlong(r));
@@ -3555,7 +3561,13 @@ __device__ void emit_hit(const LibView &L, const BatchView &B, const QueryView &
     tm_hit *h = O.hits + slot;
     double R[9], T[3];
     const uint8_t *hi = cand_hi(O, c);
-    h->rmsd = superpose_candidate(L, B, Q, c, hi, R, T);
+    const unsigned long long ci = (unsigned long long)(&c - O.cands);
+    if (ci < O.cand_fit_capacity) {  // (kept by k_superpose: an emitted candidate lies within its threshold)
+        const double *fit = O.cand_fit + 12 * ci;
+        for (int a = 0; a < 9; ++a) R[a] = fit[a];
+        for (int a = 0; a < 3; ++a) T[a] = fit[9 + a];
+        h->rmsd = O.cand_rmsd[ci];
+    } else h->rmsd = superpose_candidate(L, B, Q, c, hi, R, T);
     for (int a = 0; a < 9; ++a) h->rot[a] = R[a];
     for (int a = 0; a < 3; ++a) h->trans[a] = T[a];
     h->structure = pe.s;
