@@ -32,7 +32,12 @@ off_grid = [helpers.subset_molecule(m, np.arange(len(m)), xyz=m._xyz + 3.3e-6 * 
 pool = [amy, af, _multichain(amy, 2, shift=38.0), _multichain(af, 3, shift=45.0), pyjess.Molecule(), _scattered(synth[5]), _scattered(off_grid[0])] + synth + off_grid
 wide = _copies(af, 17, "AFx17")
 wide._xyz[:] = np.round(wide._xyz + rng.normal(0.0, 0.01, size=wide._xyz.shape), 3)
-stats = dict(trials=0, searches=0, hits=0, candidates=0, truncated_pairs=0, all_hits_rows=0, wide_trials=0, mismatches=0, seconds=0.0)
+# a LONG narrow structure (three copies of the AlphaFold model, 12 237 atoms: beyond every LDS layout, 16-bit indices): its
+# batch is searched out of global memory -- segmented index build, gathered and culled table build, block search and k_deep
+# on records in L2
+long_narrow = _copies(af, 3, "AFx3")
+long_narrow._xyz[:] = np.round(long_narrow._xyz + rng.normal(0.0, 0.01, size=long_narrow._xyz.shape), 3)
+stats = dict(trials=0, searches=0, hits=0, candidates=0, truncated_pairs=0, all_hits_rows=0, wide_trials=0, long_trials=0, mismatches=0, seconds=0.0)
 t_start = time.time()
 for trial in range(trials):
     dense = trial % 3 == 1
@@ -49,6 +54,9 @@ for trial in range(trials):
     if use_wide:
         mols = mols[:2] + [wide]
         stats["wide_trials"] += 1
+    if trial % 20 == 13:
+        mols = mols[:2] + [long_narrow]
+        stats["long_trials"] += 1
     n = len(product)
     jess, olib = pyjess.Jess(product), oracle.OracleLibrary(oracle_tpls)
     rmsd = rng.uniform(0.8, 3.0, size=n)
