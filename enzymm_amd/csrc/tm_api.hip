@@ -2259,7 +2259,7 @@ static int build_tables(const tm_library *lib, tm_batch *b, const StagedSelectio
     // their own beside the batch's layout, or the only one when the batch is mostly large), from position records and
     // chunk spheres gathered first (k_tab_gather; ENZYMM_AMD_TAB_CULL=0: records through the kind lists, plain sweeps)
     const uint32_t long_from = mostly_large ? 0u : atom_cap != 0u ? atom_cap : 4096u;
-    static const bool cull_on = [] { const char *e = std::getenv("ENZYMM_AMD_TAB_CULL"); return !(e && std::atoi(e) == 0); }();
+    const bool cull_on = [] { const char *e = std::getenv("ENZYMM_AMD_TAB_CULL"); return !(e && std::atoi(e) == 0); }();  // (read per build: tests switch it)
     // work items of the build: one per (structure, part); the long structures' items behind the others
     if (b->tab_work_tables != nt || b->tab_work_long_from != long_from) {
         std::vector<TabWork> items, items_long;

@@ -265,3 +265,72 @@ def test_kind_list_beyond_16_bit_positions_is_reported():
     with pytest.raises(_native.NativeError) as err:
         by_element.query_batch([mol], 2.0, 0.5, 0.5, max_candidates=100000, ignore_chain=True)
     assert err.value.code == _native.TM_E_UNSUPPORTED and "65535" in str(err.value)
+
+
+# ------------------------------------------------------------------------------------------- long structures (round 5)
+
+
+def test_long_structure_tables_culled_and_plain(af, amy, monkeypatch):
+    """Structures too long for the batch's LDS layout (large complexes) are built by a launch of their own: k_tab_gather
+    lays the record of every kind-list position out in global memory and gives every 16 entries of a list their bounding
+    sphere, the sweeps test the chunks of list B against a row first and lay only the surviving ones over the lanes -- in
+    the order of the plain sweep, so the pair tables are the same.  A 12 237-atom complex (three copies of AF-P0DUB6 70 A
+    apart: most chunk pairs are culled) alone and inside a batch of ordinary structures (the batch's layout for those, the
+    long-structure launch beside it), index built in segments of 4096 atoms: hit tables and candidate counts are equal with
+    ENZYMM_AMD_TAB_CULL=0 (plain sweeps, records through the kind lists), the complex equals the oracle on every fifth
+    template of the default selection, and the ordinary structures get what they get without it."""
+    from oracle import oracle
+    from tests.test_gpu_round4 import _copies
+    idx, cut = helpers.default_selection()
+    every = np.arange(0, len(idx), 5)
+    jess = pyjess.Jess(helpers.product_library_templates())
+    big = _copies(af, 3, "AFx3")
+    big._xyz[:] = np.round(big._xyz + np.random.default_rng(5).normal(0.0, 0.01, size=big._xyz.shape), 3)
+    assert 4096 * 2 < len(big) < _native.TM_NARROW_STRUCTURE_ATOMS
+    others = [amy] + synthetic.structures(5, start=70)
+    q = lambda mols: jess.query_batch(mols, 2.0, cut[every], cut[every], max_candidates=10000, ignore_chain=True,
+                                      template_index=idx[every], return_raw=True, count_candidates=True)
+    alone, alone_c = q([big])
+    mixed, mixed_c = q(others[:3] + [big] + others[3:])
+    plain_others, plain_others_c = q(others)
+    monkeypatch.setenv("ENZYMM_AMD_TAB_CULL", "0")
+    alone0, alone0_c = q([big])
+    mixed0, mixed0_c = q(others[:3] + [big] + others[3:])
+    monkeypatch.delenv("ENZYMM_AMD_TAB_CULL")
+    assert len(alone) >= 1 and alone.tobytes() == alone0.tobytes() and np.array_equal(alone_c, alone0_c)
+    assert mixed.tobytes() == mixed0.tobytes() and np.array_equal(mixed_c, mixed0_c)
+    # the complex inside the batch = the complex alone; the others = the others without it
+    sub = mixed[mixed["structure"] == 3].copy()
+    sub["structure"] = 0
+    assert sub.tobytes() == alone.tobytes() and np.array_equal(mixed_c[3], alone_c[0])
+    rest = mixed[mixed["structure"] != 3].copy()
+    rest["structure"] = np.where(rest["structure"] > 3, rest["structure"] - 1, rest["structure"])
+    assert rest.tobytes() == plain_others.tobytes() and np.array_equal(np.delete(mixed_c, 3, axis=0), plain_others_c)
+    # ... and against the oracle
+    otpl = helpers.oracle_library_templates()
+    olib = oracle.OracleLibrary([otpl[i] for i in idx[every]])
+    want = oracle.query_library(helpers.to_oracle_molecule(big), olib, 2.0, cut[every], cut[every], max_candidates=10000, ignore_chain=True)
+    ok = ~want["truncated"].astype(bool)
+    assert sorted(int(t) for t in alone["template_sel"] if ok[t]) == np.nonzero(want["hit"] & ok)[0].tolist()
+    for h in alone:
+        t = int(h["template_sel"])
+        if ok[t]:
+            k = olib.templates[t].k
+            assert np.array_equal(h["atoms"][:k], want["atoms"][t][:k]) and abs(h["rmsd"] - want["rmsd"][t]) < 1e-9, t
+    assert np.array_equal(alone_c[0] & 0x7FFFFFFF, want["candidates"])
+    # densely: library templates re-seated on residues of the chain hit every copy (dozens of candidates per template)
+    implanted = helpers.implant_templates(af, helpers.product_library_templates(), np.random.default_rng(9), max_templates=80)
+    dense = pyjess.Jess(implanted)
+    dq = lambda: dense.query_batch([amy, big], 2.0, 1.2, 1.2, max_candidates=10000, ignore_chain=True, count_candidates=True, return_raw=True)
+    table, dc = dq()
+    monkeypatch.setenv("ENZYMM_AMD_TAB_CULL", "0")
+    table0, dc0 = dq()
+    monkeypatch.delenv("ENZYMM_AMD_TAB_CULL")
+    assert table.tobytes() == table0.tobytes() and np.array_equal(dc, dc0)
+    dlib = oracle.OracleLibrary([helpers.to_oracle_template(t) for t in implanted])
+    dwant = oracle.query_library(helpers.to_oracle_molecule(big), dlib, 2.0, 1.2, 1.2, max_candidates=10000, ignore_chain=True)
+    dok = ~dwant["truncated"].astype(bool)
+    assert int(dwant["candidates"].sum()) > 500
+    assert np.array_equal((dc[1] & 0x7FFFFFFF)[dok], dwant["candidates"][dok])
+    rows = table[table["structure"] == 1]
+    assert sorted(int(t) for t in rows["template_sel"] if dok[t]) == np.nonzero(dwant["hit"] & dok)[0].tolist()
