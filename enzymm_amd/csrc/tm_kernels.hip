@@ -3032,15 +3032,20 @@ __device__ __forceinline__ void deep_templates(const SearchArgs &A, WaveScratchT
     slab_init(C);
     // two runs are claimed ahead: while run n is searched, the entries of run n + 1 are on their way (and, towards the
     // end of run n, the constants of its first template), and the claim of run n + 2 is
+    // (A structure in global memory -- a large complex: a search below one of its triples takes from a tenth of a
+    // millisecond to several -- claims ONE run at a time, when the wave is done with the one before: with two claimed ahead
+    // up to four triples waited behind a long search while other waves of the structure had nothing left,
+    // tests/gpu_deep_timeline.py.  The round trips of a claim do not show beside such searches.)
+    constexpr bool kAhead = kLds;
     uint32_t run = 0;
-    if (lane == 0) run = atomicAdd(&A.O.dir_head[s], 2u);
+    if (lane == 0) run = atomicAdd(&A.O.dir_head[s], kAhead ? 2u : 1u);
     run = uni(run);
-    uint32_t run1 = run + 1u;
+    uint32_t run1 = kAhead ? run + 1u : 0xffffffffu;
     DeepEntry t;
     uint32_t nt = fetch(run, t);
     while (run < n_runs) {
         uint32_t claimed = 0;
-        if (lane == 0) claimed = atomicAdd(&A.O.dir_head[s], 1u);
+        if (kAhead && lane == 0) claimed = atomicAdd(&A.O.dir_head[s], 1u);
         DeepEntry tn;
         const uint32_t nn = fetch(run1, tn);
         for (uint32_t q = 0; q < nt; ++q) {
@@ -3104,10 +3109,16 @@ __device__ __forceinline__ void deep_templates(const SearchArgs &A, WaveScratchT
             }
 #endif
         }
-        run = run1;
-        run1 = uni(claimed);
-        t = tn;
-        nt = nn;
+        if constexpr (kAhead) {
+            run = run1;
+            run1 = uni(claimed);
+            t = tn;
+            nt = nn;
+        } else {
+            if (lane == 0) claimed = atomicAdd(&A.O.dir_head[s], 1u);
+            run = uni(claimed);
+            nt = fetch(run, t);
+        }
     }
     if (D.ti != 0xffffffffu && Q.cost && lane == 0) atomicAdd(&Q.cost[D.ti], __builtin_amdgcn_s_memtime() - D.since);
     slab_release(C);
