@@ -649,6 +649,7 @@ struct tm_batch {
     DevBuf<TabWork> d_tab_work;
     PinnedBuf<TabWork> h_tab_work;   // likewise
     uint32_t tab_work_items = 0, tab_work_tables = 0xffffffffu;
+    uint32_t tab_work_n_lead = 0xffffffffu;
     uint32_t tab_work_small = 0, tab_work_long_from = 0xffffffffu;  // items [0, small): the batch's LDS layout; the rest: long structures
     // long structures: position records and chunk spheres for their table build (k_tab_gather), regions laid out by the host
     DevBuf<TabGather> d_tab_gather;
@@ -2261,7 +2262,7 @@ static int build_tables(const tm_library *lib, tm_batch *b, const StagedSelectio
     const uint32_t long_from = mostly_large ? 0u : atom_cap != 0u ? atom_cap : 4096u;
     const bool cull_on = [] { const char *e = std::getenv("ENZYMM_AMD_TAB_CULL"); return !(e && std::atoi(e) == 0); }();  // (read per build: tests switch it)
     // work items of the build: one per (structure, part); the long structures' items behind the others
-    if (b->tab_work_tables != nt || b->tab_work_long_from != long_from) {
+    if (b->tab_work_tables != nt || b->tab_work_long_from != long_from || b->tab_work_n_lead != lib->n_lead) {  // (the sphere regions hold a slot per lead kind)
         std::vector<TabWork> items, items_long;
         std::vector<TabGather> gather;
         uint64_t lr_total = 0, sph_total = 0;
@@ -2300,7 +2301,7 @@ static int build_tables(const tm_library *lib, tm_batch *b, const StagedSelectio
             HIP_TRY(b->d_tab_lr.alloc(lr_total)); HIP_TRY(b->d_tab_sph.alloc(sph_total));
             HIP_TRY(b->d_tab_lr_base.alloc(ns)); HIP_TRY(b->d_tab_sph_base.alloc(ns));
         }
-        b->tab_work_items = (uint32_t)items.size(); b->tab_work_tables = nt; b->tab_work_long_from = long_from;
+        b->tab_work_items = (uint32_t)items.size(); b->tab_work_tables = nt; b->tab_work_long_from = long_from; b->tab_work_n_lead = lib->n_lead;
     }
     TabAux aux = {};
     hipLaunchKernelGGL(k_tab_layout, dim3(ns), dim3(256), 0, stream, lib->n_lead, B, S->d_tables.p, b->d_tab_dir.p,
