@@ -1708,6 +1708,9 @@ __device__ __forceinline__ bool on_complete(const Ctx &C, WaveRegs &W, PairState
     const double2 *exact = A->Q.exact + (size_t)P.ti * kMaxPairs;  // (template distance, threshold) per pair, staged once
     const double *qx = A->B.q_xyz + 3 * (size_t)A->B.s_off[P.s];
     bool bad = false;
+#if defined(TM_STATS) || defined(TM_ABLATE)
+    if (A->Q.flags & 0x40000u) return true;  // phase timing: complete assignments dropped where they are found
+#endif
     for (int p0 = 0; p0 < npairs; p0 += 64) {  // uniform trip count: the shuffles below need every lane
         const int p = p0 + lane;
         int i = 1, j = 0;
@@ -1726,6 +1729,9 @@ __device__ __forceinline__ bool on_complete(const Ctx &C, WaveRegs &W, PairState
         TM_STAT(51, 1);
         return true;
     }
+#if defined(TM_STATS) || defined(TM_ABLATE)
+    if (A->Q.flags & 0x80000u) return true;  // phase timing: complete assignments verified, not numbered or stored
+#endif
     // The pair's candidate count: every verified assignment takes a number; those beyond max_candidates give it back
     // and mark the pair as cut short (so the count ends on min(assignments found, max_candidates) whatever the order
     // in which the waves working on the pair get here).
