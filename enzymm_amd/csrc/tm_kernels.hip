@@ -1371,6 +1371,12 @@ constexpr uint32_t kSharedTriples = TM_SHARED_TRIPLES;
 #ifndef TM_MIN_BLOCK_GLOBAL
 #define TM_MIN_BLOCK_GLOBAL 2  // ... of a structure that is not in LDS (search_templates)
 #endif
+#ifndef TM_BLOCKS_GIVE_ABOVE
+#define TM_BLOCKS_GIVE_ABOVE 1  // the block search (structure in LDS) hands over survivors of every level but the last
+#endif
+#ifndef TM_DEEP_GIVE_ABOVE
+#define TM_DEEP_GIVE_ABOVE 3  // k_deep on a structure in global memory hands over survivors of levels below k - this (dfs)
+#endif
 constexpr uint32_t kMinBlock = TM_MIN_BLOCK;  // templates a wave claims at least (guided block sizes: 64 while much of the chunk is left)
 #ifndef TM_RES_FIRST
 #define TM_RES_FIRST 2
@@ -1897,14 +1903,14 @@ __device__ __forceinline__ bool dfs(const Ctx &C, WaveRegs &W, PairState &P, int
             }
             WL(W.cur, level, cur);
             WL(W.base, level, base);
-            if constexpr (Ctx::kLaunchMode == kModeBlocks) {
+            if constexpr (Ctx::kLaunchMode == kModeBlocks || Ctx::kResCache) {
                 // survivors while waves of the workgroup wait for work: they take all but one -- all of them when this level
                 // has further chunks to look at (a long kind list with a survivor here and there: the subtrees are searched
                 // while the list is still being read).  At ANY level: the subtrees that held a CU for 0.25 ms after fifteen
                 // waves had finished fan out below the lead levels -- two interchangeable atoms per residue (OD1/OD2,
                 // NH1/NH2, ring flips), eight residues
                 const unsigned long long give = cur < cnt ? pend : pend & (pend - 1ull);
-                if (share != nullptr && give != 0ull && level < k - 1) {
+                if (share != nullptr && give != 0ull && level < k - (Ctx::kResCache ? TM_DEEP_GIVE_ABOVE : TM_BLOCKS_GIVE_ABOVE)) {
                     const uint32_t busy = uni(__hip_atomic_load(&share->busy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
                     const uint32_t tail = uni(__hip_atomic_load(&share->tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
                     // (test hooks, ENZYMM_AMD_HANDOVER: 0 = never; 2 = always, whether or not a wave waits -- every queue
@@ -2979,7 +2985,7 @@ template <bool kLds, bool kIgnoreChain, bool kPoolLds>
 __device__ __forceinline__ void deep_templates(const SearchArgs &A, WaveScratchT<kModeDeep> *scratch, const float4 *s_rec,
                                                const uint16_t *s_res, const uint32_t *s_kl, const uint16_t *s_pool,
                                                const uint32_t *kl_off, uint32_t s, uint32_t a0, uint32_t r0, uint32_t n_listed,
-                                               ResCache *cache, const uint32_t *s_run, uint32_t n_compact) {
+                                               ResCache *cache, const uint32_t *s_run, uint32_t n_compact, SharedTriples *shared = nullptr) {
     const BatchView &B = A.B;
     const QueryView &Q = A.Q;
     SearchCtx<kIgnoreChain, kPoolLds, kModeDeep, !kLds> C;
@@ -3038,6 +3044,60 @@ __device__ __forceinline__ void deep_templates(const SearchArgs &A, WaveScratchT
     slab_init(C);
     // two runs are claimed ahead: while run n is searched, the entries of run n + 1 are on their way (and, towards the
     // end of run n, the constants of its first template), and the claim of run n + 2 is
+    // What the waves of this workgroup hand over (a structure in global memory; dfs: give_away): partial assignments in the
+    // workgroup's queue, searched by whichever wave has nothing else to do -- between two runs, and when the runs are gone.
+    auto drain = [&]() {
+        if constexpr (!kLds) {
+            if (shared == nullptr) return;
+            SharedTriples &Q2 = *shared;
+            for (;;) {
+                uint32_t idx = 0xffffffffu;
+                if (lane == 0u) {
+                    uint32_t head = __hip_atomic_load(&Q2.head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    for (;;) {
+                        const uint32_t tail = min(__hip_atomic_load(&Q2.tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), kSharedTriples);
+                        if (head >= tail) break;
+                        if (__hip_atomic_compare_exchange_strong(&Q2.head, &head, head + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                            idx = head;
+                            break;
+                        }
+                    }
+                }
+                idx = uni(idx);
+                if (idx == 0xffffffffu) break;
+                uint32_t ti;  // (reserved before it is written: wait for the writer, a wave of this workgroup a few instructions behind)
+                do {
+                    ti = uni(__hip_atomic_load(&Q2.entry[idx].ti, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                } while (ti == 0xffffffffu);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                const uint32_t depth = uni(Q2.entry[idx].depth) & 0xffu;
+                const uint32_t mine = Q2.entry[idx].atoms[min(lane, (uint32_t)kMaxK - 1u)];  // lane L < depth: the atom of level L
+                if (ti != D.ti) {
+                    if (D.ti != 0xffffffffu && Q.cost && lane == 0) atomicAdd(&Q.cost[D.ti], __builtin_amdgcn_s_memtime() - D.since);
+                    TemplateRegs T;
+                    load_template(Q, ti, (int)lane, T);
+                    D.feasible = setup_template(C, W, T, kl, Q, ti);
+                    D.ti = ti;
+                    D.P.ti = ti;
+                    D.P.truncated = false;
+                    D.since = Q.cost ? __builtin_amdgcn_s_memtime() : 0ull;
+                    D.next_ti = 0xffffffffu;
+                }
+                if (D.P.truncated || !D.feasible) continue;
+                {
+                    const uint32_t atom = lane < depth ? mine : 0u;
+                    const float4 r = C.rec[atom];
+                    if (lane < depth) {
+                        W.aidx = atom;
+                        W.ax = r.x; W.ay = r.y; W.az = r.z;
+                        W.ameta = __float_as_uint(r.w);
+                        if (!C.ignore_chain) W.achain = (uint32_t)C.qchain[atom];
+                    }
+                }
+                dfs(C, W, D.P, (int)depth, shared);
+            }
+        }
+    };
     // (A structure in global memory -- a large complex: a search below one of its triples takes from a tenth of a
     // millisecond to several -- claims ONE run at a time, when the wave is done with the one before: with two claimed ahead
     // up to four triples waited behind a long search while other waves of the structure had nothing left,
@@ -3104,7 +3164,7 @@ __device__ __forceinline__ void deep_templates(const SearchArgs &A, WaveScratchT
 #ifdef TM_STATS
             const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();
 #endif
-            dfs(C, W, D.P, 3);  // false: cut short by max_candidates (D.P.truncated is set)
+            dfs(C, W, D.P, 3, kLds ? nullptr : shared);  // false: cut short by max_candidates (D.P.truncated is set)
 #ifdef TM_STATS
             if (!kLds) {  // (a structure in global memory: the block search queues nothing, the histogram of entry durations is free)
                 const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - t_entry;
@@ -3121,9 +3181,30 @@ __device__ __forceinline__ void deep_templates(const SearchArgs &A, WaveScratchT
             t = tn;
             nt = nn;
         } else {
+            drain();
             if (lane == 0) claimed = atomicAdd(&A.O.dir_head[s], 1u);
             run = uni(claimed);
             nt = fetch(run, t);
+        }
+    }
+    if constexpr (!kLds) {
+        // out of runs: wait for what the waves still at work hand over until none of them is left (search_templates)
+        if (shared != nullptr) {
+            SharedTriples &Q2 = *shared;
+            drain();
+            if (lane == 0u) atomicSub(&Q2.busy, 1u);
+            for (;;) {
+                const uint32_t head = uni(__hip_atomic_load(&Q2.head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                const uint32_t tail = min(uni(__hip_atomic_load(&Q2.tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)), kSharedTriples);
+                if (head < tail) {
+                    if (lane == 0u) atomicAdd(&Q2.busy, 1u);
+                    drain();
+                    if (lane == 0u) atomicSub(&Q2.busy, 1u);
+                    continue;
+                }
+                if (uni(__hip_atomic_load(&Q2.busy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0u) break;
+                __builtin_amdgcn_s_sleep(16);
+            }
         }
     }
     if (D.ti != 0xffffffffu && Q.cost && lane == 0) atomicAdd(&Q.cost[D.ti], __builtin_amdgcn_s_memtime() - D.since);
@@ -3291,7 +3372,10 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
     if (threadIdx.x == 0) s_next = 0u;
     // the block search's queue of triples for the depth-first search (static LDS of that mode only)
     SharedTriples *shared = nullptr;
-    if constexpr (kMode == kModeBlocks) {
+    // (... and of k_deep on a structure in global memory: a large complex's last waves sit in searches of thousands of
+    // evaluations -- two interchangeable atoms per residue, eight residues -- while the other waves of their workgroups have
+    // run out of triples: the same hand-over among the sixteen waves of a workgroup, deep_templates)
+    if constexpr (kMode == kModeBlocks || (kMode == kModeDeep && !kLds)) {
         __shared__ SharedTriples s_shared;
         shared = &s_shared;
         for (uint32_t i = threadIdx.x; i < kSharedTriples; i += blockDim.x) s_shared.entry[i].ti = 0xffffffffu;
@@ -3345,8 +3429,8 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
             }
             __syncthreads();
         }
-        if (pool_in_lds) deep_templates<kLds, kIgnoreChain, true>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, s, a0, r0, n_listed, cache, s_run, n_compact);
-        else deep_templates<kLds, kIgnoreChain, false>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, s, a0, r0, n_listed, cache, s_run, n_compact);
+        if (pool_in_lds) deep_templates<kLds, kIgnoreChain, true>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, s, a0, r0, n_listed, cache, s_run, n_compact, shared);
+        else deep_templates<kLds, kIgnoreChain, false>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, s, a0, r0, n_listed, cache, s_run, n_compact, shared);
     } else {
         if (pool_in_lds)
             search_templates<kLds, kIgnoreChain, true, kSingly>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, &s_next, s, a0, r0, chunk, n_chunks, shared);
