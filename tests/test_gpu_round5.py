@@ -334,3 +334,35 @@ def test_long_structure_tables_culled_and_plain(af, amy, monkeypatch):
     assert np.array_equal((dc[1] & 0x7FFFFFFF)[dok], dwant["candidates"][dok])
     rows = table[table["structure"] == 1]
     assert sorted(int(t) for t in rows["template_sel"] if dok[t]) == np.nonzero(dwant["hit"] & dok)[0].tolist()
+
+
+def test_deep_search_handover_on_a_long_structure(af, monkeypatch):
+    """k_deep on a structure in global memory: the sixteen waves of a workgroup hand each other subtrees through the
+    workgroup's queue in LDS (survivors of levels below k - 3).  A 12 237-atom complex against implanted templates at a loose
+    cutoff (deep subtrees: interchangeable atoms in every residue; thousands of candidates): hit tables and candidate counts
+    are equal without hand-over (ENZYMM_AMD_HANDOVER=0), with the shipped rule and with everything handed over that can be
+    (=2), and the shipped one equals the oracle (candidate counts of the pairs that were not cut short, hit sets)."""
+    from oracle import oracle
+    from tests.test_gpu_round4 import _copies
+    big = _copies(af, 3, "AFx3")
+    big._xyz[:] = np.round(big._xyz + np.random.default_rng(21).normal(0.0, 0.01, size=big._xyz.shape), 3)
+    implanted = helpers.implant_templates(af, helpers.product_library_templates(), np.random.default_rng(17), max_templates=60)
+    dense = pyjess.Jess(implanted)
+    q = lambda: dense.query_batch([big], 2.0, 2.0, 2.0, max_candidates=10000, ignore_chain=True, count_candidates=True, return_raw=True)
+    table, cands = q()
+    assert int((cands[0] & 0x7FFFFFFF).sum()) > 2000
+    for mode in ("0", "2"):
+        monkeypatch.setenv("ENZYMM_AMD_HANDOVER", mode)
+        t2, c2 = q()
+        # (a pair that was cut short keeps whichever 10 000 candidates came first: its best may differ between two runs)
+        full = (cands[0] >> 31) == 0
+        assert np.array_equal(c2[0], cands[0]), mode
+        keep = lambda t: t[np.isin(t["template_sel"], np.nonzero(full)[0])]
+        assert keep(t2).tobytes() == keep(table).tobytes(), mode
+    monkeypatch.delenv("ENZYMM_AMD_HANDOVER")
+    dlib = oracle.OracleLibrary([helpers.to_oracle_template(t) for t in implanted])
+    want = oracle.query_library(helpers.to_oracle_molecule(big), dlib, 2.0, 2.0, 2.0, max_candidates=10000, ignore_chain=True)
+    ok = ~want["truncated"].astype(bool)
+    assert np.array_equal((cands[0] >> 31).astype(bool), want["truncated"].astype(bool))
+    assert np.array_equal((cands[0] & 0x7FFFFFFF)[ok], want["candidates"][ok])
+    assert sorted(int(t) for t in table["template_sel"] if ok[t]) == np.nonzero(want["hit"] & ok)[0].tolist()
