@@ -694,7 +694,7 @@ def main():
             def collect():
                 b, res = in_flight.popleft()
                 t = res.hits()
-                if keep is not None:
+                if keep is not None and len(keep) < len(chunks):  # (the first pass's tables only: the parity sample reads them)
                     keep.append(t)
                 res.close()
                 b.close()
@@ -817,6 +817,11 @@ def main():
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
+                         # what `frac` divides by changed in round 5: the dominant kernel's duration
+                         # ALONE on the GPU, as rocprofv3 --stats of `--pipeline 1` reports it; BENCH_r01..r04 printed what
+                         # is now `overlapped_frac`.  `value` is still the rate with two searches in flight.
+                         "frac_definition": "algorithmic bytes / exclusive kernel_ms (one search in flight) / peak; "
+                                            "r01-r04 lines used the overlapped duration = overlapped_frac",
                          # the same with the event durations of the timed region (two searches in flight)
                          "overlapped_frac": algo_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          # measured HBM bytes of a step's three hot kernels, and how many times the algorithmic bytes

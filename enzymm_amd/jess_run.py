@@ -762,7 +762,7 @@ class Matcher:
         upload and parse batches i + 1, i + 2 on the GPU (``enzymm_amd.ingest.iter_batches``) while batch i is
         searched on a stream of its own and the matches of batch i - 1 are built here.  ``ingest_options``:
         ``conservation_cutoff`` (default 0: like ``load_molecules``, which computes the filtered molecule and
-        drops it), ``ignore_endmdl``, and ``workers`` / ``prefetch`` of ``iter_batches`` (2 / 2).  The result is
+        drops it), ``ignore_endmdl``, and ``workers`` / ``prefetch`` of ``iter_batches`` (3 / 3).  The result is
         that of ``run(load_molecules(paths))``, insertion order included, keyed by lazy molecules."""
         from . import ingest
         self.refused = []

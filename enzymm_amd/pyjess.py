@@ -579,6 +579,24 @@ class Template:
     def copy(self) -> "Template":
         return Template(self._atoms, id=self.id)
 
+    # What a template caches for the device is process state: ``_rows[6]`` numbers the atoms' keys in THIS process's
+    # ``_atom_kind_list``, ``_vocab_version`` says the names were registered with THIS process's vocabulary.  Neither may
+    # travel in a pickle (spawned workers, a template cache on disk): the rows are made again where the template arrives,
+    # as PyJess rebuilds its C template when a ``Template`` is unpickled.
+    _PROCESS_STATE = ("_rows", "_orient_rows", "_vocab_version")
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        for name in Template._PROCESS_STATE:
+            state.pop(name, None)
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        for name in Template._PROCESS_STATE:  # (a state written by an older build that kept them)
+            self.__dict__.pop(name, None)
+        self._rows = _template_rows(self._atoms)
+
     @property
     def dimension(self) -> int:
         """Number of template residues (distinct chain + residue number)."""
@@ -598,6 +616,7 @@ class Template:
 _atom_kinds: dict = {}          # (match_mode, raw names, raw residues) -> number, in order of first appearance
 _atom_kind_list: list = []      # ... and back
 _atom_kinds_lock = threading.Lock()
+_PROCESS_TOKEN = object()       # rows carry it: kind numbers made in another process (a copied __dict__) are not trusted
 
 
 def _kind_numbers(keys) -> np.ndarray:
@@ -630,7 +649,15 @@ def _template_rows(atoms) -> tuple:
     chain = np.array([chains.setdefault(a.chain_id, len(chains)) for a in atoms], dtype=np.uint8)
     keys = tuple((a.match_mode, a._raw_names, a._raw_residues) for a in atoms)
     any_res = np.array([1 if key[0] >= 100 else 0 for key in keys], dtype=np.uint8)
-    return xyz, weight, any_res, group, chain, keys, _kind_numbers(keys)
+    return xyz, weight, any_res, group, chain, keys, _kind_numbers(keys), _PROCESS_TOKEN
+
+
+def _rows_of(t):
+    """The template's rows if they were made in this process for the atoms it has, else None."""
+    r = getattr(t, "_rows", None)
+    if r is None or len(r) != 8 or r[7] is not _PROCESS_TOKEN or len(r[5]) != len(t._atoms):
+        return None
+    return r
 
 
 class _PackedLibrary:
@@ -650,8 +677,8 @@ class _PackedLibrary:
         for t in templates:
             if len(t._atoms) == 0:
                 raise ValueError("cannot search an empty template")
-            r = getattr(t, "_rows", None)
-            if r is None or len(r) != 7 or len(r[5]) != len(t._atoms):  # (an object made without Template.__init__)
+            r = _rows_of(t)
+            if r is None:  # (an object made without Template.__init__, or rows that came out of another process)
                 r = _template_rows(t._atoms)
                 try:
                     t._rows = r
@@ -771,13 +798,16 @@ def _settle_library_objects(n_templates: int) -> None:
     if _settled or n_templates < 512 or os.environ.get("ENZYMM_AMD_GC_FREEZE", "1") == "0":
         return
     import gc
-    import warnings
+    import logging
     _settled = True
     gc.collect()
     gc.freeze()
-    warnings.warn(f"enzymm_amd: a library of {n_templates} templates was packed; the objects alive now were moved to the "
-                  "garbage collector's permanent generation (gc.freeze) so that full collections stop walking them "
-                  "(ENZYMM_AMD_GC_FREEZE=0 leaves the collector alone)", UserWarning, stacklevel=3)
+    # (a log record, not a warning: this is the intended default of every run with the full library, and the reference's
+    # CLI shows warnings to its users -- ADVICE r05)
+    logging.getLogger("enzymm_amd").info(
+        "a library of %d templates was packed; the objects alive now were moved to the garbage collector's permanent "
+        "generation (gc.freeze) so that full collections stop walking them (ENZYMM_AMD_GC_FREEZE=0 leaves the "
+        "collector alone)", n_templates)
 
 
 _pack_lock = threading.Lock()
@@ -1043,8 +1073,8 @@ def register_vocabulary(templates) -> None:
         return
     keys = set()
     for t in todo:  # (the distinct (match mode, names, residues) of their atoms: a thousand for the whole library)
-        rows = getattr(t, "_rows", None)
-        if rows is not None and len(rows[5]) == len(t._atoms):
+        rows = _rows_of(t)
+        if rows is not None:
             keys.update(rows[5])
         else:
             keys.update((a.match_mode, a._raw_names, a._raw_residues) for a in t._atoms)

@@ -132,6 +132,9 @@ class Residue:
     def __setattr__(self, key, value):
         raise AttributeError("Residue is immutable")
 
+    def __reduce__(self):  # (immutable + slots: unpickled through the constructor, which recomputes the orientation)
+        return (type(self), (self._atoms,))
+
     def __eq__(self, other):
         return isinstance(other, Residue) and self._atoms == other._atoms
 

@@ -243,6 +243,65 @@ def test_library_pack_round_trip(tmp_path, monkeypatch):
         library_pack.PackedTemplates(helpers.GOLDEN / "1AMY.pdb")
 
 
+def test_pickled_templates_are_packed_right_in_a_fresh_process(tmp_path):
+    """a Template caches rows whose kind numbers index a process-wide list.  Pickled in one process and
+    unpickled in another -- one that has numbered OTHER templates first -- it must be packed from rows made there:
+    the masks, coordinates and orientation tables that would go to tm_library_create equal the ones of templates
+    loaded from text in that process.  Also a state written with the rows still inside (a copied __dict__) is refused."""
+    import pickle
+    import subprocess
+    import sys
+    lib = template.load_packed_library()
+    mine = lib[5::97]
+    state = tmp_path / "templates.pkl"
+    with open(state, "wb") as handle:
+        pickle.dump(mine, handle)
+    dirty = tmp_path / "dirty.pkl"  # what a pickler that copies __dict__ verbatim would have written
+    with open(dirty, "wb") as handle:
+        pickle.dump([(type(t), dict(t.__dict__)) for t in mine[:9]], handle)
+    assert "_rows" not in mine[0].__getstate__() and "_vocab_version" not in mine[0].__getstate__()
+    back = pickle.loads(pickle.dumps(mine[3]))
+    assert back == mine[3] and pyjess._rows_of(back) is not None and back.effective_size == mine[3].effective_size
+    child = f"""
+import pickle, sys
+import numpy as np
+sys.path.insert(0, {str(helpers.ROOT)!r})
+from enzymm_amd import _native, pyjess, template
+lib = template.load_packed_library()
+others = lib[::-1][:400]                       # number other templates' kinds first, in another order
+captured = {{}}
+class FakeLibrary:
+    def __init__(self, device, *args, orientation=None):
+        captured["args"], captured["orientation"] = args, orientation
+_native.Library = FakeLibrary
+pyjess._PackedLibrary(others, 0)
+want_list = lib[5::97]
+pyjess._PackedLibrary(want_list, 0)
+want = dict(captured)
+got_list = pickle.load(open({str(state)!r}, "rb"))
+assert got_list == want_list
+pyjess.register_vocabulary(got_list)
+pyjess._PackedLibrary(got_list, 0)
+for a, b in zip(want["args"], captured["args"]):
+    assert np.array_equal(np.asarray(a), np.asarray(b))
+for a, b in zip(want["orientation"], captured["orientation"]):
+    assert np.array_equal(np.asarray(a), np.asarray(b))
+made = []
+for cls, d in pickle.load(open({str(dirty)!r}, "rb")):
+    t = cls.__new__(cls); t.__dict__.update(d); made.append(t)
+assert all(pyjess._rows_of(t) is None for t in made)       # rows of another process: not trusted
+pyjess._PackedLibrary(made, 0)
+got = dict(captured)
+pyjess._PackedLibrary(want_list[:9], 0)
+for a, b in zip(captured["args"], got["args"]):
+    assert np.array_equal(np.asarray(a), np.asarray(b))
+print("PICKLE_OK")
+"""
+    out = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, timeout=600,
+                         env={**__import__("os").environ, "ENZYMM_AMD_GC_FREEZE": "0"})
+    assert out.returncode == 0 and "PICKLE_OK" in out.stdout, out.stderr[-2000:]
+
+
 def test_native_pdb_reader_equals_numpy_reference():
     """tm_pdb_parse_host against the vectorised numpy reader it replaced: same columns on the fixtures, and on
     randomly damaged records either the same table or the same ValueError (same offending line quoted)."""
