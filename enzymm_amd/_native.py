@@ -15,6 +15,7 @@ import numpy as np
 TM_MAX_TEMPLATE_ATOMS = 24
 TM_MAX_TEMPLATE_GROUPS = 8
 TM_MAX_STRUCTURE_ATOMS = 16777215   # beyond it a structure is refused (kept in its batch as an empty one)
+TM_MAX_STRUCTURE_RESIDUES = 65533   # residues of one structure (the kernels number them with 16 bits); beyond: refused like the above
 TM_NARROW_STRUCTURE_ATOMS = 65535  # up to here the 16-bit atom indices of the tuned kernels; larger: the template-at-a-time launch, 24-bit indices
 TM_RES_OTHER = 31
 TM_NAME_OTHER = 63
@@ -91,7 +92,7 @@ EXPORTS = (
     "tm_abi_version", "tm_last_error", "tm_device_count", "tm_library_create", "tm_library_destroy",
     "tm_batch_create", "tm_batch_create_from_columns", "tm_batch_create_from_structures", "tm_batch_create_from_pdb", "tm_batch_atom_counts", "tm_batch_line_offsets",
     "tm_batch_residue_counts",
-    "tm_batch_destroy", "tm_query", "tm_result_wait", "tm_result_needed", "tm_result_hit_count",
+    "tm_batch_destroy", "tm_query", "tm_result_wait", "tm_result_needed", "tm_result_unsearched", "tm_result_hit_count",
     "tm_batch_refused", "tm_result_copy_hits", "tm_result_copy_candidates", "tm_result_timing", "tm_result_search_split", "tm_result_page_census", "tm_result_wait_appended", "tm_result_device_hits",
     "tm_result_append_hits", "tm_result_destroy", "tm_pdb_count_host", "tm_pdb_parse_host", "tm_pdb_count_host_many",
     "tm_pdb_parse_host_many", "tm_files_sizes", "tm_files_read", "tm_batch_create_from_files", "tm_batch_file_text",
@@ -617,6 +618,18 @@ class Result:
         a, b = C.c_uint64(0), C.c_uint64(0)
         _check(load().tm_result_needed(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def unsearched(self):
+        """Structure numbers of the batch this query could not search with its library (a wide structure with more than
+        65 535 atoms admissible to one template-atom kind): no hits for them, the rest of the batch searched."""
+        lib = load()
+        count = C.c_uint32(0)
+        _check(lib.tm_result_unsearched(self._h, None, C.c_uint32(0), C.byref(count)))
+        if count.value == 0:
+            return []
+        idx = np.zeros(count.value, dtype=np.uint32)
+        _check(lib.tm_result_unsearched(self._h, _ptr(idx), C.c_uint32(count.value), C.byref(count)))
+        return [int(i) for i in idx[:count.value]]
 
     def device_hits_ptr(self) -> int:
         return load().tm_result_device_hits(self._h) or 0

@@ -629,6 +629,7 @@ struct tm_batch {
     DevBuf<KindLong> d_kind_longs;
     PinnedBuf<KindLong> h_kind_longs;
     DevBuf<uint32_t> d_kind_seg_cnt;  // [segments][lead kinds]: counts, then places
+    DevBuf<uint32_t> d_kind_unsearchable;  // [long structures]: a kind list beyond 16-bit positions (k_kind_seg_offsets)
     uint32_t n_kind_segs = 0, n_kind_longs = 0;
     bool kind_segs_made = false;
     // search work items (structure, round), cached for the (cx, n_sel) they were planned for
@@ -719,6 +720,9 @@ struct tm_result {
     // on it (bench.py's N > 1 loop finishes pass j while pass j + 1 runs).  [0..3] counters, [4] overflow word,
     // [5] kind-list entries the index needed, [6..7] pair-table row slots / entries.
     PinnedBuf<unsigned long long> h_outcome;
+    // wide batches only: per long structure of the batch, whether the index build found it unsearchable (see tm_query)
+    PinnedBuf<uint32_t> h_unsearchable;
+    std::vector<uint32_t> long_structures, unsearched;
     hipEvent_t ev_done = nullptr, ev_appended = nullptr;
     bool outcome_queued = false, appended = false;
     ~tm_result() {
@@ -1110,12 +1114,22 @@ int tm_batch_create(int device, const tm_batch_desc *d, tm_batch **out) {
         for (uint32_t s = 0; s < ns; ++s) xyz_of[s] = d->xyz + 3 * (size_t)d->atom_offsets[s];
     // a structure beyond TM_MAX_STRUCTURE_ATOMS stays in the batch as an empty one (tm_batch_refused): the per-atom
     // columns are copied without its atoms
+    // (so does one of more than TM_MAX_STRUCTURE_RESIDUES residues: the kernels number residues with 16 bits)
     std::vector<uint32_t> refused, refused_atoms;
-    for (uint32_t s = 0; s < ns; ++s)
-        if (d->atom_offsets[s + 1] >= d->atom_offsets[s] && d->atom_offsets[s + 1] - d->atom_offsets[s] > TM_MAX_STRUCTURE_ATOMS) {
-            refused.push_back(s);
-            refused_atoms.push_back(d->atom_offsets[s + 1] - d->atom_offsets[s]);
+    for (uint32_t s = 0; s < ns; ++s) {
+        if (d->atom_offsets[s + 1] < d->atom_offsets[s]) continue;
+        const uint32_t o = d->atom_offsets[s], n = d->atom_offsets[s + 1] - o;
+        bool drop = n > TM_MAX_STRUCTURE_ATOMS;
+        if (!drop && n > TM_MAX_STRUCTURE_RESIDUES && d->residue) {
+            uint32_t top = 0;
+            for (uint32_t i = 0; i < n; ++i) top = std::max(top, d->residue[o + i]);
+            drop = top >= TM_MAX_STRUCTURE_RESIDUES;
         }
+        if (drop) {
+            refused.push_back(s);
+            refused_atoms.push_back(n);
+        }
+    }
     if (refused.empty()) return batch_from_encoded(device, d, d->xyz ? xyz_of.data() : nullptr, nullptr, out);
     if (d->atom_offsets[ns] && (!d->res_type || !d->name_id || !d->residue)) return fail(TM_E_INVALID, "tm_batch_create: NULL argument");
     std::vector<uint32_t> off(ns + 1, 0), residue;
@@ -1187,7 +1201,37 @@ inline bool to_milli(const double *x, size_t n3, int32_t *out) {
     return exact;
 }
 
-int batch_from_structures(int device, uint32_t ns, const tm_structure_columns *src, const tm_vocab *vocab, tm_batch **out) {
+int batch_from_structures(int device, uint32_t ns, const tm_structure_columns *src, const tm_vocab *vocab, tm_batch **out,
+                          std::vector<uint32_t> *many_residues = nullptr);
+
+// A structure of more than TM_MAX_STRUCTURE_RESIDUES residues is found out by the encoder: the batch is then laid out
+// once more with that structure emptied -- it stays in the batch without atoms, listed by tm_batch_refused -- instead
+// of failing the other structures with it (as a file beyond the atom limit is treated).
+int batch_from_structures_refusing(int device, uint32_t ns, const tm_structure_columns *src, const tm_vocab *vocab,
+                                   tm_batch **out) {
+    std::vector<uint32_t> many;
+    int rc = batch_from_structures(device, ns, src, vocab, out, &many);
+    if (rc != TM_OK || many.empty()) return rc;
+    std::vector<tm_structure_columns> kept(src, src + ns);
+    std::vector<uint32_t> atoms;
+    for (uint32_t s : many) {
+        atoms.push_back((uint32_t)std::min<uint64_t>(kept[s].n_atoms, 0xffffffffull));
+        kept[s].n_atoms = 0;
+    }
+    rc = batch_from_structures(device, ns, kept.data(), vocab, out, nullptr);
+    if (rc != TM_OK) return rc;
+    // merge with what the second pass refused for its atom count (ascending structure numbers)
+    std::vector<std::pair<uint32_t, uint32_t>> all;
+    for (size_t i = 0; i < (*out)->refused.size(); ++i) all.emplace_back((*out)->refused[i], (*out)->refused_atoms[i]);
+    for (size_t i = 0; i < many.size(); ++i) all.emplace_back(many[i], atoms[i]);
+    std::sort(all.begin(), all.end());
+    (*out)->refused.clear(); (*out)->refused_atoms.clear();
+    for (auto &e : all) { (*out)->refused.push_back(e.first); (*out)->refused_atoms.push_back(e.second); }
+    return TM_OK;
+}
+
+int batch_from_structures(int device, uint32_t ns, const tm_structure_columns *src, const tm_vocab *vocab, tm_batch **out,
+                          std::vector<uint32_t> *many_residues) {
     PhaseTrace trace("tm_batch_create_from_structures");
     *out = nullptr;
     HIP_TRY(hipSetDevice(device));
@@ -1397,6 +1441,11 @@ int batch_from_structures(int device, uint32_t ns, const tm_structure_columns *s
     uint32_t max_atoms = 0, max_res = 0;
     size_t side_xyz = 0, side_orig = 0;
     float extent = 0.f;
+    if (many_residues) {
+        for (uint32_t s = 0; s < ns; ++s)
+            if (enc[s].nres > TM_MAX_STRUCTURE_RESIDUES) many_residues->push_back(s);
+        if (!many_residues->empty()) return TM_OK;  // (*out is still NULL: the caller lays the batch out again without them)
+    }
     for (uint32_t s = 0; s < ns; ++s) {
         const uint32_t n = atom_offsets[s + 1] - atom_offsets[s];
         const EncodedStructure &E = enc[s];
@@ -1492,7 +1541,7 @@ int tm_batch_create_from_structures(int device, uint32_t n_structures, const tm_
                                     const tm_vocab *vocab, tm_batch **out) {
     if (!vocab || !out || (n_structures && !structures))
         return fail(TM_E_INVALID, "tm_batch_create_from_structures: NULL argument");
-    return batch_from_structures(device, n_structures, structures, vocab, out);
+    return batch_from_structures_refusing(device, n_structures, structures, vocab, out);
 }
 
 // The same from columns that hold all structures back to back.
@@ -1515,7 +1564,7 @@ int tm_batch_create_from_columns(int device, const tm_columns_desc *d, const tm_
         src[s].residue_number = d->residue_number + o;
         src[s].insertion_code = d->insertion_code + o;
     }
-    return batch_from_structures(device, ns, src.data(), vocab, out);
+    return batch_from_structures_refusing(device, ns, src.data(), vocab, out);
 }
 
 // exclusive prefix sum of n u32 values on the device; *total (device) receives the sum
@@ -1644,9 +1693,10 @@ static int flatten_pdb_on_host(const char *text, uint64_t length, uint32_t flags
         chain[j] = (uint8_t)(c & 0xffu);
     }
     const uint32_t nres = (uint32_t)by_key.size();
-    if (nres > TM_MAX_STRUCTURE_RESIDUES)
-        return fail(TM_E_UNSUPPORTED, "structure " + std::to_string(file) + " has more than " +
-                                          std::to_string(TM_MAX_STRUCTURE_RESIDUES) + " residues");
+    if (nres > TM_MAX_STRUCTURE_RESIDUES) {  // (the caller refuses this file alone, not its batch)
+        out->n_res = nres;
+        return TM_OK;
+    }
     // stable counting sort by residue ordinal, centred fp32 records
     std::vector<uint32_t> count(nres + 1, 0), fill;
     for (uint32_t j = 0; j < n; ++j) count[residue[j] + 1]++;
@@ -1878,6 +1928,16 @@ static int batch_from_pdb_text(int device, uint32_t n_files, const char *const *
                                          vocab->element_ids, v_res, vocab->residue_ids, v_counted, n, f, &h);
             if (rc != TM_OK) return rc;
             runs[f] = h.n_res;
+            if (h.n_res > TM_MAX_STRUCTURE_RESIDUES) {
+                // more residues than the kernels number (16 bits): refused like a file beyond the atom limit -- it stays
+                // in the batch as an empty structure, the other files are searched
+                if (!oversized)
+                    return fail(TM_E_UNSUPPORTED, "structure " + std::to_string(f) + " has more than " +
+                                                      std::to_string(TM_MAX_STRUCTURE_RESIDUES) + " residues");
+                oversized->push_back(f);
+                oversized_atoms->push_back(n);
+                continue;
+            }
         }
         s_roff[f + 1] = s_roff[f] + runs[f] + 1;
         max_atoms = std::max(max_atoms, n);
@@ -2120,9 +2180,10 @@ static int build_index(const tm_library *lib, tm_batch *b, tm_result *r, hipStre
                                (const KindSeg *)b->d_kind_segs.p, b->d_kind_seg_cnt.p, b->d_kl_off.p, b->d_kl_pool.p, pool_hi,
                                b->d_cursor.p, cap, b->d_overflow.p, kKindSeg);
             HIP_TRY(hipGetLastError());
+            if (b->d_kind_unsearchable.n < b->n_kind_longs) HIP_TRY(b->d_kind_unsearchable.alloc(b->n_kind_longs));
             hipLaunchKernelGGL(k_kind_seg_offsets, dim3(b->n_kind_longs), dim3(256), ((size_t)lib->n_lead + 1) * sizeof(uint32_t), stream,
                                lib->n_lead, (const KindLong *)b->d_kind_longs.p, b->d_kind_seg_cnt.p, b->d_kl_off.p,
-                               b->d_cursor.p, cap, b->d_overflow.p);
+                               b->d_cursor.p, cap, b->d_overflow.p, b->d_kind_unsearchable.p);
             HIP_TRY(hipGetLastError());
             hipLaunchKernelGGL(k_kind_lists<kKindWrite>, dim3(b->n_kind_segs), dim3(512), lds_seg, stream, lib->view(), b->view(),
                                (const KindSeg *)b->d_kind_segs.p, b->d_kind_seg_cnt.p, b->d_kl_off.p, b->d_kl_pool.p, pool_hi,
@@ -2645,6 +2706,15 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
         int rc = carry_build_outcome(b, r, stream);
         if (rc != TM_OK) return rc;
     }
+    if (b->has_wide && b->n_kind_longs && b->d_kind_unsearchable.n >= b->n_kind_longs) {
+        // which long structures the index build found unsearchable with this library (a kind list beyond 16-bit
+        // positions; bit 0x100 of the overflow word): the flags travel with the result, tm_result_unsearched lists them
+        HIP_TRY(r->h_unsearchable.alloc(b->n_kind_longs));
+        r->long_structures.resize(b->n_kind_longs);
+        for (uint32_t i = 0; i < b->n_kind_longs; ++i) { r->h_unsearchable[i] = 0u; r->long_structures[i] = b->h_kind_longs.p[i].s; }
+        HIP_TRY(hipMemcpyAsync(r->h_unsearchable.p, b->d_kind_unsearchable.p, b->n_kind_longs * sizeof(uint32_t),
+                               hipMemcpyDeviceToHost, stream));
+    }
     HIP_TRY(hipEventRecord(r->ev[1], stream));
     trace.mark("index+tables");
 
@@ -2976,9 +3046,12 @@ int tm_result_wait(tm_result *r) {
             r->index_shared->stale = true;
         }
     }
-    if (r->overflow & 0x100u)
-        return fail(TM_E_UNSUPPORTED, "a structure of this batch has more than 65535 atoms admissible to one template atom kind: "
-                                      "beyond the 16-bit list positions of the pair tables");
+    if ((r->overflow & 0x100u) && r->unsearched.empty()) {
+        // a structure with more than 65535 atoms admissible to one template atom kind (beyond the 16-bit list positions of
+        // the pair tables) was given empty lists: it has no hits, tm_result_unsearched names it, the others were searched
+        for (size_t i = 0; i < r->long_structures.size(); ++i)
+            if (r->h_unsearchable.p && r->h_unsearchable[i]) r->unsearched.push_back(r->long_structures[i]);
+    }
     if (r->overflow & 16u)
         return fail(TM_E_OVERFLOW, "pair-table pools too small (" + std::to_string(r->row_capacity) + " row slots, " +
                                        std::to_string(r->ent_capacity) +
@@ -2993,6 +3066,16 @@ int tm_result_wait(tm_result *r) {
         return fail(TM_E_OVERFLOW, "result tables too small: " + std::to_string(r->n_cands) + " candidates (capacity " +
                                        std::to_string(r->cand_capacity) + "), " + std::to_string(r->n_pairs) +
                                        " pairs (capacity " + std::to_string(r->hit_capacity) + ")");
+    return TM_OK;
+}
+
+int tm_result_unsearched(tm_result *r, uint32_t *structures, uint32_t capacity, uint32_t *count) {
+    if (!r || !count) return fail(TM_E_INVALID, "tm_result_unsearched: NULL argument");
+    int rc = tm_result_wait(r);
+    if (rc != TM_OK && rc != TM_E_OVERFLOW) return rc;
+    *count = (uint32_t)r->unsearched.size();
+    for (uint32_t i = 0; i < capacity && i < r->unsearched.size(); ++i)
+        if (structures) structures[i] = r->unsearched[i];
     return TM_OK;
 }
 

@@ -450,7 +450,7 @@ template __global__ void k_kind_lists<kKindWrite>(LibView, BatchView, const Kind
 __global__ __launch_bounds__(256) void k_kind_seg_offsets(uint32_t nl, const KindLong *__restrict__ longs,
                                                            uint32_t *__restrict__ seg_cnt, uint32_t *__restrict__ kl_off,
                                                            unsigned long long *__restrict__ cursor, unsigned long long capacity,
-                                                           uint32_t *__restrict__ overflow) {
+                                                           uint32_t *__restrict__ overflow, uint32_t *__restrict__ unsearchable) {
     extern __shared__ uint32_t s_tot[];  // [nl + 1]
     __shared__ unsigned long long s_base;
     __shared__ uint32_t s_long;
@@ -481,11 +481,17 @@ __global__ __launch_bounds__(256) void k_kind_seg_offsets(uint32_t nl, const Kin
         }
         if (lane == 0) {
             s_tot[nl] = run;
-            if (s_long) atomicOr(overflow, 0x100u);  // a kind list beyond 65535 atoms (a wide structure): not searchable
-            unsigned long long base = atomicAdd(cursor, (unsigned long long)run);
-            if (base + run > capacity) {
-                atomicOr(overflow, 1u);
-                base = ~0ull;
+            // a kind list beyond 65535 atoms (a wide structure): THIS structure is not searchable with this library -- it gets
+            // empty lists (no tables, no hits) and is listed by tm_result_unsearched; the rest of the batch is searched
+            unsearchable[blockIdx.x] = s_long;
+            unsigned long long base = ~0ull;
+            if (s_long) atomicOr(overflow, 0x100u);
+            else {
+                base = atomicAdd(cursor, (unsigned long long)run);
+                if (base + run > capacity) {
+                    atomicOr(overflow, 1u);
+                    base = ~0ull;
+                }
             }
             s_base = base;
         }

@@ -528,10 +528,6 @@ class Matcher:
             device_batch, molecules = molecules, molecules.molecules
             for k, n in getattr(device_batch, "refused", ()):
                 self.refused.append((molecules[k], n))
-        else:
-            # (beyond the engine's atom limit: the molecule is kept in the batch as an empty structure -- no matches -- and
-            # listed here; pyjess.make_batch warns)
-            self.refused.extend((m, len(m)) for m in molecules if len(m) > pyjess._native.TM_MAX_STRUCTURE_ATOMS)
         plan = self._plan()
         sizes, searched, rmsd, dist, dyn, size_of, pairwise, models, jess = plan
         pending = None
@@ -544,12 +540,18 @@ class Matcher:
                 pending = jess.query_batch(molecules, rmsd, dist, dyn, _async=True, stream=stream, return_raw=True, **kw)
             else:  # a stand-in engine (tests): synchronous
                 pending = pyjess._Ready(jess.query_batch(molecules, rmsd, dist, dyn, **kw))
+            if device_batch is None:
+                # beyond the engine's atom or residue limit: the molecule was kept in the batch as an empty structure -- no
+                # matches -- and is listed here (pyjess.make_batch warns)
+                self.refused.extend((molecules[k], n) for k, n in getattr(pending, "refused", ()))
         return plan, device_batch, molecules, pending
 
     def _collect(self, submitted) -> Dict[pyjess.Molecule, List[Match]]:
         plan, device_batch, molecules, pending = submitted
         sizes, searched, rmsd, dist, dyn, size_of, pairwise, models, jess = plan
         result = pending.result() if pending is not None else [[] for _ in molecules]
+        for k in getattr(pending, "unsearched", ()):  # (a kind list beyond the engine's 16-bit positions: no hits, listed)
+            self.refused.append((molecules[k], len(molecules[k])))
         table = result if isinstance(result, np.ndarray) else None
         if table is not None:
             if device_batch is not None and hasattr(device_batch, "annotate_hits"):

@@ -842,18 +842,32 @@ def make_batch(molecules: Sequence[Molecule], device: int) -> "_native.Batch":
         rows[i] = m._pointer_row()
     batch = _native.Batch.from_structures(device, rows, tables)
     batch.vocab_version = tables[-1]  # ids are only meaningful against this state of the vocabulary
-    if any(len(m) > _native.TM_MAX_STRUCTURE_ATOMS for m in molecules):
-        warn_refused([(molecules[i].id, n) for i, n in batch.refused()])
+    # (a molecule beyond the atom limit or with more residues than the kernels number stays in the batch as an empty
+    # structure; only a molecule with more atoms than the residue limit can be either)
+    batch.refused_list = batch.refused() if any(len(m) > _native.TM_MAX_STRUCTURE_RESIDUES for m in molecules) else []
+    warn_refused([(molecules[i].id, n) for i, n in batch.refused_list])
     return batch
 
 
 def warn_refused(refused) -> None:
-    """Structures beyond the engine's atom limit are kept in their batch as empty structures: they get no hits, the
-    rest of the batch is searched as usual (``tm_batch_refused``).  ``refused``: ``[(id or path, atoms)]``."""
+    """Structures beyond the engine's limits -- more than TM_MAX_STRUCTURE_ATOMS atoms or TM_MAX_STRUCTURE_RESIDUES
+    residues -- are kept in their batch as empty structures: they get no hits, the rest of the batch is searched as usual
+    (``tm_batch_refused``).  ``refused``: ``[(id or path, atoms)]``."""
     if refused:
         import warnings
         listed = ", ".join(f"{ident} ({atoms} atoms)" for ident, atoms in refused[:8]) + (" ..." if len(refused) > 8 else "")
-        warnings.warn(f"{len(refused)} structure(s) with more than {_native.TM_MAX_STRUCTURE_ATOMS} atoms are not searched: {listed}")
+        warnings.warn(f"{len(refused)} structure(s) with more than {_native.TM_MAX_STRUCTURE_ATOMS} atoms or "
+                      f"{_native.TM_MAX_STRUCTURE_RESIDUES} residues are not searched: {listed}")
+
+
+def warn_unsearched(unsearched) -> None:
+    """Wide structures (more than 65 535 atoms) with more than 65 535 atoms admissible to ONE template-atom kind cannot
+    be searched with that library (``tm_result_unsearched``): they get no hits, the rest of their batch is searched."""
+    if unsearched:
+        import warnings
+        listed = ", ".join(f"{ident} ({atoms} atoms)" for ident, atoms in unsearched[:8]) + (" ..." if len(unsearched) > 8 else "")
+        warnings.warn(f"{len(unsearched)} structure(s) with more than 65535 atoms admissible to one template atom kind are not "
+                      f"searched with these templates: {listed}")
 
 
 class _SingleBatches:
@@ -997,6 +1011,9 @@ class Hit:
 class _Ready:
     """Result of a query that needed no launch."""
 
+    unsearched = ()
+    refused = ()
+
     def __init__(self, value):
         self._value = value
 
@@ -1014,6 +1031,8 @@ class _PendingQuery:
         self._jess, self._molecules, self._sel, self._args, self._models = jess, molecules, sel, args, models
         self._owned_batch, self._count, self._raw, self._stream = owned_batch, count_candidates, return_raw, stream
         self._release = release  # hands a cached single-molecule batch back (see _single_batch)
+        self.unsearched = []
+        self.refused = list(getattr(args[1], "refused_list", ()))  # [(structure, atoms)] the batch was made without
         self._res = _native.query(*args, models=models, retry=False, stream=stream)
 
     def result(self):
@@ -1030,6 +1049,10 @@ class _PendingQuery:
                                           hit_capacity=max(int(1.25 * pairs) + 1024, 4096))
                 table = self._res.hits()
             cands = self._res.candidates() if self._count else None
+            # structures this library cannot search (a kind list beyond 16-bit positions): no hits, reported, the rest searched
+            self.unsearched = self._res.unsearched()
+            if self.unsearched:
+                warn_unsearched([(getattr(self._molecules[k], "id", None) or k, len(self._molecules[k])) for k in self.unsearched])
         finally:
             self._res.close()
             if self._owned_batch is not None:

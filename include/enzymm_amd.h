@@ -228,7 +228,9 @@ int tm_batch_text_layout(tm_batch *batch, const char **base, uint64_t *offsets);
  * TM_MAX_STRUCTURE_ATOMS, is searched as well -- template at a time, its records in global memory, 24-bit indices --
  * with the same results at a lower rate.  Structures beyond TM_MAX_STRUCTURE_ATOMS are kept in the batch as EMPTY
  * structures -- no hits, the other structures of the batch unaffected -- and listed here with the atom counts they came
- * with.  *count receives how many there are; up to `capacity` of them are written. */
+ * with.  *count receives how many there are; up to `capacity` of them are written.
+ * The same holds for a structure of more than TM_MAX_STRUCTURE_RESIDUES residues (the kernels number a structure's
+ * residues with 16 bits): emptied, listed, the rest of its batch searched -- on all three ways into a batch. */
 int tm_batch_refused(const tm_batch *batch, uint32_t *structures, uint32_t *atoms, uint32_t capacity, uint32_t *count);
 int tm_batch_atom_counts(tm_batch *batch, uint32_t *atom_offsets);            /* [n_structures + 1] */
 /* tm_batch_create_from_structures / _from_columns return when their host-to-device copies are QUEUED (17 bytes per atom:
@@ -263,6 +265,13 @@ int tm_query(const tm_library *lib, tm_batch *batch, const tm_query_params *para
 int tm_result_wait(tm_result *res);                          /* blocks; TM_E_OVERFLOW if a result table or the batch's
                                                                 candidate-index pool filled up: query again */
 int tm_result_needed(tm_result *res, uint64_t *candidates, uint64_t *pairs); /* sizes a retry needs */
+/* Structures of the batch this query could NOT search with its library: a wide structure (more than
+ * TM_NARROW_STRUCTURE_ATOMS atoms) with more than 65535 atoms admissible to one template-atom kind -- the pair tables
+ * hold list positions in 16 bits.  Such a structure gets empty candidate lists (no hits), the rest of its batch is
+ * searched as usual and the query succeeds (until round 5 it ended with TM_E_UNSUPPORTED for the whole batch).  The
+ * reference's pyjess.Jess.query would have searched it (/root/reference/enzymm/jess_run.py:803-811): the caller must
+ * report these, as enzymm_amd.pyjess and Matcher.refused do.  Implies wait; *count = how many, up to `capacity` written. */
+int tm_result_unsearched(tm_result *res, uint32_t *structures, uint32_t capacity, uint32_t *count);
 int tm_result_hit_count(tm_result *res, uint64_t *n_hits);   /* implies wait */
 int tm_result_copy_hits(tm_result *res, tm_hit *out, uint64_t capacity); /* sorted by (structure, template_sel, atoms) */
 int tm_result_copy_candidates(tm_result *res, uint32_t *out, uint64_t n); /* [n_structures * n_selected], needs TM_FLAG_COUNT_CANDIDATES */
