@@ -3062,7 +3062,7 @@ int tm_result_wait(tm_result *r) {
     if (r->overflow & 32u)
         return fail(TM_E_OVERFLOW, "page directory of the depth-first stage too small (" + std::to_string(r->page_capacity) +
                                        " pages): query again, the selection now reserves what this query needed");
-    if (r->overflow)
+    if (r->overflow & ~0x100u)
         return fail(TM_E_OVERFLOW, "result tables too small: " + std::to_string(r->n_cands) + " candidates (capacity " +
                                        std::to_string(r->cand_capacity) + "), " + std::to_string(r->n_pairs) +
                                        " pairs (capacity " + std::to_string(r->hit_capacity) + ")");

@@ -1391,12 +1391,25 @@ constexpr uint32_t kMinBlock = TM_MIN_BLOCK;  // templates a wave claims at leas
 #define TM_D0_UNROLL 1  // stage D0's loop over a residue's atoms: atoms looked at per trip (experiments: 2)
 #endif
 constexpr uint32_t kResFirst = TM_RES_FIRST;  // stage D0: levels looked at in its first round
+// Table entries of TM_B_BATCH passes of stage B (TM_C_BATCH of stage C) are asked for TOGETHER: a pass is one dependent
+// trip to L2 or HBM, four waves per SIMD do not hide it, and the block search is a chain of forty such trips per block of
+// 64 templates (round 6).  The survivors of a group of passes are queued before any of them is worked off, so the queues
+// hold 63 + 64 x batch entries -- inside the union below, whose other member (the depth-first part's bounds and lead
+// chunks, 3232 bytes) is larger than both queues anyway.
+#ifndef TM_B_BATCH
+#define TM_B_BATCH 2
+#endif
+#ifndef TM_C_BATCH
+#define TM_C_BATCH 2
+#endif
+constexpr uint32_t kBBatch = TM_B_BATCH, kCBatch = TM_C_BATCH;
+constexpr int kBlockPairQueue = 64 * (TM_B_BATCH + 1), kBlockTripleQueue = 64 * (TM_C_BATCH + 1);
 template <>
 struct __align__(16) WaveScratchT<kModeBlocks> {
     union {
         struct {
-            uint2 pairs[kPairQueue];
-            uint2 triples[kTripleQueue];
+            uint2 pairs[kBlockPairQueue];
+            uint2 triples[kBlockTripleQueue];
         };
         struct {
             float2 bnd[kMaxPairs];
@@ -2400,12 +2413,12 @@ __device__ __forceinline__ void page_append(PageWriter &PW, uint32_t s, uint32_t
 //       in its kind list that fits the three leads?  Only for the triples D0 left.
 template <class Ctx>
 __device__ __forceinline__ void block_look(Ctx &C, const SearchArgs &A, SlotRegs &R, PageWriter &PW, uint32_t s,
-                                           const uint32_t *kl, uint32_t nt) {
+                                           const uint32_t *kl, uint32_t nt, uint32_t from = 0u) {
     auto &S = *C.S;
     const uint32_t lane = (uint32_t)C.lane;
     const bool vt = lane < nt;
     uint2 t = make_uint2(0u, 0u);
-    if (vt) t = S.triples[lane];
+    if (vt) t = S.triples[from + lane];
     const uint32_t slot = t.y >> 16, c = t.y & 0xffffu, x0 = t.x & 0xffffu, x1 = t.x >> 16;
     const uint32_t ti = lane_get(R.ti, slot);
 
@@ -2436,7 +2449,7 @@ __device__ __forceinline__ void block_look(Ctx &C, const SearchArgs &A, SlotRegs
                 const uint4 *rec4 = reinterpret_cast<const uint4 *>(A.Q.rescheck + (size_t)pti * kResChecks + j);
                 const uint4 ra = rec4[0], rb = rec4[1];
                 const uint2 rw2 = *reinterpret_cast<const uint2 *>(rec4 + 2);
-                const uint2 pt = S.triples[p];  // (the owner's queue entry: its three atoms)
+                const uint2 pt = S.triples[from + p];  // (the owner's queue entry: its three atoms)
                 const uint32_t px0 = pt.x & 0xffffu, px1 = pt.x >> 16, pc = pt.y & 0xffffu;
                 const float4 l0 = C.rec[px0], l1 = C.rec[px1], l2 = C.rec[pc];
                 const uint32_t ref = ra.w & 0xffu;
@@ -2618,12 +2631,12 @@ __device__ __forceinline__ void queue_shift(uint2 *queue, uint32_t from, uint32_
 // off (stage D1) whenever it holds 64.
 template <class Ctx>
 __device__ __forceinline__ void block_pairs(Ctx &C, const SearchArgs &A, SlotRegs &R, PageWriter &PW, uint32_t s,
-                                            const uint32_t *kl, uint32_t np, uint32_t &nq3) {
+                                            const uint32_t *kl, uint32_t np, uint32_t &nq3, uint32_t from = 0u) {
     auto &S = *C.S;
     const uint32_t lane = (uint32_t)C.lane;
     const bool vp = lane < np;
     uint2 pq = make_uint2(0u, 0u);
-    if (vp) pq = S.pairs[lane];
+    if (vp) pq = S.pairs[from + lane];
     const uint32_t slot = pq.y, pos = pq.x;
     const uint32_t flags = lane_get(R.flags, slot);
     const bool key1 = (flags & 1u) != 0u;
@@ -2653,54 +2666,71 @@ __device__ __forceinline__ void block_pairs(Ctx &C, const SearchArgs &A, SlotReg
     const uint32_t incl = wave_scan_add(len), excl = incl - len;
     const uint32_t total = RL(incl, 63);
     const uint32_t row_base = lane_get(R.tbegin, slot) + r0 - excl;  // entry of item w of this pair's row: row_base + w
-    for (uint32_t w0 = 0; w0 < total; w0 += 64u) {
-        // owner of item w: each pair writes its lane where its row starts (or at item w0), a running maximum spreads it
-        S.owner[lane] = 0u;
-        {
-            const uint32_t start = max(excl, w0);
-            if (len != 0u && start < w0 + 64u && incl > w0) S.owner[start - w0] = lane;
-        }
-        wave_sync();
-        const uint32_t p = wave_scan_max(S.owner[lane]);
-        wave_sync();
-        const uint32_t w = min(w0 + lane, total - 1u);  // lanes past the last item repeat it and are masked out of the vote
-        const uint2 ent = C.tab_ent[lane_get(row_base, p) + w];
-        const float dk2 = __uint_as_float(ent.y);
-        bool ok = (w0 + lane < total) & (dk2 >= lane_getf(wklo, p)) & (dk2 <= lane_getf(wkhi, p));
-        const uint32_t c2 = C.pool_at(lane_get(lo2, p) + (ent.x >> 16));
-        const float4 rc = C.rec[c2];
-        const float ox = lane_getf(ro.x, p), oy = lane_getf(ro.y, p), oz = lane_getf(ro.z, p);
-        const uint32_t ores = meta_res(lane_get(__float_as_uint(ro.w), p));
-        const float dx = rc.x - ox, dy = rc.y - oy, dz = rc.z - oz;
-        const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-        ok = ok & (d2 >= lane_getf(wolo, p)) & (d2 <= lane_getf(wohi, p)) & (meta_res(__float_as_uint(rc.w)) != ores);
-        const uint32_t pa01 = lane_get(a01, p), pslot = lane_get(slot, p);
-        if (!C.ignore_chain) {
-            const uint32_t pf = lane_get(flags, p);  // (every lane takes part in the exchange: not under `if (ok)`)
-            if (ok) {
-                const uint8_t qc = C.qchain[c2];
-                ok = ((qc == C.qchain[pa01 & 0xffffu]) == (((pf >> 2) & 1u) != 0u)) &
-                     ((qc == C.qchain[pa01 >> 16]) == (((pf >> 3) & 1u) != 0u));
+    for (uint32_t w0 = 0; w0 < total; w0 += 64u * kCBatch) {
+        // owner of item w: each pair writes its lane where its row starts (or at item w0), a running maximum spreads it;
+        // the entries of the group's passes are asked for before the first of them is looked at
+        uint32_t owner_of[kCBatch];
+        uint2 ent_of[kCBatch];
+#pragma unroll
+        for (uint32_t k = 0; k < kCBatch; ++k) {
+            const uint32_t wk = w0 + 64u * k;
+            owner_of[k] = 0u; ent_of[k] = make_uint2(0u, 0u);
+            if (k != 0u && wk >= total) continue;
+            S.owner[lane] = 0u;
+            {
+                const uint32_t start = max(excl, wk);
+                if (len != 0u && start < wk + 64u && incl > wk) S.owner[start - wk] = lane;
             }
-        }
-        unsigned long long m = ballot64(ok);
-        {
-            const uint32_t n_m = (uint32_t)__popcll(m);
-            (void)n_m;
-            TM_STAT(67, 1);
-            TM_STAT(68, n_m);
-        }
-#if defined(TM_STATS) || defined(TM_ABLATE)
-        if (A.Q.flags & 0x400u) m = 0ull;
-#endif
-        if (m == 0ull) continue;
-        if (ok) S.triples[nq3 + rank_in(m)] = make_uint2(pa01, c2 | (pslot << 16));
-        nq3 += (uint32_t)__popcll(m);
-        if (nq3 >= 64u) {
             wave_sync();
-            block_look(C, A, R, PW, s, kl, 64u);
-            queue_shift(S.triples, 64u, nq3 - 64u, lane);
-            nq3 -= 64u;
+            owner_of[k] = wave_scan_max(S.owner[lane]);
+            wave_sync();
+            const uint32_t w = min(wk + lane, total - 1u);  // lanes past the last item repeat it and are masked out of the vote
+            ent_of[k] = C.tab_ent[lane_get(row_base, owner_of[k]) + w];
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kCBatch; ++k) {
+            const uint32_t wk = w0 + 64u * k;
+            if (k != 0u && wk >= total) continue;
+            const uint32_t p = owner_of[k];
+            const uint2 ent = ent_of[k];
+            const float dk2 = __uint_as_float(ent.y);
+            bool ok = (wk + lane < total) & (dk2 >= lane_getf(wklo, p)) & (dk2 <= lane_getf(wkhi, p));
+            const uint32_t c2 = C.pool_at(lane_get(lo2, p) + (ent.x >> 16));
+            const float4 rc = C.rec[c2];
+            const float ox = lane_getf(ro.x, p), oy = lane_getf(ro.y, p), oz = lane_getf(ro.z, p);
+            const uint32_t ores = meta_res(lane_get(__float_as_uint(ro.w), p));
+            const float dx = rc.x - ox, dy = rc.y - oy, dz = rc.z - oz;
+            const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            ok = ok & (d2 >= lane_getf(wolo, p)) & (d2 <= lane_getf(wohi, p)) & (meta_res(__float_as_uint(rc.w)) != ores);
+            const uint32_t pa01 = lane_get(a01, p), pslot = lane_get(slot, p);
+            if (!C.ignore_chain) {
+                const uint32_t pf = lane_get(flags, p);  // (every lane takes part in the exchange: not under `if (ok)`)
+                if (ok) {
+                    const uint8_t qc = C.qchain[c2];
+                    ok = ((qc == C.qchain[pa01 & 0xffffu]) == (((pf >> 2) & 1u) != 0u)) &
+                         ((qc == C.qchain[pa01 >> 16]) == (((pf >> 3) & 1u) != 0u));
+                }
+            }
+            unsigned long long m = ballot64(ok);
+            {
+                const uint32_t n_m = (uint32_t)__popcll(m);
+                (void)n_m;
+                TM_STAT(67, 1);
+                TM_STAT(68, n_m);
+            }
+#if defined(TM_STATS) || defined(TM_ABLATE)
+            if (A.Q.flags & 0x400u) m = 0ull;
+#endif
+            if (m == 0ull) continue;
+            if (ok) S.triples[nq3 + rank_in(m)] = make_uint2(pa01, c2 | (pslot << 16));
+            nq3 += (uint32_t)__popcll(m);
+        }
+        if (nq3 >= 64u) {  // (at most 63 + 64 x kCBatch queued: worked off 64 at a time, the rest moved to the front)
+            wave_sync();
+            uint32_t qh = 0;
+            for (; nq3 - qh >= 64u; qh += 64u) block_look(C, A, R, PW, s, kl, 64u, qh);
+            queue_shift(S.triples, qh, nq3 - qh, lane);
+            nq3 -= qh;
         }
     }
 }
@@ -2827,41 +2857,57 @@ __device__ __forceinline__ void search_block(Ctx &C, const SearchArgs &A, PageWr
 #if defined(TM_STATS) || defined(TM_ABLATE)
     skip = (Q.flags & 0x200u) != 0u;
 #endif
-    for (uint32_t w0 = 0; w0 < total && !skip; w0 += 64u) {
-        S.owner[lane] = 0u;
-        {
-            const uint32_t start = max(excl, w0);
-            if (len != 0u && start < w0 + 64u && incl > w0) S.owner[start - w0] = lane;
-        }
-        wave_sync();
-        const uint32_t p = wave_scan_max(S.owner[lane]);
-        wave_sync();
-        const uint32_t w = min(w0 + lane, total - 1u);
-        const uint2 ent = C.tab_ent[lane_get(R.base, p) + w];
-        const float d2 = __uint_as_float(ent.y);
-        bool ok = (w0 + lane < total) & (d2 >= lane_getf(R.w10lo, p)) & (d2 <= lane_getf(R.w10hi, p));
-        if (!C.ignore_chain) {
-            const uint32_t l0 = lane_get(R.lo0, p), l1 = lane_get(R.lo1, p), pf = lane_get(R.flags, p);
-            if (ok) ok = (C.qchain[C.pool_at(l0 + (ent.x & 0xffffu))] == C.qchain[C.pool_at(l1 + (ent.x >> 16))]) == (((pf >> 1) & 1u) != 0u);
-        }
-        unsigned long long m = ballot64(ok);
-        {
-            const uint32_t n_m = (uint32_t)__popcll(m);
-            (void)n_m;
-            TM_STAT(52, 1);
-            TM_STAT(53, n_m);
-        }
-#if defined(TM_STATS) || defined(TM_ABLATE)
-        if (Q.flags & 0x100u) m = 0ull;
-#endif
-        if (m == 0ull) continue;
-        if (ok) S.pairs[nq + rank_in(m)] = make_uint2(ent.x, p);
-        nq += (uint32_t)__popcll(m);
-        if (nq >= 64u) {
+    for (uint32_t w0 = 0; w0 < total && !skip; w0 += 64u * kBBatch) {
+        uint32_t owner_of[kBBatch];
+        uint2 ent_of[kBBatch];
+#pragma unroll
+        for (uint32_t k = 0; k < kBBatch; ++k) {
+            const uint32_t wk = w0 + 64u * k;
+            owner_of[k] = 0u; ent_of[k] = make_uint2(0u, 0u);
+            if (k != 0u && wk >= total) continue;
+            S.owner[lane] = 0u;
+            {
+                const uint32_t start = max(excl, wk);
+                if (len != 0u && start < wk + 64u && incl > wk) S.owner[start - wk] = lane;
+            }
             wave_sync();
-            block_pairs(C, A, R, PW, s, kl, 64u, nq3);
-            queue_shift(S.pairs, 64u, nq - 64u, lane);
-            nq -= 64u;
+            owner_of[k] = wave_scan_max(S.owner[lane]);
+            wave_sync();
+            const uint32_t w = min(wk + lane, total - 1u);
+            ent_of[k] = C.tab_ent[lane_get(R.base, owner_of[k]) + w];
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kBBatch; ++k) {
+            const uint32_t wk = w0 + 64u * k;
+            if (k != 0u && wk >= total) continue;
+            const uint32_t p = owner_of[k];
+            const uint2 ent = ent_of[k];
+            const float d2 = __uint_as_float(ent.y);
+            bool ok = (wk + lane < total) & (d2 >= lane_getf(R.w10lo, p)) & (d2 <= lane_getf(R.w10hi, p));
+            if (!C.ignore_chain) {
+                const uint32_t l0 = lane_get(R.lo0, p), l1 = lane_get(R.lo1, p), pf = lane_get(R.flags, p);
+                if (ok) ok = (C.qchain[C.pool_at(l0 + (ent.x & 0xffffu))] == C.qchain[C.pool_at(l1 + (ent.x >> 16))]) == (((pf >> 1) & 1u) != 0u);
+            }
+            unsigned long long m = ballot64(ok);
+            {
+                const uint32_t n_m = (uint32_t)__popcll(m);
+                (void)n_m;
+                TM_STAT(52, 1);
+                TM_STAT(53, n_m);
+            }
+#if defined(TM_STATS) || defined(TM_ABLATE)
+            if (Q.flags & 0x100u) m = 0ull;
+#endif
+            if (m == 0ull) continue;
+            if (ok) S.pairs[nq + rank_in(m)] = make_uint2(ent.x, p);
+            nq += (uint32_t)__popcll(m);
+        }
+        if (nq >= 64u) {  // (at most 63 + 64 x kBBatch queued: worked off 64 at a time, the rest moved to the front)
+            wave_sync();
+            uint32_t qh = 0;
+            for (; nq - qh >= 64u; qh += 64u) block_pairs(C, A, R, PW, s, kl, 64u, nq3, qh);
+            queue_shift(S.pairs, qh, nq - qh, lane);
+            nq -= qh;
         }
     }
     if (nq != 0u) {
