@@ -142,7 +142,7 @@ struct __align__(16) BlockHdr {
     float2 wother;   // ... of (lead 2, the other of leads 0 and 1): computed from the atom records
     uint16_t li[3];  // lead-kind indices of leads 0, 1, 2 (0xffff: the template has fewer residues)
     uint16_t flags;  // bit 0: rows of the triple table are positions of lead 1 (else lead 0); bits 1-3: template chains of
-                     // (1,0), (2,0), (2,1) equal; bits 4-7: residues; bits 8-12: atoms
+                     // (1,0), (2,0), (2,1) equal; bits 4-7: residues; bits 8-12: ResCheck records (= LookHdr::n_rescheck)
 };
 static_assert(sizeof(BlockHdr) == 32, "BlockHdr layout");
 

@@ -219,7 +219,10 @@ __global__ __launch_bounds__(64) void k_stage_templates(LibView L, uint32_t n_se
         h.wother = g >= 3 ? window(2, 1 - (int)key) : make_float2(0.f, 0.f);
         for (int i = 0; i < 3; ++i) h.li[i] = i < g ? (uint16_t)L.k_lead[L.a_kind[off + i]] : (uint16_t)0xffffu;
         const auto tc = [&](int i, int j) { return i < k && j < k && L.a_chain[off + i] == L.a_chain[off + j] ? 1u : 0u; };
-        h.flags = (uint16_t)(key | (tc(1, 0) << 1) | (tc(2, 0) << 2) | (tc(2, 1) << 3) | ((uint32_t)g << 4) | ((uint32_t)k << 8));
+        // (bits 8-12: the number of stage D0's records -- the block search has it in a register with the rest of the header
+        // when a triple reaches D0, instead of asking the look record for it: one trip to L2 less at the head of the stage)
+        h.flags = (uint16_t)(key | (tc(1, 0) << 1) | (tc(2, 0) << 2) | (tc(2, 1) << 3) | ((uint32_t)g << 4) |
+                             (min((uint32_t)__popcll(rc_mask), (uint32_t)kResChecks) << 8));
         hdr[ti] = h;
         // ... and of the look at level 3 (search position 3: the lead of a fourth residue, or another atom of one of
         // the first three)
@@ -1402,6 +1405,9 @@ constexpr uint32_t kResFirst = TM_RES_FIRST;  // stage D0: levels looked at in i
 #ifndef TM_C_BATCH
 #define TM_C_BATCH 2
 #endif
+#ifndef TM_C_RESTART
+#define TM_C_RESTART 1
+#endif
 constexpr uint32_t kBBatch = TM_B_BATCH, kCBatch = TM_C_BATCH;
 constexpr int kBlockPairQueue = 64 * (TM_B_BATCH + 1), kBlockTripleQueue = 64 * (TM_C_BATCH + 1);
 template <>
@@ -2426,7 +2432,7 @@ __device__ __forceinline__ void block_look(Ctx &C, const SearchArgs &A, SlotRegs
     // every triple, then the others of the triples that are left (most are not: 42 M items per launch become 25 M)
     bool fail = false;
     {
-        const uint32_t n_all = vt ? A.Q.look[ti].n_rescheck : 0u;
+        const uint32_t n_all = vt ? (lane_get(R.flags, slot) >> 8) & 31u : 0u;  // (= LookHdr::n_rescheck, from the block's header)
         for (uint32_t round = 0; round < 2u; ++round) {
             const uint32_t j_first = round == 0u ? 0u : min(n_all, kResFirst);
             const uint32_t n_rl = fail ? 0u : (round == 0u ? min(n_all, kResFirst) : n_all - j_first);
@@ -2630,8 +2636,9 @@ __device__ __forceinline__ void queue_shift(uint2 *queue, uint32_t from, uint32_
 // Stage C over the first `np` queued pairs; survivors go to the triple queue (nq3 entries in it), which is worked
 // off (stage D1) whenever it holds 64.
 template <class Ctx>
-__device__ __forceinline__ void block_pairs(Ctx &C, const SearchArgs &A, SlotRegs &R, PageWriter &PW, uint32_t s,
-                                            const uint32_t *kl, uint32_t np, uint32_t &nq3, uint32_t from = 0u) {
+__device__ __forceinline__ uint32_t block_pairs(Ctx &C, const SearchArgs &A, SlotRegs &R, PageWriter &PW, uint32_t s,
+                                                const uint32_t *kl, uint32_t np, uint32_t &nq3, uint32_t from = 0u,
+                                                uint32_t w_start = 0u) {
     auto &S = *C.S;
     const uint32_t lane = (uint32_t)C.lane;
     const bool vp = lane < np;
@@ -2666,7 +2673,14 @@ __device__ __forceinline__ void block_pairs(Ctx &C, const SearchArgs &A, SlotReg
     const uint32_t incl = wave_scan_add(len), excl = incl - len;
     const uint32_t total = RL(incl, 63);
     const uint32_t row_base = lane_get(R.tbegin, slot) + r0 - excl;  // entry of item w of this pair's row: row_base + w
-    for (uint32_t w0 = 0; w0 < total; w0 += 64u * kCBatch) {
+    for (uint32_t w0 = w_start; w0 < total; w0 += 64u * kCBatch) {
+#if TM_C_RESTART
+        // The triple queue is worked off by the CALLER (pairs_group), not from inside this loop: stages D0/D1 inlined here
+        // had this stage's two dozen live values on top of their own (the kernel sits at the 128 registers of four waves
+        // per SIMD).  When the queue could not take another group of passes -- rare: a dozen triples come out of 64 pairs
+        // -- the stage returns where it stands and is called again for the same pairs once the queue has been worked off.
+        if (nq3 + 64u * kCBatch > (uint32_t)kBlockTripleQueue) return w0;
+#endif
         // owner of item w: each pair writes its lane where its row starts (or at item w0), a running maximum spreads it;
         // the entries of the group's passes are asked for before the first of them is looked at
         uint32_t owner_of[kCBatch];
@@ -2725,6 +2739,7 @@ __device__ __forceinline__ void block_pairs(Ctx &C, const SearchArgs &A, SlotReg
             if (ok) S.triples[nq3 + rank_in(m)] = make_uint2(pa01, c2 | (pslot << 16));
             nq3 += (uint32_t)__popcll(m);
         }
+#if !TM_C_RESTART
         if (nq3 >= 64u) {  // (at most 63 + 64 x kCBatch queued: worked off 64 at a time, the rest moved to the front)
             wave_sync();
             uint32_t qh = 0;
@@ -2732,6 +2747,28 @@ __device__ __forceinline__ void block_pairs(Ctx &C, const SearchArgs &A, SlotReg
             queue_shift(S.triples, qh, nq3 - qh, lane);
             nq3 -= qh;
         }
+#endif
+    }
+    return 0xffffffffu;
+}
+
+// Stage C over `n` queued pairs from queue position `qh`, and stages D0/D1 over the triple queue whenever it holds 64.
+template <class Ctx>
+__device__ __forceinline__ void pairs_group(Ctx &C, const SearchArgs &A, SlotRegs &R, PageWriter &PW, uint32_t s,
+                                            const uint32_t *kl, uint32_t n, uint32_t &nq3, uint32_t qh) {
+    auto &S = *C.S;
+    for (uint32_t w = 0;;) {
+        w = block_pairs(C, A, R, PW, s, kl, n, nq3, qh, w);
+#if TM_C_RESTART
+        if (nq3 >= 64u) {  // (at most 63 + 64 x kCBatch queued: worked off 64 at a time, the rest moved to the front)
+            wave_sync();
+            uint32_t th = 0;
+            for (; nq3 - th >= 64u; th += 64u) block_look(C, A, R, PW, s, kl, 64u, th);
+            queue_shift(S.triples, th, nq3 - th, (uint32_t)C.lane);
+            nq3 -= th;
+        }
+#endif
+        if (w == 0xffffffffu) break;
     }
 }
 
@@ -2905,14 +2942,14 @@ __device__ __forceinline__ void search_block(Ctx &C, const SearchArgs &A, PageWr
         if (nq >= 64u) {  // (at most 63 + 64 x kBBatch queued: worked off 64 at a time, the rest moved to the front)
             wave_sync();
             uint32_t qh = 0;
-            for (; nq - qh >= 64u; qh += 64u) block_pairs(C, A, R, PW, s, kl, 64u, nq3, qh);
+            for (; nq - qh >= 64u; qh += 64u) pairs_group(C, A, R, PW, s, kl, 64u, nq3, qh);
             queue_shift(S.pairs, qh, nq - qh, lane);
             nq -= qh;
         }
     }
     if (nq != 0u) {
         wave_sync();
-        block_pairs(C, A, R, PW, s, kl, nq, nq3);
+        pairs_group(C, A, R, PW, s, kl, nq, nq3, 0u);
     }
     if (nq3 != 0u) {
         wave_sync();
