@@ -613,7 +613,12 @@ struct tm_batch {
     DevBuf<uint8_t> d_stage, d_side;
     hipEvent_t ready = nullptr;
     uint64_t upload_bytes = 0;  // host-to-device bytes the constructor queued (tm_batch_upload_bytes)
+    std::mutex ready_mutex;  // `ready` and the staging blocks: two threads may issue the first query of a batch
     void settle() {  // the upload and k_flatten are known to have finished: release what only they needed
+        std::lock_guard<std::mutex> lock(ready_mutex);
+        settle_locked();
+    }
+    void settle_locked() {
         h_stage.release(); h_side.release(); h_stage_off.release(); d_stage.release(); d_side.release();
         if (ready) { (void)hipEventDestroy(ready); ready = nullptr; }
     }
@@ -1731,6 +1736,14 @@ static int flatten_pdb_on_host(const char *text, uint64_t length, uint32_t flags
 
 extern "C" {
 
+// Waits for a stream when it goes out of scope while armed: declared AFTER the buffers whose copies are queued on the
+// stream, it runs before they return to their pools on every early return.
+struct StreamWaitGuard {
+    hipStream_t s;
+    bool armed;
+    ~StreamWaitGuard() { if (armed) (void)hipStreamSynchronize(s); }
+};
+
 static int batch_from_pdb_text(int device, uint32_t n_files, const char *const *text, const uint64_t *length,
                                const tm_vocab *vocab, uint32_t flags, double min_bfactor, tm_batch **out,
                                std::vector<uint32_t> *oversized, std::vector<uint32_t> *oversized_atoms,
@@ -1787,6 +1800,9 @@ static int batch_from_pdb_text(int device, uint32_t n_files, const char *const *
     const bool have_text = uploaded && uploaded->p && uploaded->bytes >= n_bytes + 16;
     if (have_text) d_text.swap(*uploaded);
     else HIP_TRY(d_text.alloc(n_bytes + 16));
+    // (the caller's chunk copies into d_text, or the copies queued below, may be in flight when a call further down fails:
+    // the stream is waited for before d_text goes back to its pool; disarmed at the first wait of the normal path)
+    StreamWaitGuard text_guard{stream, true};
     trace.mark("text alloc");
     HIP_TRY(hipMemsetAsync(d_text.p + file_off[n_files], ' ', n_bytes + 16 - file_off[n_files], stream));
     // files that already sit back to back in host memory, each ending in a newline (tm_batch_create_from_files
@@ -1817,6 +1833,7 @@ static int batch_from_pdb_text(int device, uint32_t n_files, const char *const *
         if (rc != TM_OK) return rc;
         HIP_TRY(hipMemcpyAsync(&n_lines, d_total.p, sizeof n_lines, hipMemcpyDeviceToHost, stream));
         HIP_TRY(wait_blocking(stream));
+        text_guard.armed = false;
         trace.mark("sync0");
     }
     HIP_TRY(d_nl.alloc(n_lines)); HIP_TRY(d_line_file.alloc(n_lines)); HIP_TRY(d_kind.alloc(n_lines));
@@ -2028,9 +2045,12 @@ int tm_batch_upload_bytes(const tm_batch *b, uint64_t *bytes) {
 int tm_batch_wait(tm_batch *b) {
     if (!b) return fail(TM_E_INVALID, "NULL argument");
     HIP_TRY(hipSetDevice(b->device));
-    if (b->ready) {
-        HIP_TRY(hipEventSynchronize(b->ready));
-        b->settle();
+    {
+        std::lock_guard<std::mutex> lock(b->ready_mutex);
+        if (b->ready) {
+            HIP_TRY(hipEventSynchronize(b->ready));
+            b->settle_locked();
+        }
     }
     return TM_OK;
 }
@@ -2417,9 +2437,12 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
     hipStream_t stream = (hipStream_t)p->stream;
     // a batch whose constructor returned with its copies queued (tm_batch_create_from_structures): this stream waits
     // for them on the device, the host does not
-    if (b->ready) {
-        if (hipEventQuery(b->ready) == hipSuccess) b->settle();
-        else HIP_TRY(hipStreamWaitEvent(stream, b->ready, 0));
+    {
+        std::lock_guard<std::mutex> lock(b->ready_mutex);
+        if (b->ready) {
+            if (hipEventQuery(b->ready) == hipSuccess) b->settle_locked();
+            else HIP_TRY(hipStreamWaitEvent(stream, b->ready, 0));
+        }
     }
 
     tm_result *r = new (std::nothrow) tm_result;
@@ -3206,6 +3229,17 @@ int tm_debug_stats(unsigned long long *out) {
 }
 #endif
 
+#ifdef TM_TIMES
+// diagnostic build only (-DTM_TIMES): read and reset the block search's per-stage wave clocks (g_times in tm_kernels.hip)
+int tm_debug_times(unsigned long long *out) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(tmx::g_times), 16 * sizeof(unsigned long long)));
+    unsigned long long zero[16] = {0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(tmx::g_times), zero, sizeof zero));
+    return TM_OK;
+}
+#endif
+
 #ifdef TM_ABLATE
 // timing build only (make ablate): read and reset the block search's log of units -- n x {start, end, hw_id | xcc_id << 32, first wave's end, sum of the waves' ends}
 // (n with bit 31 set: the log of k_tab_build's workgroups instead)
@@ -3544,6 +3578,11 @@ int tm_batch_create_from_files(int device, uint32_t n_files, const char *const *
     HIP_TRY(ingest_stream(device, &stream));
     const uint64_t n_bytes = (off[n_files] + 15) & ~15ull;
     HIP_TRY(d_text.alloc(n_bytes + 16));
+    // Declared after `text` and `d_text`, so destroyed BEFORE them: whatever way this function is left once a chunk's copy
+    // is queued, the ingest stream is waited for before the page-locked and the device block go back to their pools (a
+    // failing HIP call further down returned with DMA still reading `text` -- ADVICE r05); disarmed when the batch takes
+    // the buffers over.
+    StreamWaitGuard copy_guard{stream, false};
     {
         std::vector<uint8_t> failed(n_files, 0);
         static const uint32_t n_chunks = [] {
@@ -3599,8 +3638,10 @@ int tm_batch_create_from_files(int device, uint32_t n_files, const char *const *
             });
             bool any = false;
             for (uint32_t f = f0; f < f1; ++f) any = any || failed[f];
-            if (!any && off[f1] > off[f0])
+            if (!any && off[f1] > off[f0]) {
+                copy_guard.armed = true;
                 HIP_TRY(hipMemcpyAsync(d_text.p + off[f0], text.p + off[f0], off[f1] - off[f0], hipMemcpyHostToDevice, stream));
+            }
             f0 = f1;
         }
         for (uint32_t f = 0; f < n_files; ++f)
@@ -3616,8 +3657,9 @@ int tm_batch_create_from_files(int device, uint32_t n_files, const char *const *
     for (uint32_t f = 0; f < n_files; ++f) { ptr[f] = text.p + off[f]; len[f] = sizes[f] + 1; }
     rc = batch_from_pdb(device, n_files, ptr.data(), len.data(), vocab, flags, min_bfactor, out, &d_text);
     trace.mark("from_pdb");
-    if (rc != TM_OK) { (void)hipStreamSynchronize(stream); return rc; }
+    if (rc != TM_OK) return rc;  // (copy_guard waits)
     tm_batch *b = *out;
+    copy_guard.armed = false;
     std::swap(b->h_text.p, text.p); std::swap(b->h_text.n, text.n); std::swap(b->h_text.bytes, text.bytes);
     b->h_text_off = std::move(off);
     return TM_OK;

@@ -37,6 +37,20 @@ __device__ unsigned long long g_stats[320];
 #else
 #define TM_STAT(i, v) do { } while (0)
 #endif
+#ifdef TM_TIMES
+// diagnostic build only (make variant NAME=times EXTRA=-DTM_TIMES, tests/gpu_stage_times.py): shader-clock cycles the
+// WAVES of the block search spend per stage, waiting included -- [0] A, [1] B, [2] C, [3] D0, [4] D1 + queueing, [5] the
+// depth-first search below queued triples, [6] waiting at the end of a unit, [7] staging a unit's structure, [8] whole
+// units, [9] blocks, [10] C calls, [11] look flushes, [12] queue entries searched
+__device__ unsigned long long g_times[16];
+#define TM_T0(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define TM_T1(slot, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_times[slot], __builtin_amdgcn_s_memtime() - (v)); } while (0)
+#define TM_TN(slot, n) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_times[slot], (unsigned long long)(n)); } while (0)
+#else
+#define TM_T0(v) ((void)0)
+#define TM_T1(slot, v) ((void)0)
+#define TM_TN(slot, n) ((void)0)
+#endif
 #ifdef TM_ABLATE
 // timing build only: when every workgroup of the block search started and ended (10 ns ticks) and where it ran
 // (HW_ID: CU, SE; XCC_ID), for tests/gpu_wg_timeline.py
@@ -50,6 +64,16 @@ __device__ WgLog g_deep_log[kWgLog]; // ... and of k_deep
 // ------------------------------------------------------------------ wave helpers
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+#ifndef TM_D0_MAX_NAMES
+#define TM_D0_MAX_NAMES 64  // stage D0 asks about levels that admit at most this many atom names (experiments: 2)
+#endif
+// -DTM_MARKS: comments in the ISA around the block search's stages (static instruction counts per stage; a diagnostic
+// compile -- the markers pin the schedule -- never shipped)
+#ifdef TM_MARKS
+#define TM_MARK(name) asm volatile("; TM_MARK " name)
+#else
+#define TM_MARK(name) ((void)0)
+#endif
 // wave-wide vote straight into an SGPR pair (HIP's __ballot goes through an integer compare)
 __device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 // number of set bits of `m` below this lane (v_mbcnt_lo + v_mbcnt_hi)
@@ -192,7 +216,13 @@ __global__ __launch_bounds__(64) void k_stage_templates(LibView L, uint32_t n_se
     // stage D0's records: the levels that are not leads and belong to template residues 0, 1, 2, in search order
     unsigned long long rc_mask = 0ull;
     {
-        const bool qual = lane < k && L.a_ref[off + min(lane, k - 1)] != lane && L.a_ref[off + min(lane, k - 1)] < 3 && k > 3;
+        bool qual = lane < k && L.a_ref[off + min(lane, k - 1)] != lane && L.a_ref[off + min(lane, k - 1)] < 3 && k > 3;
+#if TM_D0_MAX_NAMES < 64
+        // (experiment: stage D0 asks only about levels that admit few atom names -- a level that matches by element admits a
+        // dozen names, several atoms of a residue pass its name test and each costs the three windows; D0 is a filter of
+        // necessary conditions, a level it does not ask about is left to the search)
+        if (qual) qual = __popcll(L.k_namemask[L.a_kind[off + lane]]) <= TM_D0_MAX_NAMES;
+#endif
         rc_mask = ballot64(qual);
         if (qual) {
             const uint32_t kind = L.a_kind[off + lane];
@@ -2430,9 +2460,15 @@ __device__ __forceinline__ void block_look(Ctx &C, const SearchArgs &A, SlotRegs
 
     // ---- D0: lane = (triple, level of residues 0-2 that is not a lead), in two rounds: the first two such levels of
     // every triple, then the others of the triples that are left (most are not: 42 M items per launch become 25 M)
+    TM_MARK("D0_begin");
+    TM_T0(t_d0);
+    TM_TN(11, 1);
     bool fail = false;
     {
-        const uint32_t n_all = vt ? (lane_get(R.flags, slot) >> 8) & 31u : 0u;  // (= LookHdr::n_rescheck, from the block's header)
+        // (= LookHdr::n_rescheck, from the block's header; the exchange is made by EVERY lane: a lane that does not take part
+        // hands out nothing, and the slots of a partly filled flush sit in lanes beyond its triples)
+        const uint32_t slot_flags = lane_get(R.flags, slot);
+        const uint32_t n_all = vt ? (slot_flags >> 8) & 31u : 0u;
         for (uint32_t round = 0; round < 2u; ++round) {
             const uint32_t j_first = round == 0u ? 0u : min(n_all, kResFirst);
             const uint32_t n_rl = fail ? 0u : (round == 0u ? min(n_all, kResFirst) : n_all - j_first);
@@ -2440,6 +2476,7 @@ __device__ __forceinline__ void block_look(Ctx &C, const SearchArgs &A, SlotRegs
             const uint32_t total = RL(incl, 63);
             TM_STAT(62, total);
             for (uint32_t w0 = 0; w0 < total; w0 += 64u) {
+                TM_MARK("D0_pass_begin");
                 S.owner[lane] = 0u;
                 {
                     const uint32_t start = max(excl, w0);
@@ -2467,6 +2504,7 @@ __device__ __forceinline__ void block_look(Ctx &C, const SearchArgs &A, SlotRegs
                 const float2 w0b = make_float2(__uint_as_float(rb.x), __uint_as_float(rb.y)), w1b = make_float2(__uint_as_float(rb.z), __uint_as_float(rb.w)),
                              w2b = make_float2(__uint_as_float(rw2.x), __uint_as_float(rw2.y));
                 bool found = false;
+                TM_MARK("D0_resloop_begin");
 #if TM_D0_UNROLL == 2
                 // two atoms of the residue per trip: their packed words are asked for together (one LDS round trip for two
                 // names; the loop is a chain of dependent round trips -- five on average, one per atom)
@@ -2495,6 +2533,7 @@ __device__ __forceinline__ void block_look(Ctx &C, const SearchArgs &A, SlotRegs
                     }
                 }
 #endif
+                TM_MARK("D0_resloop_end");
                 const unsigned long long missing = ballot64(item && !found);
                 TM_STAT(63, 1);
                 // does any of MY triple's levels of this pass lack a candidate?  (items [max(excl, w0), min(incl, w0 + 64)) - w0)
@@ -2506,6 +2545,9 @@ __device__ __forceinline__ void block_look(Ctx &C, const SearchArgs &A, SlotRegs
             }
         }
     }
+    TM_MARK("D0_end");
+    TM_T1(3, t_d0);
+    TM_T0(t_d1);
     const bool alive = vt && !fail;
     {
         const uint32_t n_failed = (uint32_t)__popcll(ballot64(vt && fail));
@@ -2587,6 +2629,7 @@ __device__ __forceinline__ void block_look(Ctx &C, const SearchArgs &A, SlotRegs
             f = ballot64(fits(u, C.rec[C.pool_at(u.lo + min(base + lane, u.cnt - 1u))], base + lane)) != 0ull;
         if (f) found_lead |= 1ull << q;
     }
+    TM_MARK("D1_end");
     pass = pass | (((found_lead >> lane) & 1ull) != 0ull);
     unsigned long long keep = ballot64(pass);
     {
@@ -2622,6 +2665,7 @@ __device__ __forceinline__ void block_look(Ctx &C, const SearchArgs &A, SlotRegs
         }
         if (keep) page_append(PW, s, lane, keep, t.x, c, ti);
     }
+    TM_T1(4, t_d1);
 }
 
 // Moves queue entries [from, from + n) to the front (n < 64).
@@ -2641,6 +2685,7 @@ __device__ __forceinline__ uint32_t block_pairs(Ctx &C, const SearchArgs &A, Slo
                                                 uint32_t w_start = 0u) {
     auto &S = *C.S;
     const uint32_t lane = (uint32_t)C.lane;
+    TM_MARK("C_setup_begin");
     const bool vp = lane < np;
     uint2 pq = make_uint2(0u, 0u);
     if (vp) pq = S.pairs[from + lane];
@@ -2673,7 +2718,9 @@ __device__ __forceinline__ uint32_t block_pairs(Ctx &C, const SearchArgs &A, Slo
     const uint32_t incl = wave_scan_add(len), excl = incl - len;
     const uint32_t total = RL(incl, 63);
     const uint32_t row_base = lane_get(R.tbegin, slot) + r0 - excl;  // entry of item w of this pair's row: row_base + w
+    TM_MARK("C_setup_end");
     for (uint32_t w0 = w_start; w0 < total; w0 += 64u * kCBatch) {
+        TM_MARK("C_group_begin");
 #if TM_C_RESTART
         // The triple queue is worked off by the CALLER (pairs_group), not from inside this loop: stages D0/D1 inlined here
         // had this stage's two dozen live values on top of their own (the kernel sits at the 128 registers of four waves
@@ -2739,6 +2786,7 @@ __device__ __forceinline__ uint32_t block_pairs(Ctx &C, const SearchArgs &A, Slo
             if (ok) S.triples[nq3 + rank_in(m)] = make_uint2(pa01, c2 | (pslot << 16));
             nq3 += (uint32_t)__popcll(m);
         }
+        TM_MARK("C_group_end");
 #if !TM_C_RESTART
         if (nq3 >= 64u) {  // (at most 63 + 64 x kCBatch queued: worked off 64 at a time, the rest moved to the front)
             wave_sync();
@@ -2758,7 +2806,10 @@ __device__ __forceinline__ void pairs_group(Ctx &C, const SearchArgs &A, SlotReg
                                             const uint32_t *kl, uint32_t n, uint32_t &nq3, uint32_t qh) {
     auto &S = *C.S;
     for (uint32_t w = 0;;) {
+        TM_T0(t_c);
         w = block_pairs(C, A, R, PW, s, kl, n, nq3, qh, w);
+        TM_T1(2, t_c);
+        TM_TN(10, 1);
 #if TM_C_RESTART
         if (nq3 >= 64u) {  // (at most 63 + 64 x kCBatch queued: worked off 64 at a time, the rest moved to the front)
             wave_sync();
@@ -2802,6 +2853,8 @@ __device__ __forceinline__ void drain_shared(Ctx &C, const SearchArgs &A, PageWr
         }
         idx = uni(idx);
         if (idx == 0xffffffffu) break;
+        TM_T0(t_q);
+        TM_TN(12, 1);
         uint32_t ti;  // (reserved before it is written: wait for the writer, a wave of this workgroup a few instructions behind)
         do {
             ti = uni(__hip_atomic_load(&Q2.entry[idx].ti, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
@@ -2845,6 +2898,7 @@ __device__ __forceinline__ void drain_shared(Ctx &C, const SearchArgs &A, PageWr
         const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();
 #endif
         dfs(C, W, P, (int)depth, &Q2);
+        TM_T1(5, t_q);
 #ifdef TM_STATS
         {
             const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - t_entry;
@@ -2868,6 +2922,9 @@ __device__ __forceinline__ void search_block(Ctx &C, const SearchArgs &A, PageWr
     const unsigned long long t_block = Q.cost ? __builtin_amdgcn_s_memtime() : 0ull;
 
     // ---- A: lane = template
+    TM_MARK("A_begin");
+    TM_T0(t_a);
+    TM_TN(9, 1);
     const bool valid = lane < count;
     SlotRegs R;
     R.ti = chunk + n_chunks * (m0 + (valid ? lane : 0u));
@@ -2888,6 +2945,8 @@ __device__ __forceinline__ void search_block(Ctx &C, const SearchArgs &A, PageWr
     R.base = ref.x - excl;
     TM_STAT(49, count);
 
+    TM_MARK("A_end");
+    TM_T1(0, t_a);
     // ---- B: lane = entry of a pair segment
     uint32_t nq = 0, nq3 = 0;
     bool skip = false;
@@ -2895,6 +2954,8 @@ __device__ __forceinline__ void search_block(Ctx &C, const SearchArgs &A, PageWr
     skip = (Q.flags & 0x200u) != 0u;
 #endif
     for (uint32_t w0 = 0; w0 < total && !skip; w0 += 64u * kBBatch) {
+        TM_MARK("B_group_begin");
+        TM_T0(t_b);
         uint32_t owner_of[kBBatch];
         uint2 ent_of[kBBatch];
 #pragma unroll
@@ -2939,6 +3000,8 @@ __device__ __forceinline__ void search_block(Ctx &C, const SearchArgs &A, PageWr
             if (ok) S.pairs[nq + rank_in(m)] = make_uint2(ent.x, p);
             nq += (uint32_t)__popcll(m);
         }
+        TM_MARK("B_group_end");
+        TM_T1(1, t_b);
         if (nq >= 64u) {  // (at most 63 + 64 x kBBatch queued: worked off 64 at a time, the rest moved to the front)
             wave_sync();
             uint32_t qh = 0;
@@ -3038,6 +3101,7 @@ __device__ __forceinline__ void search_templates(const SearchArgs &A, WaveScratc
         // (`busy` only tells a waiting wave when to stop looking: whoever queues an entry also comes back for the queue)
         SharedTriples &Q2 = *PW.shared;
         if (lane == 0) atomicSub(&Q2.busy, 1u);
+        TM_T0(t_wait);
         for (;;) {
             const uint32_t head = uni(__hip_atomic_load(&Q2.head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
             const uint32_t tail = min(uni(__hip_atomic_load(&Q2.tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)), kSharedTriples);
@@ -3050,6 +3114,7 @@ __device__ __forceinline__ void search_templates(const SearchArgs &A, WaveScratc
             if (uni(__hip_atomic_load(&Q2.busy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0u) break;
             __builtin_amdgcn_s_sleep(16);
         }
+        TM_T1(6, t_wait);
     }
     page_publish(PW, s, (uint32_t)lane);
     slab_release(C);
@@ -3349,6 +3414,7 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
     __shared__ uint32_t s_claim;
     const uint32_t cx = A.chunk_xcd_shift;
     for (;;) {
+    TM_T0(t_unit);
 #ifdef TM_STATS
     const unsigned long long t_wg = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -3521,10 +3587,12 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
         if (pool_in_lds) deep_templates<kLds, kIgnoreChain, true>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, s, a0, r0, n_listed, cache, s_run, n_compact, shared);
         else deep_templates<kLds, kIgnoreChain, false>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, s, a0, r0, n_listed, cache, s_run, n_compact, shared);
     } else {
+        if constexpr (kMode == kModeBlocks) TM_T1(7, t_unit);
         if (pool_in_lds)
             search_templates<kLds, kIgnoreChain, true, kSingly>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, &s_next, s, a0, r0, chunk, n_chunks, shared);
         else
             search_templates<kLds, kIgnoreChain, false, kSingly>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, &s_next, s, a0, r0, chunk, n_chunks, shared);
+        if constexpr (kMode == kModeBlocks) TM_T1(8, t_unit);
     }
 #ifdef TM_ABLATE
     if (kMode != kModeSingly && (threadIdx.x & 63) == 0 && log_at < kWgLog) {
