@@ -40,12 +40,14 @@ __device__ unsigned long long g_stats[320];
 #ifdef TM_TIMES
 // diagnostic build only (make variant NAME=times EXTRA=-DTM_TIMES, tests/gpu_stage_times.py): shader-clock cycles the
 // WAVES of the block search spend per stage, waiting included -- [0] A, [1] B, [2] C, [3] D0, [4] D1 + queueing, [5] the
-// depth-first search below queued triples, [6] waiting at the end of a unit, [7] staging a unit's structure, [8] whole
-// units, [9] blocks, [10] C calls, [11] look flushes, [12] queue entries searched
+// depth-first search below queued triples, [6] waiting at the end of a unit, [7] unused, [8] the waves' whole time in
+// the template loop of their units, [9] blocks, [10] C calls, [11] look flushes, [12] queue entries searched
 __device__ unsigned long long g_times[16];
+// (accumulated in the wave's search context C, written out once per unit: an atomic per stage visit took the launch from 1.8
+// to 30 ms and measured mostly itself)
 #define TM_T0(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
-#define TM_T1(slot, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_times[slot], __builtin_amdgcn_s_memtime() - (v)); } while (0)
-#define TM_TN(slot, n) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_times[slot], (unsigned long long)(n)); } while (0)
+#define TM_T1(slot, v) (C.tacc[slot] += __builtin_amdgcn_s_memtime() - (v))
+#define TM_TN(slot, n) (C.tacc[slot] += (unsigned long long)(n))
 #else
 #define TM_T0(v) ((void)0)
 #define TM_T1(slot, v) ((void)0)
@@ -64,6 +66,9 @@ __device__ WgLog g_deep_log[kWgLog]; // ... and of k_deep
 // ------------------------------------------------------------------ wave helpers
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+#ifndef TM_D0_SCAN
+#define TM_D0_SCAN 1  // stage D0: names scanned in a wave-uniform loop, candidates tested in lock step (0: the per-lane walk of rounds 4-5)
+#endif
 #ifndef TM_D0_MAX_NAMES
 #define TM_D0_MAX_NAMES 64  // stage D0 asks about levels that admit at most this many atom names (experiments: 2)
 #endif
@@ -1559,6 +1564,9 @@ struct SearchCtx {
     WaveScratchT<kMode> *S;
     int lane, k, n_groups;
     static constexpr bool ignore_chain = kIgnoreChain;
+#ifdef TM_TIMES
+    mutable unsigned long long tacc[13];
+#endif
 };
 
 // Tests up to 64 candidates for `level`; returns the survivor mask.
@@ -2505,7 +2513,48 @@ __device__ __forceinline__ void block_look(Ctx &C, const SearchArgs &A, SlotRegs
                              w2b = make_float2(__uint_as_float(rw2.x), __uint_as_float(rw2.y));
                 bool found = false;
                 TM_MARK("D0_resloop_begin");
-#if TM_D0_UNROLL == 2
+#if TM_D0_SCAN
+                // Round 6.  The loop this replaces walked the residue's atoms with `found` and the end of the residue as per-lane
+                // exits: a wave ran as many trips as its longest residue has atoms (a dozen), and in nearly every trip SOME lane
+                // had an admissible name, so the three windows -- forty instructions under a handful of lanes -- were issued a
+                // dozen times per pass.  Now the names are scanned first, in a loop whose trip count is the wave's (no per-lane
+                // control flow, two atoms per trip: their packed words are asked for together), and leave a bit per admissible
+                // atom; then the lanes test their candidates in lock step, lowest first -- once for a level that admits one name
+                // (every lane tests its one atom in the same trip), a few times for a level that matches by element.  The same
+                // atoms pass the same tests: a superset filter as before, parity cannot move.  Residues of more than 32 atoms
+                // (hydrogens, ligands) go 32 atoms at a time.
+                const uint32_t n_res_atoms = item && a_end > a ? a_end - a : 0u;
+                for (uint32_t base = 0; ballot64(base < n_res_atoms && !found) != 0ull; base += 32u) {
+                    const bool here = base < n_res_atoms && !found;
+                    const uint32_t n_here = here ? min(32u, n_res_atoms - base) : 0u;
+                    const uint32_t a_here = a + (here ? base : 0u);  // (a lane that is done keeps reading inside its residue)
+                    uint32_t cand = 0u;
+                    for (uint32_t i = 0; i < 32u; i += 2u) {
+                        const bool act0 = i < n_here, act1 = i + 1u < n_here;
+                        if (ballot64(act0) == 0ull) break;
+                        // (a lane past its residue reads its residue's first atom: inside the arrays whatever the memory)
+                        const uint32_t m0 = __float_as_uint(C.rec[a_here + (act0 ? i : 0u)].w);
+                        const uint32_t m1 = __float_as_uint(C.rec[a_here + (act1 ? i + 1u : 0u)].w);
+                        const bool adm0 = act0 & (((nm >> meta_name(m0)) & 1ull) != 0ull) & (any | (((ra.z >> meta_rtype(m0)) & 1u) != 0u));
+                        const bool adm1 = act1 & (((nm >> meta_name(m1)) & 1ull) != 0ull) & (any | (((ra.z >> meta_rtype(m1)) & 1u) != 0u));
+                        cand |= (adm0 ? 1u << i : 0u) | (adm1 ? 2u << i : 0u);
+                    }
+                    // the placed leads are not candidates (only the one this level shares its residue with can lie here)
+                    {
+                        const uint32_t d0 = px0 - a_here, d1 = px1 - a_here, d2 = pc - a_here;
+                        cand &= ~((d0 < 32u ? 1u << d0 : 0u) | (d1 < 32u ? 1u << d1 : 0u) | (d2 < 32u ? 1u << d2 : 0u));
+                    }
+                    for (;;) {
+                        const bool has = cand != 0u && !found;
+                        if (ballot64(has) == 0ull) break;
+                        const uint32_t bit = has ? (uint32_t)__builtin_ctz(cand) : 0u;
+                        const float4 r = C.rec[a_here + bit];
+                        const bool ok = in_window(r, l0, w0b) & in_window(r, l1, w1b) & in_window(r, l2, w2b);
+                        found = found | (has & ok);
+                        cand &= cand - 1u;
+                    }
+                }
+#elif TM_D0_UNROLL == 2
                 // two atoms of the residue per trip: their packed words are asked for together (one LDS round trip for two
                 // names; the loop is a chain of dependent round trips -- five on average, one per atom)
                 auto admits = [&](uint32_t m, uint32_t at) {
@@ -3054,6 +3103,10 @@ __device__ __forceinline__ void search_templates(const SearchArgs &A, WaveScratc
     C.S = scratch + (threadIdx.x >> 6);
     C.lane = lane_id();
     C.k = 0; C.n_groups = 0; C.bnd = Q.bounds;
+#ifdef TM_TIMES
+    for (int i = 0; i < 13; ++i) C.tacc[i] = 0ull;
+    const unsigned long long t_templates = __builtin_amdgcn_s_memtime();
+#endif
     const int lane = C.lane;
     const uint32_t *kl = kLds ? s_kl : kl_off;
     const uint4 *tab_ref = B.tab_ref + (size_t)s * Q.n_sel;
@@ -3118,6 +3171,11 @@ __device__ __forceinline__ void search_templates(const SearchArgs &A, WaveScratc
     }
     page_publish(PW, s, (uint32_t)lane);
     slab_release(C);
+#ifdef TM_TIMES
+    C.tacc[8] += __builtin_amdgcn_s_memtime() - t_templates;
+    if (lane == 0)
+        for (int i = 0; i < 13; ++i) atomicAdd(&g_times[i], C.tacc[i]);
+#endif
     }
 }
 
@@ -3414,7 +3472,6 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
     __shared__ uint32_t s_claim;
     const uint32_t cx = A.chunk_xcd_shift;
     for (;;) {
-    TM_T0(t_unit);
 #ifdef TM_STATS
     const unsigned long long t_wg = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -3587,12 +3644,10 @@ __global__ __launch_bounds__(kSearchBlock) void k_search(SearchArgs A) {
         if (pool_in_lds) deep_templates<kLds, kIgnoreChain, true>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, s, a0, r0, n_listed, cache, s_run, n_compact, shared);
         else deep_templates<kLds, kIgnoreChain, false>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, s, a0, r0, n_listed, cache, s_run, n_compact, shared);
     } else {
-        if constexpr (kMode == kModeBlocks) TM_T1(7, t_unit);
         if (pool_in_lds)
             search_templates<kLds, kIgnoreChain, true, kSingly>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, &s_next, s, a0, r0, chunk, n_chunks, shared);
         else
             search_templates<kLds, kIgnoreChain, false, kSingly>(A, scratch, s_rec, s_res, s_kl, s_pool, kl_off, &s_next, s, a0, r0, chunk, n_chunks, shared);
-        if constexpr (kMode == kModeBlocks) TM_T1(8, t_unit);
     }
 #ifdef TM_ABLATE
     if (kMode != kModeSingly && (threadIdx.x & 63) == 0 && log_at < kWgLog) {
