@@ -2503,6 +2503,25 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
                 std::stable_sort(S->order.begin(), S->order.end(), [&](uint32_t x, uint32_t y) {
                     return lib->cost_weight[S->sel[x]] > lib->cost_weight[S->sel[y]];
                 });
+                // ENZYMM_AMD_ORDER (experiments, round 6): 1 = templates that read the same pair table -- the same lead kinds
+                // 0 and 1 -- next to each other (a block's lanes then ask for the same table entries, and a table read by six
+                // templates comes from HBM once), in the a-priori order within a group and the groups by their heaviest member;
+                // 2 = the same with lead kind 2 (the triple table's second list) as a further key
+                static const int order_env = [] { const char *e = std::getenv("ENZYMM_AMD_ORDER"); return e ? std::atoi(e) : 0; }();
+                if (order_env == 1 || order_env == 2) {
+                    auto key_of = [&](uint32_t x) {
+                        const uint32_t t = S->sel[x], off = lib->t_off[t];
+                        const int G = lib->h_n_groups[t];
+                        const uint64_t a = G >= 1 ? lib->h_lead_li[off] : 0xffffu, b = G >= 2 ? lib->h_lead_li[off + 1] : 0xffffu,
+                                       c = G >= 3 && order_env == 2 ? lib->h_lead_li[off + 2] : 0u;
+                        return (a << 32) | (b << 16) | c;
+                    };
+                    std::map<uint64_t, uint32_t> first_seen;  // group -> rank of its heaviest member in the a-priori order
+                    for (uint32_t i = 0; i < n_sel; ++i) first_seen.emplace(key_of(S->order[i]), i);
+                    std::stable_sort(S->order.begin(), S->order.end(), [&](uint32_t x, uint32_t y) {
+                        return first_seen[key_of(x)] < first_seen[key_of(y)];
+                    });
+                }
             }
             {
                 std::vector<uint32_t> sel(n_sel);

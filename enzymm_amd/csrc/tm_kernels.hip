@@ -66,6 +66,9 @@ __device__ WgLog g_deep_log[kWgLog]; // ... and of k_deep
 // ------------------------------------------------------------------ wave helpers
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+#ifndef TM_D0_INTERLEAVE
+#define TM_D0_INTERLEAVE 0  // stage D0's records ordered (ordinal within residue, residue) instead of search order (experiment)
+#endif
 #ifndef TM_D0_SCAN
 #define TM_D0_SCAN 1  // stage D0: names scanned in a wave-uniform loop, candidates tested in lock step (0: the per-lane walk of rounds 4-5)
 #endif
@@ -239,7 +242,25 @@ __global__ __launch_bounds__(64) void k_stage_templates(LibView L, uint32_t n_se
             r.w0 = window(lane, 0); r.w1 = window(lane, 1); r.w2 = window(lane, 2);
             // a template whose first three residues hold more than kResChecks such levels (one residue of 23 or 24 atoms)
             // keeps the first kResChecks: D0 is a necessary-condition filter, a level it does not ask about is left to the search
+#if TM_D0_INTERLEAVE
+            // The records in the order (ordinal within its residue, residue): D0's first round then asks about one atom of each
+            // of two RESIDUES instead of two atoms of the first -- whether a second atom of a residue fits is nearly decided by
+            // the first, so a round over two residues ends more triples.  (Which levels a round asks about changes, the set of
+            // levels does not: the same triples pass D0.)
+            uint32_t slot = 0;
+            {
+                const uint32_t my_ref = L.a_ref[off + lane];
+                unsigned long long of_ref[3];
+                for (uint32_t r = 0; r < 3u; ++r) of_ref[r] = ballot64(qual && L.a_ref[off + min(lane, k - 1)] == (int)r);
+                const uint32_t j = (uint32_t)__popcll(of_ref[my_ref] & ((1ull << lane) - 1ull));  // my ordinal within my residue
+                for (uint32_t r = 0; r < 3u; ++r) {
+                    const uint32_t cnt = (uint32_t)__popcll(of_ref[r]);
+                    slot += min(cnt, j) + (r < my_ref && cnt > j ? 1u : 0u);
+                }
+            }
+#else
             const uint32_t slot = rank_in(rc_mask);
+#endif
             if (slot < (uint32_t)kResChecks) rescheck[(size_t)ti * kResChecks + slot] = r;
         }
     }
@@ -2524,36 +2545,40 @@ __device__ __forceinline__ void block_look(Ctx &C, const SearchArgs &A, SlotRegs
                 // atoms pass the same tests: a superset filter as before, parity cannot move.  Residues of more than 32 atoms
                 // (hydrogens, ligands) go 32 atoms at a time.
                 const uint32_t n_res_atoms = item && a_end > a ? a_end - a : 0u;
-                for (uint32_t base = 0; ballot64(base < n_res_atoms && !found) != 0ull; base += 32u) {
-                    const bool here = base < n_res_atoms && !found;
+                const uint32_t anybit = any ? 1u : 0u;
+                uint32_t fnd = 0u;
+                for (uint32_t base = 0; ballot64(base < n_res_atoms && fnd == 0u) != 0ull; base += 32u) {
+                    const bool here = base < n_res_atoms && fnd == 0u;
                     const uint32_t n_here = here ? min(32u, n_res_atoms - base) : 0u;
                     const uint32_t a_here = a + (here ? base : 0u);  // (a lane that is done keeps reading inside its residue)
+                    const uint32_t a_last = a_here + (n_here != 0u ? n_here - 1u : 0u);
                     uint32_t cand = 0u;
                     for (uint32_t i = 0; i < 32u; i += 2u) {
-                        const bool act0 = i < n_here, act1 = i + 1u < n_here;
-                        if (ballot64(act0) == 0ull) break;
-                        // (a lane past its residue reads its residue's first atom: inside the arrays whatever the memory)
-                        const uint32_t m0 = __float_as_uint(C.rec[a_here + (act0 ? i : 0u)].w);
-                        const uint32_t m1 = __float_as_uint(C.rec[a_here + (act1 ? i + 1u : 0u)].w);
-                        const bool adm0 = act0 & (((nm >> meta_name(m0)) & 1ull) != 0ull) & (any | (((ra.z >> meta_rtype(m0)) & 1u) != 0u));
-                        const bool adm1 = act1 & (((nm >> meta_name(m1)) & 1ull) != 0ull) & (any | (((ra.z >> meta_rtype(m1)) & 1u) != 0u));
-                        cand |= (adm0 ? 1u << i : 0u) | (adm1 ? 2u << i : 0u);
+                        if (ballot64(i < n_here) == 0ull) break;
+                        // (a lane past its residue repeats its last atom -- inside the arrays whatever the memory --; its bits are
+                        // masked off after the loop)
+                        const uint32_t m0 = __float_as_uint(C.rec[min(a_here + i, a_last)].w);
+                        const uint32_t m1 = __float_as_uint(C.rec[min(a_here + i + 1u, a_last)].w);
+                        const uint32_t b0 = (uint32_t)(nm >> meta_name(m0)) & ((ra.z >> meta_rtype(m0)) | anybit) & 1u;
+                        const uint32_t b1 = (uint32_t)(nm >> meta_name(m1)) & ((ra.z >> meta_rtype(m1)) | anybit) & 1u;
+                        cand |= (b0 << i) | (b1 << (i + 1u));
                     }
+                    cand &= n_here >= 32u ? 0xffffffffu : (1u << n_here) - 1u;
                     // the placed leads are not candidates (only the one this level shares its residue with can lie here)
                     {
                         const uint32_t d0 = px0 - a_here, d1 = px1 - a_here, d2 = pc - a_here;
                         cand &= ~((d0 < 32u ? 1u << d0 : 0u) | (d1 < 32u ? 1u << d1 : 0u) | (d2 < 32u ? 1u << d2 : 0u));
                     }
                     for (;;) {
-                        const bool has = cand != 0u && !found;
-                        if (ballot64(has) == 0ull) break;
-                        const uint32_t bit = has ? (uint32_t)__builtin_ctz(cand) : 0u;
+                        if (ballot64(cand != 0u) == 0ull) break;
+                        const uint32_t bit = cand != 0u ? (uint32_t)__builtin_ctz(cand) : 0u;
                         const float4 r = C.rec[a_here + bit];
-                        const bool ok = in_window(r, l0, w0b) & in_window(r, l1, w1b) & in_window(r, l2, w2b);
-                        found = found | (has & ok);
-                        cand &= cand - 1u;
+                        const bool ok = (cand != 0u) & in_window(r, l0, w0b) & in_window(r, l1, w1b) & in_window(r, l2, w2b);
+                        fnd |= ok ? 1u : 0u;
+                        cand = ok ? 0u : cand & (cand - 1u);
                     }
                 }
+                found = fnd != 0u;
 #elif TM_D0_UNROLL == 2
                 // two atoms of the residue per trip: their packed words are asked for together (one LDS round trip for two
                 // names; the loop is a chain of dependent round trips -- five on average, one per atom)
