@@ -2920,7 +2920,9 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
                                 search_kl_words(lib->view().n_lead) * sizeof(uint32_t);
             static const size_t lds_budget = std::getenv("ENZYMM_AMD_LDS_BUDGET") ? (size_t)std::atol(std::getenv("ENZYMM_AMD_LDS_BUDGET")) : 160 * 1024;  // experiments
             const size_t lds_limit = lds_budget - 64 - search_static_bytes(mode);
-            const bool lds_path = base <= lds_limit && !force_global;
+            // (a structure in LDS has fewer than 8192 atoms -- 128 KB of records alone would not fit --, which the block search's
+            // packed pair queue relies on: list positions in 13 bits; said here rather than assumed)
+            const bool lds_path = base <= lds_limit && !force_global && b->max_atoms_narrow < 8192u;
             args.pool_cap = lds_path ? (uint32_t)((lds_limit - base) / sizeof(uint16_t)) & ~7u : 0u;  // (copied in 16-byte words)
             const size_t lds_bytes = lds_path ? lds_limit : scratch + (mode == kModeDeep ? search_cache_bytes() : 0);
             void (*kernel)(SearchArgs) = nullptr;

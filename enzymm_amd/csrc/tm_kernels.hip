@@ -237,7 +237,7 @@ __global__ __launch_bounds__(64) void k_stage_templates(LibView L, uint32_t n_se
             const uint64_t nm = L.k_namemask[kind];
             ResCheck r = {};
             r.nm_lo = (uint32_t)nm; r.nm_hi = (uint32_t)(nm >> 32);
-            r.resmask = L.k_resmask[kind];
+            r.resmask = L.k_any[kind] ? 0xffffffffu : L.k_resmask[kind];  // (any residue type: every type's bit, one test in D0's scan)
             r.ref_any = (uint32_t)L.a_ref[off + lane] | (L.k_any[kind] ? 256u : 0u);
             r.w0 = window(lane, 0); r.w1 = window(lane, 1); r.w2 = window(lane, 2);
             // a template whose first three residues hold more than kResChecks such levels (one residue of 23 or 24 atoms)
@@ -1462,9 +1462,17 @@ constexpr uint32_t kResFirst = TM_RES_FIRST;  // stage D0: levels looked at in i
 #define TM_C_BATCH 2
 #endif
 #ifndef TM_C_RESTART
-#define TM_C_RESTART 1
+#define TM_C_RESTART 0
 #endif
-constexpr uint32_t kBBatch = TM_B_BATCH, kCBatch = TM_C_BATCH;
+// With the structure in LDS (fewer than 8192 atoms: tm_api.hip) a queued pair is ONE word -- two 13-bit list positions and
+// the block's 6-bit template slot -- so the same queue memory holds twice the pairs, and stage B asks for the entries of
+// TM_B_BATCH_LDS passes at a time; a structure in global memory (list positions up to 65535) keeps 8-byte entries.
+#ifndef TM_B_BATCH_LDS
+#define TM_B_BATCH_LDS 4
+#endif
+constexpr uint32_t kBBatch = TM_B_BATCH, kBBatchLds = TM_B_BATCH_LDS, kCBatch = TM_C_BATCH;
+static_assert(TM_B_BATCH_LDS + 1 <= 2 * (TM_B_BATCH + 1), "the packed pair queue holds twice the entries of the plain one");
+constexpr uint32_t kPackedPos = 13, kPackedPosMask = (1u << kPackedPos) - 1u;
 constexpr int kBlockPairQueue = 64 * (TM_B_BATCH + 1), kBlockTripleQueue = 64 * (TM_C_BATCH + 1);
 template <>
 struct __align__(16) WaveScratchT<kModeBlocks> {
@@ -1550,9 +1558,12 @@ struct __align__(16) ResCache {
     uint32_t count[kMaxG];  // its atoms
 };
 
-template <bool kIgnoreChain, bool kPoolLds, int kMode, bool kCache = false, bool kWideOk = false>
+template <bool kIgnoreChain, bool kPoolLds, int kMode, bool kCache = false, bool kWideOk = false, bool kRecLds = false>
 struct SearchCtx {
     static constexpr bool kResCache = kCache;
+    // the structure's atom records are in LDS (a read past the end of the arrays returns zero instead of faulting: index
+    // clamps that only keep a masked-out lane inside the arrays are left out)
+    static constexpr bool kRecInLds = kRecLds;
     static constexpr int kLaunchMode = kMode;
     static constexpr bool kPoolInLds = kPoolLds;
     ResCache *rc;               // kResCache: this wave's slots
@@ -2518,12 +2529,15 @@ __device__ __forceinline__ void block_look(Ctx &C, const SearchArgs &A, SlotRegs
                 const uint32_t w = min(w0 + lane, total - 1u);
                 const uint32_t j = w - lane_get(excl, p) + lane_get(j_first, p);  // which of the triple's records
                 const uint32_t pti = lane_get(ti, p);
-                const uint4 *rec4 = reinterpret_cast<const uint4 *>(A.Q.rescheck + (size_t)pti * kResChecks + j);
-                const uint4 ra = rec4[0], rb = rec4[1];
-                const uint2 rw2 = *reinterpret_cast<const uint2 *>(rec4 + 2);
+                // (the triple's three records are asked for BEFORE the level's record: the compiler had put the queue entry into
+                // the registers the first 16 bytes of the record were on their way to, and so waited for L2 before it even
+                // asked LDS -- the two chains now run side by side)
                 const uint2 pt = S.triples[from + p];  // (the owner's queue entry: its three atoms)
                 const uint32_t px0 = pt.x & 0xffffu, px1 = pt.x >> 16, pc = pt.y & 0xffffu;
                 const float4 l0 = C.rec[px0], l1 = C.rec[px1], l2 = C.rec[pc];
+                const uint4 *rec4 = reinterpret_cast<const uint4 *>(A.Q.rescheck + (size_t)pti * kResChecks + j);
+                const uint4 ra = rec4[0], rb = rec4[1];
+                const uint2 rw2 = *reinterpret_cast<const uint2 *>(rec4 + 2);
                 const uint32_t ref = ra.w & 0xffu;
                 const uint32_t res = meta_res(__float_as_uint(ref == 0u ? l0.w : ref == 1u ? l1.w : l2.w));
                 uint32_t a = C.res_start[res];
@@ -2545,7 +2559,6 @@ __device__ __forceinline__ void block_look(Ctx &C, const SearchArgs &A, SlotRegs
                 // atoms pass the same tests: a superset filter as before, parity cannot move.  Residues of more than 32 atoms
                 // (hydrogens, ligands) go 32 atoms at a time.
                 const uint32_t n_res_atoms = item && a_end > a ? a_end - a : 0u;
-                const uint32_t anybit = any ? 1u : 0u;
                 uint32_t fnd = 0u;
                 for (uint32_t base = 0; ballot64(base < n_res_atoms && fnd == 0u) != 0ull; base += 32u) {
                     const bool here = base < n_res_atoms && fnd == 0u;
@@ -2555,12 +2568,14 @@ __device__ __forceinline__ void block_look(Ctx &C, const SearchArgs &A, SlotRegs
                     uint32_t cand = 0u;
                     for (uint32_t i = 0; i < 32u; i += 2u) {
                         if (ballot64(i < n_here) == 0ull) break;
-                        // (a lane past its residue repeats its last atom -- inside the arrays whatever the memory --; its bits are
-                        // masked off after the loop)
-                        const uint32_t m0 = __float_as_uint(C.rec[min(a_here + i, a_last)].w);
-                        const uint32_t m1 = __float_as_uint(C.rec[min(a_here + i + 1u, a_last)].w);
-                        const uint32_t b0 = (uint32_t)(nm >> meta_name(m0)) & ((ra.z >> meta_rtype(m0)) | anybit) & 1u;
-                        const uint32_t b1 = (uint32_t)(nm >> meta_name(m1)) & ((ra.z >> meta_rtype(m1)) | anybit) & 1u;
+                        // (a lane past its residue repeats its last atom when the records are in global memory -- inside the
+                        // arrays --, with the records in LDS it reads on; its bits are masked off after the loop)
+                        const uint32_t i0 = Ctx::kRecInLds ? a_here + i : min(a_here + i, a_last);
+                        const uint32_t i1 = Ctx::kRecInLds ? a_here + i + 1u : min(a_here + i + 1u, a_last);
+                        const uint32_t m0 = __float_as_uint(C.rec[i0].w), m1 = __float_as_uint(C.rec[i1].w);
+                        // (ra.z holds every type's bit when the level admits any residue type: k_stage_templates)
+                        const uint32_t b0 = (uint32_t)(nm >> meta_name(m0)) & (ra.z >> meta_rtype(m0)) & 1u;
+                        const uint32_t b1 = (uint32_t)(nm >> meta_name(m1)) & (ra.z >> meta_rtype(m1)) & 1u;
                         cand |= (b0 << i) | (b1 << (i + 1u));
                     }
                     cand &= n_here >= 32u ? 0xffffffffu : (1u << n_here) - 1u;
@@ -2751,6 +2766,33 @@ __device__ __forceinline__ void queue_shift(uint2 *queue, uint32_t from, uint32_
     wave_sync();
 }
 
+// The pair queue of the block search: {list positions i | j << 16, template slot} -- 8 bytes, or packed into one word when
+// the structure is in LDS (Ctx::kRecInLds).
+template <class Ctx, class Scratch>
+__device__ __forceinline__ void pair_put(Scratch &S, uint32_t at, uint32_t pos, uint32_t slot) {
+    if constexpr (Ctx::kRecInLds)
+        reinterpret_cast<uint32_t *>(S.pairs)[at] = (pos & kPackedPosMask) | ((pos >> 16) << kPackedPos) | (slot << (2u * kPackedPos));
+    else S.pairs[at] = make_uint2(pos, slot);
+}
+template <class Ctx, class Scratch>
+__device__ __forceinline__ uint2 pair_get(const Scratch &S, uint32_t at) {
+    if constexpr (Ctx::kRecInLds) {
+        const uint32_t w = reinterpret_cast<const uint32_t *>(S.pairs)[at];
+        return make_uint2((w & kPackedPosMask) | (((w >> kPackedPos) & kPackedPosMask) << 16), w >> (2u * kPackedPos));
+    } else return S.pairs[at];
+}
+template <class Ctx, class Scratch>
+__device__ __forceinline__ void pair_shift(Scratch &S, uint32_t from, uint32_t n, uint32_t lane) {
+    if constexpr (Ctx::kRecInLds) {
+        uint32_t *q = reinterpret_cast<uint32_t *>(S.pairs);
+        uint32_t v = 0u;
+        if (lane < n) v = q[from + lane];
+        wave_sync();
+        if (lane < n) q[lane] = v;
+        wave_sync();
+    } else queue_shift(S.pairs, from, n, lane);
+}
+
 // Stage C over the first `np` queued pairs; survivors go to the triple queue (nq3 entries in it), which is worked
 // off (stage D1) whenever it holds 64.
 template <class Ctx>
@@ -2762,7 +2804,7 @@ __device__ __forceinline__ uint32_t block_pairs(Ctx &C, const SearchArgs &A, Slo
     TM_MARK("C_setup_begin");
     const bool vp = lane < np;
     uint2 pq = make_uint2(0u, 0u);
-    if (vp) pq = S.pairs[from + lane];
+    if (vp) pq = pair_get<Ctx>(S, from + lane);
     const uint32_t slot = pq.y, pos = pq.x;
     const uint32_t flags = lane_get(R.flags, slot);
     const bool key1 = (flags & 1u) != 0u;
@@ -3027,13 +3069,14 @@ __device__ __forceinline__ void search_block(Ctx &C, const SearchArgs &A, PageWr
 #if defined(TM_STATS) || defined(TM_ABLATE)
     skip = (Q.flags & 0x200u) != 0u;
 #endif
-    for (uint32_t w0 = 0; w0 < total && !skip; w0 += 64u * kBBatch) {
+    constexpr uint32_t kBB = Ctx::kRecInLds ? kBBatchLds : kBBatch;  // passes whose table entries are asked for together
+    for (uint32_t w0 = 0; w0 < total && !skip; w0 += 64u * kBB) {
         TM_MARK("B_group_begin");
         TM_T0(t_b);
-        uint32_t owner_of[kBBatch];
-        uint2 ent_of[kBBatch];
+        uint32_t owner_of[kBB];
+        uint2 ent_of[kBB];
 #pragma unroll
-        for (uint32_t k = 0; k < kBBatch; ++k) {
+        for (uint32_t k = 0; k < kBB; ++k) {
             const uint32_t wk = w0 + 64u * k;
             owner_of[k] = 0u; ent_of[k] = make_uint2(0u, 0u);
             if (k != 0u && wk >= total) continue;
@@ -3049,7 +3092,7 @@ __device__ __forceinline__ void search_block(Ctx &C, const SearchArgs &A, PageWr
             ent_of[k] = C.tab_ent[lane_get(R.base, owner_of[k]) + w];
         }
 #pragma unroll
-        for (uint32_t k = 0; k < kBBatch; ++k) {
+        for (uint32_t k = 0; k < kBB; ++k) {
             const uint32_t wk = w0 + 64u * k;
             if (k != 0u && wk >= total) continue;
             const uint32_t p = owner_of[k];
@@ -3071,16 +3114,16 @@ __device__ __forceinline__ void search_block(Ctx &C, const SearchArgs &A, PageWr
             if (Q.flags & 0x100u) m = 0ull;
 #endif
             if (m == 0ull) continue;
-            if (ok) S.pairs[nq + rank_in(m)] = make_uint2(ent.x, p);
+            if (ok) pair_put<Ctx>(S, nq + rank_in(m), ent.x, p);
             nq += (uint32_t)__popcll(m);
         }
         TM_MARK("B_group_end");
         TM_T1(1, t_b);
-        if (nq >= 64u) {  // (at most 63 + 64 x kBBatch queued: worked off 64 at a time, the rest moved to the front)
+        if (nq >= 64u) {  // (at most 63 + 64 x kBB queued: worked off 64 at a time, the rest moved to the front)
             wave_sync();
             uint32_t qh = 0;
             for (; nq - qh >= 64u; qh += 64u) pairs_group(C, A, R, PW, s, kl, 64u, nq3, qh);
-            queue_shift(S.pairs, qh, nq - qh, lane);
+            pair_shift<Ctx>(S, qh, nq - qh, lane);
             nq -= qh;
         }
     }
@@ -3111,7 +3154,7 @@ __device__ __forceinline__ void search_templates(const SearchArgs &A, WaveScratc
                                                  uint32_t r0, uint32_t chunk, uint32_t n_chunks, SharedTriples *shared = nullptr) {
     const BatchView &B = A.B;
     const QueryView &Q = A.Q;
-    SearchCtx<kIgnoreChain, kPoolLds, kSingly ? kModeSingly : kModeBlocks, false, kSingly && !kLds> C;
+    SearchCtx<kIgnoreChain, kPoolLds, kSingly ? kModeSingly : kModeBlocks, false, kSingly && !kLds, kLds> C;
     C.rc = nullptr;
     C.rec = kLds ? s_rec : B.q_rec + a0;
     C.res_start = kLds ? s_res : B.res_start + r0;
