@@ -66,6 +66,12 @@ __device__ WgLog g_deep_log[kWgLog]; // ... and of k_deep
 // ------------------------------------------------------------------ wave helpers
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+#ifndef TM_TAB_GROUP_TURNS
+#define TM_TAB_GROUP_TURNS 1  // k_tab_build: every table of a group is built in its leader's turn (0: only the derived ones)
+#endif
+#ifndef TM_TAB_DESC_AT_ONCE
+#define TM_TAB_DESC_AT_ONCE 1  // k_tab_build: a table's descriptor and row-slot base loaded together at the head of its turn (0: where first used)
+#endif
 #ifndef TM_D0_INTERLEAVE
 #define TM_D0_INTERLEAVE 0  // stage D0's records ordered (ordinal within residue, residue) instead of search order (experiment)
 #endif
@@ -989,22 +995,51 @@ __device__ __forceinline__ void tab_build_tables(const BatchView &B, const Table
     // tests/gpu_wg_timeline.py)
     uint32_t *next_table = s_count + kTabBlock / 64;
     for (;;) {
+        TM_MARK("T_claim");
         uint32_t taken = 0;
         if (lane == 0) taken = atomicAdd(next_table, 1u);
         const uint32_t t = w.part + w.parts * uni(taken);
         if (t >= nt) break;
+#if TM_TAB_DESC_AT_ONCE
+        // Round 6: the table's descriptor and its row-slot base in ONE round of scalar loads.  Left to itself the compiler
+        // fetched the descriptor's fields where they are first used -- lead kinds, then (behind a branch) the leader, then
+        // the limit, the chain link and the row-slot base: five dependent trips to the scalar cache or L2 per table, a
+        // thousand tables per structure.  The empty asm makes the four words exist here, together.
+        TableDesc T;
+        uint32_t row_slots;
+        {
+            const uint32_t *tw = reinterpret_cast<const uint32_t *>(tables + t);
+            uint32_t t0 = tw[0], t1 = tw[1], t2 = tw[2];
+            row_slots = B.tab_dir[(size_t)uni(w.s) * nt + t];  // (said to be uniform: a scalar load, like the descriptor's)
+            asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(row_slots));
+            t0 = uni(t0); t1 = uni(t1); t2 = uni(t2); row_slots = uni(row_slots);
+            T.li_a = (uint16_t)(t0 & 0xffffu); T.li_b = (uint16_t)(t0 >> 16);
+            T.dmax2 = __uint_as_float(t1);
+            T.src = (uint16_t)(t2 & 0xffffu); T.next = (uint16_t)(t2 >> 16);
+        }
+#else
         const TableDesc T = tables[t];
+        const uint32_t row_slots = B.tab_dir[(size_t)w.s * nt + t];
+#endif
         // wave-uniform values, said so: loop counters and branches of the sweep stay scalar
         const uint32_t a_lo = uni(kl[T.li_a]), n_a = uni(kl[T.li_a + 1]) - a_lo, b_lo = uni(kl[T.li_b]),
                        n_b = uni(kl[T.li_b + 1]) - b_lo;
-        uint32_t *rows = tab_rows + B.tab_dir[(size_t)w.s * nt + t];
+        uint32_t *rows = tab_rows + row_slots;
         const unsigned long long bound = (unsigned long long)n_a * n_b;
         if (bound > shared_limit) continue;  // a big table: all waves build it together, below
         // Tables of one group (same two lists, different limits): when the cross product is large, only the leader is
         // swept and the others are derived from its entries by the wave that builds it (below); a small cross product
         // -- a few dozen tiles out of LDS -- is cheaper to sweep per table than to read a leader back from L2.
         const bool derive = bound > derive_min;
+#if TM_TAB_GROUP_TURNS
+        // Round 6: the tables of a group -- same two lists, different limits -- are ALL built in their leader's turn: the big
+        // ones derived from its entries as before, the small ones swept there one after the other.  A table's turn starts
+        // with a claim, a descriptor, four list bounds and a row-slot base -- dependent trips that a member swept in the
+        // leader's turn does not make (its lists are the leader's), and there are 432 members among 1 081 tables.
+        if (T.src != t) continue;
+#else
         if (derive && T.src != t) continue;
+#endif
         unsigned long long first = 0;
         uint32_t total = 0;
         if (dbg_mode == 2u) {
@@ -1016,6 +1051,7 @@ __device__ __forceinline__ void tab_build_tables(const BatchView &B, const Table
             }
             if (rows_ok && chunk != ~0ull) {
                 first = chunk + used;
+                TM_MARK("T_sweep_once");
                 total = sweep_any(fill_yes, a_lo, n_a, b_lo, n_b, T.li_b, T.dmax2, rows, tab_ent + first, 0u, 0u);
             } else {
                 // no room (or no row slots): count only, and let the wave's chunk fill up exactly as it would have --
@@ -1030,6 +1066,7 @@ __device__ __forceinline__ void tab_build_tables(const BatchView &B, const Table
             if (!rows_ok) first = ~0ull;
             if (first != ~0ull && dbg_mode == 0u) sweep_any(fill_yes, a_lo, n_a, b_lo, n_b, T.li_b, T.dmax2, rows, tab_ent + first, 0u, 0u);
         }
+        TM_MARK("T_swept");
         if (lane == 0 && rows_ok) {
             tab_seg[(size_t)w.s * nt + t] = first == ~0ull ? make_uint2(0u, 0u) : make_uint2((uint32_t)first, (uint32_t)first + total);
             rows[n_a] = total;
@@ -1042,13 +1079,77 @@ __device__ __forceinline__ void tab_build_tables(const BatchView &B, const Table
             TM_STAT(284 + min(15u, bl), 1);
         }
 #endif
+#if TM_TAB_GROUP_TURNS
+        // ---- the other tables of a small group: swept here, each like a small table in a turn of its own
+        if (!derive && T.next != 0xffffu && dbg_mode != 2u) {
+            for (uint32_t d = T.next; d != 0xffffu;) {
+                const uint32_t *tw = reinterpret_cast<const uint32_t *>(tables + d);
+                uint32_t t1 = tw[1], t2 = tw[2];
+                uint32_t row_slots_d = B.tab_dir[(size_t)uni(w.s) * nt + uni(d)];
+                asm volatile("" : "+v"(t1), "+v"(t2), "+v"(row_slots_d));
+                t1 = uni(t1); t2 = uni(t2); row_slots_d = uni(row_slots_d);
+                const float dmax2_d = __uint_as_float(t1);
+                uint32_t *rows_d = tab_rows + row_slots_d;
+                unsigned long long first_d = 0;
+                uint32_t total_d = 0;
+                if (bound <= kTabChunk) {  // (the rule: derive_min is below the smallest chunk unless a test hook raised it)
+                    if (used + (uint32_t)bound > kTabChunk) {
+                        chunk = allocate(kTabChunk);
+                        used = 0;
+                    }
+                    if (rows_ok && chunk != ~0ull) {
+                        first_d = chunk + used;
+                        total_d = sweep_any(fill_yes, a_lo, n_a, b_lo, n_b, T.li_b, dmax2_d, rows_d, tab_ent + first_d, 0u, 0u);
+                    } else {
+                        first_d = ~0ull;
+                        total_d = sweep_any(fill_no, a_lo, n_a, b_lo, n_b, T.li_b, dmax2_d, nullptr, nullptr, 0u, 0u);
+                    }
+                    used += total_d;
+                } else {
+                    total_d = sweep_any(fill_no, a_lo, n_a, b_lo, n_b, T.li_b, dmax2_d, nullptr, nullptr, 0u, 0u);
+                    first_d = allocate(total_d);
+                    if (!rows_ok) first_d = ~0ull;
+                    if (first_d != ~0ull && dbg_mode == 0u) sweep_any(fill_yes, a_lo, n_a, b_lo, n_b, T.li_b, dmax2_d, rows_d, tab_ent + first_d, 0u, 0u);
+                }
+                if (lane == 0 && rows_ok) {
+                    tab_seg[(size_t)w.s * nt + d] = first_d == ~0ull ? make_uint2(0u, 0u) : make_uint2((uint32_t)first_d, (uint32_t)first_d + total_d);
+                    rows_d[n_a] = total_d;
+                }
+#ifdef TM_STATS
+                {
+                    const uint32_t bl = min(23u, 64u - (uint32_t)__clzll((long long)bound));
+                    TM_STAT(120 + bl, bound);
+                    TM_STAT(168 + bl, total_d);
+                    TM_STAT(284 + min(15u, bl), 1);
+                }
+#endif
+                d = t2 >> 16;
+            }
+        }
+#endif
         // ---- the tables derived from this one (same lists, smaller limits): its entries within their limit
         if (derive && T.next != 0xffffu && dbg_mode != 2u) {
             const bool have = first != ~0ull && rows_ok && dbg_mode == 0u;
             if (have) wave_sync();  // the leader's rows and entries are read back below (by this wave, which wrote them)
             for (uint32_t d = T.next; d != 0xffffu;) {
+#if TM_TAB_DESC_AT_ONCE
+                TableDesc Td;
+                uint32_t row_slots_d;
+                {
+                    const uint32_t *tw = reinterpret_cast<const uint32_t *>(tables + d);
+                    uint32_t t1 = tw[1], t2 = tw[2];
+                    row_slots_d = B.tab_dir[(size_t)uni(w.s) * nt + uni(d)];
+                    asm volatile("" : "+v"(t1), "+v"(t2), "+v"(row_slots_d));
+                    t1 = uni(t1); t2 = uni(t2); row_slots_d = uni(row_slots_d);
+                    Td.li_a = T.li_a; Td.li_b = T.li_b;
+                    Td.dmax2 = __uint_as_float(t1);
+                    Td.src = (uint16_t)(t2 & 0xffffu); Td.next = (uint16_t)(t2 >> 16);
+                }
+                uint32_t *rows_d = tab_rows + row_slots_d;
+#else
                 const TableDesc Td = tables[d];
                 uint32_t *rows_d = tab_rows + B.tab_dir[(size_t)w.s * nt + d];
+#endif
                 unsigned long long first_d = ~0ull;
                 uint32_t total_d = 0;
                 // room for as many entries as the leader has (an upper bound), from the wave's chunk like a small table;
@@ -1204,6 +1305,7 @@ __device__ __forceinline__ void tab_build_global(const BatchView &B, const Table
 #ifndef TM_TAB_EU
 #define TM_TAB_EU 8
 #endif
+
 // kLayout 0: a record per list position in LDS (one workgroup per CU); 1: the compact layout; 2: a batch of mostly large
 // structures (complexes of tens of thousands of atoms): records through L2, 64 KB of LDS for the staged list B of the big
 // tables -- two workgroups per CU as well, and the same eight waves per SIMD (as part of layout 0's kernel that path had
@@ -2544,6 +2646,7 @@ __device__ __forceinline__ void block_look(Ctx &C, const SearchArgs &A, SlotRegs
                 const uint32_t a_end = C.res_start[res + 1u];
                 const unsigned long long nm = ((unsigned long long)ra.y << 32) | ra.x;
                 const bool any = (ra.w & 256u) != 0u;
+                (void)any;  // (the scan reads the flag out of ra.z: see k_stage_templates)
                 const float2 w0b = make_float2(__uint_as_float(rb.x), __uint_as_float(rb.y)), w1b = make_float2(__uint_as_float(rb.z), __uint_as_float(rb.w)),
                              w2b = make_float2(__uint_as_float(rw2.x), __uint_as_float(rw2.y));
                 bool found = false;
@@ -2921,6 +3024,7 @@ template <class Ctx>
 __device__ __forceinline__ void pairs_group(Ctx &C, const SearchArgs &A, SlotRegs &R, PageWriter &PW, uint32_t s,
                                             const uint32_t *kl, uint32_t n, uint32_t &nq3, uint32_t qh) {
     auto &S = *C.S;
+    (void)S;
     for (uint32_t w = 0;;) {
         TM_T0(t_c);
         w = block_pairs(C, A, R, PW, s, kl, n, nq3, qh, w);

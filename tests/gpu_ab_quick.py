@@ -17,12 +17,19 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     import numpy as np
     from tests import helpers
     from enzymm_amd import pyjess, synthetic, _native
+    import time
     n = int(sys.argv[2])
+    t0 = time.time()
     idx, cut = helpers.default_selection()
     jess = pyjess.Jess(helpers.product_library_templates())
+    t1 = time.time()
     mols = synthetic.structures(n)
+    t2 = time.time()
     packed = pyjess._packed(jess._templates, jess._device)
     batch = pyjess.make_batch(mols, jess._device)
+    t3 = time.time()
+    if os.environ.get("AB_VERBOSE"):
+        print("setup: library %.1f s, structures %.1f s, device %.1f s" % (t1 - t0, t2 - t1, t3 - t2), file=sys.stderr)
     flags = _native.TM_FLAG_BEST_MATCH | _native.TM_FLAG_IGNORE_CHAIN | _native.TM_FLAG_REBUILD_INDEX
     rows = []
     digest = None
