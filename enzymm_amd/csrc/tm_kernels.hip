@@ -67,10 +67,10 @@ __device__ WgLog g_deep_log[kWgLog]; // ... and of k_deep
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 #ifndef TM_TAB_GROUP_TURNS
-#define TM_TAB_GROUP_TURNS 1  // k_tab_build: every table of a group is built in its leader's turn (0: only the derived ones)
+#define TM_TAB_GROUP_TURNS 0  // k_tab_build: every table of a group is built in its leader's turn (0: only the derived ones)
 #endif
 #ifndef TM_TAB_DESC_AT_ONCE
-#define TM_TAB_DESC_AT_ONCE 1  // k_tab_build: a table's descriptor and row-slot base loaded together at the head of its turn (0: where first used)
+#define TM_TAB_DESC_AT_ONCE 0  // k_tab_build: a table's descriptor and row-slot base loaded together at the head of its turn (0: where first used)
 #endif
 #ifndef TM_D0_INTERLEAVE
 #define TM_D0_INTERLEAVE 0  // stage D0's records ordered (ordinal within residue, residue) instead of search order (experiment)
@@ -1534,6 +1534,9 @@ struct __align__(16) WaveScratchT {
 constexpr uint32_t kSharedTriples = TM_SHARED_TRIPLES;
 #ifndef TM_MIN_BLOCK
 #define TM_MIN_BLOCK 32
+#endif
+#ifndef TM_TAIL_MIN
+#define TM_TAIL_MIN 32  // see search_templates (32 = off)
 #endif
 #ifndef TM_MIN_BLOCK_GLOBAL
 #define TM_MIN_BLOCK_GLOBAL 2  // ... of a structure that is not in LDS (search_templates)
@@ -3312,7 +3315,9 @@ __device__ __forceinline__ void search_templates(const SearchArgs &A, WaveScratc
             // (a structure that is not in LDS -- a large complex: hundreds of table entries per template, and a batch of few
             // structures is cut into chunks of a few dozen templates -- takes blocks from 2 templates: with the LDS path's
             // minimum one wave of sixteen took a workgroup's whole chunk: 7 % of the wave-time of the launch at work)
-            count = min(64u, max(kLds ? kMinBlock : (uint32_t)TM_MIN_BLOCK_GLOBAL, (left / (2u * kSearchWaves)) & ~7u));
+            // (TM_TAIL_MIN, experiment: blocks of at least that many templates once less than a round of minimum blocks is left)
+            const uint32_t floor_lds = (uint32_t)TM_TAIL_MIN < kMinBlock && left < kSearchWaves * kMinBlock ? (uint32_t)TM_TAIL_MIN : kMinBlock;
+            count = min(64u, max(kLds ? floor_lds : (uint32_t)TM_MIN_BLOCK_GLOBAL, (left / (2u * kSearchWaves)) & ~7u));
             m0 = atomicAdd(s_next_p, count);
         }
         m0 = uni(m0);
