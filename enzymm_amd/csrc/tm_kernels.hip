@@ -2978,6 +2978,13 @@ __device__ __forceinline__ uint32_t block_pairs(Ctx &C, const SearchArgs &A, Slo
             const uint2 ent = ent_of[k];
             const float dk2 = __uint_as_float(ent.y);
             bool ok = (wk + lane < total) & (dk2 >= lane_getf(wklo, p)) & (dk2 <= lane_getf(wkhi, p));
+#ifdef TM_STATS
+            {
+                const uint32_t n_key = (uint32_t)__popcll(ballot64(ok)), n_items = (uint32_t)__popcll(ballot64(wk + lane < total));
+                TM_STAT(302, n_key);   // items of stage C whose stored distance to the key lead lies in the window
+                TM_STAT(303, n_items); // items of stage C
+            }
+#endif
             const uint32_t c2 = C.pool_at(lane_get(lo2, p) + (ent.x >> 16));
             const float4 rc = C.rec[c2];
             const float ox = lane_getf(ro.x, p), oy = lane_getf(ro.y, p), oz = lane_getf(ro.z, p);
