@@ -8,8 +8,10 @@ import numpy as np
 import pytest
 
 from tests import helpers
+from tests.test_gpu_parity import compare
 from tests.test_gpu_round5 import _encoded_batch
 from enzymm_amd import _native, ingest, jess_run, pyjess, synthetic, template
+from oracle import oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -177,3 +179,62 @@ def test_unsearchable_structure_leaves_its_batch_searched(af, amy):
     # (the golden templates match TRP carbons by exact name or not at all: whether the lattice is searchable with them is
     # the engine's call -- either it is listed or it was searched)
     assert matcher.refused in ([], [(mol, 210000)])
+
+
+# ------------------------------------------------------------------------------------------- stage D0's scan (round 6)
+
+
+def _padded(mol, every=7, extra=37, ident="padded"):
+    """``mol`` with ``extra`` dummy atoms (hydrogens named H001 ..., far from everything) put IN FRONT of the atoms of every
+    ``every``-th residue, so that the residue's real atoms sit beyond position 32 of a residue of more than 32 atoms."""
+    c = mol._cols
+    keys = list(zip(c["chain_id"].tolist(), c["residue_number"].tolist(), c["insertion_code"].tolist()))
+    starts = [0] + [i for i in range(1, len(keys)) if keys[i] != keys[i - 1]] + [len(keys)]
+    order, dummy = [], []
+    for r in range(len(starts) - 1):
+        lo, hi = starts[r], starts[r + 1]
+        if r % every == 0:
+            order.extend([-(lo + 1)] * extra)  # (negative: a dummy copied from atom lo)
+        order.extend(range(lo, hi))
+    src = np.array([(-o - 1) if o < 0 else o for o in order])
+    is_dummy = np.array([o < 0 for o in order])
+    cols = {k: v[src].copy() for k, v in c.items() if k != "serial"}
+    n_d = int(is_dummy.sum())
+    cols["name"][is_dummy] = np.array([("H%03d" % (i % 1000)).encode() for i in range(n_d)], dtype="S4")
+    cols["element"][is_dummy] = b" H"
+    xyz = mol._xyz[src].copy()
+    xyz[is_dummy] = np.round(xyz[is_dummy] + 400.0 + np.arange(n_d)[:, None] * 0.001, 3)
+    return pyjess.Molecule.from_columns(id=ident, xyz=xyz, **cols)
+
+
+@pytest.mark.parametrize("which", ["lds", "global"])
+def test_residues_of_more_than_32_atoms(amy, af, which):
+    """Stage D0 scans a residue's names 32 atoms at a time (round 6).  Residues padded to 40-50 atoms with dummy hydrogens in
+    FRONT of their real atoms -- the atoms a level asks for sit beyond position 32 -- against implanted templates that hit
+    those residues and every fifth template of the default selection: hit sets, atoms, RMSD and candidate counts equal the
+    oracle's, with the structure in LDS (1AMY, every thirteenth residue padded) and in global memory (AF-P0DUB6, all
+    of them: 23 000 atoms)."""
+    base = amy if which == "lds" else af
+    mol = _padded(base, every=13 if which == "lds" else 1, ident="padded_" + which)
+    assert (len(mol) < 5200) == (which == "lds")
+    implanted = helpers.implant_templates(mol, helpers.product_library_templates(), np.random.default_rng(17), max_templates=150)
+    assert len(implanted) > 100
+    jess = pyjess.Jess(implanted)
+    table, cands = jess.query_batch([mol, synthetic.structure(5)], 2.0, 1.0, 1.0, max_candidates=10000, ignore_chain=True,
+                                    count_candidates=True, return_raw=True)
+    olib = oracle.OracleLibrary([helpers.to_oracle_template(t) for t in implanted])
+    hits = 0
+    for s, m in enumerate([mol, synthetic.structure(5)]):
+        want = oracle.query_library(helpers.to_oracle_molecule(m), olib, 2.0, 1.0, 1.0, max_candidates=10000, ignore_chain=True)
+        hits += compare(table, cands, s, want, olib)
+    assert hits > 100
+    # ... and the library's own templates (sparse hits; every level of D0 asked of padded residues)
+    idx, cut = helpers.default_selection()
+    every = np.arange(0, len(idx), 5)
+    lib = pyjess.Jess(helpers.product_library_templates())
+    table, cands = lib.query_batch([mol], 2.0, cut[every], cut[every], max_candidates=10000, ignore_chain=True,
+                                   template_index=idx[every], count_candidates=True, return_raw=True)
+    otpl = helpers.oracle_library_templates()
+    olib2 = oracle.OracleLibrary([otpl[i] for i in idx[every]])
+    want = oracle.query_library(helpers.to_oracle_molecule(mol), olib2, 2.0, cut[every], cut[every], max_candidates=10000, ignore_chain=True)
+    compare(table, cands, 0, want, olib2)
