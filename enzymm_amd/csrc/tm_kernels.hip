@@ -1566,6 +1566,9 @@ constexpr uint32_t kResFirst = TM_RES_FIRST;  // stage D0: levels looked at in i
 #ifndef TM_C_BATCH
 #define TM_C_BATCH 2
 #endif
+#ifndef TM_C_ROWS_AHEAD
+#define TM_C_ROWS_AHEAD 1  // stage C asks for the next call's row bounds while its own are on their way (0: every call asks at its head)
+#endif
 #ifndef TM_C_RESTART
 #define TM_C_RESTART 0
 #endif
@@ -1574,6 +1577,10 @@ constexpr uint32_t kResFirst = TM_RES_FIRST;  // stage D0: levels looked at in i
 // TM_B_BATCH_LDS passes at a time; a structure in global memory (list positions up to 65535) keeps 8-byte entries.
 #ifndef TM_B_BATCH_LDS
 #define TM_B_BATCH_LDS 4
+#endif
+#if TM_C_RESTART && TM_C_ROWS_AHEAD
+#undef TM_C_ROWS_AHEAD
+#define TM_C_ROWS_AHEAD 0  // (a restarted call would take the rows asked for its successor)
 #endif
 constexpr uint32_t kBBatch = TM_B_BATCH, kBBatchLds = TM_B_BATCH_LDS, kCBatch = TM_C_BATCH;
 static_assert(TM_B_BATCH_LDS + 1 <= 2 * (TM_B_BATCH + 1), "the packed pair queue holds twice the entries of the plain one");
@@ -2901,10 +2908,17 @@ __device__ __forceinline__ void pair_shift(Scratch &S, uint32_t from, uint32_t n
 
 // Stage C over the first `np` queued pairs; survivors go to the triple queue (nq3 entries in it), which is worked
 // off (stage D1) whenever it holds 64.
+// The row bounds of the NEXT 64 queued pairs, asked for while this call's rows are on their way (TM_C_ROWS_AHEAD): when a
+// flush of stage B works off more than 64 pairs, the second and later calls of stage C start with their rows in registers
+// instead of a trip to L2 or HBM.
+struct RowsAhead {
+    uint32_t r0, r1;
+    bool have;
+};
 template <class Ctx>
 __device__ __forceinline__ uint32_t block_pairs(Ctx &C, const SearchArgs &A, SlotRegs &R, PageWriter &PW, uint32_t s,
-                                                const uint32_t *kl, uint32_t np, uint32_t &nq3, uint32_t from = 0u,
-                                                uint32_t w_start = 0u) {
+                                                const uint32_t *kl, uint32_t np, uint32_t &nq3, uint32_t from,
+                                                uint32_t w_start, RowsAhead &ahead, bool has_next) {
     auto &S = *C.S;
     const uint32_t lane = (uint32_t)C.lane;
     TM_MARK("C_setup_begin");
@@ -2917,7 +2931,20 @@ __device__ __forceinline__ uint32_t block_pairs(Ctx &C, const SearchArgs &A, Slo
     const uint32_t key = key1 ? pos >> 16 : pos & 0xffffu;
     const uint32_t trows = lane_get(R.trows, slot);
     // the row of the key atom (lanes without a pair read slot 0's first row: a valid address)
-    const uint32_t r0 = C.tab_rows[trows + key], r1 = C.tab_rows[trows + key + 1u];
+    uint32_t r0, r1;
+    if (ahead.have) { r0 = ahead.r0; r1 = ahead.r1; }  // (uniform: asked for by the call before this one)
+    else { r0 = C.tab_rows[trows + key]; r1 = C.tab_rows[trows + key + 1u]; }
+    ahead.have = false;
+#if TM_C_ROWS_AHEAD
+    if (has_next) {  // (uniform; the next call works off the 64 pairs behind this call's: a full group)
+        const uint2 nq = pair_get<Ctx>(S, from + 64u + lane);
+        const uint32_t nflags = lane_get(R.flags, nq.y), ntrows = lane_get(R.trows, nq.y);
+        const uint32_t nkey = (nflags & 1u) != 0u ? nq.x >> 16 : nq.x & 0xffffu;
+        ahead.r0 = C.tab_rows[ntrows + nkey];
+        ahead.r1 = C.tab_rows[ntrows + nkey + 1u];
+        ahead.have = true;
+    }
+#endif
     // (A lane without a pair reads through slot 0: position 0 of that template's lead lists.  Should the template in slot 0 have
     // no second lead, or an empty list, that position is the first entry BEHIND a list -- for the last list of the pool
     // whatever the allocation held before --, and the atom record it names is read: harmless while the records are in LDS
@@ -3032,12 +3059,13 @@ __device__ __forceinline__ uint32_t block_pairs(Ctx &C, const SearchArgs &A, Slo
 // Stage C over `n` queued pairs from queue position `qh`, and stages D0/D1 over the triple queue whenever it holds 64.
 template <class Ctx>
 __device__ __forceinline__ void pairs_group(Ctx &C, const SearchArgs &A, SlotRegs &R, PageWriter &PW, uint32_t s,
-                                            const uint32_t *kl, uint32_t n, uint32_t &nq3, uint32_t qh) {
+                                            const uint32_t *kl, uint32_t n, uint32_t &nq3, uint32_t qh, RowsAhead &ahead,
+                                            bool has_next) {
     auto &S = *C.S;
     (void)S;
     for (uint32_t w = 0;;) {
         TM_T0(t_c);
-        w = block_pairs(C, A, R, PW, s, kl, n, nq3, qh, w);
+        w = block_pairs(C, A, R, PW, s, kl, n, nq3, qh, w, ahead, has_next && w == 0u);
         TM_T1(2, t_c);
         TM_TN(10, 1);
 #if TM_C_RESTART
@@ -3236,14 +3264,16 @@ __device__ __forceinline__ void search_block(Ctx &C, const SearchArgs &A, PageWr
         if (nq >= 64u) {  // (at most 63 + 64 x kBB queued: worked off 64 at a time, the rest moved to the front)
             wave_sync();
             uint32_t qh = 0;
-            for (; nq - qh >= 64u; qh += 64u) pairs_group(C, A, R, PW, s, kl, 64u, nq3, qh);
+            RowsAhead ahead = {0u, 0u, false};
+            for (; nq - qh >= 64u; qh += 64u) pairs_group(C, A, R, PW, s, kl, 64u, nq3, qh, ahead, nq - qh >= 128u);
             pair_shift<Ctx>(S, qh, nq - qh, lane);
             nq -= qh;
         }
     }
     if (nq != 0u) {
         wave_sync();
-        pairs_group(C, A, R, PW, s, kl, nq, nq3, 0u);
+        RowsAhead none = {0u, 0u, false};
+        pairs_group(C, A, R, PW, s, kl, nq, nq3, 0u, none, false);
     }
     if (nq3 != 0u) {
         wave_sync();
