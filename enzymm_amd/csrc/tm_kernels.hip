@@ -1567,7 +1567,7 @@ constexpr uint32_t kResFirst = TM_RES_FIRST;  // stage D0: levels looked at in i
 #define TM_C_BATCH 2
 #endif
 #ifndef TM_C_ROWS_AHEAD
-#define TM_C_ROWS_AHEAD 1  // stage C asks for the next call's row bounds while its own are on their way (0: every call asks at its head)
+#define TM_C_ROWS_AHEAD 0  // stage C asks for the next call's row bounds while its own are on their way (0: every call asks at its head)
 #endif
 #ifndef TM_C_RESTART
 #define TM_C_RESTART 0
