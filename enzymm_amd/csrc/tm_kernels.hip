@@ -66,12 +66,6 @@ __device__ WgLog g_deep_log[kWgLog]; // ... and of k_deep
 // ------------------------------------------------------------------ wave helpers
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
-#ifndef TM_TAB_GROUP_TURNS
-#define TM_TAB_GROUP_TURNS 0  // k_tab_build: every table of a group is built in its leader's turn (0: only the derived ones)
-#endif
-#ifndef TM_TAB_DESC_AT_ONCE
-#define TM_TAB_DESC_AT_ONCE 0  // k_tab_build: a table's descriptor and row-slot base loaded together at the head of its turn (0: where first used)
-#endif
 #ifndef TM_D0_INTERLEAVE
 #define TM_D0_INTERLEAVE 0  // stage D0's records ordered (ordinal within residue, residue) instead of search order (experiment)
 #endif
@@ -995,51 +989,22 @@ __device__ __forceinline__ void tab_build_tables(const BatchView &B, const Table
     // tests/gpu_wg_timeline.py)
     uint32_t *next_table = s_count + kTabBlock / 64;
     for (;;) {
-        TM_MARK("T_claim");
         uint32_t taken = 0;
         if (lane == 0) taken = atomicAdd(next_table, 1u);
         const uint32_t t = w.part + w.parts * uni(taken);
         if (t >= nt) break;
-#if TM_TAB_DESC_AT_ONCE
-        // Round 6: the table's descriptor and its row-slot base in ONE round of scalar loads.  Left to itself the compiler
-        // fetched the descriptor's fields where they are first used -- lead kinds, then (behind a branch) the leader, then
-        // the limit, the chain link and the row-slot base: five dependent trips to the scalar cache or L2 per table, a
-        // thousand tables per structure.  The empty asm makes the four words exist here, together.
-        TableDesc T;
-        uint32_t row_slots;
-        {
-            const uint32_t *tw = reinterpret_cast<const uint32_t *>(tables + t);
-            uint32_t t0 = tw[0], t1 = tw[1], t2 = tw[2];
-            row_slots = B.tab_dir[(size_t)uni(w.s) * nt + t];  // (said to be uniform: a scalar load, like the descriptor's)
-            asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(row_slots));
-            t0 = uni(t0); t1 = uni(t1); t2 = uni(t2); row_slots = uni(row_slots);
-            T.li_a = (uint16_t)(t0 & 0xffffu); T.li_b = (uint16_t)(t0 >> 16);
-            T.dmax2 = __uint_as_float(t1);
-            T.src = (uint16_t)(t2 & 0xffffu); T.next = (uint16_t)(t2 >> 16);
-        }
-#else
         const TableDesc T = tables[t];
-        const uint32_t row_slots = B.tab_dir[(size_t)w.s * nt + t];
-#endif
         // wave-uniform values, said so: loop counters and branches of the sweep stay scalar
         const uint32_t a_lo = uni(kl[T.li_a]), n_a = uni(kl[T.li_a + 1]) - a_lo, b_lo = uni(kl[T.li_b]),
                        n_b = uni(kl[T.li_b + 1]) - b_lo;
-        uint32_t *rows = tab_rows + row_slots;
+        uint32_t *rows = tab_rows + B.tab_dir[(size_t)w.s * nt + t];
         const unsigned long long bound = (unsigned long long)n_a * n_b;
         if (bound > shared_limit) continue;  // a big table: all waves build it together, below
         // Tables of one group (same two lists, different limits): when the cross product is large, only the leader is
         // swept and the others are derived from its entries by the wave that builds it (below); a small cross product
         // -- a few dozen tiles out of LDS -- is cheaper to sweep per table than to read a leader back from L2.
         const bool derive = bound > derive_min;
-#if TM_TAB_GROUP_TURNS
-        // Round 6: the tables of a group -- same two lists, different limits -- are ALL built in their leader's turn: the big
-        // ones derived from its entries as before, the small ones swept there one after the other.  A table's turn starts
-        // with a claim, a descriptor, four list bounds and a row-slot base -- dependent trips that a member swept in the
-        // leader's turn does not make (its lists are the leader's), and there are 432 members among 1 081 tables.
-        if (T.src != t) continue;
-#else
         if (derive && T.src != t) continue;
-#endif
         unsigned long long first = 0;
         uint32_t total = 0;
         if (dbg_mode == 2u) {
@@ -1051,7 +1016,6 @@ __device__ __forceinline__ void tab_build_tables(const BatchView &B, const Table
             }
             if (rows_ok && chunk != ~0ull) {
                 first = chunk + used;
-                TM_MARK("T_sweep_once");
                 total = sweep_any(fill_yes, a_lo, n_a, b_lo, n_b, T.li_b, T.dmax2, rows, tab_ent + first, 0u, 0u);
             } else {
                 // no room (or no row slots): count only, and let the wave's chunk fill up exactly as it would have --
@@ -1066,7 +1030,6 @@ __device__ __forceinline__ void tab_build_tables(const BatchView &B, const Table
             if (!rows_ok) first = ~0ull;
             if (first != ~0ull && dbg_mode == 0u) sweep_any(fill_yes, a_lo, n_a, b_lo, n_b, T.li_b, T.dmax2, rows, tab_ent + first, 0u, 0u);
         }
-        TM_MARK("T_swept");
         if (lane == 0 && rows_ok) {
             tab_seg[(size_t)w.s * nt + t] = first == ~0ull ? make_uint2(0u, 0u) : make_uint2((uint32_t)first, (uint32_t)first + total);
             rows[n_a] = total;
@@ -1079,77 +1042,13 @@ __device__ __forceinline__ void tab_build_tables(const BatchView &B, const Table
             TM_STAT(284 + min(15u, bl), 1);
         }
 #endif
-#if TM_TAB_GROUP_TURNS
-        // ---- the other tables of a small group: swept here, each like a small table in a turn of its own
-        if (!derive && T.next != 0xffffu && dbg_mode != 2u) {
-            for (uint32_t d = T.next; d != 0xffffu;) {
-                const uint32_t *tw = reinterpret_cast<const uint32_t *>(tables + d);
-                uint32_t t1 = tw[1], t2 = tw[2];
-                uint32_t row_slots_d = B.tab_dir[(size_t)uni(w.s) * nt + uni(d)];
-                asm volatile("" : "+v"(t1), "+v"(t2), "+v"(row_slots_d));
-                t1 = uni(t1); t2 = uni(t2); row_slots_d = uni(row_slots_d);
-                const float dmax2_d = __uint_as_float(t1);
-                uint32_t *rows_d = tab_rows + row_slots_d;
-                unsigned long long first_d = 0;
-                uint32_t total_d = 0;
-                if (bound <= kTabChunk) {  // (the rule: derive_min is below the smallest chunk unless a test hook raised it)
-                    if (used + (uint32_t)bound > kTabChunk) {
-                        chunk = allocate(kTabChunk);
-                        used = 0;
-                    }
-                    if (rows_ok && chunk != ~0ull) {
-                        first_d = chunk + used;
-                        total_d = sweep_any(fill_yes, a_lo, n_a, b_lo, n_b, T.li_b, dmax2_d, rows_d, tab_ent + first_d, 0u, 0u);
-                    } else {
-                        first_d = ~0ull;
-                        total_d = sweep_any(fill_no, a_lo, n_a, b_lo, n_b, T.li_b, dmax2_d, nullptr, nullptr, 0u, 0u);
-                    }
-                    used += total_d;
-                } else {
-                    total_d = sweep_any(fill_no, a_lo, n_a, b_lo, n_b, T.li_b, dmax2_d, nullptr, nullptr, 0u, 0u);
-                    first_d = allocate(total_d);
-                    if (!rows_ok) first_d = ~0ull;
-                    if (first_d != ~0ull && dbg_mode == 0u) sweep_any(fill_yes, a_lo, n_a, b_lo, n_b, T.li_b, dmax2_d, rows_d, tab_ent + first_d, 0u, 0u);
-                }
-                if (lane == 0 && rows_ok) {
-                    tab_seg[(size_t)w.s * nt + d] = first_d == ~0ull ? make_uint2(0u, 0u) : make_uint2((uint32_t)first_d, (uint32_t)first_d + total_d);
-                    rows_d[n_a] = total_d;
-                }
-#ifdef TM_STATS
-                {
-                    const uint32_t bl = min(23u, 64u - (uint32_t)__clzll((long long)bound));
-                    TM_STAT(120 + bl, bound);
-                    TM_STAT(168 + bl, total_d);
-                    TM_STAT(284 + min(15u, bl), 1);
-                }
-#endif
-                d = t2 >> 16;
-            }
-        }
-#endif
         // ---- the tables derived from this one (same lists, smaller limits): its entries within their limit
         if (derive && T.next != 0xffffu && dbg_mode != 2u) {
             const bool have = first != ~0ull && rows_ok && dbg_mode == 0u;
             if (have) wave_sync();  // the leader's rows and entries are read back below (by this wave, which wrote them)
             for (uint32_t d = T.next; d != 0xffffu;) {
-#if TM_TAB_DESC_AT_ONCE
-                TableDesc Td;
-                uint32_t row_slots_d;
-                {
-                    const uint32_t *tw = reinterpret_cast<const uint32_t *>(tables + d);
-                    uint32_t t1 = tw[1], t2 = tw[2];
-                    row_slots_d = B.tab_dir[(size_t)uni(w.s) * nt + uni(d)];
-                    asm volatile("" : "+v"(t1), "+v"(t2), "+v"(row_slots_d));
-                    t1 = uni(t1); t2 = uni(t2); row_slots_d = uni(row_slots_d);
-                    Td.li_a = T.li_a; Td.li_b = T.li_b;
-                    Td.dmax2 = __uint_as_float(t1);
-                    Td.src = (uint16_t)(t2 & 0xffffu); Td.next = (uint16_t)(t2 >> 16);
-                }
-                uint32_t *rows_d = tab_rows + row_slots_d;
-#else
                 const TableDesc Td = tables[d];
                 uint32_t *rows_d = tab_rows + B.tab_dir[(size_t)w.s * nt + d];
-#endif
                 unsigned long long first_d = ~0ull;
                 uint32_t total_d = 0;
                 // room for as many entries as the leader has (an upper bound), from the wave's chunk like a small table;
@@ -1305,7 +1204,6 @@ __device__ __forceinline__ void tab_build_global(const BatchView &B, const Table
 #ifndef TM_TAB_EU
 #define TM_TAB_EU 8
 #endif
-
 // kLayout 0: a record per list position in LDS (one workgroup per CU); 1: the compact layout; 2: a batch of mostly large
 // structures (complexes of tens of thousands of atoms): records through L2, 64 KB of LDS for the staged list B of the big
 // tables -- two workgroups per CU as well, and the same eight waves per SIMD (as part of layout 0's kernel that path had
@@ -1535,9 +1433,6 @@ constexpr uint32_t kSharedTriples = TM_SHARED_TRIPLES;
 #ifndef TM_MIN_BLOCK
 #define TM_MIN_BLOCK 32
 #endif
-#ifndef TM_TAIL_MIN
-#define TM_TAIL_MIN 32  // see search_templates (32 = off)
-#endif
 #ifndef TM_MIN_BLOCK_GLOBAL
 #define TM_MIN_BLOCK_GLOBAL 2  // ... of a structure that is not in LDS (search_templates)
 #endif
@@ -1566,9 +1461,6 @@ constexpr uint32_t kResFirst = TM_RES_FIRST;  // stage D0: levels looked at in i
 #ifndef TM_C_BATCH
 #define TM_C_BATCH 2
 #endif
-#ifndef TM_C_ROWS_AHEAD
-#define TM_C_ROWS_AHEAD 0  // stage C asks for the next call's row bounds while its own are on their way (0: every call asks at its head)
-#endif
 #ifndef TM_C_RESTART
 #define TM_C_RESTART 0
 #endif
@@ -1577,10 +1469,6 @@ constexpr uint32_t kResFirst = TM_RES_FIRST;  // stage D0: levels looked at in i
 // TM_B_BATCH_LDS passes at a time; a structure in global memory (list positions up to 65535) keeps 8-byte entries.
 #ifndef TM_B_BATCH_LDS
 #define TM_B_BATCH_LDS 4
-#endif
-#if TM_C_RESTART && TM_C_ROWS_AHEAD
-#undef TM_C_ROWS_AHEAD
-#define TM_C_ROWS_AHEAD 0  // (a restarted call would take the rows asked for its successor)
 #endif
 constexpr uint32_t kBBatch = TM_B_BATCH, kBBatchLds = TM_B_BATCH_LDS, kCBatch = TM_C_BATCH;
 static_assert(TM_B_BATCH_LDS + 1 <= 2 * (TM_B_BATCH + 1), "the packed pair queue holds twice the entries of the plain one");
@@ -2908,17 +2796,10 @@ __device__ __forceinline__ void pair_shift(Scratch &S, uint32_t from, uint32_t n
 
 // Stage C over the first `np` queued pairs; survivors go to the triple queue (nq3 entries in it), which is worked
 // off (stage D1) whenever it holds 64.
-// The row bounds of the NEXT 64 queued pairs, asked for while this call's rows are on their way (TM_C_ROWS_AHEAD): when a
-// flush of stage B works off more than 64 pairs, the second and later calls of stage C start with their rows in registers
-// instead of a trip to L2 or HBM.
-struct RowsAhead {
-    uint32_t r0, r1;
-    bool have;
-};
 template <class Ctx>
 __device__ __forceinline__ uint32_t block_pairs(Ctx &C, const SearchArgs &A, SlotRegs &R, PageWriter &PW, uint32_t s,
-                                                const uint32_t *kl, uint32_t np, uint32_t &nq3, uint32_t from,
-                                                uint32_t w_start, RowsAhead &ahead, bool has_next) {
+                                                const uint32_t *kl, uint32_t np, uint32_t &nq3, uint32_t from = 0u,
+                                                uint32_t w_start = 0u) {
     auto &S = *C.S;
     const uint32_t lane = (uint32_t)C.lane;
     TM_MARK("C_setup_begin");
@@ -2931,20 +2812,7 @@ __device__ __forceinline__ uint32_t block_pairs(Ctx &C, const SearchArgs &A, Slo
     const uint32_t key = key1 ? pos >> 16 : pos & 0xffffu;
     const uint32_t trows = lane_get(R.trows, slot);
     // the row of the key atom (lanes without a pair read slot 0's first row: a valid address)
-    uint32_t r0, r1;
-    if (ahead.have) { r0 = ahead.r0; r1 = ahead.r1; }  // (uniform: asked for by the call before this one)
-    else { r0 = C.tab_rows[trows + key]; r1 = C.tab_rows[trows + key + 1u]; }
-    ahead.have = false;
-#if TM_C_ROWS_AHEAD
-    if (has_next) {  // (uniform; the next call works off the 64 pairs behind this call's: a full group)
-        const uint2 nq = pair_get<Ctx>(S, from + 64u + lane);
-        const uint32_t nflags = lane_get(R.flags, nq.y), ntrows = lane_get(R.trows, nq.y);
-        const uint32_t nkey = (nflags & 1u) != 0u ? nq.x >> 16 : nq.x & 0xffffu;
-        ahead.r0 = C.tab_rows[ntrows + nkey];
-        ahead.r1 = C.tab_rows[ntrows + nkey + 1u];
-        ahead.have = true;
-    }
-#endif
+    const uint32_t r0 = C.tab_rows[trows + key], r1 = C.tab_rows[trows + key + 1u];
     // (A lane without a pair reads through slot 0: position 0 of that template's lead lists.  Should the template in slot 0 have
     // no second lead, or an empty list, that position is the first entry BEHIND a list -- for the last list of the pool
     // whatever the allocation held before --, and the atom record it names is read: harmless while the records are in LDS
@@ -3005,13 +2873,6 @@ __device__ __forceinline__ uint32_t block_pairs(Ctx &C, const SearchArgs &A, Slo
             const uint2 ent = ent_of[k];
             const float dk2 = __uint_as_float(ent.y);
             bool ok = (wk + lane < total) & (dk2 >= lane_getf(wklo, p)) & (dk2 <= lane_getf(wkhi, p));
-#ifdef TM_STATS
-            {
-                const uint32_t n_key = (uint32_t)__popcll(ballot64(ok)), n_items = (uint32_t)__popcll(ballot64(wk + lane < total));
-                TM_STAT(302, n_key);   // items of stage C whose stored distance to the key lead lies in the window
-                TM_STAT(303, n_items); // items of stage C
-            }
-#endif
             const uint32_t c2 = C.pool_at(lane_get(lo2, p) + (ent.x >> 16));
             const float4 rc = C.rec[c2];
             const float ox = lane_getf(ro.x, p), oy = lane_getf(ro.y, p), oz = lane_getf(ro.z, p);
@@ -3059,13 +2920,12 @@ __device__ __forceinline__ uint32_t block_pairs(Ctx &C, const SearchArgs &A, Slo
 // Stage C over `n` queued pairs from queue position `qh`, and stages D0/D1 over the triple queue whenever it holds 64.
 template <class Ctx>
 __device__ __forceinline__ void pairs_group(Ctx &C, const SearchArgs &A, SlotRegs &R, PageWriter &PW, uint32_t s,
-                                            const uint32_t *kl, uint32_t n, uint32_t &nq3, uint32_t qh, RowsAhead &ahead,
-                                            bool has_next) {
+                                            const uint32_t *kl, uint32_t n, uint32_t &nq3, uint32_t qh) {
     auto &S = *C.S;
     (void)S;
     for (uint32_t w = 0;;) {
         TM_T0(t_c);
-        w = block_pairs(C, A, R, PW, s, kl, n, nq3, qh, w, ahead, has_next && w == 0u);
+        w = block_pairs(C, A, R, PW, s, kl, n, nq3, qh, w);
         TM_T1(2, t_c);
         TM_TN(10, 1);
 #if TM_C_RESTART
@@ -3264,16 +3124,14 @@ __device__ __forceinline__ void search_block(Ctx &C, const SearchArgs &A, PageWr
         if (nq >= 64u) {  // (at most 63 + 64 x kBB queued: worked off 64 at a time, the rest moved to the front)
             wave_sync();
             uint32_t qh = 0;
-            RowsAhead ahead = {0u, 0u, false};
-            for (; nq - qh >= 64u; qh += 64u) pairs_group(C, A, R, PW, s, kl, 64u, nq3, qh, ahead, nq - qh >= 128u);
+            for (; nq - qh >= 64u; qh += 64u) pairs_group(C, A, R, PW, s, kl, 64u, nq3, qh);
             pair_shift<Ctx>(S, qh, nq - qh, lane);
             nq -= qh;
         }
     }
     if (nq != 0u) {
         wave_sync();
-        RowsAhead none = {0u, 0u, false};
-        pairs_group(C, A, R, PW, s, kl, nq, nq3, 0u, none, false);
+        pairs_group(C, A, R, PW, s, kl, nq, nq3, 0u);
     }
     if (nq3 != 0u) {
         wave_sync();
@@ -3352,9 +3210,7 @@ __device__ __forceinline__ void search_templates(const SearchArgs &A, WaveScratc
             // (a structure that is not in LDS -- a large complex: hundreds of table entries per template, and a batch of few
             // structures is cut into chunks of a few dozen templates -- takes blocks from 2 templates: with the LDS path's
             // minimum one wave of sixteen took a workgroup's whole chunk: 7 % of the wave-time of the launch at work)
-            // (TM_TAIL_MIN, experiment: blocks of at least that many templates once less than a round of minimum blocks is left)
-            const uint32_t floor_lds = (uint32_t)TM_TAIL_MIN < kMinBlock && left < kSearchWaves * kMinBlock ? (uint32_t)TM_TAIL_MIN : kMinBlock;
-            count = min(64u, max(kLds ? floor_lds : (uint32_t)TM_MIN_BLOCK_GLOBAL, (left / (2u * kSearchWaves)) & ~7u));
+            count = min(64u, max(kLds ? kMinBlock : (uint32_t)TM_MIN_BLOCK_GLOBAL, (left / (2u * kSearchWaves)) & ~7u));
             m0 = atomicAdd(s_next_p, count);
         }
         m0 = uni(m0);

@@ -42,8 +42,9 @@ print("per search: pair passes %.3f  pair survivors %.3f  triple passes %.3f  tr
       (s[52] / searches, s[53] / searches, s[67] / searches, s[68] / searches))
 print("per search: look flushes %.4f  triples looked at %.3f  ended by the residue check (D0) %.3f  asked for a fourth lead (D1) %.3f (chunks each %.2f)  paged out %.3f" %
       (s[64] / searches, s[66] / searches, s[69] / searches, s[60] / searches, s[61] / max(s[60], 1), s[65] / searches))
-print("stage C: %.2f items per search, %.2f of them inside the window of the stored distance (%.1f %%)" %
-      (s[303] / searches, s[302] / searches, 100.0 * s[302] / max(s[303], 1)))
+if s[303]:  # (counters of profiles/r06_logs/experiments_after_v41.patch: not in the tree's stats build)
+    print("stage C: %.2f items per search, %.2f of them inside the window of the stored distance (%.1f %%)" %
+          (s[303] / searches, s[302] / searches, 100.0 * s[302] / max(s[303], 1)))
 print("residue-check items per triple looked at %.2f, passes of 64 items per search %.4f" % (s[62] / max(s[66], 1), s[63] / searches))
 paged = max(s[65], 1)
 print("k_deep chunk evaluations per level (per paged triple)", np.round(s[3:24] / paged, 2))
