@@ -320,7 +320,15 @@ class DevicePool {
     }
 
   private:
-    static constexpr size_t kMaxCached = size_t(16) << 30;  // of 288 GB HBM
+    // Round 6: 48 GB of 288 GB HBM (ENZYMM_AMD_DEVICE_CACHE_GB; 16 until then).  A batch of a thousand structures holds
+    // 2.8 GB while it lives -- 2.2 GB of it the generously sized pair-table pool -- and Matcher.run keeps six alive (three
+    // handed over ahead, two searched, one collected): with 16 GB every second batch's release went to hipFree, which
+    // waits for the device, and its successor's acquire to hipMalloc (tm_query's host time 2.2 ms instead of 0.55).
+    const size_t kMaxCached = [] {
+        const char *e = std::getenv("ENZYMM_AMD_DEVICE_CACHE_GB");
+        const long gb = e ? std::atol(e) : 48;
+        return (size_t)std::max<long>(1, std::min<long>(gb, 256)) << 30;
+    }();
     std::mutex mu_;
     std::multimap<std::pair<int, size_t>, void *> free_;
     size_t cached_ = 0;
@@ -407,7 +415,14 @@ class PinnedPool {
     }
 
   private:
-    static constexpr size_t kMaxCached = size_t(2) << 30;
+    // (ENZYMM_AMD_PINNED_CACHE_GB, default 6, 2 until round 6: Matcher.run_files keeps the text of the batches it has in
+    // flight -- 190 MB each -- in page-locked memory, and a release beyond the cap is a hipHostFree, its successor a
+    // hipHostMalloc of 8 ms)
+    const size_t kMaxCached = [] {
+        const char *e = std::getenv("ENZYMM_AMD_PINNED_CACHE_GB");
+        const long gb = e ? std::atol(e) : 6;
+        return (size_t)std::max<long>(1, std::min<long>(gb, 64)) << 30;
+    }();
     std::mutex mu_;
     std::multimap<size_t, void *> free_;
     size_t cached_ = 0;
