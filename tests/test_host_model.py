@@ -302,6 +302,31 @@ print("PICKLE_OK")
     assert out.returncode == 0 and "PICKLE_OK" in out.stdout, out.stderr[-2000:]
 
 
+def test_packing_a_large_library_logs_instead_of_warning(monkeypatch, caplog):
+    """moving the library's objects to the collector's permanent generation is the intended default of every run
+    with the full library -- said in an INFO record of the ``enzymm_amd`` logger, not in a warning (the reference's CLI shows
+    warnings to its users, and harnesses run with -W error)."""
+    import gc
+    import logging
+    import warnings
+    lib = template.load_packed_library()[:600]
+
+    class FakeLibrary:
+        def __init__(self, device, *args, orientation=None):
+            pass
+
+    monkeypatch.setattr(_native, "Library", FakeLibrary)
+    monkeypatch.setattr(pyjess, "_settled", False)
+    monkeypatch.delenv("ENZYMM_AMD_GC_FREEZE", raising=False)
+    frozen = []
+    monkeypatch.setattr(gc, "freeze", lambda: frozen.append(True))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        with caplog.at_level(logging.INFO, logger="enzymm_amd"):
+            pyjess._PackedLibrary(lib, 0)
+    assert frozen == [True] and any("gc.freeze" in r.getMessage() for r in caplog.records)
+
+
 def test_native_pdb_reader_equals_numpy_reference():
     """tm_pdb_parse_host against the vectorised numpy reader it replaced: same columns on the fixtures, and on
     randomly damaged records either the same table or the same ValueError (same offending line quoted)."""
