@@ -2755,6 +2755,7 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
         int rc = build_index(lib, b, r, stream);
         if (rc != TM_OK) return rc;
     }
+    trace.mark("index");
     if (rebuild || b->tables_for != S->serial) {
         int rc = build_tables(lib, b, S.get(), stream);
         if (rc != TM_OK) return rc;
@@ -2773,7 +2774,7 @@ int tm_query(const tm_library *lib, tm_batch *b, const tm_query_params *p, tm_re
                                hipMemcpyDeviceToHost, stream));
     }
     HIP_TRY(hipEventRecord(r->ev[1], stream));
-    trace.mark("index+tables");
+    trace.mark("tables");
 
     QueryView Q;
     Q.n_sel = n_sel; Q.sel = S->d_sel.p; Q.rmsd_thr = S->d_rmsd.p; Q.cutoff = S->d_cut.p; Q.maxdyn = S->d_maxdyn.p;
