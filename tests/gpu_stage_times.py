@@ -30,13 +30,13 @@ ms = res.timing()[1]
 res.close()
 lib.tm_debug_times(buf)
 t = [float(v) for v in buf]
-names = ["A", "B", "C", "D0", "D1 + queueing", "search below queued triples", "waiting at the end of a unit", "staging a unit",
-         "whole units"]
+names = ["A", "B", "C (with the D0/D1 flushes nested in it)", "D0", "D1 + queueing", "search below queued triples",
+         "waiting at the end of a unit", "(unused)", "the waves' whole time in their units' template loops"]
 searches = n * len(idx)
 print("k_search + k_deep %.3f ms (instrumented build), %d searches" % (ms, searches))
 unit = max(t[8], 1.0)
 for i, name in enumerate(names):
-    print("  %-32s %14.0f cycles  %5.1f %% of the waves' time in units  %8.1f cycles per search" % (name, t[i], 100.0 * t[i] / unit, t[i] / searches))
+    print("  %-52s %14.0f cycles  %5.1f %% of the waves' time in units  %8.1f cycles per search" % (name, t[i], 100.0 * t[i] / unit, t[i] / searches))
 acc = sum(t[0:7])
 print("  stages + waits accounted: %.1f %% of unit time net of staging" % (100.0 * acc / max(unit - t[7], 1.0)))
 print("  blocks %d (%.1f templates each), C calls %d (%.2f per block), look flushes %d (%.2f per block), queue entries searched %d (%.3f per search)" %
