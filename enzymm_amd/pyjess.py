@@ -27,6 +27,7 @@ from __future__ import annotations
 
 import collections
 import collections.abc
+import ctypes
 import io
 import math
 import os
@@ -122,6 +123,18 @@ class Atom:
 
 
 # ---------------------------------------------------------------------------------- Molecule
+
+
+def _address_of(a: np.ndarray) -> int:
+    """Address of a contiguous array's first byte.  Through the buffer protocol where the array is writable (0.7 us;
+    ``__array_interface__`` builds a dictionary: 2 us -- six of them per molecule were most of the 17 us a fresh
+    ``Molecule`` cost ``make_batch`` under the GIL, round 6)."""
+    if a.size:
+        try:
+            return ctypes.addressof(ctypes.c_char.from_buffer(a))
+        except (TypeError, ValueError, BufferError):  # read-only or exotic: the slow way
+            pass
+    return a.__array_interface__["data"][0]
 
 
 _MOL_COLUMNS = (
@@ -303,7 +316,7 @@ class Molecule:
         if row is None:
             keep = [np.ascontiguousarray(self._xyz, dtype=np.float64)]
             keep += [np.ascontiguousarray(self._cols[k], dtype=dt) for k, dt in self._ROW_COLUMNS]
-            rec = np.array([len(self)] + [a.__array_interface__["data"][0] for a in keep], dtype=np.uint64)
+            rec = np.array([len(self)] + [_address_of(a) for a in keep], dtype=np.uint64)
             row = self._row = (rec, keep)
         return row[0]
 
