@@ -327,6 +327,35 @@ def test_packing_a_large_library_logs_instead_of_warning(monkeypatch, caplog):
     assert frozen == [True] and any("gc.freeze" in r.getMessage() for r in caplog.records)
 
 
+def test_loaded_molecules_share_their_hand_over_records(tmp_path):
+    """Round 6: ``Molecule.load_many`` (what ``load_molecules`` calls) makes the ``tm_structure_columns`` records of its
+    molecules in one vectorised step -- their tables are consecutive slices of the same arrays --; each must equal the
+    record the molecule would make on its own at first use, empty files among them; copies and subsets make their own."""
+    from enzymm_amd import synthetic
+    mols = synthetic.structures(12, start=300)
+    paths = []
+    for i, m in enumerate(mols):
+        p = tmp_path / f"s{i}.pdb"
+        p.write_text(synthetic.to_pdb(m))
+        paths.append(p)
+    (tmp_path / "empty.pdb").write_text("REMARK nothing\nEND\n")
+    paths.insert(4, tmp_path / "empty.pdb")
+    paths.append(tmp_path / "empty.pdb")
+    loaded = pyjess.Molecule.load_many(paths)
+    assert [len(m) for m in loaded] == [len(m) for m in mols[:4]] + [0] + [len(m) for m in mols[4:]] + [0]
+    for m in loaded:
+        assert m._row is not None
+        shared = m._row[0].copy()
+        m._row = None
+        own = m._pointer_row()
+        assert shared[0] == own[0] == len(m)
+        if len(m):
+            assert np.array_equal(shared, own)
+    assert loaded[2].copy()._row is None and loaded[2].conserved(50.0)._row is None
+    one = pyjess.Molecule.load_many(paths[:1])
+    assert one[0]._row is None and one[0]._pointer_row()[0] == len(mols[0])
+
+
 def test_native_pdb_reader_equals_numpy_reference():
     """tm_pdb_parse_host against the vectorised numpy reader it replaced: same columns on the fixtures, and on
     randomly damaged records either the same table or the same ValueError (same offending line quoted)."""
