@@ -3368,6 +3368,32 @@ inline bool parse_field(const PdbLine &l, int lo, int width, bool blank_ok, bool
     return !bad && ndig <= 18 && (ndig > 0 || (!started && blank_ok)) && !(integer && seen_dot);
 }
 
+// The same field when it has the plain shape [spaces][sign]digits[.digits][spaces] and lies inside the line -- every field a
+// PDB writer produces --, in one pass of dependent-free loops (round 6: the general parser's eight flags per character were
+// 0.3 us per record of the host reader).  Anything else -- blank, a stray character, a second dot, a sign in the middle, an
+// integer field with a dot -- returns false and is left to parse_field, which alone decides what is an error.
+inline bool parse_field_plain(const char *p, int width, bool integer, long long *mant_out, int *frac_out) {
+    int k = 0;
+    while (k < width && p[k] == ' ') ++k;
+    if (k == width) return false;
+    bool neg = false;
+    if (p[k] == '-') { neg = true; ++k; }
+    else if (p[k] == '+') ++k;
+    unsigned long long m = 0;
+    int nd = 0, fr = 0;
+    while (k < width && (unsigned)(p[k] - '0') < 10u) { m = m * 10ull + (unsigned long long)(p[k] - '0'); ++k; ++nd; }
+    if (k < width && p[k] == '.') {
+        if (integer) return false;
+        ++k;
+        while (k < width && (unsigned)(p[k] - '0') < 10u) { m = m * 10ull + (unsigned long long)(p[k] - '0'); ++k; ++nd; ++fr; }
+    }
+    while (k < width && p[k] == ' ') ++k;
+    if (k != width || nd == 0 || nd > 18) return false;
+    *mant_out = neg ? -(long long)m : (long long)m;
+    *frac_out = fr;
+    return true;
+}
+
 const double kPow10[19] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16,
                            1e17, 1e18};
 
@@ -3431,8 +3457,10 @@ int tm_pdb_parse_host(const char *text, uint64_t length, uint32_t flags, uint64_
         }
         long long mant[7];
         int frac[7];
-        for (int f = 0; f < 7; ++f)
+        for (int f = 0; f < 7; ++f) {
+            if ((uint32_t)(lo[f] + width[f]) <= l.len && parse_field_plain(l.p + lo[f], width[f], f < 2, &mant[f], &frac[f])) continue;
             if (!parse_field(l, lo[f], width[f], f >= 5, f < 2, &mant[f], &frac[f]) && !bad_field[f].p) bad_field[f] = l;
+        }
         out->serial[n] = (int32_t)mant[0];
         out->residue_number[n] = (int32_t)mant[1];
         for (int a = 0; a < 3; ++a) out->xyz[3 * n + a] = (double)mant[2 + a] / kPow10[std::min(frac[2 + a], 18)];
