@@ -271,9 +271,15 @@ def load_molecules(molecule_paths: List[Path], conservation_cutoff: float = 0, w
     seen: collections.Counter = collections.Counter()
     paths, ids = [], []
     for path in molecule_paths:
-        stem = Path(path).stem
+        text = os.fspath(path)
+        name = os.path.basename(text)
+        if name:  # (pathlib's rule for .stem on the final component, without building a Path: 5 us per file)
+            dot = name.rfind(".")
+            stem = name[:dot] if 0 < dot < len(name) - 1 else name
+        else:
+            stem = Path(path).stem
         seen[stem] += 1
-        paths.append(str(path))
+        paths.append(text)
         ids.append(stem if seen[stem] == 1 else f"{stem}_{seen[stem]}")
     molecules = []
     for path, mol in zip(paths, pyjess.Molecule.load_many(paths, ids)):
